@@ -1,0 +1,28 @@
+"""beamforming-lk_amd -- MI355X (gfx950) delay-and-sum heatmap engine behind the
+aw_processing_unit API of acoustic-warfare/beamforming-lk.
+
+The product is the C-ABI library libawpu_hip.so (include/awpu_hip.h, sources in csrc/)
+and the C++ host mirror of the reference's MIMO worker (host/).  This Python package is
+plumbing: it builds and loads the library (ctypes) for the tests and bench.py.
+
+The directory name has a hyphen; import it with
+    importlib.import_module("beamforming-lk_amd")
+"""
+from . import _build, binding, synthetic  # noqa: F401
+from .binding import (  # noqa: F401
+    MATH_F32_EXACT,
+    MATH_F32_FAST,
+    AwpuError,
+    Engine,
+    build_delay_table,
+    create_antenna,
+    create_tiled_antenna,
+    heatmap_u8,
+    steering_delays,
+)
+
+__all__ = [
+    "Engine", "AwpuError", "MATH_F32_EXACT", "MATH_F32_FAST", "build_delay_table",
+    "create_antenna", "create_tiled_antenna", "steering_delays", "heatmap_u8", "binding",
+    "synthetic", "_build",
+]

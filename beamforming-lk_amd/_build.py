@@ -1,0 +1,67 @@
+"""Build recipe for libawpu_hip.so (gfx950 only, in-tree).
+
+hipcc cross-compiles without a GPU, so this runs in the authoring container and on the GPU
+box alike.  The library is written next to this file; it is git-ignored but travels with
+the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+REPO = PKG_DIR.parent
+CSRC = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libawpu_hip.so"
+
+SOURCES = [CSRC / "das_kernels.hip", CSRC / "awpu_hip.cpp", CSRC / "geometry_host.cpp"]
+HEADERS = [CSRC / "das_kernels.h", REPO / "include" / "awpu_hip.h"]
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: libawpu_hip.so cannot be built (there is no CPU fallback)")
+
+
+def stale() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    built = LIB_PATH.stat().st_mtime
+    return any(p.stat().st_mtime > built for p in SOURCES + HEADERS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP kernels and the C ABI into beamforming-lk_amd/libawpu_hip.so."""
+    if not force and not stale():
+        return LIB_PATH
+    cmd = [
+        hipcc_path(),
+        "--offload-arch=gfx950",
+        "-O3",
+        "-std=c++17",
+        "-fPIC",
+        "-shared",
+        "-Wall",
+        "-Wno-unused-result",
+        "-x", "hip",
+        f"-I{REPO / 'include'}",
+        f"-I{CSRC}",
+        *[str(s) for s in SOURCES],
+        "-o", str(LIB_PATH),
+    ]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    if verbose and proc.stderr.strip():
+        print(proc.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

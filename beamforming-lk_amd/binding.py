@@ -1,0 +1,264 @@
+"""ctypes binding of libawpu_hip.so (include/awpu_hip.h).
+
+Plumbing only: it loads the in-tree HIP library and forwards to the C ABI.  There is no
+Python or CPU implementation of the sweep behind it -- if the library cannot be built or
+loaded, importing a compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _build
+
+N_SAMPLES = 256
+HIST = 1024
+ELEMENTS = 64
+
+INTERP_LERP, INTERP_FIR8 = 0, 1
+MATH_F32_EXACT, MATH_F32_FAST = 0, 1
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_RANGE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("device", C.c_int32),
+        ("n_streams", C.c_int32),
+        ("hist", C.c_int32),
+        ("n_pixels", C.c_int32),
+        ("lut_stride", C.c_int32),
+        ("interp", C.c_int32),
+        ("math", C.c_int32),
+        ("max_batch", C.c_int32),
+        ("pixel_begin", C.c_int32),
+        ("pixel_count", C.c_int32),
+        ("reserved", C.c_int32 * 5),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("frames", C.c_uint64),
+        ("launches", C.c_uint64),
+        ("last_kernel_ms", C.c_double),
+        ("total_kernel_ms", C.c_double),
+        ("alg_bytes_frame", C.c_uint64),
+        ("alg_flops_frame", C.c_uint64),
+        ("tau_max", C.c_int32),
+        ("window", C.c_int32),
+        ("usable", C.c_int32),
+        ("kernel_variant", C.c_int32),
+    ]
+
+
+class AwpuError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str):
+        self.status = status
+        super().__init__(f"{where}: status {status} ({detail})")
+
+
+_lib: Optional[C.CDLL] = None
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+_SIGNATURES = {
+    "awpu_hip_default_cfg": (None, [C.POINTER(Cfg)]),
+    "awpu_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Cfg)]),
+    "awpu_hip_destroy": (C.c_int, [C.c_void_p]),
+    "awpu_hip_set_delay_table": (C.c_int, [C.c_void_p, _i32p, _f32p]),
+    "awpu_hip_set_active_mics": (C.c_int, [C.c_void_p, _i32p, C.c_int32]),
+    "awpu_hip_set_fir_table": (C.c_int, [C.c_void_p, _f32p]),
+    "awpu_hip_process": (C.c_int, [C.c_void_p, _f32p, C.c_int32, _f32p]),
+    "awpu_hip_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "awpu_hip_synchronize": (C.c_int, [C.c_void_p]),
+    "awpu_hip_heatmap_u8": (C.c_int, [_f32p, C.c_int32, _u8p]),
+    "awpu_hip_create_antenna": (C.c_int, [C.c_int32, C.c_int32, C.c_float, _f32p]),
+    "awpu_hip_create_tiled_antenna": (C.c_int, [C.c_int32, C.c_int32, C.c_float, _f32p]),
+    "awpu_hip_steering_delays": (C.c_int, [_f32p, C.c_int32, C.c_double, C.c_double, _f32p]),
+    "awpu_hip_build_delay_table": (
+        C.c_int,
+        [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, _i32p, _f32p],
+    ),
+    "awpu_hip_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "awpu_hip_strerror": (C.c_char_p, [C.c_int]),
+    "awpu_hip_last_error": (C.c_char_p, []),
+    "awpu_hip_abi_version": (C.c_int, []),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load(build: bool = True) -> C.CDLL:
+    """Load (building first if stale) the in-tree libawpu_hip.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build_library() if build else _build.LIB_PATH
+    if not path.exists():
+        raise RuntimeError(f"{path} is missing and there is no CPU fallback")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(status: int, where: str) -> None:
+    if status != OK:
+        lib = load()
+        detail = lib.awpu_hip_strerror(status).decode()
+        last = lib.awpu_hip_last_error().decode()
+        raise AwpuError(status, where, f"{detail}; {last}" if last else detail)
+
+
+def _f32(a: np.ndarray):
+    return a.ctypes.data_as(_f32p)
+
+
+def _i32(a: np.ndarray):
+    return a.ctypes.data_as(_i32p)
+
+
+# ----------------------------------------------------------------------------- geometry
+
+
+def create_antenna(columns: int = 8, rows: int = 8, distance: float = 0.02) -> np.ndarray:
+    """create_antenna, src/geometry/antenna.cpp:60-87 -> xyz[3, rows*columns]."""
+    xyz = np.empty((3, rows * columns), np.float32)
+    _check(load().awpu_hip_create_antenna(columns, rows, distance, _f32(xyz)), "create_antenna")
+    return xyz
+
+
+def create_tiled_antenna(arrays_x: int, arrays_y: int, distance: float = 0.02) -> np.ndarray:
+    xyz = np.empty((3, 64 * arrays_x * arrays_y), np.float32)
+    _check(load().awpu_hip_create_tiled_antenna(arrays_x, arrays_y, distance, _f32(xyz)),
+           "create_tiled_antenna")
+    return xyz
+
+
+def steering_delays(xyz: np.ndarray, theta: float, phi: float) -> np.ndarray:
+    """steering_vector_spherical, src/geometry/antenna.cpp:126-129."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    tau = np.empty(xyz.shape[1], np.float32)
+    _check(load().awpu_hip_steering_delays(_f32(xyz), xyz.shape[1], theta, phi, _f32(tau)),
+           "steering_delays")
+    return tau
+
+
+def build_delay_table(xyz: np.ndarray, rows: int, columns: int, fov_deg: float = 180.0,
+                      row_begin: int = 0, row_count: Optional[int] = None):
+    """MIMOWorker::computeDelayLUT, src/dsp/mimo.cpp:20-59 -> (off, frac) [row_count*columns, n]."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    n = xyz.shape[1]
+    row_count = rows - row_begin if row_count is None else row_count
+    off = np.empty((row_count * columns, n), np.int32)
+    frac = np.empty((row_count * columns, n), np.float32)
+    _check(load().awpu_hip_build_delay_table(_f32(xyz), n, rows, columns, fov_deg, row_begin,
+                                             row_count, _i32(off), _f32(frac)), "build_delay_table")
+    return off, frac
+
+
+def heatmap_u8(power: np.ndarray) -> np.ndarray:
+    """MIMOWorker::populateHeatmap (USE_DB 0), src/dsp/mimo.cpp:61-95."""
+    power = np.ascontiguousarray(power, np.float32)
+    pix = np.empty(power.shape, np.uint8)
+    _check(load().awpu_hip_heatmap_u8(_f32(power), power.size, pix.ctypes.data_as(_u8p)), "heatmap_u8")
+    return pix
+
+
+# ------------------------------------------------------------------------------- engine
+
+
+class Engine:
+    """One awpu_hip handle = one MIMO worker's sweep state on one GPU (src/dsp/mimo.h:74-91)."""
+
+    def __init__(self, n_pixels: int, n_streams: int = ELEMENTS, lut_stride: Optional[int] = None,
+                 hist: int = HIST, math: int = MATH_F32_FAST, interp: int = INTERP_LERP,
+                 max_batch: int = 1, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0):
+        lib = load()
+        cfg = Cfg()
+        lib.awpu_hip_default_cfg(C.byref(cfg))
+        cfg.device = device
+        cfg.n_streams = n_streams
+        cfg.hist = hist
+        cfg.n_pixels = n_pixels
+        cfg.lut_stride = n_streams if lut_stride is None else lut_stride
+        cfg.interp = interp
+        cfg.math = math
+        cfg.max_batch = max_batch
+        cfg.pixel_begin = pixel_begin
+        cfg.pixel_count = pixel_count
+        self._h = C.c_void_p()
+        _check(lib.awpu_hip_create(C.byref(self._h), C.byref(cfg)), "awpu_hip_create")
+        self.cfg = cfg
+        self.pixel_count = pixel_count or n_pixels
+        self._lib = lib
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.awpu_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_delay_table(self, off: np.ndarray, frac: np.ndarray) -> None:
+        off = np.ascontiguousarray(off, np.int32)
+        frac = np.ascontiguousarray(frac, np.float32)
+        want = (self.pixel_count, self.cfg.lut_stride)
+        if off.shape != want or frac.shape != want:
+            raise ValueError(f"delay tables must be {want}, got {off.shape} / {frac.shape}")
+        _check(self._lib.awpu_hip_set_delay_table(self._h, _i32(off), _f32(frac)), "set_delay_table")
+
+    def set_active_mics(self, index: Optional[np.ndarray] = None, usable: Optional[int] = None) -> None:
+        if index is None:
+            n = self.cfg.n_streams if usable is None else usable
+            _check(self._lib.awpu_hip_set_active_mics(self._h, None, n), "set_active_mics")
+        else:
+            index = np.ascontiguousarray(index, np.int32)
+            _check(self._lib.awpu_hip_set_active_mics(self._h, _i32(index), index.size),
+                   "set_active_mics")
+
+    def process(self, frames: np.ndarray) -> np.ndarray:
+        """frames [batch, n_streams, hist] (or one frame [n_streams, hist]) -> power [batch, pixels]."""
+        frames = np.ascontiguousarray(frames, np.float32)
+        single = frames.ndim == 2
+        if single:
+            frames = frames[None]
+        if frames.shape[1:] != (self.cfg.n_streams, self.cfg.hist):
+            raise ValueError(f"frames must be [batch, {self.cfg.n_streams}, {self.cfg.hist}]")
+        power = np.empty((frames.shape[0], self.pixel_count), np.float32)
+        _check(self._lib.awpu_hip_process(self._h, _f32(frames), frames.shape[0], _f32(power)),
+               "awpu_hip_process")
+        return power[0] if single else power
+
+    def process_device(self, d_frames_ptr: int, batch: int, d_power_ptr: int, stream: int = 0) -> None:
+        """Asynchronous sweep on device pointers (e.g. torch tensors' data_ptr()) on `stream`."""
+        _check(self._lib.awpu_hip_process_device(self._h, C.c_void_p(d_frames_ptr), batch,
+                                                 C.c_void_p(d_power_ptr), C.c_void_p(stream)),
+               "awpu_hip_process_device")
+
+    def synchronize(self) -> None:
+        _check(self._lib.awpu_hip_synchronize(self._h), "awpu_hip_synchronize")
+
+    def stats(self) -> Stats:
+        st = Stats()
+        _check(self._lib.awpu_hip_get_stats(self._h, C.byref(st)), "get_stats")
+        return st

@@ -1,0 +1,369 @@
+// awpu_hip.cpp -- the C ABI of libawpu_hip.so (include/awpu_hip.h): handle lifetime, table
+// packing, frame upload, kernel dispatch.  No CPU fallback: every compute entry point ends
+// in a gfx950 kernel launch or an error status.
+#include "awpu_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "das_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int hip_fail(hipError_t e, const char *what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return AWPU_ERR_HIP;
+}
+
+#define AWPU_HIP_TRY(call)                               \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+int invalid(const char *why) {
+    g_last_error = why;
+    return AWPU_ERR_INVALID;
+}
+
+}  // namespace
+
+struct awpu_hip {
+    awpu_hip_cfg cfg{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool timing = true;
+
+    // host copies of what the reference keeps in MIMOWorker / Antenna
+    std::vector<int32_t> off;   // [pixel_count][lut_stride]  offsetDelays
+    std::vector<float> frac;    // [pixel_count][lut_stride]  fractionalDelays
+    std::vector<int32_t> index; // [usable]                   antenna.index
+    bool have_table = false, have_mics = false, prepared = false;
+
+    // device state
+    awpu::LutEntry *d_lut = nullptr;
+    int32_t *d_index = nullptr;
+    float *d_frames = nullptr;
+    float *d_power = nullptr;
+    size_t frames_cap = 0, power_cap = 0;  // in floats
+    int wstart = 0, window = 0, tau_max = 0;
+
+    awpu_hip_stats stats{};
+
+    int usable() const { return static_cast<int>(index.size()); }
+};
+
+namespace {
+
+void release_device(awpu_hip *h) {
+    if (h->d_lut) (void) hipFree(h->d_lut);
+    if (h->d_index) (void) hipFree(h->d_index);
+    if (h->d_frames) (void) hipFree(h->d_frames);
+    if (h->d_power) (void) hipFree(h->d_power);
+    h->d_lut = nullptr;
+    h->d_index = nullptr;
+    h->d_frames = nullptr;
+    h->d_power = nullptr;
+    h->frames_cap = h->power_cap = 0;
+}
+
+// Pack the reference-format tables into the kernels' layout once both the tables and the
+// active-mic list are known.  Validates that no entry reads outside the frame history:
+// delay() reads signal[0..256] from &signals[s][offset] (delay.cpp:19-22).
+int prepare(awpu_hip *h) {
+    const auto &c = h->cfg;
+    const int U = h->usable();
+    const int P = c.pixel_count;
+    int lo = c.hist, hi = -1;
+    for (int p = 0; p < P; p++) {
+        const int32_t *row = &h->off[(size_t) p * c.lut_stride];
+        for (int s = 0; s < U; s++) {
+            const int o = row[h->index[s]];
+            lo = std::min(lo, o);
+            hi = std::max(hi, o);
+        }
+    }
+    if (lo < 0 || hi + awpu::kSamples > c.hist - 1) {
+        g_last_error = "delay table entry reads outside the frame history";
+        return AWPU_ERR_RANGE;
+    }
+    h->wstart = lo;
+    h->window = hi - lo + awpu::kSamples + 1;
+    h->tau_max = awpu::kSamples - lo;
+
+    std::vector<awpu::LutEntry> packed((size_t) P * U);
+    for (int p = 0; p < P; p++) {
+        const int32_t *orow = &h->off[(size_t) p * c.lut_stride];
+        const float *frow = &h->frac[(size_t) p * c.lut_stride];
+        awpu::LutEntry *dst = &packed[(size_t) p * U];
+        for (int s = 0; s < U; s++) {
+            const int id = h->index[s];
+            dst[s].off_rel = orow[id] - lo;
+            dst[s].frac = frow[id];
+        }
+    }
+    if (h->d_lut) (void) hipFree(h->d_lut);
+    if (h->d_index) (void) hipFree(h->d_index);
+    h->d_lut = nullptr;
+    h->d_index = nullptr;
+    AWPU_HIP_TRY(hipMalloc(&h->d_lut, packed.size() * sizeof(awpu::LutEntry)));
+    AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
+    AWPU_HIP_TRY(hipMemcpy(h->d_lut, packed.data(), packed.size() * sizeof(awpu::LutEntry),
+                           hipMemcpyHostToDevice));
+    AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
+                           hipMemcpyHostToDevice));
+
+    if (c.math == AWPU_MATH_F32_EXACT || true) {
+        int chunk = 0;
+        if (awpu::das_exact_lds_bytes(h->window, U, &chunk) == 0)
+            return invalid("delay window does not fit the LDS budget");
+    }
+
+    auto &st = h->stats;
+    st.tau_max = h->tau_max;
+    st.window = h->window;
+    st.usable = U;
+    st.alg_bytes_frame = 4ull * U * h->window + 8ull * P * U + 4ull * P;
+    st.alg_flops_frame = 4ull * P * U * awpu::kSamples + 6ull * P * (awpu::kSamples - 2);
+    st.kernel_variant = c.math;
+    h->prepared = true;
+    return AWPU_OK;
+}
+
+int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s) {
+    awpu::SweepArgs a{};
+    a.frames = d_frames;
+    a.lut = h->d_lut;
+    a.index = h->d_index;
+    a.power = d_power;
+    a.n_streams = h->cfg.n_streams;
+    a.hist = h->cfg.hist;
+    a.usable = h->usable();
+    a.pixel_count = h->cfg.pixel_count;
+    a.wstart = h->wstart;
+    a.window = h->window;
+    a.batch = batch;
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_das_exact(a, s));
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_end, s));
+    h->stats.launches += 1;
+    h->stats.frames += (uint64_t) batch;
+    return AWPU_OK;
+}
+
+int check_ready(awpu_hip *h, int batch) {
+    if (!h) return invalid("null handle");
+    if (batch < 1 || batch > h->cfg.max_batch) return invalid("batch outside [1, max_batch]");
+    if (!h->have_table || !h->have_mics) {
+        g_last_error = "delay table and active mics must be set before processing";
+        return AWPU_ERR_STATE;
+    }
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    if (!h->prepared) {
+        const int rc = prepare(h);
+        if (rc != AWPU_OK) return rc;
+    }
+    return AWPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void awpu_hip_default_cfg(awpu_hip_cfg *cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (int32_t) sizeof(*cfg);
+    cfg->device = 0;
+    cfg->n_streams = AWPU_ELEMENTS;
+    cfg->hist = AWPU_HIST;
+    cfg->n_pixels = 0;
+    cfg->lut_stride = AWPU_ELEMENTS;
+    cfg->interp = AWPU_INTERP_LERP;
+    cfg->math = AWPU_MATH_F32_FAST;
+    cfg->max_batch = 1;
+    cfg->pixel_begin = 0;
+    cfg->pixel_count = 0;
+}
+
+int awpu_hip_create(awpu_hip_t **out, const awpu_hip_cfg *cfg) {
+    if (!out || !cfg) return invalid("null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t) sizeof(awpu_hip_cfg)) return invalid("cfg.struct_size");
+    if (cfg->n_streams < 1 || cfg->lut_stride < 1 || cfg->n_pixels < 1 || cfg->max_batch < 1)
+        return invalid("n_streams, lut_stride, n_pixels and max_batch must be >= 1");
+    if (cfg->hist < AWPU_N_SAMPLES + 1) return invalid("hist must hold at least 257 samples");
+    if (cfg->max_batch > 65535) return invalid("max_batch above 65535");
+    if (cfg->interp != AWPU_INTERP_LERP) return invalid("only AWPU_INTERP_LERP is implemented");
+    if (cfg->math != AWPU_MATH_F32_EXACT && cfg->math != AWPU_MATH_F32_FAST)
+        return invalid("cfg.math");
+    awpu_hip_cfg c = *cfg;
+    if (c.pixel_count == 0) {
+        c.pixel_begin = 0;
+        c.pixel_count = c.n_pixels;
+    }
+    if (c.pixel_begin < 0 || c.pixel_count < 1 || c.pixel_begin + c.pixel_count > c.n_pixels)
+        return invalid("pixel shard outside the grid");
+
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || c.device < 0 || c.device >= n_dev) {
+        g_last_error = "no usable HIP device (this library has no CPU path)";
+        return AWPU_ERR_NO_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c.device) != hipSuccess ||
+        std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_last_error = "device is not gfx950 (MI355X); kernels are built for gfx950 only";
+        return AWPU_ERR_NO_DEVICE;
+    }
+    AWPU_HIP_TRY(hipSetDevice(c.device));
+
+    awpu_hip *h = new (std::nothrow) awpu_hip();
+    if (!h) return AWPU_ERR_NOMEM;
+    h->cfg = c;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
+    if (e != hipSuccess) {
+        awpu_hip_destroy(h);
+        return hip_fail(e, "stream/event creation");
+    }
+    *out = h;
+    return AWPU_OK;
+}
+
+int awpu_hip_destroy(awpu_hip_t *h) {
+    if (!h) return AWPU_OK;
+    (void) hipSetDevice(h->cfg.device);
+    if (h->stream) (void) hipStreamSynchronize(h->stream);
+    release_device(h);
+    if (h->ev_begin) (void) hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void) hipEventDestroy(h->ev_end);
+    if (h->stream) (void) hipStreamDestroy(h->stream);
+    delete h;
+    return AWPU_OK;
+}
+
+int awpu_hip_set_delay_table(awpu_hip_t *h, const int32_t *off, const float *frac) {
+    if (!h || !off || !frac) return invalid("null argument");
+    const size_t n = (size_t) h->cfg.pixel_count * h->cfg.lut_stride;
+    for (size_t i = 0; i < n; i++) {
+        if (!(frac[i] >= 0.0f && frac[i] <= 1.0f)) return invalid("fraction outside [0, 1]");
+    }
+    h->off.assign(off, off + n);
+    h->frac.assign(frac, frac + n);
+    h->have_table = true;
+    h->prepared = false;
+    return AWPU_OK;
+}
+
+int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable) {
+    if (!h) return invalid("null handle");
+    const int limit = std::min(h->cfg.n_streams, h->cfg.lut_stride);
+    if (usable < 1 || usable > limit) return invalid("usable outside [1, min(n_streams, lut_stride)]");
+    std::vector<int32_t> idx(usable);
+    for (int s = 0; s < usable; s++) {
+        idx[s] = index ? index[s] : s;
+        if (idx[s] < 0 || idx[s] >= limit) return invalid("mic id outside the streams / table");
+    }
+    h->index.swap(idx);
+    h->have_mics = true;
+    h->prepared = false;
+    return AWPU_OK;
+}
+
+int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {
+    (void) coeffs;
+    if (!h) return invalid("null handle");
+    return invalid("AWPU_INTERP_FIR8 is not implemented");
+}
+
+int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *power) {
+    if (!frames || !power) return invalid("null argument");
+    int rc = check_ready(h, batch);
+    if (rc != AWPU_OK) return rc;
+    const size_t frame_floats = (size_t) h->cfg.n_streams * h->cfg.hist;
+    const size_t need_frames = frame_floats * batch, need_power = (size_t) h->cfg.pixel_count * batch;
+    if (h->frames_cap < need_frames) {
+        if (h->d_frames) (void) hipFree(h->d_frames);
+        h->d_frames = nullptr;
+        h->frames_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_frames, need_frames * sizeof(float)));
+        h->frames_cap = need_frames;
+    }
+    if (h->power_cap < need_power) {
+        if (h->d_power) (void) hipFree(h->d_power);
+        h->d_power = nullptr;
+        h->power_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
+        h->power_cap = need_power;
+    }
+    AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, frames, need_frames * sizeof(float),
+                                hipMemcpyHostToDevice, h->stream));
+    rc = launch(h, h->d_frames, batch, h->d_power, h->stream);
+    if (rc != AWPU_OK) return rc;
+    AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_power, need_power * sizeof(float),
+                                hipMemcpyDeviceToHost, h->stream));
+    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->timing) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, h->ev_begin, h->ev_end) == hipSuccess) {
+            h->stats.last_kernel_ms = ms;
+            h->stats.total_kernel_ms += ms;
+        }
+    }
+    return AWPU_OK;
+}
+
+int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch, float *d_power,
+                            void *stream) {
+    if (!d_frames || !d_power) return invalid("null argument");
+    const int rc = check_ready(h, batch);
+    if (rc != AWPU_OK) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    const bool keep = h->timing;
+    h->timing = false;  // asynchronous path: the caller times its own stream
+    const int rc2 = launch(h, d_frames, batch, d_power, s);
+    h->timing = keep;
+    return rc2;
+}
+
+int awpu_hip_synchronize(awpu_hip_t *h) {
+    if (!h) return invalid("null handle");
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
+    return AWPU_OK;
+}
+
+int awpu_hip_get_stats(awpu_hip_t *h, awpu_hip_stats *stats) {
+    if (!h || !stats) return invalid("null argument");
+    *stats = h->stats;
+    return AWPU_OK;
+}
+
+const char *awpu_hip_strerror(int status) {
+    switch (status) {
+        case AWPU_OK: return "ok";
+        case AWPU_ERR_INVALID: return "invalid argument or configuration";
+        case AWPU_ERR_NO_DEVICE: return "no gfx950 HIP device (no CPU fallback exists)";
+        case AWPU_ERR_HIP: return "HIP runtime error";
+        case AWPU_ERR_STATE: return "delay table / active mics not set";
+        case AWPU_ERR_RANGE: return "delay table reads outside the frame history";
+        case AWPU_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char *awpu_hip_last_error(void) { return g_last_error.c_str(); }
+
+int awpu_hip_abi_version(void) { return AWPU_HIP_ABI_VERSION; }
+
+}  // extern "C"

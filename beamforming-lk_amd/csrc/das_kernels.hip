@@ -1,0 +1,134 @@
+// das_kernels.hip -- gfx950 (MI355X, CDNA4) delay-and-sum sweep kernels.
+//
+// The path replaced is MIMOWorker::update, src/dsp/mimo.cpp:121-151, whose inner kernel is
+// delay(), src/dsp/delay.cpp:16-26 (reference tree acoustic-warfare/beamforming-lk):
+//
+//   for pixel p:  out[0..255] = 0
+//     for active mic s:  out[i] += X_s[off+i+1] + frac * (X_s[off+i] - X_s[off+i+1])
+//     power[p] = sum_{i=1..254} (0.5 out[i] - 0.25 (out[i+1] + out[i-1]))^2 / (256 * usable)
+//
+// Written for wave64 / 160 KiB LDS / gfx950 only.  No MFMA: this is a gather-and-reduce.
+#include "das_kernels.h"
+
+namespace awpu {
+
+// ---------------------------------------------------------------------------------------
+// Epilogue shared by the kernels whose lanes own samples {l, l+64, l+128, l+192}.
+// MA[i] = 0.5 out[i] - 0.25 (out[i+1] + out[i-1]) for i in [1, 254]  (mimo.cpp:132-135);
+// returns the wave-wide sum of MA^2 in every lane.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float epilogue_interleaved(const float (&o)[4], int lane) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float prev = __shfl_up(o[k], 1);    // lane l-1, same k
+        float next = __shfl_down(o[k], 1);  // lane l+1, same k
+        // sample l+64k-1 of lane 0 lives in lane 63 of register k-1; likewise the far end
+        const float wrap_prev = __shfl(o[k > 0 ? k - 1 : 0], 63);
+        const float wrap_next = __shfl(o[k < 3 ? k + 1 : 3], 0);
+        if (lane == 0) prev = wrap_prev;
+        if (lane == 63) next = wrap_next;
+        const int i = lane + 64 * k;
+        const float ma = o[k] * 0.5f - 0.25f * (next + prev);
+        if (i >= 1 && i <= kSamples - 2) sum += ma * ma;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
+    return sum;
+}
+
+// ---------------------------------------------------------------------------------------
+// Exact-order kernel (AWPU_MATH_F32_EXACT).
+//
+// One workgroup = 4 waves; wave w sweeps PPW consecutive pixels.  The touched window of a
+// chunk of mics ([chunk][W] fp32) is staged once in LDS; a table entry is wave-uniform, so
+// (off, frac) travel in SGPRs; lane l owns samples l, l+64, l+128, l+192, so every LDS
+// read of a wave is 64 consecutive dwords (conflict-free).  Per sample the operations are
+// those of delay.cpp:19-25 in the same order -- d = cur - next; t = fma(frac, d, next);
+// out += t -- and mics are visited in the reference's order s = 0..usable-1, so the
+// pre-epilogue sums are bit-identical to the reference kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int kExactThreads = 256;
+constexpr int kExactPPW = 4;
+constexpr size_t kExactLdsBudget = 64 * 1024;
+
+template <int PPW>
+__global__ __launch_bounds__(kExactThreads) void das_exact_kernel(SweepArgs a, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int W = a.window;
+    const int pix0 = (blockIdx.x * (kExactThreads / 64) + wave) * PPW;
+    const float *frame = a.frames + (size_t) b * a.n_streams * a.hist;
+
+    float acc[PPW][4];
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[pp][k] = 0.0f;
+
+    for (int m0 = 0; m0 < a.usable; m0 += chunk) {
+        const int mc = min(chunk, a.usable - m0);
+        __syncthreads();  // previous chunk fully consumed
+        for (int m = wave; m < mc; m += kExactThreads / 64) {
+            const float *src = frame + (size_t) a.index[m0 + m] * a.hist + a.wstart;
+            for (int t = lane; t < W; t += 64) lds[m * W + t] = src[t];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pp = 0; pp < PPW; pp++) {
+            const int p = pix0 + pp;
+            if (p < a.pixel_count) {
+                const LutEntry *row = a.lut + (size_t) p * a.usable + m0;
+                for (int m = 0; m < mc; m++) {
+                    const LutEntry e = row[m];  // wave-uniform address: scalar load
+                    const float f = e.frac;
+                    const float *x = lds + m * W + e.off_rel + lane;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float cur = x[64 * k];
+                        const float nxt = x[64 * k + 1];
+                        const float d = cur - nxt;
+                        const float t = __builtin_fmaf(f, d, nxt);
+                        acc[pp][k] = acc[pp][k] + t;
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) {
+        const int p = pix0 + pp;
+        if (p < a.pixel_count) {
+            const float sum = epilogue_interleaved(acc[pp], lane);
+            if (lane == 0) {
+                a.power[(size_t) b * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
+            }
+        }
+    }
+}
+
+size_t das_exact_lds_bytes(int window, int usable, int *chunk_out) {
+    const size_t row = (size_t) window * sizeof(float);
+    if (row == 0 || row > kExactLdsBudget) return 0;
+    int chunk = (int) (kExactLdsBudget / row);
+    if (chunk > usable) chunk = usable;
+    if (chunk < 1) return 0;
+    if (chunk_out) *chunk_out = chunk;
+    return (size_t) chunk * row;
+}
+
+hipError_t launch_das_exact(const SweepArgs &a, hipStream_t stream) {
+    int chunk = 0;
+    const size_t lds = das_exact_lds_bytes(a.window, a.usable, &chunk);
+    if (lds == 0) return hipErrorInvalidValue;
+    const int pix_per_block = (kExactThreads / 64) * kExactPPW;
+    dim3 grid((a.pixel_count + pix_per_block - 1) / pix_per_block, a.batch);
+    hipLaunchKernelGGL(das_exact_kernel<kExactPPW>, grid, dim3(kExactThreads), lds, stream, a,
+                       chunk);
+    return hipGetLastError();
+}
+
+}  // namespace awpu

@@ -1,0 +1,95 @@
+"""Multi-GPU decomposition of the heatmap sweep: one process per GPU, each owning a slab of
+grid rows; the frame batch is broadcast from the ingest rank once per step (RCCL over xGMI when
+the backend is "nccl", gloo on CPU for the tests); no other collective is on the data path.
+
+The reference is single-process (one MIMOWorker thread, src/dsp/mimo.cpp:12) -- this module has
+no counterpart there.  Pixels are independent until display-time normalisation
+(src/dsp/mimo.cpp:61-95), so the grid shards with no halo.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class RowShard:
+    rank: int
+    world: int
+    res_rows: int
+    res_cols: int
+    row_begin: int
+    row_count: int
+
+    @property
+    def pixel_begin(self) -> int:
+        return self.row_begin * self.res_cols
+
+    @property
+    def pixel_count(self) -> int:
+        return self.row_count * self.res_cols
+
+
+def shard_rows(res_rows: int, res_cols: int, world: int, rank: int) -> RowShard:
+    """Contiguous, balanced row slabs: the first (res_rows % world) ranks get one extra row."""
+    if not (0 <= rank < world):
+        raise ValueError("rank outside world")
+    if world > res_rows:
+        raise ValueError("more ranks than grid rows")
+    base, extra = divmod(res_rows, world)
+    begin = rank * base + min(rank, extra)
+    count = base + (1 if rank < extra else 0)
+    return RowShard(rank, world, res_rows, res_cols, begin, count)
+
+
+def all_shards(res_rows: int, res_cols: int, world: int) -> List[RowShard]:
+    return [shard_rows(res_rows, res_cols, world, r) for r in range(world)]
+
+
+class FrameBroadcaster:
+    """Double-buffered broadcast of frame batches from `src` to every rank.
+
+    post(k) starts the broadcast of batch k into buffer k % 2 (async); wait(k) returns that
+    buffer once the batch has landed.  The sweep of batch k runs while batch k+1 is in flight.
+    With world size 1 (or no process group) it degenerates to handing out the local buffer.
+    """
+
+    def __init__(self, buffers: Tuple[torch.Tensor, torch.Tensor], src: int = 0,
+                 group: Optional[dist.ProcessGroup] = None):
+        self.buffers = buffers
+        self.src = src
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self._work = [None, None]
+
+    def post(self, k: int) -> None:
+        if self.active:
+            self._work[k % 2] = dist.broadcast(self.buffers[k % 2], src=self.src, group=self.group, async_op=True)
+
+    def wait(self, k: int) -> torch.Tensor:
+        w = self._work[k % 2]
+        if w is not None:
+            w.wait()  # on CUDA this orders the current stream after the collective
+            self._work[k % 2] = None
+        return self.buffers[k % 2]
+
+
+def gather_power(local: torch.Tensor, shards: List[RowShard], dst: int = 0,
+                 group: Optional[dist.ProcessGroup] = None) -> Optional[torch.Tensor]:
+    """Assemble the [batch, P] heatmap on `dst` from per-rank [batch, pixel_count] tiles.
+    Not on the timed data path (each rank can hand its tile to its own consumer)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    rank = dist.get_rank(group)
+    batch = local.shape[0]
+    widest = max(s.pixel_count for s in shards)
+    padded = torch.zeros((batch, widest), dtype=local.dtype, device=local.device)
+    padded[:, : local.shape[1]] = local
+    tiles = [torch.empty_like(padded) for _ in shards] if rank == dst else None
+    dist.gather(padded, tiles, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([t[:, : s.pixel_count] for t, s in zip(tiles, shards)], dim=1)

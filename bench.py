@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- heatmap frames/s of the delay-and-sum sweep on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline] [--batch B]
+
+One "step" = one pass of the hot path over one batch of B synthetic frames already resident
+in HBM: (N > 1: RCCL broadcast of the batch from rank 0, overlapped with the previous
+step's sweep) + one sweep launch per rank over that rank's slab of the steering grid.
+N > 1 is launched by torch.distributed.run, one rank per GPU; the grid (total work) is fixed,
+so scaling is "strong".  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak fp32 vector
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="headline", help="c1 | c2 | headline | c3 | c4")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step (per sweep launch)")
+    ap.add_argument("--math", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def cpu_baseline(S, spec, xyz, off, frac, frame, seconds):
+    """The reference's own delay() (oracle/_ref) in the loop nest of mimo.cpp:121-151, one
+    thread, whole frames of the same workload until `seconds` have passed."""
+    from oracle import oracle_py
+
+    kind = "reference" if oracle_py.ref_available() else "port"
+    if kind == "reference":
+        fps, frames = oracle_py.ref_bench(frame, off, frac, None, min_seconds=seconds)
+    else:
+        t0 = time.perf_counter()
+        frames = 0
+        while True:
+            oracle_py.das_f32(frame, off, frac)
+            frames += 1
+            if time.perf_counter() - t0 >= seconds:
+                break
+        fps = frames / (time.perf_counter() - t0)
+    return {
+        "value": fps, "unit": "frames/s", "cores": 1, "kind": kind,
+        "sample": f"{frames} whole frames of the same workload ({spec.name}), 1 thread, "
+                  f"{os.cpu_count()} host cores present",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the sweep has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("beamforming-lk_amd")
+    sharding = importlib.import_module("beamforming-lk_amd.sharding")
+    S = pkg.synthetic
+    spec = S.WORKLOADS[args.workload]
+    B, K, W = args.batch, args.steps, args.warmup
+    math = pkg.MATH_F32_FAST if args.math == "fast" else pkg.MATH_F32_EXACT
+
+    # ---- one-off setup: geometry, this rank's slab of the delay table, frames in HBM
+    shard = sharding.shard_rows(spec.res, spec.res, world, rank)
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz, shard.row_begin, shard.row_count)
+    eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, math=math, max_batch=B,
+                     device=local_rank, pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count)
+    eng.set_delay_table(off, frac)
+    eng.set_active_mics(None)
+
+    host_frames = S.make_frames(xyz, B, seed=args.seed) if rank == 0 else None
+    bufs = tuple(torch.zeros((B, spec.n_mics, pkg.binding.HIST), dtype=torch.float32, device=dev) for _ in range(2))
+    if rank == 0:
+        for b in bufs:
+            b.copy_(torch.from_numpy(host_frames))
+    d_power = torch.zeros((B, shard.pixel_count), dtype=torch.float32, device=dev)
+    bcast = sharding.FrameBroadcaster(bufs, src=0)
+    # a real (non-null) stream: its handle goes to the C ABI, and the torch events that time
+    # the sweep are recorded on the same stream
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+
+    def run_steps(n, ev=None):
+        with torch.cuda.stream(stream):
+            _run_steps(n, ev)
+
+    def _run_steps(n, ev):
+        bcast.post(0)
+        for k in range(n):
+            frames = bcast.wait(k)
+            if k + 1 < n:
+                bcast.post(k + 1)  # next batch travels while this one is swept
+            if ev is not None:
+                ev[0][k].record(stream)
+            eng.process_device(frames.data_ptr(), B, d_power.data_ptr(), stream.cuda_stream)
+            if ev is not None:
+                ev[1][k].record(stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run_steps(W)
+    fence()
+    events = ([torch.cuda.Event(enable_timing=True) for _ in range(K)],
+              [torch.cuda.Event(enable_timing=True) for _ in range(K)])
+    t0 = time.perf_counter()
+    run_steps(K, events)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(*events)]))  # this rank's sweep launch
+
+    # ---- parity of what was just computed (frame 0, a sample of this rank's pixels)
+    st = eng.stats()
+    parity = None
+    if rank == 0:
+        from oracle import oracle_py
+
+        got = d_power[0].cpu().numpy()
+        pick = np.linspace(0, shard.pixel_count - 1, num=min(256, shard.pixel_count)).astype(np.int64)
+        want = oracle_py.das_f32(host_frames[0], off[pick], frac[pick])
+        floor = 1e-4 * want.max()
+        parity = float((np.abs(got[pick] - want) / np.maximum(want, floor)).max())
+
+    if rank == 0:
+        fps = B * K / elapsed
+        full_bytes = S.algorithmic_bytes_per_frame(spec.n_mics, spec.n_pixels, st.window)
+        # dominant kernel = the sweep launch on this rank: algorithmic bytes of its slab x B frames
+        launch_bytes = int(st.alg_bytes_frame) * B
+        launch_flops = int(st.alg_flops_frame) * B
+        ach_gbs = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "heatmap frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": spec.name, "mics": spec.n_mics, "grid": f"{spec.res}x{spec.res}",
+                "block_samples": 256, "frames_per_step": B, "math": args.math,
+                "sharding": f"grid rows over {world} GPU(s), frame batch broadcast from rank 0" if world > 1
+                            else "single GPU",
+                "alg_bytes_per_frame": full_bytes,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "das sweep", "kernel_ms": kernel_ms, "launch_bytes": launch_bytes,
+                "note": "the sweep is fp32-VALU/LDS bound (126 flop/B >> ridge), see valu",
+            },
+            "valu": {
+                "achieved": launch_flops / (kernel_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": launch_flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+            },
+            "parity_max_rel_err": parity,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            off_full, frac_full = (off, frac)
+            out["cpu_baseline"] = cpu_baseline(S, spec, xyz, off_full, frac_full, host_frames[0], args.cpu_seconds)
+            out["speedup_vs_cpu_1t"] = fps / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/*
+ * awpu_hip.h -- C ABI of libawpu_hip.so, the MI355X (gfx950) delay-and-sum heatmap engine
+ * that replaces the body of the reference's MIMO sweep behind its aw_processing_unit API.
+ *
+ * The reference (acoustic-warfare/beamforming-lk @ 2024_08_07) has no FFI or plugin
+ * registry: the seam is the C++ class boundary AWProcessingUnit -> Worker (MIMOWorker).
+ * Each entry point below names the reference interface it replaces (file:line relative
+ * to the reference tree).  The reference-side binding (a MIMOWorker whose update() calls
+ * awpu_hip_process) is shown in INTEGRATION.md and implemented in
+ * beamforming-lk_amd/host/mimo_worker_hip.{h,cpp}.
+ *
+ * Conventions
+ *   - plain C: opaque handle, plain pointers and sizes, no C++/torch types.
+ *   - every function returns an awpu_status (0 = OK, negative = error); nothing throws
+ *     across the boundary.  The reference's own convention is int 0 / -1
+ *     (src/fpga/pipeline.h:57-77) and bool for start/stop.
+ *   - the caller owns every host pointer; the library copies on call and owns all device
+ *     memory.  `power` buffers are caller-allocated.
+ *   - one handle per worker; a handle is used by one thread at a time; handles are
+ *     independent (one HIP stream each), like one MIMOWorker thread per AWPU
+ *     (src/dsp/mimo.cpp:12).
+ *   - there is NO CPU fallback: without a usable HIP device awpu_hip_create fails with
+ *     AWPU_ERR_NO_DEVICE.
+ */
+#ifndef AWPU_HIP_H
+#define AWPU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AWPU_HIP_ABI_VERSION 1
+
+/* compile-time constants of the reference */
+#define AWPU_N_SAMPLES 256 /* src/fpga/streams.hpp:28  N_SAMPLES */
+#define AWPU_HIST 1024     /* src/fpga/streams.hpp:32  N_ITEMS_BUFFER = PAGE_SIZE/4 */
+#define AWPU_ELEMENTS 64   /* src/geometry/antenna.h:20 ELEMENTS */
+
+typedef enum {
+    AWPU_OK = 0,
+    AWPU_ERR_INVALID = -1,   /* bad argument / bad configuration */
+    AWPU_ERR_NO_DEVICE = -2, /* no HIP device, or not gfx950 */
+    AWPU_ERR_HIP = -3,       /* a HIP runtime call failed (see awpu_hip_last_error) */
+    AWPU_ERR_STATE = -4,     /* call order: table or mic list not set */
+    AWPU_ERR_RANGE = -5,     /* a table entry would read outside the frame history */
+    AWPU_ERR_NOMEM = -6
+} awpu_status;
+
+/* interpolation of delay(): src/dsp/delay.cpp */
+typedef enum {
+    AWPU_INTERP_LERP = 0, /* :16-26, the shipped (-mavx2) variant */
+    AWPU_INTERP_FIR8 = 1  /* :31-40, 8-tap table variant (needs awpu_hip_set_fir_table) */
+} awpu_interp;
+
+/* arithmetic of the sweep */
+typedef enum {
+    /* fp32, the reference's operation order per sample (sub, fma, add) and mic order
+     * s = 0..usable-1: the pre-epilogue sums are bit-identical to delay.cpp:19-25 */
+    AWPU_MATH_F32_EXACT = 0,
+    /* fp32, two FMAs per sample (f*cur + (1-f)*next), LDS-tiled fast kernel; differs from
+     * EXACT by fp32 rounding only */
+    AWPU_MATH_F32_FAST = 1
+} awpu_math;
+
+typedef struct awpu_hip awpu_hip_t;
+
+typedef struct {
+    int32_t struct_size; /* sizeof(awpu_hip_cfg), for ABI growth */
+    int32_t device;      /* HIP device ordinal */
+    int32_t n_streams;   /* mic streams per frame snapshot (Pipeline::get_n_sensors,
+                            src/fpga/pipeline.h:107) */
+    int32_t hist;        /* floats per stream in a snapshot; AWPU_HIST (streams.hpp:113-116) */
+    int32_t n_pixels;    /* P = rows*columns of the steering grid (mimo.cpp:8 maxIndex) */
+    int32_t lut_stride;  /* row length of the delay tables = number of physical mic ids
+                            (ELEMENTS in mimo.cpp:26-27) */
+    int32_t interp;      /* awpu_interp */
+    int32_t math;        /* awpu_math */
+    int32_t max_batch;   /* frames per awpu_hip_process call, >= 1 */
+    /* pixel shard owned by this handle (multi-GPU: one handle per rank); the tables passed
+     * to awpu_hip_set_delay_table and the power rows written cover exactly these pixels */
+    int32_t pixel_begin;
+    int32_t pixel_count; /* 0 = all n_pixels */
+    int32_t reserved[5];
+} awpu_hip_cfg;
+
+typedef struct {
+    uint64_t frames;          /* frames processed since creation */
+    uint64_t launches;        /* sweep kernel launches */
+    double last_kernel_ms;    /* device time of the last sweep launch (hipEvent) */
+    double total_kernel_ms;   /* sum over launches */
+    uint64_t alg_bytes_frame; /* 4*U*W + 8*P*U + 4*P, W = 256 + tau_max + 1 */
+    uint64_t alg_flops_frame; /* 4*P*U*256 + 6*P*254 */
+    int32_t tau_max;          /* largest integer delay in the table = 256 - min(off) */
+    int32_t window;           /* W */
+    int32_t usable;           /* U */
+    int32_t kernel_variant;   /* which sweep kernel the handle dispatches to */
+} awpu_hip_stats;
+
+/* fills cfg with the reference defaults (64 streams, hist 1024, LERP, F32_FAST, batch 1) */
+void awpu_hip_default_cfg(awpu_hip_cfg *cfg);
+
+/* replaces: MIMOWorker::MIMOWorker allocation of its state, src/dsp/mimo.cpp:7-13 /
+ * src/dsp/mimo.h:74-91 */
+int awpu_hip_create(awpu_hip_t **h, const awpu_hip_cfg *cfg);
+
+/* replaces: MIMOWorker::~MIMOWorker / Worker::~Worker, src/dsp/worker.h:104-107 */
+int awpu_hip_destroy(awpu_hip_t *h);
+
+/* uploads the tables MIMOWorker::computeDelayLUT produced (src/dsp/mimo.cpp:20-59):
+ * off[pixel_count][lut_stride] (offsetDelays, = 256 - floor(tau)), frac[..][..]
+ * (fractionalDelays in [0,1)), pixel-major like mimo.h:86-88.  Entries of mic ids that are
+ * not in the active list are ignored. */
+int awpu_hip_set_delay_table(awpu_hip_t *h, const int32_t *off, const float *frac);
+
+/* sets antenna.usable / antenna.index as filled by AWProcessingUnit::calibrate
+ * (src/aw_processing_unit/aw_processing_unit.cpp:157-200, src/geometry/antenna.h:89-90):
+ * index[s] is both the stream read for signals[s] (mimo.cpp:100-103) and the table column
+ * (mimo.cpp:125-127).  index == NULL means identity 0..usable-1. */
+int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable);
+
+/* FIR8 coefficient table, the caller's copy of filter_coeffs[101][8] (src/dsp/filter.h:10-112) */
+int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs);
+
+/* replaces: the body of MIMOWorker::update, src/dsp/mimo.cpp:97-151.
+ *   frames [batch][n_streams][hist] host floats; each frame is the snapshot update() takes
+ *          with Streams::read_stream (mimo.cpp:100-103; oldest..newest, streams.hpp:113-116)
+ *   power  [batch][pixel_count] host floats = powerdB (mimo.cpp:150)
+ * Synchronous: returns when power is written. */
+int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *power);
+
+/* same sweep on buffers already resident in device memory, enqueued on `stream`
+ * (a hipStream_t, NULL = the handle's own stream); asynchronous.  d_frames
+ * [batch][n_streams][hist], d_power [batch][pixel_count]. */
+int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch, float *d_power,
+                            void *stream);
+
+/* blocks until everything enqueued through this handle has finished */
+int awpu_hip_synchronize(awpu_hip_t *h);
+
+/* replaces: MIMOWorker::populateHeatmap (USE_DB 0), src/dsp/mimo.cpp:61-95, with the
+ * cv::Mat replaced by a plain rows*columns uint8 image: pix = clip(power/max*255).
+ * power/pix are host buffers of `n` elements (n = whole grid). */
+int awpu_hip_heatmap_u8(const float *power, int32_t n, uint8_t *pix);
+
+/* ---- host-side geometry, one-off (not on the per-frame path) ------------------------- */
+
+/* create_antenna, src/geometry/antenna.cpp:60-87: xyz[3][rows*columns] */
+int awpu_hip_create_antenna(int32_t columns, int32_t rows, float distance, float *xyz);
+
+/* tiled multi-array geometry (build-defined): arrays_x*arrays_y arrays of 8x8,
+ * stream id = a*64 + r*8 + c (aw_processing_unit.cpp:120), xyz[3][64*arrays_x*arrays_y] */
+int awpu_hip_create_tiled_antenna(int32_t arrays_x, int32_t arrays_y, float distance, float *xyz);
+
+/* steering_vector_spherical, src/geometry/antenna.cpp:126-129: tau[n] in samples, min 0 */
+int awpu_hip_steering_delays(const float *xyz, int32_t n, double theta, double phi, float *tau);
+
+/* MIMOWorker::computeDelayLUT, src/dsp/mimo.cpp:20-59, for grid rows
+ * [row_begin, row_begin+row_count) of a rows x columns grid:
+ * off/frac [row_count*columns][n] */
+int awpu_hip_build_delay_table(const float *xyz, int32_t n, int32_t rows, int32_t columns,
+                               float fov_deg, int32_t row_begin, int32_t row_count, int32_t *off,
+                               float *frac);
+
+/* ---- introspection -------------------------------------------------------------------- */
+
+int awpu_hip_get_stats(awpu_hip_t *h, awpu_hip_stats *stats);
+const char *awpu_hip_strerror(int status);
+/* text of the last HIP error seen by this thread ("" if none) */
+const char *awpu_hip_last_error(void);
+int awpu_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWPU_HIP_H */

@@ -1,0 +1,217 @@
+"""ctypes access to the CPU checker: oracle/liboracle_das.so (the C restatement) and
+oracle/_ref/libref_das_*.so (the reference's own delay.cpp compiled in place).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under beamforming-lk_amd/ may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ORACLE_LIB = HERE / "liboracle_das.so"
+REF_AVX2_LIB = HERE / "_ref" / "libref_das_avx2.so"
+REF_FIR_LIB = HERE / "_ref" / "libref_das_fir.so"
+REFERENCE_TREE = Path("/root/reference")
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build(ref: bool = True) -> None:
+    """make the restatement, and (when the reference tree is present) oracle/_ref."""
+    subprocess.run(["make", "-s", "-C", str(HERE), "oracle"], check=True)
+    if ref and (REFERENCE_TREE / "src/dsp/delay.cpp").exists():
+        subprocess.run(["make", "-s", "-C", str(HERE), "ref"], check=True)
+
+
+_oracle: Optional[C.CDLL] = None
+_refs: dict = {}
+
+
+def oracle() -> C.CDLL:
+    global _oracle
+    if _oracle is None:
+        src_m = max((HERE / "das_oracle.c").stat().st_mtime, (HERE / "das_oracle.h").stat().st_mtime)
+        if not ORACLE_LIB.exists() or ORACLE_LIB.stat().st_mtime < src_m:
+            build(ref=False)
+        lib = C.CDLL(str(ORACLE_LIB))
+        lib.oracle_create_antenna.argtypes = [C.c_int, C.c_int, C.c_float, _f32p]
+        lib.oracle_create_tiled_antenna.argtypes = [C.c_int, C.c_int, C.c_float, _f32p]
+        lib.oracle_steering_delays_f32.argtypes = [_f32p, C.c_int, C.c_double, C.c_double, _f32p]
+        lib.oracle_steering_delays_f64.argtypes = [_f32p, C.c_int, C.c_double, C.c_double, _f64p]
+        lib.oracle_compute_delay_lut.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_float, _i32p, _f32p]
+        lib.oracle_compute_delays_f64.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_float, _f64p]
+        lib.oracle_delay_lerp.argtypes = [_f32p, _f32p, C.c_float]
+        lib.oracle_delay_fir8.argtypes = [_f32p, _f32p, C.c_float, _f32p]
+        lib.oracle_das_f32.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
+        lib.oracle_das_f64.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f64p]
+        lib.oracle_das_fir8_f32.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
+        lib.oracle_heatmap_u8.argtypes = [_f32p, C.c_int, _u8p]
+        lib.oracle_calibrate.argtypes = [_f32p, C.c_int, C.c_float, _i32p, _f32p, _f32p]
+        lib.oracle_calibrate.restype = C.c_int
+        lib.oracle_unpack_exposure.argtypes = [_i32p, C.c_int, C.c_int, _f32p]
+        for name in ("oracle_create_antenna", "oracle_create_tiled_antenna", "oracle_steering_delays_f32",
+                     "oracle_steering_delays_f64", "oracle_compute_delay_lut", "oracle_compute_delays_f64",
+                     "oracle_delay_lerp", "oracle_delay_fir8", "oracle_das_f32", "oracle_das_f64",
+                     "oracle_das_fir8_f32", "oracle_heatmap_u8", "oracle_unpack_exposure"):
+            getattr(lib, name).restype = None
+        _oracle = lib
+    return _oracle
+
+
+def ref_available(variant: str = "avx2") -> bool:
+    return (REF_AVX2_LIB if variant == "avx2" else REF_FIR_LIB).exists()
+
+
+def ref(variant: str = "avx2") -> C.CDLL:
+    """The reference's compiled delay() + loop-nest driver.  Raises if oracle/_ref is absent."""
+    if variant not in _refs:
+        path = REF_AVX2_LIB if variant == "avx2" else REF_FIR_LIB
+        if not path.exists():
+            build(ref=True)
+        if not path.exists():
+            raise FileNotFoundError(f"{path} missing and {REFERENCE_TREE} not available to build it")
+        lib = C.CDLL(str(path))
+        lib.ref_variant.restype = C.c_int
+        lib.ref_delay.argtypes = [_f32p, _f32p, C.c_float]
+        lib.ref_delay.restype = None
+        lib.ref_das.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
+        lib.ref_das.restype = None
+        lib.ref_das_bench.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p,
+                                      C.c_double, C.POINTER(C.c_int)]
+        lib.ref_das_bench.restype = C.c_double
+        _refs[variant] = lib
+    return _refs[variant]
+
+
+def _p32(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_i32p)
+
+
+# ------------------------------------------------------------------ numpy-level helpers
+
+
+def create_antenna(columns=8, rows=8, distance=0.02) -> np.ndarray:
+    xyz = np.empty((3, rows * columns), np.float32)
+    oracle().oracle_create_antenna(columns, rows, distance, _p32(xyz))
+    return xyz
+
+
+def create_tiled_antenna(arrays_x, arrays_y, distance=0.02) -> np.ndarray:
+    xyz = np.empty((3, 64 * arrays_x * arrays_y), np.float32)
+    oracle().oracle_create_tiled_antenna(arrays_x, arrays_y, distance, _p32(xyz))
+    return xyz
+
+
+def steering_delays_f32(xyz, theta, phi) -> np.ndarray:
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    tau = np.empty(xyz.shape[1], np.float32)
+    oracle().oracle_steering_delays_f32(_p32(xyz), xyz.shape[1], theta, phi, _p32(tau))
+    return tau
+
+
+def steering_delays_f64(xyz, theta, phi) -> np.ndarray:
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    tau = np.empty(xyz.shape[1], np.float64)
+    oracle().oracle_steering_delays_f64(_p32(xyz), xyz.shape[1], theta, phi, tau.ctypes.data_as(_f64p))
+    return tau
+
+
+def compute_delay_lut(xyz, rows, columns, fov_deg=180.0):
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    n = xyz.shape[1]
+    off = np.empty((rows * columns, n), np.int32)
+    frac = np.empty((rows * columns, n), np.float32)
+    oracle().oracle_compute_delay_lut(_p32(xyz), n, rows, columns, fov_deg, _pi(off), _p32(frac))
+    return off, frac
+
+
+def compute_delays_f64(xyz, rows, columns, fov_deg=180.0) -> np.ndarray:
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    n = xyz.shape[1]
+    tau = np.empty((rows * columns, n), np.float64)
+    oracle().oracle_compute_delays_f64(_p32(xyz), n, rows, columns, fov_deg, tau.ctypes.data_as(_f64p))
+    return tau
+
+
+def _sweep_args(X, off, frac, index):
+    X = np.ascontiguousarray(X, np.float32)
+    off = np.ascontiguousarray(off, np.int32)
+    frac = np.ascontiguousarray(frac, np.float32)
+    if index is None:
+        index = np.arange(X.shape[0], dtype=np.int32)
+    index = np.ascontiguousarray(index, np.int32)
+    assert X.ndim == 2 and off.shape == frac.shape and off.ndim == 2
+    assert index.max() < min(X.shape[0], off.shape[1])
+    assert off[:, index].min() >= 0 and off[:, index].max() + 257 <= X.shape[1]
+    return X, off, frac, index
+
+
+def das_f32(X, off, frac, index=None, want_out=False, impl="oracle"):
+    """power[P] (and out[P,256]) for one frame X[n_streams, hist]; impl = oracle | ref."""
+    X, off, frac, index = _sweep_args(X, off, frac, index)
+    P = off.shape[0]
+    power = np.empty(P, np.float32)
+    out = np.empty((P, 256), np.float32) if want_out else None
+    fn = oracle().oracle_das_f32 if impl == "oracle" else ref("avx2").ref_das
+    fn(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index), index.size,
+       _p32(power), _p32(out) if want_out else None)
+    return (power, out) if want_out else power
+
+
+def das_f64(X, off, frac, index=None) -> np.ndarray:
+    X, off, frac, index = _sweep_args(X, off, frac, index)
+    P = off.shape[0]
+    power = np.empty(P, np.float64)
+    oracle().oracle_das_f64(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index),
+                            index.size, power.ctypes.data_as(_f64p))
+    return power
+
+
+def ref_bench(X, off, frac, index=None, min_seconds=1.0):
+    """frames/s of the reference-kernel loop nest on one thread over the P pixels of `off`."""
+    X, off, frac, index = _sweep_args(X, off, frac, index)
+    P = off.shape[0]
+    power = np.empty(P, np.float32)
+    done = C.c_int(0)
+    fps = ref("avx2").ref_das_bench(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1],
+                                    _pi(index), index.size, _p32(power), float(min_seconds), C.byref(done))
+    return fps, done.value
+
+
+def heatmap_u8(power) -> np.ndarray:
+    power = np.ascontiguousarray(power, np.float32)
+    pix = np.empty(power.shape, np.uint8)
+    oracle().oracle_heatmap_u8(_p32(power), power.size, pix.ctypes.data_as(_u8p))
+    return pix
+
+
+def calibrate(X, reference_power_level=1e-5):
+    X = np.ascontiguousarray(X, np.float32)
+    assert X.shape[0] == 64
+    index = np.empty(64, np.int32)
+    corr = np.empty(64, np.float32)
+    med = C.c_float(0)
+    n = oracle().oracle_calibrate(_p32(X), X.shape[1], reference_power_level, _pi(index), _p32(corr),
+                                  C.byref(med))
+    return index[:n].copy(), corr[:n].copy(), med.value
+
+
+def unpack_exposure(stream, n_sensors) -> np.ndarray:
+    stream = np.ascontiguousarray(stream, np.int32)
+    assert stream.shape[0] == 256
+    block = np.empty((n_sensors, 256), np.float32)
+    oracle().oracle_unpack_exposure(_pi(stream), stream.shape[1], n_sensors, _p32(block))
+    return block

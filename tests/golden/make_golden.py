@@ -1,0 +1,87 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own compiled delay() (oracle/_ref).
+
+Run in the authoring container (needs /root/reference to build oracle/_ref):
+
+    python tests/golden/make_golden.py
+
+What is stored is data only: table inputs (off, frac, index), seeds of the exact integer-hash
+frames (tests/util.hash_frames) and the outputs the reference kernel produced for them.
+Expected values come from oracle/_ref/libref_das_avx2.so, i.e. /root/reference/src/dsp/delay.cpp
+compiled unmodified with the reference's flags (oracle/Makefile), driven through the loop nest of
+src/dsp/mimo.cpp:121-151 (oracle/ref_mimo_driver.cpp).  Table inputs come from the oracle's
+restatement of src/dsp/mimo.cpp:20-59.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+
+from oracle import oracle_py as O  # noqa: E402
+import util  # noqa: E402
+
+_f32p = C.POINTER(C.c_float)
+
+
+def delay_kat():
+    """Known answers of delay(out, signal, fraction), src/dsp/delay.cpp:16-26."""
+    ref = O.ref("avx2")
+    assert ref.ref_variant() == 1
+    sig = util.hash_frames(1, 300, seed=11, scale=1.0)[0, 0]
+    acc0 = util.hash_frames(1, 256, seed=12, scale=4.0)[0, 0]
+    fractions = np.array([0.0, 1.0, 0.5, 0.25, 0.999999, 1e-7, 0.3333333, 0.75, 0.6180339], np.float32)
+    starts = np.array([0, 1, 7, 43, 0, 13, 2, 30, 5], np.int32)
+    outs = np.empty((fractions.size, 256), np.float32)
+    for j, (f, s) in enumerate(zip(fractions, starts)):
+        out = acc0.copy()
+        window = np.ascontiguousarray(sig[s:s + 257])
+        ref.ref_delay(out.ctypes.data_as(_f32p), window.ctypes.data_as(_f32p), float(f))
+        outs[j] = out
+    np.savez_compressed(HERE / "delay_kat.npz", sig_seed=11, acc_seed=12, fractions=fractions,
+                        starts=starts, expected=outs)
+    print("delay_kat.npz", outs.shape)
+
+
+def sweep_case(name, arrays_x, arrays_y, res, pixels, seed, index=None, hist=1024, fov=180.0):
+    xyz = O.create_tiled_antenna(arrays_x, arrays_y)
+    off, frac = O.compute_delay_lut(xyz, res, res, fov)
+    off, frac = off[pixels], frac[pixels]
+    n = xyz.shape[1]
+    X = util.hash_frames(n, hist, seed=seed)[0]
+    power, out = O.das_f32(X, off, frac, index, want_out=True, impl="ref")
+    np.savez_compressed(
+        HERE / f"{name}.npz", arrays=np.array([arrays_x, arrays_y]), res=res, fov=fov, pixels=pixels,
+        seed=seed, hist=hist, off=off, frac=frac,
+        index=np.arange(n, dtype=np.int32) if index is None else index.astype(np.int32),
+        power=power, out_first=out[:4], out_last=out[-1:])
+    print(f"{name}.npz", off.shape, "power range", power.min(), power.max())
+
+
+def main():
+    O.build(ref=True)
+    delay_kat()
+    rng = np.random.Generator(np.random.PCG64(2024))
+    # c1 geometry (one 8x8 array, 32x32 grid, fov 180): every 7th pixel, all 64 mics
+    sweep_case("sweep_c1", 1, 1, 32, np.arange(0, 1024, 7), seed=101)
+    # ragged active-mic list as calibrate() would leave it: 51 of 64 mics, not in id order at the ends
+    keep = np.sort(rng.choice(64, size=51, replace=False)).astype(np.int32)
+    sweep_case("sweep_c1_ragged", 1, 1, 32, np.arange(3, 1024, 19), seed=102, index=keep)
+    # a single active mic (degenerate) and fov 90
+    sweep_case("sweep_c1_onemic", 1, 1, 32, np.arange(0, 1024, 97), seed=103, index=np.array([37]), fov=90.0)
+    # 256 mics (4 arrays side by side), 128x128 grid: 48 pixels incl. the corners (theta clipped)
+    pix = np.unique(np.concatenate([[0, 127, 16256, 16383], rng.choice(16384, 44, replace=False)]))
+    sweep_case("sweep_headline", 4, 1, 128, pix, seed=104, hist=640)
+    # 512 mics (4x2 arrays), 128x128 grid, shortest legal history
+    pix = np.unique(np.concatenate([[0, 16383], rng.choice(16384, 22, replace=False)]))
+    sweep_case("sweep_c3", 4, 2, 128, pix, seed=105, hist=520)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""The C-ABI library on a box without a GPU: it loads, exports every symbol include/awpu_hip.h
+declares, fails loudly instead of falling back to a CPU path, and its one-off host geometry
+(create_antenna / steering_vector_spherical / computeDelayLUT mirrors) equals the oracle."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    text = (REPO / "include" / "awpu_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(awpu_hip_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.binding.load()
+    names = declared_symbols()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/awpu_hip.h but not exported"
+    assert sorted(pkg.binding.EXPORTED_SYMBOLS) == names
+    assert lib.awpu_hip_abi_version() == 1
+
+
+def test_cfg_struct_matches_header(pkg):
+    cfg = pkg.binding.Cfg()
+    pkg.binding.load().awpu_hip_default_cfg(C.byref(cfg))
+    assert cfg.struct_size == C.sizeof(pkg.binding.Cfg) == 64
+    assert (cfg.n_streams, cfg.hist, cfg.lut_stride, cfg.max_batch) == (64, 1024, 64, 1)
+    assert cfg.math == pkg.MATH_F32_FAST and cfg.interp == 0
+
+
+def test_no_cpu_fallback_without_device(pkg):
+    """Without a gfx950 device creation fails with AWPU_ERR_NO_DEVICE -- never a CPU path."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device path is exercised on CPU-only boxes")
+    with pytest.raises(pkg.AwpuError) as ei:
+        pkg.Engine(n_pixels=16)
+    assert ei.value.status == pkg.binding.ERR_NO_DEVICE
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: no product source may reference it."""
+    for path in (REPO / "beamforming-lk_amd").rglob("*"):
+        if path.suffix in {".py", ".cpp", ".hip", ".h"}:
+            text = path.read_text()
+            assert "oracle_py" not in text and "das_oracle" not in text and "liboracle" not in text, path
+
+
+def test_argument_errors(pkg):
+    lib = pkg.binding.load()
+    assert lib.awpu_hip_create(None, None) == pkg.binding.ERR_INVALID
+    cfg = pkg.binding.Cfg()
+    lib.awpu_hip_default_cfg(C.byref(cfg))
+    h = C.c_void_p()
+    assert lib.awpu_hip_create(C.byref(h), C.byref(cfg)) == pkg.binding.ERR_INVALID  # n_pixels 0
+    cfg.n_pixels = 4
+    cfg.struct_size = 8
+    assert lib.awpu_hip_create(C.byref(h), C.byref(cfg)) == pkg.binding.ERR_INVALID
+    assert b"struct_size" in lib.awpu_hip_last_error()
+    assert lib.awpu_hip_destroy(None) == 0
+    assert lib.awpu_hip_strerror(-2).startswith(b"no gfx950")
+
+
+@pytest.mark.parametrize("arrays", [(1, 1), (4, 1), (4, 2)])
+def test_host_geometry_equals_oracle(pkg, oracle, arrays):
+    xyz = pkg.create_tiled_antenna(*arrays)
+    assert np.array_equal(xyz, oracle.create_tiled_antenna(*arrays))
+    for theta, phi in [(0.0, 0.0), (0.3, 1.1), (1.2, -2.5), (np.pi / 2, 0.7)]:
+        assert np.array_equal(pkg.steering_delays(xyz, theta, phi), oracle.steering_delays_f32(xyz, theta, phi))
+
+
+def test_create_antenna_equals_oracle(pkg, oracle):
+    for cols, rows in [(8, 8), (32, 8), (5, 3)]:
+        assert np.array_equal(pkg.create_antenna(cols, rows), oracle.create_antenna(cols, rows))
+
+
+@pytest.mark.parametrize("arrays,res,fov", [((1, 1), 32, 180.0), ((4, 1), 20, 180.0), ((1, 1), 10, 90.0), ((4, 2), 12, 120.0)])
+def test_delay_table_equals_oracle(pkg, oracle, arrays, res, fov):
+    """awpu_hip_build_delay_table mirrors MIMOWorker::computeDelayLUT, src/dsp/mimo.cpp:20-59."""
+    xyz = pkg.create_tiled_antenna(*arrays)
+    off, frac = pkg.build_delay_table(xyz, res, res, fov)
+    off_o, frac_o = oracle.compute_delay_lut(xyz, res, res, fov)
+    assert np.array_equal(off, off_o) and np.array_equal(frac, frac_o)
+    # row slabs (the per-rank shard of the multi-GPU path) tile the full table
+    a = pkg.build_delay_table(xyz, res, res, fov, 0, res // 2)
+    b = pkg.build_delay_table(xyz, res, res, fov, res // 2, res - res // 2)
+    assert np.array_equal(np.concatenate([a[0], b[0]]), off) and np.array_equal(np.concatenate([a[1], b[1]]), frac)
+
+
+def test_heatmap_equals_oracle(pkg, oracle):
+    rng = np.random.default_rng(0)
+    p = rng.uniform(0, 3e-5, 4096).astype(np.float32)
+    assert np.array_equal(pkg.heatmap_u8(p), oracle.heatmap_u8(p))

@@ -1,0 +1,260 @@
+"""Parity of the gfx950 sweep (through the C ABI) with the oracle, the reference-generated
+golden vectors and size-independent properties.  Everything here needs a real MI355X."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+SWEEPS = ["sweep_c1", "sweep_c1_ragged", "sweep_c1_onemic", "sweep_headline", "sweep_c3"]
+MATHS = ["exact", "fast"]
+
+
+def math_id(pkg, name):
+    return {"exact": pkg.MATH_F32_EXACT, "fast": pkg.MATH_F32_FAST}[name]
+
+
+def run_engine(pkg, X, off, frac, index=None, math="fast", max_batch=None, **kw):
+    X = np.asarray(X, np.float32)
+    frames = X if X.ndim == 3 else X[None]
+    eng = pkg.Engine(n_pixels=off.shape[0], n_streams=frames.shape[1], lut_stride=off.shape[1],
+                     hist=frames.shape[2], math=math_id(pkg, math), max_batch=max_batch or frames.shape[0], **kw)
+    with eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(index)
+        power = eng.process(frames)
+        st = eng.stats()
+    return (power if X.ndim == 3 else power[0]), st
+
+
+def test_native_library_is_loaded(pkg):
+    """The GPU tests run the in-tree HIP library, not a fallback."""
+    lib = pkg.binding.load()
+    assert "libawpu_hip.so" in lib._name
+    maps = Path("/proc/self/maps").read_text()
+    assert "beamforming-lk_amd/libawpu_hip.so" in maps
+
+
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("name", SWEEPS)
+def test_golden_vectors(pkg, name, math):
+    """GPU power vs the power the reference's compiled delay() produced (tests/golden)."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    ax, ay = g["arrays"]
+    X = util.hash_frames(64 * int(ax) * int(ay), int(g["hist"]), seed=int(g["seed"]))[0]
+    power, _ = run_engine(pkg, X, g["off"], g["frac"], g["index"], math=math)
+    assert util.power_rel_err(power, g["power"]) < util.POWER_RTOL
+
+
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("wl", ["c1", "c2"])
+def test_full_grid_vs_oracle(pkg, oracle, wl, math):
+    """BASELINE configs c1 (64 mics, 32x32) and c2 (256 mics, 64x64), plane wave + noise."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS[wl]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    X = S.make_frames(xyz, 1, seed=1234)[0]
+    power, st = run_engine(pkg, X, off, frac, math=math)
+    want = oracle.das_f32(X, off, frac)
+    assert util.power_rel_err(power, want) < util.POWER_RTOL
+    # against fp64 the GPU is no worse than twice the fp32 CPU restatement (plus rounding slack)
+    p64 = oracle.das_f64(X, off, frac)
+    assert util.power_rel_err(power, p64) < max(2 * util.power_rel_err(want, p64), 2e-6)
+    r, c = divmod(int(power.argmax()), spec.res)
+    er, ec = S.source_pixel(spec)
+    assert abs(r - er) <= 1 and abs(c - ec) <= 1
+    assert st.usable == spec.n_mics and st.window == 256 + st.tau_max + 1
+    assert st.alg_bytes_frame == S.algorithmic_bytes_per_frame(spec.n_mics, spec.n_pixels, st.window)
+
+
+@pytest.mark.parametrize("math", MATHS)
+def test_headline_rows_vs_oracle(pkg, oracle, math):
+    """Headline shape (256 mics, 128x128): a slab of grid rows through the pixel-shard interface."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["headline"]
+    xyz = S.geometry(spec)
+    rows = (40, 6)
+    off, frac = S.delay_table(spec, xyz, *rows)
+    X = S.make_frames(xyz, 1, seed=77)[0]
+    power, _ = run_engine(pkg, X, off, frac, math=math, pixel_begin=rows[0] * spec.res, pixel_count=off.shape[0])
+    # n_pixels is the whole grid; the handle owns rows 40..45
+    want = oracle.das_f32(X, off, frac)
+    assert util.power_rel_err(power, want) < util.POWER_RTOL
+
+
+def run_engine_shard(pkg, X, off, frac, n_pixels, pixel_begin, math="fast"):
+    eng = pkg.Engine(n_pixels=n_pixels, n_streams=X.shape[0], lut_stride=off.shape[1], hist=X.shape[1],
+                     math=math_id(pkg, math), pixel_begin=pixel_begin, pixel_count=off.shape[0])
+    with eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        return eng.process(X)
+
+
+@pytest.mark.parametrize("math", MATHS)
+def test_pixel_shards_tile_the_grid(pkg, oracle, math):
+    """Multi-GPU decomposition: per-rank slabs concatenate to the single-handle result bit for bit."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    X = S.make_frames(xyz, 1, seed=5)[0]
+    whole, _ = run_engine(pkg, X, off, frac, math=math)
+    cuts = [0, 300, 301, 777, 1024]  # ragged, not multiples of any tile
+    parts = [run_engine_shard(pkg, X, off[a:b], frac[a:b], spec.n_pixels, a, math) for a, b in zip(cuts, cuts[1:])]
+    assert np.array_equal(np.concatenate(parts), whole)
+
+
+@pytest.mark.parametrize("math", MATHS)
+def test_batch_equals_single_frames(pkg, oracle, math):
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    off, frac = off[:200], frac[:200]
+    frames = S.make_frames(xyz, 5, seed=8)
+    batch, _ = run_engine(pkg, frames, off, frac, math=math)
+    for b in range(5):
+        single, _ = run_engine(pkg, frames[b], off, frac, math=math)
+        assert np.array_equal(batch[b], single)
+        assert util.power_rel_err(batch[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
+
+
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("n_pix", [1, 3, 17, 63, 65])
+def test_ragged_pixel_counts(pkg, oracle, math, n_pix):
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 12, 12)
+    off, frac = off[5:5 + n_pix], frac[5:5 + n_pix]
+    X = util.hash_frames(64, 1024, seed=n_pix)[0]
+    power, _ = run_engine(pkg, X, off, frac, math=math)
+    assert util.power_rel_err(power, oracle.das_f32(X, off, frac)) < util.POWER_RTOL
+
+
+@pytest.mark.parametrize("math", MATHS)
+def test_active_mic_subsets(pkg, oracle, math):
+    """antenna.index semantics (mimo.cpp:100-103,125-127): unsorted subset, table wider than streams used."""
+    xyz = oracle.create_tiled_antenna(4, 1)
+    off, frac = oracle.compute_delay_lut(xyz, 10, 10)
+    X = util.hash_frames(256, 700, seed=31)[0]
+    rng = np.random.default_rng(4)
+    for usable in (1, 2, 63, 64, 65, 200, 256):
+        index = rng.permutation(256)[:usable].astype(np.int32)
+        power, st = run_engine(pkg, X, off, frac, index, math=math)
+        assert st.usable == usable
+        assert util.power_rel_err(power, oracle.das_f32(X, off, frac, index)) < util.POWER_RTOL
+
+
+@pytest.mark.parametrize("math", MATHS)
+def test_extreme_offsets_and_fractions(pkg, oracle, math):
+    """Offsets at both ends of the history and fractions 0 / 1-ulp: window edges are read correctly."""
+    rng = np.random.default_rng(12)
+    P, M, hist = 40, 64, 1024
+    off = rng.integers(0, hist - 256, size=(P, M)).astype(np.int32)
+    off[0, :] = 0
+    off[1, :] = hist - 257
+    off[2, ::2] = 0
+    off[2, 1::2] = hist - 257
+    frac = rng.uniform(0, 1, size=(P, M)).astype(np.float32)
+    frac[3, :] = 0.0
+    frac[4, :] = np.nextafter(np.float32(1.0), np.float32(0.0))
+    X = util.hash_frames(M, hist, seed=77)[0]
+    power, st = run_engine(pkg, X, off, frac, math=math)
+    assert st.window == hist
+    assert util.power_rel_err(power, oracle.das_f32(X, off, frac)) < util.POWER_RTOL
+
+
+@pytest.mark.parametrize("math", MATHS)
+def test_linearity_and_scaling(pkg, math):
+    """Size-independent properties on the full c2 shape: power(a*X) = a^2 power(X) exactly for a
+    power of two, and a zero frame gives zero power."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c2"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    X = S.make_frames(xyz, 1, seed=2)[0]
+    frames = np.stack([X, 4.0 * X, np.zeros_like(X)])
+    power, _ = run_engine(pkg, frames, off, frac, math=math)
+    assert np.array_equal(power[1], 16.0 * power[0])
+    assert np.all(power[2] == 0.0)
+    assert np.all(power[0] > 0.0)
+
+
+def test_exact_mode_matches_oracle_to_rounding(pkg, oracle):
+    """AWPU_MATH_F32_EXACT keeps delay.cpp:19-25's operation and mic order: only the epilogue's
+    254-term sum order differs from the scalar restatement."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    X = S.make_frames(xyz, 1, seed=10)[0]
+    power, _ = run_engine(pkg, X, off, frac, math="exact")
+    want = oracle.das_f32(X, off, frac)
+    assert np.abs(power / want - 1).max() < 1e-6
+
+
+def test_error_paths(pkg, oracle):
+    B = pkg.binding
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 4, 4)
+    X = util.hash_frames(64, 1024, seed=1)
+    eng = pkg.Engine(n_pixels=16, max_batch=2)
+    with eng:
+        with pytest.raises(pkg.AwpuError) as ei:
+            eng.process(X)
+        assert ei.value.status == B.ERR_STATE
+        eng.set_active_mics(None)
+        bad = off.copy()
+        bad[3, 5] = 1024 - 256  # reads signal[..+256] one past the history
+        eng.set_delay_table(bad, frac)
+        with pytest.raises(pkg.AwpuError) as ei:
+            eng.process(X)
+        assert ei.value.status == B.ERR_RANGE
+        neg = off.copy()
+        neg[0, 0] = -1
+        eng.set_delay_table(neg, frac)
+        with pytest.raises(pkg.AwpuError) as ei:
+            eng.process(X)
+        assert ei.value.status == B.ERR_RANGE
+        with pytest.raises(pkg.AwpuError):
+            eng.set_delay_table(off, frac + 2.0)
+        with pytest.raises(pkg.AwpuError):
+            eng.set_active_mics(np.array([64], np.int32))
+        eng.set_delay_table(off, frac)
+        with pytest.raises(pkg.AwpuError) as ei:
+            eng.process(np.concatenate([X, X, X]))  # batch 3 > max_batch 2
+        assert ei.value.status == B.ERR_INVALID
+        ok = eng.process(X)
+        assert util.power_rel_err(ok[0], oracle.das_f32(X[0], off, frac)) < util.POWER_RTOL
+
+
+def test_device_pointer_entry_with_torch(pkg, oracle):
+    """awpu_hip_process_device on torch-owned HBM buffers and a torch stream (the bench.py path)."""
+    import torch
+
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 3, seed=6)
+    dev = torch.device("cuda:0")
+    d_frames = torch.from_numpy(frames).to(dev)
+    d_power = torch.zeros((3, spec.n_pixels), dtype=torch.float32, device=dev)
+    eng = pkg.Engine(n_pixels=spec.n_pixels, max_batch=3)
+    with eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            eng.process_device(d_frames.data_ptr(), 3, d_power.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        host = eng.process(frames)
+    got = d_power.cpu().numpy()
+    assert np.array_equal(got, host)
+    for b in range(3):
+        assert util.power_rel_err(got[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL

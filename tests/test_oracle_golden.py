@@ -1,0 +1,148 @@
+"""The CPU oracle against (a) the committed golden vectors, which were produced by the
+reference's own compiled delay() (tests/golden/make_golden.py), (b) that reference build
+itself when oracle/_ref is present, (c) an fp64 restatement, (d) the physics known answer."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import util
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+SWEEPS = ["sweep_c1", "sweep_c1_ragged", "sweep_c1_onemic", "sweep_headline", "sweep_c3"]
+
+
+def test_delay_known_answers_bit_exact(oracle):
+    """delay(), src/dsp/delay.cpp:16-26: the restatement reproduces the reference bit for bit."""
+    import ctypes as C
+
+    g = np.load(GOLDEN / "delay_kat.npz")
+    sig = util.hash_frames(1, 300, seed=int(g["sig_seed"]), scale=1.0)[0, 0]
+    acc0 = util.hash_frames(1, 256, seed=int(g["acc_seed"]), scale=4.0)[0, 0]
+    f32p = C.POINTER(C.c_float)
+    for f, s, want in zip(g["fractions"], g["starts"], g["expected"]):
+        out = acc0.copy()
+        window = np.ascontiguousarray(sig[s:s + 257])
+        oracle.oracle().oracle_delay_lerp(out.ctypes.data_as(f32p), window.ctypes.data_as(f32p), float(f))
+        assert np.array_equal(out, want), f"fraction {f}"
+
+
+@pytest.mark.parametrize("name", SWEEPS)
+def test_sweep_golden(oracle, name):
+    """MIMOWorker::update, src/dsp/mimo.cpp:121-151: pre-epilogue sums bit-exact, power to 2e-6."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    ax, ay = g["arrays"]
+    X = util.hash_frames(64 * int(ax) * int(ay), int(g["hist"]), seed=int(g["seed"]))[0]
+    power, out = oracle.das_f32(X, g["off"], g["frac"], g["index"], want_out=True)
+    assert np.array_equal(out[:4], g["out_first"])
+    assert np.array_equal(out[-1:], g["out_last"])
+    # the reference build is -Ofast: its epilogue sum order is the compiler's; power agrees to rounding
+    assert util.power_rel_err(power, g["power"]) < 2e-6
+
+
+@pytest.mark.parametrize("name", SWEEPS)
+def test_golden_tables_match_lut_restatement(oracle, name):
+    """The stored tables are what the restated computeDelayLUT (mimo.cpp:20-59) gives today."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    ax, ay = (int(v) for v in g["arrays"])
+    xyz = oracle.create_tiled_antenna(ax, ay)
+    off, frac = oracle.compute_delay_lut(xyz, int(g["res"]), int(g["res"]), float(g["fov"]))
+    assert np.array_equal(off[g["pixels"]], g["off"])
+    assert np.array_equal(frac[g["pixels"]], g["frac"])
+
+
+def test_oracle_matches_reference_build_live(oracle):
+    """Same seeded plane-wave frame through the restatement and through oracle/_ref."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 24, 24)
+    X = util.hash_frames(64, 1024, seed=5)[0]
+    p_o, out_o = oracle.das_f32(X, off, frac, want_out=True)
+    p_r, out_r = oracle.das_f32(X, off, frac, want_out=True, impl="ref")
+    assert np.array_equal(out_o, out_r)
+    assert util.power_rel_err(p_o, p_r) < 2e-6
+
+
+def test_f32_sweep_close_to_f64(oracle):
+    xyz = oracle.create_tiled_antenna(4, 1)
+    off, frac = oracle.compute_delay_lut(xyz, 16, 16)
+    X = util.hash_frames(256, 640, seed=9)[0]
+    p32 = oracle.das_f32(X, off, frac)
+    p64 = oracle.das_f64(X, off, frac)
+    assert util.power_rel_err(p32, p64) < 5e-6
+
+
+@pytest.mark.parametrize("arrays,res", [((1, 1), 32), ((4, 1), 32), ((4, 2), 24)])
+def test_lut_against_fp64(oracle, arrays, res):
+    """fp32 table (mimo.cpp:46-54) vs the fp64 closed form: recombined delay within 5e-5 samples (a few fp32 ulps at tau ~ 100),
+    fractions in [0,1), offsets inside the history, one zero-delay mic per pixel."""
+    xyz = oracle.create_tiled_antenna(*arrays)
+    off, frac = oracle.compute_delay_lut(xyz, res, res)
+    tau64 = oracle.compute_delays_f64(xyz, res, res)
+    tau32 = (256 - off) + frac.astype(np.float64)
+    assert np.abs(tau32 - tau64).max() < 5e-5
+    assert frac.min() >= 0.0 and frac.max() < 1.0
+    assert off.max() == 256 and off.min() >= 0
+    assert np.all((tau32 == 0).sum(axis=1) >= 1)
+
+
+def test_tau_max_of_baseline_geometries(oracle):
+    """8x8 -> tau_max 28, 32x8 -> 91, 32x16 -> 98 samples (the survey rounds to ~99)."""
+    for arrays, want in [((1, 1), 28), ((4, 1), 91), ((4, 2), 98)]:
+        xyz = oracle.create_tiled_antenna(*arrays)
+        off, _ = oracle.compute_delay_lut(xyz, 32, 32)
+        assert 256 - off.min() == want
+
+
+def test_tiled_antenna_1x1_is_create_antenna(oracle):
+    assert np.array_equal(oracle.create_tiled_antenna(1, 1), oracle.create_antenna(8, 8, 0.02))
+    xyz = oracle.create_antenna()
+    # antenna.cpp:66-73 at 8x8: x = c*0.02 - 0.07, y = r*0.02 - 0.07
+    assert np.allclose(xyz[0, :8], np.arange(8) * 0.02 - 0.07, atol=1e-7)
+    assert np.allclose(xyz[1, ::8], np.arange(8) * 0.02 - 0.07, atol=1e-7)
+    assert np.all(xyz[2] == 0)
+
+
+def test_plane_wave_peaks_at_source_pixel(oracle, pkg):
+    """Physics known answer (pipeline.cpp:105-135 signal model): the heatmap maximum is the
+    pixel that looks at the source."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = oracle.create_tiled_antenna(spec.arrays_x, spec.arrays_y)
+    off, frac = oracle.compute_delay_lut(xyz, spec.res, spec.res, spec.fov)
+    for theta_deg, phi_deg in [(20.0, 35.0), (0.5, 0.0), (35.0, -120.0)]:
+        th, ph = np.deg2rad(theta_deg), np.deg2rad(phi_deg)
+        X = S.make_frames(xyz, 1, seed=3, theta=th, phi=ph)[0]
+        power = oracle.das_f32(X, off, frac)
+        r, c = divmod(int(power.argmax()), spec.res)
+        er, ec = S.source_pixel(spec, th, ph)
+        assert abs(r - er) <= 1 and abs(c - ec) <= 1, (theta_deg, phi_deg, (r, c), (er, ec))
+
+
+def test_heatmap_u8(oracle):
+    p = np.array([0.0, 1e-6, 5e-6, 1e-5], np.float32)
+    pix = oracle.heatmap_u8(p)
+    assert pix.tolist() == [0, 25, 127, 255]
+
+
+def test_calibrate_restatement(oracle):
+    """aw_processing_unit.cpp:128-200: a dead mic and a loud mic are dropped."""
+    X = util.hash_frames(64, 1024, seed=21, scale=2.0 ** -7)[0].copy()
+    X[5] = 0.0      # dead: power < median * 1e-3
+    X[17] *= 64.0   # far too loud: |power - median| > 1e-4
+    index, corr, median = oracle.calibrate(X)
+    assert 5 not in index and 17 not in index and index.size == 62
+    pw = (X.astype(np.float64) ** 2).mean(axis=1)
+    assert np.allclose(corr, 1e-5 / pw[index], rtol=1e-4)
+
+
+def test_unpack_exposure(oracle):
+    """pipeline.cpp:277-290: every other group of 8 columns is mirrored, scaled by 2^-23."""
+    stream = np.arange(256 * 256, dtype=np.int32).reshape(256, 256) - 30000
+    block = oracle.unpack_exposure(stream, 128)
+    # first group of 8 is "inverted" (inverted toggles to 1 at sensor 0)
+    assert block[0, 0] == np.float32(stream[0, 7]) / np.float32(8388608.0)
+    assert block[7, 3] == np.float32(stream[3, 0]) / np.float32(8388608.0)
+    assert block[8, 0] == np.float32(stream[0, 8]) / np.float32(8388608.0)
+    assert block[16, 255] == np.float32(stream[255, 23]) / np.float32(8388608.0)

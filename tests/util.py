@@ -1,0 +1,32 @@
+"""Shared helpers for the tests: exact deterministic inputs and the parity metric."""
+from __future__ import annotations
+
+import numpy as np
+
+# per-pixel power tolerance of the fp32 sweep (BASELINE.json north_star: "per-pixel power
+# within 1e-5 relative of reference"); relative to max(|ref|, FLOOR * frame peak) so that
+# beam nulls, where fp32 summation-order noise dominates, do not divide by ~0.
+POWER_RTOL = 1e-5
+NULL_FLOOR = 1e-4
+
+
+def hash_frames(n_streams: int, hist: int, seed: int, batch: int = 1, scale: float = 2.0 ** -6) -> np.ndarray:
+    """[batch, n_streams, hist] float32 from an integer hash (splitmix64 finaliser): every value
+    is k * 2^-23 * scale with a 24-bit signed integer k (like the FPGA samples), so the array is
+    bit-reproducible on any machine -- no libm, no RNG-version dependence."""
+    n = batch * n_streams * hist
+    with np.errstate(over="ignore"):
+        z = (np.arange(n, dtype=np.uint64) + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    k = (z >> np.uint64(40)).astype(np.int64) - (1 << 23)
+    x = k.astype(np.float32) * np.float32(2.0 ** -23) * np.float32(scale)
+    return x.reshape(batch, n_streams, hist)
+
+
+def power_rel_err(got: np.ndarray, ref: np.ndarray) -> float:
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    floor = NULL_FLOOR * np.abs(ref).max(axis=-1, keepdims=True)
+    return float((np.abs(got - ref) / np.maximum(np.abs(ref), floor)).max())

@@ -1,0 +1,229 @@
+// ubench.hip -- gfx950 micro-benchmarks that size the sweep kernel's inner loop:
+// how fast one CU issues v_fmac_f32 / v_pk_fma_f32, how fast it reads LDS with
+// ds_read_b32/b64/b128, and what the planned per-(pixel, mic) item
+//   { 1 v_add_u32 (address), 2 ds_read_b64, 8 v_fmac_f32 with an SGPR multiplier }
+// sustains at 1, 2 and 4 waves per SIMD.  Build: hipcc --offload-arch=gfx950 -O3 ubench.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define CHECK(x)                                                                      \
+    do {                                                                              \
+        hipError_t e = (x);                                                           \
+        if (e != hipSuccess) {                                                        \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            exit(1);                                                                  \
+        }                                                                             \
+    } while (0)
+
+// ---- 16 independent v_fmac_f32 per iteration, multiplier in an SGPR
+__global__ void k_fmac(float *out, int iters, float f) {
+    float a[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) a[j] = threadIdx.x * 0.001f + j;
+    float x = threadIdx.x * 0.5f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[j]) : "s"(f), "v"(x));
+    }
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) s += a[j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// ---- 8 independent v_pk_fma_f32 per iteration (16 lane-FMAs)
+__global__ void k_pkfma(float *out, int iters, float f) {
+    f2 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = f2{threadIdx.x * 0.001f + j, 1.0f};
+    f2 x = f2{threadIdx.x * 0.5f, 2.0f};
+    f2 ff = f2{f, f};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[j]) : "v"(ff), "v"(x));
+    }
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += a[j].x + a[j].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// ---- LDS reads only.  WIDTH = 4, 8, 16 bytes per lane, conflict-free consecutive lanes
+template <int WIDTH>
+__global__ void k_lds(float *out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = i;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    unsigned addr = lane * WIDTH;
+    float acc = 0;
+    for (int it = 0; it < iters; it++) {
+        if (WIDTH == 4) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[j]) : "v"(addr), "n"(j * 256));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 16; j++) asm volatile("" ::"v"(v[j]));
+            acc += v[0];
+        } else if (WIDTH == 8) {
+            f2 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[j]) : "v"(addr), "n"(j * 512));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 16; j++) asm volatile("" ::"v"(v[j]));
+            acc += v[0].x;
+        } else {
+            f4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(addr), "n"(j * 1024));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 16; j++) asm volatile("" ::"v"(v[j]));
+            acc += v[0].x;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+// ---- the planned inner item, software-pipelined one item deep:
+//   v_add_u32 addr, s_off, v_lane8 ; ds_read_b64 x, addr ; ds_read_b64 y, addr offset:512
+//   8 x v_fmac_f32 acc, s_f|s_g, x|y   (6 accumulators)
+// ITEMS per iteration; s_off / f / g arrive as scalars (kernel args, varied per item).
+template <bool PK>
+__global__ void k_item(float *out, int iters, int off0, float f, float g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = i * 1e-6f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const unsigned lane8 = lane * 8;
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, pa = 0, pb = 0;
+    f2 x, y, xn, yn;
+    unsigned addr;
+    int soff = __builtin_amdgcn_readfirstlane(off0);
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(addr) : "s"(soff), "v"(lane8));
+    asm volatile("ds_read_b64 %0, %1" : "=v"(x) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(y) : "v"(addr));
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            soff = (soff + 1384) & 0x3ff8;  // scalar ALU: next item's window start (8-byte aligned)
+            asm volatile("v_add_u32 %0, %1, %2" : "=v"(addr) : "s"(soff), "v"(lane8));
+            asm volatile("ds_read_b64 %0, %1" : "=v"(xn) : "v"(addr));
+            asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(yn) : "v"(addr));
+            asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            if (!PK) {
+                asm volatile(
+                    "v_fmac_f32 %0, %6, %8\n\tv_fmac_f32 %1, %6, %9\n\t"
+                    "v_fmac_f32 %0, %7, %9\n\tv_fmac_f32 %4, %7, %8\n\t"
+                    "v_fmac_f32 %2, %6, %10\n\tv_fmac_f32 %3, %6, %11\n\t"
+                    "v_fmac_f32 %2, %7, %11\n\tv_fmac_f32 %5, %7, %10"
+                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(pa), "+v"(pb)
+                    : "s"(f), "s"(g), "v"(x.x), "v"(x.y), "v"(y.x), "v"(y.y));
+            } else {
+                // packed form: (a0,a1) += f*(x0,x1); (pa,a0') ... expressed on pairs
+                f2 A = f2{a0, a1}, Bq = f2{pa, a2}, Cc = f2{a3, pb};
+                f2 ff = f2{f, f}, gg = f2{g, g};
+                asm volatile(
+                    "v_pk_fma_f32 %0, %3, %5, %0\n\tv_pk_fma_f32 %1, %4, %5, %1\n\t"
+                    "v_pk_fma_f32 %2, %3, %6, %2\n\tv_pk_fma_f32 %1, %4, %6, %1"
+                    : "+v"(A), "+v"(Bq), "+v"(Cc)
+                    : "v"(ff), "v"(gg), "v"(x), "v"(y));
+                a0 = A.x; a1 = A.y; pa = Bq.x; a2 = Bq.y; a3 = Cc.x; pb = Cc.y;
+            }
+            x = xn;
+            y = yn;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + pa + pb + x.x + y.x;
+}
+
+struct Result {
+    double ms;
+};
+
+template <typename F>
+double time_ms(F launch, int reps = 5) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    launch();
+    CHECK(hipDeviceSynchronize());
+    double best = 1e30;
+    for (int r = 0; r < reps; r++) {
+        CHECK(hipEventRecord(a));
+        launch();
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device %s  CUs %d  clock %d kHz  LDS/block %zu\n", prop.gcnArchName, cus, prop.clockRate,
+           prop.sharedMemPerBlock);
+    float *out;
+    CHECK(hipMalloc(&out, (size_t) cus * 16 * 1024 * sizeof(float)));
+    const double ghz = 2.4;
+    CHECK(hipFuncSetAttribute((const void *) k_item<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CHECK(hipFuncSetAttribute((const void *) k_item<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+
+    for (int wps : {1, 2, 4, 8}) {  // waves per SIMD; block = 256 threads = 1 wave per SIMD
+        const int blocks = cus * wps;
+        const int iters = 4000;
+        {
+            double ms = time_ms([&] { hipLaunchKernelGGL(k_fmac, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0001f); });
+            double lane_fma = (double) blocks * 256 * iters * 16;
+            printf("fmac      wps %d: %8.3f ms  %.1f lane-FMA/clk/CU @2.4GHz  (%.1f TFLOP/s)\n", wps, ms,
+                   lane_fma / (ms * 1e-3) / (ghz * 1e9) / cus, 2 * lane_fma / (ms * 1e-3) / 1e12);
+        }
+        {
+            double ms = time_ms([&] { hipLaunchKernelGGL(k_pkfma, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0001f); });
+            double lane_fma = (double) blocks * 256 * iters * 16;
+            printf("pk_fma    wps %d: %8.3f ms  %.1f lane-FMA/clk/CU @2.4GHz  (%.1f TFLOP/s)\n", wps, ms,
+                   lane_fma / (ms * 1e-3) / (ghz * 1e9) / cus, 2 * lane_fma / (ms * 1e-3) / 1e12);
+        }
+        {
+            const int it2 = 2000;
+            double ms = time_ms([&] { hipLaunchKernelGGL(k_lds<4>, dim3(blocks), dim3(256), 32768, 0, out, it2); });
+            double bytes = (double) blocks * 256 * it2 * 16 * 4;
+            printf("ds_b32    wps %d: %8.3f ms  %.1f B/clk/CU @2.4GHz\n", wps, ms, bytes / (ms * 1e-3) / (ghz * 1e9) / cus);
+            ms = time_ms([&] { hipLaunchKernelGGL(k_lds<8>, dim3(blocks), dim3(256), 32768, 0, out, it2); });
+            bytes = (double) blocks * 256 * it2 * 16 * 8;
+            printf("ds_b64    wps %d: %8.3f ms  %.1f B/clk/CU @2.4GHz\n", wps, ms, bytes / (ms * 1e-3) / (ghz * 1e9) / cus);
+            if (wps <= 4) {
+                ms = time_ms([&] { hipLaunchKernelGGL(k_lds<16>, dim3(blocks), dim3(256), 32768, 0, out, it2); });
+                bytes = (double) blocks * 256 * it2 * 16 * 16;
+                printf("ds_b128   wps %d: %8.3f ms  %.1f B/clk/CU @2.4GHz\n", wps, ms, bytes / (ms * 1e-3) / (ghz * 1e9) / cus);
+            }
+        }
+        if (wps <= 4) {
+            const int it3 = 1000;
+            const size_t lds = 32768;
+            double ms = time_ms([&] { hipLaunchKernelGGL(k_item<false>, dim3(blocks), dim3(256), lds, 0, out, it3, 64, 0.3f, 0.7f); });
+            double items = (double) blocks * 4 * it3 * 8;  // wave-items
+            double triples = items * 256;
+            printf("item      wps %d: %8.3f ms  %.2f triples/clk/CU @2.4GHz  (%.2f G wave-items/s)\n", wps, ms,
+                   triples / (ms * 1e-3) / (ghz * 1e9) / cus, items / (ms * 1e-3) / 1e9);
+            ms = time_ms([&] { hipLaunchKernelGGL(k_item<true>, dim3(blocks), dim3(256), lds, 0, out, it3, 64, 0.3f, 0.7f); });
+            printf("item(pk)  wps %d: %8.3f ms  %.2f triples/clk/CU @2.4GHz\n", wps, ms,
+                   triples / (ms * 1e-3) / (ghz * 1e9) / cus);
+        }
+    }
+    CHECK(hipFree(out));
+    return 0;
+}
