@@ -16,7 +16,7 @@ REPO = PKG_DIR.parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libawpu_hip.so"
 
-SOURCES = [CSRC / "das_kernels.hip", CSRC / "awpu_hip.cpp", CSRC / "geometry_host.cpp"]
+SOURCES = [CSRC / "das_kernels.hip", CSRC / "das_fast.hip", CSRC / "awpu_hip.cpp", CSRC / "geometry_host.cpp"]
 HEADERS = [CSRC / "das_kernels.h", REPO / "include" / "awpu_hip.h"]
 
 

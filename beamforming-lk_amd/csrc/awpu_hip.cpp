@@ -50,6 +50,8 @@ struct awpu_hip {
 
     // device state
     awpu::LutEntry *d_lut = nullptr;
+    awpu::FastEntry *d_fast_lut[3] = {nullptr, nullptr, nullptr};  // by frames-per-item (1, 2)
+    awpu::FastPlan fast_plan[3] = {};
     int32_t *d_index = nullptr;
     float *d_frames = nullptr;
     float *d_power = nullptr;
@@ -65,6 +67,10 @@ namespace {
 
 void release_device(awpu_hip *h) {
     if (h->d_lut) (void) hipFree(h->d_lut);
+    for (auto &p : h->d_fast_lut) {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+    }
     if (h->d_index) (void) hipFree(h->d_index);
     if (h->d_frames) (void) hipFree(h->d_frames);
     if (h->d_power) (void) hipFree(h->d_power);
@@ -99,31 +105,39 @@ int prepare(awpu_hip *h) {
     h->window = hi - lo + awpu::kSamples + 1;
     h->tau_max = awpu::kSamples - lo;
 
-    std::vector<awpu::LutEntry> packed((size_t) P * U);
-    for (int p = 0; p < P; p++) {
-        const int32_t *orow = &h->off[(size_t) p * c.lut_stride];
-        const float *frow = &h->frac[(size_t) p * c.lut_stride];
-        awpu::LutEntry *dst = &packed[(size_t) p * U];
-        for (int s = 0; s < U; s++) {
-            const int id = h->index[s];
-            dst[s].off_rel = orow[id] - lo;
-            dst[s].frac = frow[id];
-        }
-    }
     if (h->d_lut) (void) hipFree(h->d_lut);
     if (h->d_index) (void) hipFree(h->d_index);
     h->d_lut = nullptr;
     h->d_index = nullptr;
-    AWPU_HIP_TRY(hipMalloc(&h->d_lut, packed.size() * sizeof(awpu::LutEntry)));
+    for (auto &p : h->d_fast_lut) {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+    }
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
-    AWPU_HIP_TRY(hipMemcpy(h->d_lut, packed.data(), packed.size() * sizeof(awpu::LutEntry),
-                           hipMemcpyHostToDevice));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
                            hipMemcpyHostToDevice));
 
-    if (c.math == AWPU_MATH_F32_EXACT || true) {
+    if (c.math == AWPU_MATH_F32_EXACT) {
         int chunk = 0;
         if (awpu::das_exact_lds_bytes(h->window, U, &chunk) == 0)
+            return invalid("delay window does not fit the LDS budget");
+        std::vector<awpu::LutEntry> packed((size_t) P * U);
+        for (int p = 0; p < P; p++) {
+            const int32_t *orow = &h->off[(size_t) p * c.lut_stride];
+            const float *frow = &h->frac[(size_t) p * c.lut_stride];
+            awpu::LutEntry *dst = &packed[(size_t) p * U];
+            for (int s = 0; s < U; s++) {
+                const int id = h->index[s];
+                dst[s].off_rel = orow[id] - lo;
+                dst[s].frac = frow[id];
+            }
+        }
+        AWPU_HIP_TRY(hipMalloc(&h->d_lut, packed.size() * sizeof(awpu::LutEntry)));
+        AWPU_HIP_TRY(hipMemcpy(h->d_lut, packed.data(), packed.size() * sizeof(awpu::LutEntry),
+                               hipMemcpyHostToDevice));
+    } else {
+        awpu::FastPlan plan;
+        if (!awpu::fast_plan(h->window, U, 1, &plan))
             return invalid("delay window does not fit the LDS budget");
     }
 
@@ -138,21 +152,77 @@ int prepare(awpu_hip *h) {
     return AWPU_OK;
 }
 
+// The fast kernel's table for `fpi` frames per item: per (pixel, active mic s) the weights and
+// the LDS byte address of X[off] inside the staged image (das_fast.hip), rows padded to whole
+// groups of four with null entries (zero weights, address of a staged row).
+int build_fast_lut(awpu_hip *h, int fpi) {
+    const auto &c = h->cfg;
+    const int U = h->usable(), P = c.pixel_count;
+    awpu::FastPlan plan;
+    if (!awpu::fast_plan(h->window, U, fpi, &plan)) return invalid("delay window does not fit the LDS budget");
+    const size_t n = (size_t) P * plan.usable_pad + 8;  // + spare groups: the kernel prefetches one ahead
+    std::vector<awpu::FastEntry> packed(n, awpu::FastEntry{0.0f, 0u, 0.0f, 0u});
+    for (int p = 0; p < P; p++) {
+        const int32_t *orow = &h->off[(size_t) p * c.lut_stride];
+        const float *frow = &h->frac[(size_t) p * c.lut_stride];
+        awpu::FastEntry *dst = &packed[(size_t) p * plan.usable_pad];
+        for (int s = 0; s < U; s++) {
+            const int id = h->index[s];
+            const int off_rel = orow[id] - h->wstart;
+            const int q = off_rel & 1;
+            const int j = s % plan.chunk;  // mic slot inside its chunk
+            dst[s].f = frow[id];
+            dst[s].g = 1.0f - frow[id];
+            dst[s].addr = (uint32_t) ((j * 2 + q) * plan.row_bytes + (off_rel - q) * 4);
+        }
+    }
+    AWPU_HIP_TRY(hipMalloc(&h->d_fast_lut[fpi], n * sizeof(awpu::FastEntry)));
+    AWPU_HIP_TRY(hipMemcpy(h->d_fast_lut[fpi], packed.data(), n * sizeof(awpu::FastEntry),
+                           hipMemcpyHostToDevice));
+    h->fast_plan[fpi] = plan;
+    return AWPU_OK;
+}
+
 int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s) {
-    awpu::SweepArgs a{};
-    a.frames = d_frames;
-    a.lut = h->d_lut;
-    a.index = h->d_index;
-    a.power = d_power;
-    a.n_streams = h->cfg.n_streams;
-    a.hist = h->cfg.hist;
-    a.usable = h->usable();
-    a.pixel_count = h->cfg.pixel_count;
-    a.wstart = h->wstart;
-    a.window = h->window;
-    a.batch = batch;
-    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    AWPU_HIP_TRY(awpu::launch_das_exact(a, s));
+    if (h->cfg.math == AWPU_MATH_F32_EXACT) {
+        awpu::SweepArgs a{};
+        a.frames = d_frames;
+        a.lut = h->d_lut;
+        a.index = h->d_index;
+        a.power = d_power;
+        a.n_streams = h->cfg.n_streams;
+        a.hist = h->cfg.hist;
+        a.usable = h->usable();
+        a.pixel_count = h->cfg.pixel_count;
+        a.wstart = h->wstart;
+        a.window = h->window;
+        a.batch = batch;
+        if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+        AWPU_HIP_TRY(awpu::launch_das_exact(a, s));
+    } else {
+        const int fpi = batch >= 2 ? 2 : 1;
+        if (!h->d_fast_lut[fpi]) {
+            const int rc = build_fast_lut(h, fpi);
+            if (rc != AWPU_OK) return rc;
+        }
+        const awpu::FastPlan &plan = h->fast_plan[fpi];
+        awpu::FastArgs a{};
+        a.frames = d_frames;
+        a.lut = h->d_fast_lut[fpi];
+        a.index = h->d_index;
+        a.power = d_power;
+        a.n_streams = h->cfg.n_streams;
+        a.hist = h->cfg.hist;
+        a.usable = h->usable();
+        a.usable_pad = plan.usable_pad;
+        a.pixel_count = h->cfg.pixel_count;
+        a.wstart = h->wstart;
+        a.wr = plan.wr;
+        a.chunk = plan.chunk;
+        a.batch = batch;
+        if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+        AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, s));
+    }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_end, s));
     h->stats.launches += 1;
     h->stats.frames += (uint64_t) batch;

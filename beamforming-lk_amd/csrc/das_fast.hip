@@ -1,0 +1,272 @@
+// das_fast.hip -- the LDS-tiled, packed-FMA sweep kernel (AWPU_MATH_F32_FAST) for gfx950.
+//
+// Replaces the loop nest of MIMOWorker::update, src/dsp/mimo.cpp:121-151, around delay(),
+// src/dsp/delay.cpp:16-26, with the interpolation written as two FMAs per sample:
+//     out[i] += f * X[off+i] + g * X[off+i+1],   g = 1 - f
+// (the reference computes X[off+i+1] + f * (X[off+i] - X[off+i+1]); the two differ by fp32
+// rounding only).
+//
+// Mapping (one (pixel, mic) pair = one "item" of 256 samples):
+//   * A workgroup = 8 waves; wave w sweeps PPW pixels; a launch covers the pixel tiles x the
+//     frame groups of a batch (FPI frames share one item's address and coefficients).
+//   * The touched window of a chunk of mics is staged once per workgroup in LDS, TWICE: copy q
+//     holds the window shifted by q floats, so that for any integer delay the run a lane needs
+//     starts 8-byte aligned in copy (off & 1) -- ds_read_b64 runs at twice the per-byte rate of
+//     ds_read_b32 but faults to a 64-cycle replay when misaligned.
+//   * An item's (f, g, LDS address) are wave-uniform and arrive by scalar loads (s_load_dwordx16
+//     = 4 items) into SGPRs; the only per-item VALU work besides the FMAs is one address add.
+//   * Lane l owns samples {2l, 2l+1} (run A) and {128+2l, 129+2l} (run B): two conflict-free
+//     ds_read_b64 per frame (64 lanes x 8 B = every bank once per half-wave) feed four
+//     v_pk_fma_f32 -- the only way to reach the fp32 peak on this chip (a plain v_fma_f32
+//     issues at half the lane rate, measured in tools/ubench.hip):
+//         A += f*x   -> out[2l], out[2l+1]          Q += g*x   -> out[2l-1], out[2l]
+//         C += f*y   -> out[128+2l], out[129+2l]    R += g*y   -> out[127+2l], out[128+2l]
+//     The one-sample skew of the g terms is undone once per pixel (wave shifts), not per mic.
+//   * The 257th sample of a window (X[off+256], weight g, lands in out[255]) is owned by no
+//     lane; it is gathered in a side pass with one lane per mic and wave-reduced per pixel.
+//   * Epilogue (mimo.cpp:131-137): MA filter via lane shifts, squares, wave reduction.
+#include "das_kernels.h"
+
+namespace awpu {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+#define AWPU_AS4 __attribute__((address_space(4)))
+
+// Four table entries = 16 dwords = one s_load_dwordx16 from the constant address space.
+typedef int i16 __attribute__((ext_vector_type(16)));
+
+struct EntryGroup {
+    i16 v;
+    __device__ __forceinline__ float f(int k) const { return __int_as_float(v[4 * k + 0]); }
+    __device__ __forceinline__ unsigned addr(int k) const { return (unsigned) v[4 * k + 1]; }
+    __device__ __forceinline__ float g(int k) const { return __int_as_float(v[4 * k + 2]); }
+};
+
+template <int FPI>
+struct Reads {
+    f2 x[FPI], y[FPI];
+};
+
+// Compiler-managed 8-byte LDS reads (so that hipcc tracks lgkmcnt itself), kept apart by an
+// empty asm with a memory clobber: without it SILoadStoreOptimizer fuses the x/y pair into one
+// ds_read2st64_b64, which the LDS serves at half the bytes per clock of two ds_read_b64.
+__device__ __forceinline__ void no_fuse() { asm volatile("" ::: "memory"); }
+
+template <int FPI>
+__device__ __forceinline__ void issue_reads(Reads<FPI> &r, unsigned entry_addr, const char *lane_base) {
+    constexpr int FS = kFastLdsBytes / FPI;
+    const char *p = lane_base + entry_addr;
+#pragma unroll
+    for (int b = 0; b < FPI; b++) {
+        r.x[b] = *(const f2 *) (p + b * FS);
+        no_fuse();
+        r.y[b] = *(const f2 *) (p + b * FS + 512);
+        no_fuse();
+    }
+}
+
+template <int FPI>
+struct Acc {
+    f2 A[FPI], Q[FPI], C[FPI], R[FPI];
+    float tail[FPI];
+};
+
+template <int FPI>
+__device__ __forceinline__ void accumulate(Acc<FPI> &a, const Reads<FPI> &r, float f, float g) {
+    const f2 F = f2{f, f}, G = f2{g, g};
+#pragma unroll
+    for (int b = 0; b < FPI; b++) {
+        a.A[b] = __builtin_elementwise_fma(F, r.x[b], a.A[b]);
+        a.Q[b] = __builtin_elementwise_fma(G, r.x[b], a.Q[b]);
+        a.C[b] = __builtin_elementwise_fma(F, r.y[b], a.C[b]);
+        a.R[b] = __builtin_elementwise_fma(G, r.y[b], a.R[b]);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+// out[] of one pixel and frame from the skewed accumulators, then mimo.cpp:131-137.
+__device__ __forceinline__ float finish_pixel(f2 A, f2 Q, f2 C, f2 R, float tail_partial, int lane) {
+    const float tail = wave_sum(tail_partial);  // sum over mics of g * X[off+256] -> out[255]
+    float q_next = __shfl_down(Q.x, 1);         // lane l+1's contribution to out[2l+1]
+    float r_next = __shfl_down(R.x, 1);         // lane l+1's contribution to out[129+2l]
+    const float r_first = __shfl(R.x, 0);       // lane 0's contribution to out[127]
+    if (lane == 63) {
+        q_next = r_first;
+        r_next = tail;
+    }
+    const float o0 = A.x + Q.y;   // out[2l]
+    const float o1 = A.y + q_next;  // out[2l+1]
+    const float o2 = C.x + R.y;   // out[128+2l]
+    const float o3 = C.y + r_next;  // out[129+2l]
+    // neighbours across lanes
+    const float o1_prev = __shfl_up(o1, 1);      // out[2l-1]
+    float o0_next = __shfl_down(o0, 1);          // out[2l+2]
+    const float o2_first = __shfl(o2, 0);        // out[128]
+    float o3_prev = __shfl_up(o3, 1);            // out[127+2l]
+    const float o1_last = __shfl(o1, 63);        // out[127]
+    const float o2_next = __shfl_down(o2, 1);    // out[130+2l]
+    if (lane == 63) o0_next = o2_first;
+    if (lane == 0) o3_prev = o1_last;
+    const float ma0 = o0 * 0.5f - 0.25f * (o1 + o1_prev);    // i = 2l      (valid for l >= 1)
+    const float ma1 = o1 * 0.5f - 0.25f * (o0_next + o0);    // i = 2l+1
+    const float ma2 = o2 * 0.5f - 0.25f * (o3 + o3_prev);    // i = 128+2l
+    const float ma3 = o3 * 0.5f - 0.25f * (o2_next + o2);    // i = 129+2l  (valid for l <= 62)
+    float sum = ma1 * ma1 + ma2 * ma2;
+    if (lane != 0) sum += ma0 * ma0;
+    if (lane != 63) sum += ma3 * ma3;
+    return wave_sum(sum);
+}
+
+template <int PPW, int FPI>
+__global__ __launch_bounds__(kFastThreads, 4) void das_fast_kernel(FastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = kFastThreads / 64;
+    constexpr int FS = kFastLdsBytes / FPI;  // byte stride between the frames of a group
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char *lane_base = (const char *) lds + lane * 8;
+    const int frame0 = blockIdx.y * FPI;
+    const int pix0 = (blockIdx.x * NW + wave) * PPW;
+    const int wr = a.wr;
+    const AWPU_AS4 FastEntry *lut = (const AWPU_AS4 FastEntry *) (unsigned long long) a.lut;
+    const AWPU_AS4 int32_t *index = (const AWPU_AS4 int32_t *) (unsigned long long) a.index;
+
+    Acc<FPI> acc[PPW];
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++)
+#pragma unroll
+        for (int b = 0; b < FPI; b++) {
+            acc[pp].A[b] = acc[pp].Q[b] = acc[pp].C[b] = acc[pp].R[b] = f2{0.0f, 0.0f};
+            acc[pp].tail[b] = 0.0f;
+        }
+
+    for (int m0 = 0; m0 < a.usable; m0 += a.chunk) {
+        const int mc = min(a.chunk, a.usable - m0);
+        const int mc4 = (mc + 3) & ~3;  // the table pads every pixel row to a multiple of 4
+        __syncthreads();                // the previous chunk is fully consumed
+
+        // ---- stage [frame][mic][copy][wr] floats: copy q = the window shifted by q samples
+        const int rows = FPI * mc * 2;
+        for (int r = wave; r < rows; r += NW) {
+            const int b = r / (2 * mc);
+            const int jr = r - b * 2 * mc;
+            const int j = jr >> 1, q = jr & 1;
+            const int fb = min(frame0 + b, a.batch - 1);
+            const int first = a.wstart + q;
+            const float *src = a.frames + ((size_t) fb * a.n_streams + index[m0 + j]) * a.hist + first;
+            float *dst = lds + b * (FS / 4) + (j * 2 + q) * wr;
+            const int valid = min(wr, a.hist - first);
+            for (int t = lane * 2; t < wr; t += 128) {
+                f2 v;
+                v.x = t < valid ? src[t] : 0.0f;
+                v.y = t + 1 < valid ? src[t + 1] : 0.0f;
+                *(f2 *) (dst + t) = v;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int pp = 0; pp < PPW; pp++) {
+            const int p = pix0 + pp;
+            if (p < a.pixel_count) {
+                const AWPU_AS4 i16 *grp = (const AWPU_AS4 i16 *) (lut + (size_t) p * a.usable_pad + m0);
+                const int ng = mc4 >> 2;
+                EntryGroup cur, nxt;
+                cur.v = grp[0];
+                for (int g = 0; g < ng; g++) {
+                    // one group ahead (the table carries spare groups at its end); while this
+                    // scalar load is pending every LDS wait is an lgkmcnt(0), so a group is
+                    // "issue all reads, wait, 16*FPI packed FMAs"; other waves fill the wait
+                    nxt.v = grp[g + 1];
+                    Reads<FPI> r0, r1, r2, r3;
+                    issue_reads<FPI>(r0, cur.addr(0), lane_base);
+                    issue_reads<FPI>(r1, cur.addr(1), lane_base);
+                    issue_reads<FPI>(r2, cur.addr(2), lane_base);
+                    issue_reads<FPI>(r3, cur.addr(3), lane_base);
+                    accumulate<FPI>(acc[pp], r0, cur.f(0), cur.g(0));
+                    accumulate<FPI>(acc[pp], r1, cur.f(1), cur.g(1));
+                    accumulate<FPI>(acc[pp], r2, cur.f(2), cur.g(2));
+                    accumulate<FPI>(acc[pp], r3, cur.f(3), cur.g(3));
+                    cur = nxt;
+                }
+                // ---- the 257th sample of every window: one lane per mic of the chunk
+                if (lane < mc4) {
+                    const FastEntry e = a.lut[(size_t) p * a.usable_pad + m0 + lane];
+#pragma unroll
+                    for (int b = 0; b < FPI; b++) {
+                        const float x = lds[(e.addr + 1024u + (unsigned) (b * FS)) >> 2];
+                        acc[pp].tail[b] = __builtin_fmaf(e.g, x, acc[pp].tail[b]);
+                    }
+                }
+            }
+        }
+    }
+
+    const float scale = 1.0f / (float) (kSamples * a.usable);
+    (void) scale;
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) {
+        const int p = pix0 + pp;
+        if (p < a.pixel_count) {
+#pragma unroll
+            for (int b = 0; b < FPI; b++) {
+                const float sum = finish_pixel(acc[pp].A[b], acc[pp].Q[b], acc[pp].C[b], acc[pp].R[b],
+                                               acc[pp].tail[b], lane);
+                if (lane == 0 && frame0 + b < a.batch) {
+                    a.power[(size_t) (frame0 + b) * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side: geometry of the LDS image and the launch
+// ---------------------------------------------------------------------------------------
+bool fast_plan(int window, int usable, int fpi, FastPlan *plan) {
+    if (fpi != 1 && fpi != 2) return false;
+    const int wr = (window + 1) & ~1;  // even: every row starts 8-byte aligned
+    const size_t row_bytes = (size_t) wr * sizeof(float);
+    const size_t frame_bytes = (size_t) kFastLdsBytes / fpi;
+    int chunk = (int) (frame_bytes / (2 * row_bytes));
+    chunk &= ~3;  // whole entry groups per chunk
+    if (chunk > 64) chunk = 64;  // the side pass gives one lane to each mic of a chunk
+    if (chunk < 4) return false;
+    const int usable_pad = (usable + 3) & ~3;
+    if (chunk > usable_pad) chunk = usable_pad;
+    plan->fpi = fpi;
+    plan->wr = wr;
+    plan->chunk = chunk;
+    plan->usable_pad = usable_pad;
+    plan->row_bytes = (int) row_bytes;
+    return true;
+}
+
+template <int PPW, int FPI>
+static hipError_t launch_variant(const FastArgs &a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *) das_fast_kernel<PPW, FPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kFastLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int pix_per_block = (kFastThreads / 64) * PPW;
+    dim3 grid((a.pixel_count + pix_per_block - 1) / pix_per_block, (a.batch + FPI - 1) / FPI);
+    hipLaunchKernelGGL((das_fast_kernel<PPW, FPI>), grid, dim3(kFastThreads), kFastLdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_das_fast(const FastArgs &a, int fpi, hipStream_t stream) {
+    if (fpi == 2) return launch_variant<kFastPPW, 2>(a, stream);
+    return launch_variant<kFastPPW, 1>(a, stream);
+}
+
+}  // namespace awpu

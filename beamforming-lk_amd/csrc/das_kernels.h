@@ -31,6 +31,41 @@ struct SweepArgs {
     int32_t batch;
 };
 
+// ---- fast kernel (das_fast.hip) ---------------------------------------------------------
+constexpr int kFastThreads = 512;        // 8 waves per workgroup
+constexpr int kFastPPW = 4;              // pixels per wave
+constexpr int kFastLdsBytes = 79 * 1024; // per workgroup: two workgroups share a CU's 160 KiB
+
+// One 16-byte entry per (pixel, active mic): what one item needs, laid out so that f and g
+// start even SGPRs after an s_load_dwordx16 (packed-FMA scalar operands are aligned pairs).
+struct FastEntry {
+    float f;        // weight of X[off+i]   (the reference's `fraction`)
+    uint32_t addr;  // LDS byte offset of X[off] in the copy of parity (off & 1), frame 0, lane 0
+    float g;        // 1 - f, weight of X[off+i+1]
+    uint32_t pad;
+};
+
+struct FastPlan {
+    int fpi;         // frames per item (1 or 2)
+    int wr;          // floats per staged row (even)
+    int chunk;       // mics staged per pass (multiple of 4, <= 64)
+    int usable_pad;  // table row length, usable rounded up to 4 (null entries at the end)
+    int row_bytes;
+};
+
+struct FastArgs {
+    const float *frames;   // [batch][n_streams][hist]
+    const FastEntry *lut;  // [pixel_count][usable_pad] (+ one spare group)
+    const int32_t *index;  // [usable]
+    float *power;          // [batch][pixel_count]
+    int32_t n_streams, hist, usable, usable_pad, pixel_count;
+    int32_t wstart, wr, chunk, batch;
+};
+
+// LDS image geometry for a window of `window` samples; false if it cannot fit.
+bool fast_plan(int window, int usable, int fpi, FastPlan *plan);
+hipError_t launch_das_fast(const FastArgs &a, int fpi, hipStream_t stream);
+
 // exact-order kernel (AWPU_MATH_F32_EXACT): sub, fma, add per sample, mics in order.
 hipError_t launch_das_exact(const SweepArgs &a, hipStream_t stream);
 

@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -146,6 +147,60 @@ __global__ void k_item(float *out, int iters, int off0, float f, float g) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + pa + pb + x.x + y.x;
 }
 
+
+// ---- design-shaped item in plain C++ (what the sweep kernel's inner loop will look like):
+// per item: one address add, FPI x 2 ds_read_b64 (frames at a constant LDS stride), FPI x 4
+// v_pk_fma_f32 with the wave-uniform (f, g) as scalar operands.  Table entries come through
+// scalar loads from `lut` (off, f, g, pad).  Reports shader cycles per block.
+struct Entry { int off; float f, g; int pad; };
+
+template <int FPI>
+__global__ __launch_bounds__(256) void k_design(float *out, long long *cyc, const Entry *lut, int n_items, int reps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = i * 1e-6f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const char *base = (const char *) lds + lane * 8;
+    f2 A[FPI], Q[FPI], C[FPI], R[FPI];
+#pragma unroll
+    for (int b = 0; b < FPI; b++) A[b] = Q[b] = C[b] = R[b] = f2{0, 0};
+    const long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < reps; r++) {
+#pragma unroll 4
+        for (int i = 0; i < n_items; i++) {
+            const Entry e = lut[i];
+            const char *p = base + e.off;
+            const f2 F = f2{e.f, e.f}, G = f2{e.g, e.g};
+#pragma unroll
+            for (int b = 0; b < FPI; b++) {
+                const f2 x = *(const f2 *) (p + b * 4096);
+                const f2 y = *(const f2 *) (p + b * 4096 + 512);
+                A[b] = __builtin_elementwise_fma(F, x, A[b]);
+                Q[b] = __builtin_elementwise_fma(G, x, Q[b]);
+                C[b] = __builtin_elementwise_fma(F, y, C[b]);
+                R[b] = __builtin_elementwise_fma(G, y, R[b]);
+            }
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+#pragma unroll
+    for (int b = 0; b < FPI; b++) s += A[b].x + A[b].y + Q[b].x + Q[b].y + C[b].x + C[b].y + R[b].x + R[b].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+__global__ void k_clock(long long *cyc, long long *rt, int spin) {
+    const long long t0 = __builtin_readcyclecounter();
+    const long long r0 = __builtin_amdgcn_s_memrealtime();
+    float a = threadIdx.x;
+    for (int i = 0; i < spin; i++) asm volatile("v_fmac_f32 %0, %0, %0" : "+v"(a));
+    const long long t1 = __builtin_readcyclecounter();
+    const long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; rt[blockIdx.x] = r1 - r0; }
+    if (a == 123.456f) cyc[0] = 0;
+}
+
 struct Result {
     double ms;
 };
@@ -223,6 +278,45 @@ int main() {
             printf("item(pk)  wps %d: %8.3f ms  %.2f triples/clk/CU @2.4GHz\n", wps, ms,
                    triples / (ms * 1e-3) / (ghz * 1e9) / cus);
         }
+    }
+
+    {   // design-shaped kernel, cycle-stamped
+        long long *cyc, *rt;
+        CHECK(hipMalloc(&cyc, 4096 * sizeof(long long)));
+        CHECK(hipMalloc(&rt, 4096 * sizeof(long long)));
+        const int n_items = 256;
+        std::vector<Entry> h(n_items);
+        for (int i = 0; i < n_items; i++) h[i] = Entry{((i * 1384) & 0x3ff8), 0.25f + i * 1e-3f, 0.75f - i * 1e-3f, 0};
+        Entry *lut;
+        CHECK(hipMalloc(&lut, n_items * sizeof(Entry)));
+        CHECK(hipMemcpy(lut, h.data(), n_items * sizeof(Entry), hipMemcpyHostToDevice));
+        auto report = [&](const char *name, int fpi, int wps, double ms, int reps) {
+            std::vector<long long> c(cus * wps);
+            CHECK(hipMemcpy(c.data(), cyc, c.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            std::sort(c.begin(), c.end());
+            const double med = (double) c[c.size() / 2];
+            const double items = (double) n_items * reps;  // per wave
+            const double triples_cu = items * fpi * 256 * 4 * wps;  // per CU: 4*wps waves
+            printf("%s fpi %d wps %d: %8.3f ms  median %.0f cyc/block  %.1f cyc/item/wave  %.2f triples/cyc/CU (in-kernel clock)  eff clock %.2f GHz\n",
+                   name, fpi, wps, ms, med, med / items, triples_cu / med, med / (ms * 1e-3) / 1e9);
+        };
+        for (int wps : {1, 2, 4}) {
+            const int blocks = cus * wps, reps = 40;
+            double ms;
+            ms = time_ms([&] { hipLaunchKernelGGL(k_design<1>, dim3(blocks), dim3(256), 36864, 0, out, cyc, lut, n_items, reps); });
+            report("design", 1, wps, ms, reps);
+            ms = time_ms([&] { hipLaunchKernelGGL(k_design<2>, dim3(blocks), dim3(256), 36864, 0, out, cyc, lut, n_items, reps); });
+            report("design", 2, wps, ms, reps);
+            ms = time_ms([&] { hipLaunchKernelGGL(k_design<4>, dim3(blocks), dim3(256), 36864, 0, out, cyc, lut, n_items, reps); });
+            report("design", 4, wps, ms, reps);
+        }
+        hipLaunchKernelGGL(k_clock, dim3(cus), dim3(256), 0, 0, cyc, rt, 2000000);
+        CHECK(hipDeviceSynchronize());
+        std::vector<long long> c(cus), r(cus);
+        CHECK(hipMemcpy(c.data(), cyc, cus * sizeof(long long), hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(r.data(), rt, cus * sizeof(long long), hipMemcpyDeviceToHost));
+        printf("clock: %lld shader cycles in %lld realtime ticks (100 MHz) -> %.3f GHz; %.2f cyc per dependent v_fmac\n", c[0], r[0],
+               (double) c[0] / ((double) r[0] / 100e6) / 1e9, (double) c[0] / 2000000);
     }
     CHECK(hipFree(out));
     return 0;
