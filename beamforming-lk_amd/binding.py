@@ -100,6 +100,13 @@ def load(build: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.build_library() if build else _build.LIB_PATH
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; a process that uses both torch and
+    # this library must run on ONE HIP runtime, and the first one loaded wins the SONAME.  Load
+    # torch's first when torch is installed, so that libawpu_hip.so binds to the same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not path.exists():
         raise RuntimeError(f"{path} is missing and there is no CPU fallback")
     lib = C.CDLL(str(path))

@@ -196,9 +196,12 @@ __global__ __launch_bounds__(kFastThreads, 4) void das_fast_kernel(FastArgs a) {
                     accumulate<FPI>(acc[pp], r3, cur.f(3), cur.g(3));
                     cur = nxt;
                 }
-                // ---- the 257th sample of every window: one lane per mic of the chunk
-                if (lane < mc4) {
-                    const FastEntry e = a.lut[(size_t) p * a.usable_pad + m0 + lane];
+                // ---- the 257th sample of every window: one lane per mic.  Lane = active-mic
+                // number mod 64, so a lane's partial sum runs over the same mics in the same order
+                // whatever the chunk size is (results do not depend on frames-per-item).
+                const int j = (lane - m0) & 63;
+                if (j < mc4) {
+                    const FastEntry e = a.lut[(size_t) p * a.usable_pad + m0 + j];
 #pragma unroll
                     for (int b = 0; b < FPI; b++) {
                         const float x = lds[(e.addr + 1024u + (unsigned) (b * FS)) >> 2];
@@ -209,8 +212,6 @@ __global__ __launch_bounds__(kFastThreads, 4) void das_fast_kernel(FastArgs a) {
         }
     }
 
-    const float scale = 1.0f / (float) (kSamples * a.usable);
-    (void) scale;
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++) {
         const int p = pix0 + pp;

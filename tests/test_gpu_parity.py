@@ -119,6 +119,9 @@ def test_batch_equals_single_frames(pkg, oracle, math):
     off, frac = off[:200], frac[:200]
     frames = S.make_frames(xyz, 5, seed=8)
     batch, _ = run_engine(pkg, frames, off, frac, math=math)
+    # the same frames in another order and another batch size: bit-identical per frame
+    rev, _ = run_engine(pkg, frames[::-1][:4], off, frac, math=math, max_batch=7)
+    assert np.array_equal(rev, batch[::-1][:4])
     for b in range(5):
         single, _ = run_engine(pkg, frames[b], off, frac, math=math)
         assert np.array_equal(batch[b], single)
