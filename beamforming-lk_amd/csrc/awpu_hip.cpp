@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -183,6 +184,31 @@ int build_fast_lut(awpu_hip *h, int fpi) {
     return AWPU_OK;
 }
 
+// Kernel shape for a call: frames per item and pixels per wave.  AWPU_FAST_VARIANT="fpi,ppw"
+// overrides the heuristic (tuning knob, read once).
+void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
+    static int env_fpi = -1, env_ppw = -1, env_nw = 0;
+    if (env_fpi == -1) {
+        env_fpi = env_ppw = 0;
+        if (const char *v = std::getenv("AWPU_FAST_VARIANT")) {
+            if (std::sscanf(v, "%d,%d,%d", &env_fpi, &env_ppw, &env_nw) < 2) env_fpi = env_ppw = env_nw = 0;
+        }
+    }
+    // few pixels per wave while the grid is too small to fill 256 CUs twice over
+    const long blocks8 = ((long) h->cfg.pixel_count + 63) / 64 * batch;
+    *fpi = 1;
+    *ppw = blocks8 >= 1024 ? 8 : (blocks8 >= 256 ? 4 : 2);
+    if (env_fpi == 1 || env_fpi == 2) *fpi = env_fpi;
+    if (env_ppw == 2 || env_ppw == 4 || env_ppw == 8) *ppw = env_ppw;
+    if (*fpi == 2 && *ppw == 8) *ppw = 4;
+    if (*fpi == 2 && batch < 2) *fpi = 1;
+    *nw = env_nw == 16 ? 16 : 8;
+    if (*nw == 16) {
+        *fpi = 1;
+        if (*ppw > 4) *ppw = 4;
+    }
+}
+
 int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s) {
     if (h->cfg.math == AWPU_MATH_F32_EXACT) {
         awpu::SweepArgs a{};
@@ -200,7 +226,8 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
         AWPU_HIP_TRY(awpu::launch_das_exact(a, s));
     } else {
-        const int fpi = batch >= 2 ? 2 : 1;
+        int fpi = 1, ppw = 8, nw = 8;
+        choose_fast_variant(h, batch, &fpi, &ppw, &nw);
         if (!h->d_fast_lut[fpi]) {
             const int rc = build_fast_lut(h, fpi);
             if (rc != AWPU_OK) return rc;
@@ -220,8 +247,10 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         a.wr = plan.wr;
         a.chunk = plan.chunk;
         a.batch = batch;
+        static const int debug = std::getenv("AWPU_FAST_DEBUG") ? std::atoi(std::getenv("AWPU_FAST_DEBUG")) : 0;
+        a.debug = debug;
         if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-        AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, s));
+        AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, s));
     }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_end, s));
     h->stats.launches += 1;

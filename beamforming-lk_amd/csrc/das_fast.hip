@@ -30,7 +30,8 @@
 namespace awpu {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
-typedef int i4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load, 4-byte aligned
 
 #define AWPU_AS4 __attribute__((address_space(4)))
 
@@ -70,7 +71,6 @@ __device__ __forceinline__ void issue_reads(Reads<FPI> &r, unsigned entry_addr, 
 template <int FPI>
 struct Acc {
     f2 A[FPI], Q[FPI], C[FPI], R[FPI];
-    float tail[FPI];
 };
 
 template <int FPI>
@@ -85,6 +85,20 @@ __device__ __forceinline__ void accumulate(Acc<FPI> &a, const Reads<FPI> &r, flo
     }
 }
 
+// One group = four items: all reads first, then 16*FPI packed FMAs.
+template <int FPI>
+__device__ __forceinline__ void sweep_group(Acc<FPI> &acc, const EntryGroup &e, const char *lane_base) {
+    Reads<FPI> r0, r1, r2, r3;
+    issue_reads<FPI>(r0, e.addr(0), lane_base);
+    issue_reads<FPI>(r1, e.addr(1), lane_base);
+    issue_reads<FPI>(r2, e.addr(2), lane_base);
+    issue_reads<FPI>(r3, e.addr(3), lane_base);
+    accumulate<FPI>(acc, r0, e.f(0), e.g(0));
+    accumulate<FPI>(acc, r1, e.f(1), e.g(1));
+    accumulate<FPI>(acc, r2, e.f(2), e.g(2));
+    accumulate<FPI>(acc, r3, e.f(3), e.g(3));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
@@ -92,134 +106,173 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // out[] of one pixel and frame from the skewed accumulators, then mimo.cpp:131-137.
-__device__ __forceinline__ float finish_pixel(f2 A, f2 Q, f2 C, f2 R, float tail_partial, int lane) {
-    const float tail = wave_sum(tail_partial);  // sum over mics of g * X[off+256] -> out[255]
-    float q_next = __shfl_down(Q.x, 1);         // lane l+1's contribution to out[2l+1]
-    float r_next = __shfl_down(R.x, 1);         // lane l+1's contribution to out[129+2l]
-    const float r_first = __shfl(R.x, 0);       // lane 0's contribution to out[127]
+// `tail` = sum over mics of g * X[off+256], the contribution to out[255].
+__device__ __forceinline__ float finish_pixel(f2 A, f2 Q, f2 C, f2 R, float tail, int lane) {
+    float q_next = __shfl_down(Q.x, 1);    // lane l+1's contribution to out[2l+1]
+    float r_next = __shfl_down(R.x, 1);    // lane l+1's contribution to out[129+2l]
+    const float r_first = __shfl(R.x, 0);  // lane 0's contribution to out[127]
     if (lane == 63) {
         q_next = r_first;
         r_next = tail;
     }
-    const float o0 = A.x + Q.y;   // out[2l]
+    const float o0 = A.x + Q.y;     // out[2l]
     const float o1 = A.y + q_next;  // out[2l+1]
-    const float o2 = C.x + R.y;   // out[128+2l]
+    const float o2 = C.x + R.y;     // out[128+2l]
     const float o3 = C.y + r_next;  // out[129+2l]
     // neighbours across lanes
-    const float o1_prev = __shfl_up(o1, 1);      // out[2l-1]
-    float o0_next = __shfl_down(o0, 1);          // out[2l+2]
-    const float o2_first = __shfl(o2, 0);        // out[128]
-    float o3_prev = __shfl_up(o3, 1);            // out[127+2l]
-    const float o1_last = __shfl(o1, 63);        // out[127]
-    const float o2_next = __shfl_down(o2, 1);    // out[130+2l]
+    const float o1_prev = __shfl_up(o1, 1);    // out[2l-1]
+    float o0_next = __shfl_down(o0, 1);        // out[2l+2]
+    const float o2_first = __shfl(o2, 0);      // out[128]
+    float o3_prev = __shfl_up(o3, 1);          // out[127+2l]
+    const float o1_last = __shfl(o1, 63);      // out[127]
+    const float o2_next = __shfl_down(o2, 1);  // out[130+2l]
     if (lane == 63) o0_next = o2_first;
     if (lane == 0) o3_prev = o1_last;
-    const float ma0 = o0 * 0.5f - 0.25f * (o1 + o1_prev);    // i = 2l      (valid for l >= 1)
-    const float ma1 = o1 * 0.5f - 0.25f * (o0_next + o0);    // i = 2l+1
-    const float ma2 = o2 * 0.5f - 0.25f * (o3 + o3_prev);    // i = 128+2l
-    const float ma3 = o3 * 0.5f - 0.25f * (o2_next + o2);    // i = 129+2l  (valid for l <= 62)
+    const float ma0 = o0 * 0.5f - 0.25f * (o1 + o1_prev);  // i = 2l      (valid for l >= 1)
+    const float ma1 = o1 * 0.5f - 0.25f * (o0_next + o0);  // i = 2l+1
+    const float ma2 = o2 * 0.5f - 0.25f * (o3 + o3_prev);  // i = 128+2l
+    const float ma3 = o3 * 0.5f - 0.25f * (o2_next + o2);  // i = 129+2l  (valid for l <= 62)
     float sum = ma1 * ma1 + ma2 * ma2;
     if (lane != 0) sum += ma0 * ma0;
     if (lane != 63) sum += ma3 * ma3;
     return wave_sum(sum);
 }
 
-template <int PPW, int FPI>
-__global__ __launch_bounds__(kFastThreads, 4) void das_fast_kernel(FastArgs a) {
+// NW waves per workgroup, PPW pixels per wave, FPI frames per item, WPS waves per SIMD the
+// register budget is sized for (two workgroups share a CU and its 160 KiB of LDS).
+template <int NW, int PPW, int FPI, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
+    static_assert(PPW <= 8, "the tail pass gives 8 lanes to each of at most 8 pixels");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NW = kFastThreads / 64;
     constexpr int FS = kFastLdsBytes / FPI;  // byte stride between the frames of a group
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const char *lane_base = (const char *) lds + lane * 8;
-    const int frame0 = blockIdx.y * FPI;
-    const int pix0 = (blockIdx.x * NW + wave) * PPW;
+    const int frame0 = blockIdx.x * FPI;  // frames vary fastest in dispatch order: the
+    const int pix0 = (blockIdx.y * NW + wave) * PPW;  // workgroups of a tile share its table rows in L2
     const int wr = a.wr;
     const AWPU_AS4 FastEntry *lut = (const AWPU_AS4 FastEntry *) (unsigned long long) a.lut;
     const AWPU_AS4 int32_t *index = (const AWPU_AS4 int32_t *) (unsigned long long) a.index;
 
     Acc<FPI> acc[PPW];
+    float tail[FPI];  // lane (8*pp + k): partial tail sum of pixel pp over the mics s = k (mod 8)
+#pragma unroll
+    for (int b = 0; b < FPI; b++) tail[b] = 0.0f;
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++)
 #pragma unroll
-        for (int b = 0; b < FPI; b++) {
-            acc[pp].A[b] = acc[pp].Q[b] = acc[pp].C[b] = acc[pp].R[b] = f2{0.0f, 0.0f};
-            acc[pp].tail[b] = 0.0f;
-        }
+        for (int b = 0; b < FPI; b++) acc[pp].A[b] = acc[pp].Q[b] = acc[pp].C[b] = acc[pp].R[b] = f2{0.0f, 0.0f};
+
+    const int tail_pp = lane >> 3;
+    const bool tail_lane = tail_pp < PPW && pix0 + tail_pp < a.pixel_count;
+    const FastEntry *tail_row = a.lut + (size_t) (pix0 + (tail_lane ? tail_pp : 0)) * a.usable_pad;
 
     for (int m0 = 0; m0 < a.usable; m0 += a.chunk) {
         const int mc = min(a.chunk, a.usable - m0);
         const int mc4 = (mc + 3) & ~3;  // the table pads every pixel row to a multiple of 4
         __syncthreads();                // the previous chunk is fully consumed
 
-        // ---- stage [frame][mic][copy][wr] floats: copy q = the window shifted by q samples
-        const int rows = FPI * mc * 2;
-        for (int r = wave; r < rows; r += NW) {
-            const int b = r / (2 * mc);
-            const int jr = r - b * 2 * mc;
-            const int j = jr >> 1, q = jr & 1;
-            const int fb = min(frame0 + b, a.batch - 1);
-            const int first = a.wstart + q;
-            const float *src = a.frames + ((size_t) fb * a.n_streams + index[m0 + j]) * a.hist + first;
-            float *dst = lds + b * (FS / 4) + (j * 2 + q) * wr;
-            const int valid = min(wr, a.hist - first);
-            for (int t = lane * 2; t < wr; t += 128) {
-                f2 v;
-                v.x = t < valid ? src[t] : 0.0f;
-                v.y = t + 1 < valid ? src[t + 1] : 0.0f;
-                *(f2 *) (dst + t) = v;
+        // ---- stage [frame][mic][copy][wr] floats: copy q = the window shifted by q samples.
+        // One wave per row, two rows per trip, 16 bytes per lane per load and all loads of a
+        // trip issued before the first LDS write, so that their L2 latencies overlap.
+        const int rows = (a.debug & 1) && m0 > 0 ? 0 : FPI * mc * 2;  // debug bit 0: stage once
+        for (int r = wave; r < rows; r += 2 * NW) {
+            const float *src[2];
+            float *dst[2];
+            int valid = wr;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int rr = min(r + u * NW, rows - 1);  // a duplicate row rewrites the same bytes
+                const int b = rr / (2 * mc);
+                const int jr = rr - b * 2 * mc;
+                const int j = jr >> 1, q = jr & 1;
+                const int fb = min(frame0 + b, a.batch - 1);
+                const int first = a.wstart + q;
+                src[u] = a.frames + ((size_t) fb * a.n_streams + index[m0 + j]) * a.hist + first;
+                dst[u] = lds + b * (FS / 4) + (j * 2 + q) * wr;
+                valid = min(valid, a.hist - first);
+            }
+            if (valid == wr) {  // the whole row lies inside the history (always, unless the
+                                // window touches the newest sample): no per-element guards
+                for (int t0 = 0; t0 < wr; t0 += 512) {
+                    f4 v[2][2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int t = t0 + k * 256 + lane * 4;
+                            if (t < wr) v[u][k] = *(const f4u *) (src[u] + t);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int t = t0 + k * 256 + lane * 4;
+                            if (t < wr) *(f4 *) (dst[u] + t) = v[u][k];
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    for (int t = lane; t < wr; t += 64) dst[u][t] = t < valid ? src[u][t] : 0.0f;
             }
         }
         __syncthreads();
 
+        if (!(a.debug & 2)) {  // debug bit 1: no sweep (staging only)
 #pragma unroll
-        for (int pp = 0; pp < PPW; pp++) {
-            const int p = pix0 + pp;
-            if (p < a.pixel_count) {
-                const AWPU_AS4 i16 *grp = (const AWPU_AS4 i16 *) (lut + (size_t) p * a.usable_pad + m0);
-                const int ng = mc4 >> 2;
-                EntryGroup cur, nxt;
-                cur.v = grp[0];
-                for (int g = 0; g < ng; g++) {
-                    // one group ahead (the table carries spare groups at its end); while this
-                    // scalar load is pending every LDS wait is an lgkmcnt(0), so a group is
-                    // "issue all reads, wait, 16*FPI packed FMAs"; other waves fill the wait
-                    nxt.v = grp[g + 1];
-                    Reads<FPI> r0, r1, r2, r3;
-                    issue_reads<FPI>(r0, cur.addr(0), lane_base);
-                    issue_reads<FPI>(r1, cur.addr(1), lane_base);
-                    issue_reads<FPI>(r2, cur.addr(2), lane_base);
-                    issue_reads<FPI>(r3, cur.addr(3), lane_base);
-                    accumulate<FPI>(acc[pp], r0, cur.f(0), cur.g(0));
-                    accumulate<FPI>(acc[pp], r1, cur.f(1), cur.g(1));
-                    accumulate<FPI>(acc[pp], r2, cur.f(2), cur.g(2));
-                    accumulate<FPI>(acc[pp], r3, cur.f(3), cur.g(3));
-                    cur = nxt;
+            for (int pp = 0; pp < PPW; pp++) {
+                const int p = pix0 + pp;
+                if (p < a.pixel_count) {
+                    const AWPU_AS4 i16 *grp = (const AWPU_AS4 i16 *) (lut + (size_t) p * a.usable_pad + m0);
+                    const int ng = mc4 >> 2;
+                    // Table entries travel one group ahead of their use (the table carries spare
+                    // groups at its end).  While a scalar load is pending every LDS wait is an
+                    // lgkmcnt(0), so a group is "issue all reads, wait, FMAs"; the other waves of
+                    // the SIMD fill the wait.  Two groups per trip: no register copies.
+                    EntryGroup e0, e1;
+                    e0.v = grp[0];
+                    for (int g = 0; g < ng; g += 2) {
+                        e1.v = grp[g + 1];
+                        sweep_group<FPI>(acc[pp], e0, lane_base);
+                        e0.v = grp[g + 2];
+                        if (g + 1 < ng) sweep_group<FPI>(acc[pp], e1, lane_base);
+                    }
                 }
-                // ---- the 257th sample of every window: one lane per mic.  Lane = active-mic
-                // number mod 64, so a lane's partial sum runs over the same mics in the same order
-                // whatever the chunk size is (results do not depend on frames-per-item).
-                const int j = (lane - m0) & 63;
-                if (j < mc4) {
-                    const FastEntry e = a.lut[(size_t) p * a.usable_pad + m0 + j];
+            }
+            // ---- the 257th sample of every window (X[off+256], weight g, goes to out[255]): lane
+            // 8*pp + k gathers it for pixel pp and the mics s = k (mod 8) of this chunk.  A lane's
+            // partial sum therefore runs over the same mics in the same order whatever the chunk
+            // size or pixels-per-wave, so results do not depend on the kernel shape.
+            for (int j0 = 0; j0 < mc4; j0 += 8) {
+                const int j = j0 + ((lane - m0 - j0) & 7);
+                if (tail_lane && j < mc4) {
+                    const FastEntry e = tail_row[m0 + j];
 #pragma unroll
                     for (int b = 0; b < FPI; b++) {
                         const float x = lds[(e.addr + 1024u + (unsigned) (b * FS)) >> 2];
-                        acc[pp].tail[b] = __builtin_fmaf(e.g, x, acc[pp].tail[b]);
+                        tail[b] = __builtin_fmaf(e.g, x, tail[b]);
                     }
                 }
             }
         }
     }
 
+    // combine the 8 partial tail sums of each pixel; lanes 8*pp .. 8*pp+7 then hold pixel pp's
+#pragma unroll
+    for (int b = 0; b < FPI; b++) {
+        tail[b] += __shfl_xor(tail[b], 1);
+        tail[b] += __shfl_xor(tail[b], 2);
+        tail[b] += __shfl_xor(tail[b], 4);
+    }
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++) {
         const int p = pix0 + pp;
         if (p < a.pixel_count) {
 #pragma unroll
             for (int b = 0; b < FPI; b++) {
-                const float sum = finish_pixel(acc[pp].A[b], acc[pp].Q[b], acc[pp].C[b], acc[pp].R[b],
-                                               acc[pp].tail[b], lane);
+                const float t = __shfl(tail[b], pp * 8);
+                const float sum = finish_pixel(acc[pp].A[b], acc[pp].Q[b], acc[pp].C[b], acc[pp].R[b], t, lane);
                 if (lane == 0 && frame0 + b < a.batch) {
                     a.power[(size_t) (frame0 + b) * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
                 }
@@ -233,7 +286,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void das_fast_kernel(FastArgs a) {
 // ---------------------------------------------------------------------------------------
 bool fast_plan(int window, int usable, int fpi, FastPlan *plan) {
     if (fpi != 1 && fpi != 2) return false;
-    const int wr = (window + 1) & ~1;  // even: every row starts 8-byte aligned
+    const int wr = (window + 3) & ~3;  // rows are whole 16-byte pieces (and start 16-byte aligned)
     const size_t row_bytes = (size_t) wr * sizeof(float);
     const size_t frame_bytes = (size_t) kFastLdsBytes / fpi;
     int chunk = (int) (frame_bytes / (2 * row_bytes));
@@ -250,24 +303,34 @@ bool fast_plan(int window, int usable, int fpi, FastPlan *plan) {
     return true;
 }
 
-template <int PPW, int FPI>
+template <int NW, int PPW, int FPI, int WPS>
 static hipError_t launch_variant(const FastArgs &a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *) das_fast_kernel<PPW, FPI>,
+        hipError_t e = hipFuncSetAttribute((const void *) das_fast_kernel<NW, PPW, FPI, WPS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kFastLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int pix_per_block = (kFastThreads / 64) * PPW;
-    dim3 grid((a.pixel_count + pix_per_block - 1) / pix_per_block, (a.batch + FPI - 1) / FPI);
-    hipLaunchKernelGGL((das_fast_kernel<PPW, FPI>), grid, dim3(kFastThreads), kFastLdsBytes, stream, a);
+    const int pix_per_block = NW * PPW;
+    dim3 grid((a.batch + FPI - 1) / FPI, (a.pixel_count + pix_per_block - 1) / pix_per_block);
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((das_fast_kernel<NW, PPW, FPI, WPS>), grid, dim3(NW * 64), kFastLdsBytes, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_das_fast(const FastArgs &a, int fpi, hipStream_t stream) {
-    if (fpi == 2) return launch_variant<kFastPPW, 2>(a, stream);
-    return launch_variant<kFastPPW, 1>(a, stream);
+hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream) {
+    if (nw == 16) {  // 1024-thread workgroups, 8 waves per SIMD: 64 VGPRs
+        if (ppw == 2) return launch_variant<16, 2, 1, 8>(a, stream);
+        return launch_variant<16, 4, 1, 8>(a, stream);
+    }
+    if (fpi == 2) {
+        if (ppw == 2) return launch_variant<8, 2, 2, 4>(a, stream);
+        return launch_variant<8, 4, 2, 4>(a, stream);
+    }
+    if (ppw == 2) return launch_variant<8, 2, 1, 4>(a, stream);
+    if (ppw == 4) return launch_variant<8, 4, 1, 4>(a, stream);
+    return launch_variant<8, 8, 1, 4>(a, stream);
 }
 
 }  // namespace awpu

@@ -32,8 +32,6 @@ struct SweepArgs {
 };
 
 // ---- fast kernel (das_fast.hip) ---------------------------------------------------------
-constexpr int kFastThreads = 512;        // 8 waves per workgroup
-constexpr int kFastPPW = 4;              // pixels per wave
 constexpr int kFastLdsBytes = 79 * 1024; // per workgroup: two workgroups share a CU's 160 KiB
 
 // One 16-byte entry per (pixel, active mic): what one item needs, laid out so that f and g
@@ -60,11 +58,13 @@ struct FastArgs {
     float *power;          // [batch][pixel_count]
     int32_t n_streams, hist, usable, usable_pad, pixel_count;
     int32_t wstart, wr, chunk, batch;
+    int32_t debug;  // timing experiments only (AWPU_FAST_DEBUG): 1 = stage first chunk only, 2 = skip the sweep
 };
 
 // LDS image geometry for a window of `window` samples; false if it cannot fit.
 bool fast_plan(int window, int usable, int fpi, FastPlan *plan);
-hipError_t launch_das_fast(const FastArgs &a, int fpi, hipStream_t stream);
+// fpi in {1,2} frames per item; ppw in {2,4,8} pixels per wave (8 only with fpi 1)
+hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream);
 
 // exact-order kernel (AWPU_MATH_F32_EXACT): sub, fma, add per sample, mics in order.
 hipError_t launch_das_exact(const SweepArgs &a, hipStream_t stream);
