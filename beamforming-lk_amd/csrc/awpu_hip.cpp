@@ -54,6 +54,7 @@ struct awpu_hip {
     awpu::FastEntry *d_fast_lut[3] = {nullptr, nullptr, nullptr};  // by frames-per-item (1, 2)
     awpu::FastPlan fast_plan[3] = {};
     int32_t *d_index = nullptr;
+    int32_t *d_row_off = nullptr;
     float *d_frames = nullptr;
     float *d_power = nullptr;
     size_t frames_cap = 0, power_cap = 0;  // in floats
@@ -73,6 +74,8 @@ void release_device(awpu_hip *h) {
         p = nullptr;
     }
     if (h->d_index) (void) hipFree(h->d_index);
+    if (h->d_row_off) (void) hipFree(h->d_row_off);
+    h->d_row_off = nullptr;
     if (h->d_frames) (void) hipFree(h->d_frames);
     if (h->d_power) (void) hipFree(h->d_power);
     h->d_lut = nullptr;
@@ -117,6 +120,16 @@ int prepare(awpu_hip *h) {
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
                            hipMemcpyHostToDevice));
+    {   // float offset, inside one frame, of staged row 2*s+q (copy q of active mic s)
+        if (h->d_row_off) (void) hipFree(h->d_row_off);
+        h->d_row_off = nullptr;
+        const int upad = (U + 3) & ~3;
+        std::vector<int32_t> ro((size_t) 2 * upad + 8, h->index[0] * c.hist + lo);
+        for (int s = 0; s < U; s++)
+            for (int q = 0; q < 2; q++) ro[2 * s + q] = h->index[s] * c.hist + lo + q;
+        AWPU_HIP_TRY(hipMalloc(&h->d_row_off, ro.size() * sizeof(int32_t)));
+        AWPU_HIP_TRY(hipMemcpy(h->d_row_off, ro.data(), ro.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
 
     if (c.math == AWPU_MATH_F32_EXACT) {
         int chunk = 0;
@@ -202,10 +215,10 @@ void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
     if (env_ppw == 2 || env_ppw == 4 || env_ppw == 8) *ppw = env_ppw;
     if (*fpi == 2 && *ppw == 8) *ppw = 4;
     if (*fpi == 2 && batch < 2) *fpi = 1;
-    *nw = env_nw == 16 ? 16 : 8;
-    if (*nw == 16) {
+    *nw = env_nw == 32 ? 32 : 8;
+    if (*nw == 32) {
         *fpi = 1;
-        if (*ppw > 4) *ppw = 4;
+        if (*ppw < 4) *ppw = 4;
     }
 }
 
@@ -233,10 +246,13 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
             if (rc != AWPU_OK) return rc;
         }
         const awpu::FastPlan &plan = h->fast_plan[fpi];
+        // the double-buffered shape reads whole 16-byte pieces of every staged row
+        if (nw == 32 && (!awpu::fast_db_fits(plan) || h->wstart + 1 + plan.wr > h->cfg.hist)) nw = 8;
         awpu::FastArgs a{};
         a.frames = d_frames;
         a.lut = h->d_fast_lut[fpi];
         a.index = h->d_index;
+        a.row_off = h->d_row_off;
         a.power = d_power;
         a.n_streams = h->cfg.n_streams;
         a.hist = h->cfg.hist;

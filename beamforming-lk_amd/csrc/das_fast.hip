@@ -99,6 +99,24 @@ __device__ __forceinline__ void sweep_group(Acc<FPI> &acc, const EntryGroup &e, 
     accumulate<FPI>(acc, r3, e.f(3), e.g(3));
 }
 
+#include "das_fast_trip.inc"
+
+// The items of one wave for one staged chunk: PPW pixels x ng groups of four, one frame per
+// item, each pixel through one hand-scheduled asm block (das_fast_trip.inc).
+template <bool LOW, int PPW>
+__device__ __forceinline__ void sweep_chunk_trips(Acc<1> (&acc)[PPW], const FastEntry *lut, int pix0, int n_pix,
+                                                  int usable_pad, int m0, int ng, unsigned lane_addr) {
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) {
+        const int p = pix0 + pp;
+        if (p < n_pix) {
+            const void *row = lut + (size_t) p * usable_pad + m0;
+            if (LOW) sweep_pixel_lo(acc[pp].A[0], acc[pp].Q[0], acc[pp].C[0], acc[pp].R[0], row, ng, lane_addr);
+            else sweep_pixel_hi(acc[pp].A[0], acc[pp].Q[0], acc[pp].C[0], acc[pp].R[0], row, ng, lane_addr);
+        }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
@@ -148,6 +166,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const char *lane_base = (const char *) lds + lane * 8;
+    // the same address as a 32-bit LDS offset, for the asm trips
+    const unsigned lane_addr = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lane_base;
     const int frame0 = blockIdx.x * FPI;  // frames vary fastest in dispatch order: the
     const int pix0 = (blockIdx.y * NW + wave) * PPW;  // workgroups of a tile share its table rows in L2
     const int wr = a.wr;
@@ -220,23 +240,23 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
         __syncthreads();
 
         if (!(a.debug & 2)) {  // debug bit 1: no sweep (staging only)
+            if constexpr (FPI == 1) {
+                sweep_chunk_trips<(WPS > 4), PPW>(acc, a.lut, pix0, a.pixel_count, a.usable_pad, m0, mc4 >> 2, lane_addr);
+            } else {
 #pragma unroll
-            for (int pp = 0; pp < PPW; pp++) {
-                const int p = pix0 + pp;
-                if (p < a.pixel_count) {
-                    const AWPU_AS4 i16 *grp = (const AWPU_AS4 i16 *) (lut + (size_t) p * a.usable_pad + m0);
-                    const int ng = mc4 >> 2;
-                    // Table entries travel one group ahead of their use (the table carries spare
-                    // groups at its end).  While a scalar load is pending every LDS wait is an
-                    // lgkmcnt(0), so a group is "issue all reads, wait, FMAs"; the other waves of
-                    // the SIMD fill the wait.  Two groups per trip: no register copies.
-                    EntryGroup e0, e1;
-                    e0.v = grp[0];
-                    for (int g = 0; g < ng; g += 2) {
-                        e1.v = grp[g + 1];
-                        sweep_group<FPI>(acc[pp], e0, lane_base);
-                        e0.v = grp[g + 2];
-                        if (g + 1 < ng) sweep_group<FPI>(acc[pp], e1, lane_base);
+                for (int pp = 0; pp < PPW; pp++) {
+                    const int p = pix0 + pp;
+                    if (p < a.pixel_count) {
+                        const AWPU_AS4 i16 *grp = (const AWPU_AS4 i16 *) (lut + (size_t) p * a.usable_pad + m0);
+                        const int ng = mc4 >> 2;
+                        EntryGroup e0, e1;
+                        e0.v = grp[0];
+                        for (int g = 0; g < ng; g += 2) {
+                            e1.v = grp[g + 1];
+                            sweep_group<FPI>(acc[pp], e0, lane_base);
+                            e0.v = grp[g + 2];
+                            if (g + 1 < ng) sweep_group<FPI>(acc[pp], e1, lane_base);
+                        }
                     }
                 }
             }
@@ -244,16 +264,21 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
             // 8*pp + k gathers it for pixel pp and the mics s = k (mod 8) of this chunk.  A lane's
             // partial sum therefore runs over the same mics in the same order whatever the chunk
             // size or pixels-per-wave, so results do not depend on the kernel shape.
-            for (int j0 = 0; j0 < mc4; j0 += 8) {
-                const int j = j0 + ((lane - m0 - j0) & 7);
-                if (tail_lane && j < mc4) {
-                    const FastEntry e = tail_row[m0 + j];
+            for (int j0 = 0; j0 < mc4; j0 += 32) {  // four passes per trip: their loads overlap
+                FastEntry e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + 8 * u + ((lane - m0) & 7);
+                    e[u] = tail_row[m0 + min(j, mc4 - 1)];
+                    if (!tail_lane || j >= mc4) e[u].g = 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
 #pragma unroll
                     for (int b = 0; b < FPI; b++) {
-                        const float x = lds[(e.addr + 1024u + (unsigned) (b * FS)) >> 2];
-                        tail[b] = __builtin_fmaf(e.g, x, tail[b]);
+                        const float x = lds[(e[u].addr + 1024u + (unsigned) (b * FS)) >> 2];
+                        tail[b] = __builtin_fmaf(e[u].g, x, tail[b]);
                     }
-                }
             }
         }
     }
@@ -277,6 +302,117 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
                     a.power[(size_t) (frame0 + b) * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Double-buffered shape for full grids: ONE 16-wave workgroup per CU, two LDS buffers.
+// While chunk c is swept out of buffer c&1, the global loads of chunk c+1 are already in flight
+// into registers; they are written to the other buffer after the sweep, then one barrier.
+// Staging is by 16-byte pieces of the flat [mic][copy][wr] image: piece -> (row, column) is the
+// same for every chunk, so each thread decodes its pieces once per launch.
+// ---------------------------------------------------------------------------------------
+constexpr int kDbThreads = 1024;
+constexpr int kDbPieces = 5;  // 16-byte pieces per thread and chunk: 5 * 1024 * 16 = 80 KiB >= one buffer
+
+template <int PPW>
+__global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = kDbThreads / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int frame = blockIdx.x;
+    const int pix0 = (blockIdx.y * NW + wave) * PPW;
+    const int wr = a.wr;
+    const int wr4 = wr >> 2;  // 16-byte pieces per row
+    const float *frame_base = a.frames + (size_t) frame * a.n_streams * a.hist;
+
+    // this thread's pieces: row (= 2*mic_slot + copy) and float column inside the row
+    int piece_rc[kDbPieces];  // row << 16 | column
+#pragma unroll
+    for (int k = 0; k < kDbPieces; k++) {
+        const int piece = threadIdx.x + k * kDbThreads;
+        const int row = piece / wr4;
+        piece_rc[k] = (row << 16) | ((piece - row * wr4) * 4);
+    }
+
+    Acc<1> acc[PPW];
+    float tail = 0.0f;
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) acc[pp].A[0] = acc[pp].Q[0] = acc[pp].C[0] = acc[pp].R[0] = f2{0.0f, 0.0f};
+    const int tail_pp = lane >> 3;
+    const bool tail_lane = tail_pp < PPW && pix0 + tail_pp < a.pixel_count;
+    const FastEntry *tail_row = a.lut + (size_t) (pix0 + (tail_lane ? tail_pp : 0)) * a.usable_pad;
+
+    f4 stage[kDbPieces];
+    auto load_chunk = [&](int m0, int mc) {
+        const int rows = 2 * mc;
+#pragma unroll
+        for (int k = 0; k < kDbPieces; k++) {
+            const int row = piece_rc[k] >> 16;
+            if (row < rows) {
+                // row_off[2*s + q] = index[s]*hist + wstart + q (floats); the host only picks this
+                // kernel when every 16-byte piece of every row lies inside the history
+                const int off = a.row_off[2 * m0 + row];
+                stage[k] = *(const f4u *) (frame_base + off + (piece_rc[k] & 0xffff));
+            }
+        }
+    };
+    auto store_chunk = [&](int mc, int buf) {
+        const int rows = 2 * mc;
+        float *dst = lds + buf * (kFastLdsBytes / 4);
+#pragma unroll
+        for (int k = 0; k < kDbPieces; k++) {
+            if ((piece_rc[k] >> 16) < rows) *(f4 *) (dst + (threadIdx.x + k * kDbThreads) * 4) = stage[k];
+        }
+    };
+
+    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
+    load_chunk(0, min(a.chunk, a.usable));
+    store_chunk(min(a.chunk, a.usable), 0);
+    __syncthreads();
+
+    for (int c = 0; c < n_chunks; c++) {
+        const int m0 = c * a.chunk;
+        const int mc = min(a.chunk, a.usable - m0);
+        const int mc4 = (mc + 3) & ~3;
+        const int buf = c & 1;
+        const bool more = c + 1 < n_chunks;
+        const int m1 = m0 + a.chunk;
+        const int mc_next = more ? min(a.chunk, a.usable - m1) : 0;
+        if (more) load_chunk(m1, mc_next);  // in flight during the sweep below
+
+        const unsigned lane_addr = lds_base + buf * kFastLdsBytes + lane * 8;
+        sweep_chunk_trips<false, PPW>(acc, a.lut, pix0, a.pixel_count, a.usable_pad, m0, mc4 >> 2, lane_addr);
+        // the 257th sample of every window: see das_fast_kernel
+        const float *buf_f = lds + buf * (kFastLdsBytes / 4);
+        for (int j0 = 0; j0 < mc4; j0 += 32) {
+            FastEntry e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 8 * u + ((lane - m0) & 7);
+                e[u] = tail_row[m0 + min(j, mc4 - 1)];
+                if (!tail_lane || j >= mc4) e[u].g = 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) tail = __builtin_fmaf(e[u].g, buf_f[(e[u].addr + 1024u) >> 2], tail);
+        }
+        if (more) store_chunk(mc_next, buf ^ 1);
+        __syncthreads();
+    }
+
+    tail += __shfl_xor(tail, 1);
+    tail += __shfl_xor(tail, 2);
+    tail += __shfl_xor(tail, 4);
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) {
+        const int p = pix0 + pp;
+        if (p < a.pixel_count) {
+            const float t = __shfl(tail, pp * 8);
+            const float sum = finish_pixel(acc[pp].A[0], acc[pp].Q[0], acc[pp].C[0], acc[pp].R[0], t, lane);
+            if (lane == 0) a.power[(size_t) frame * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
         }
     }
 }
@@ -319,10 +455,31 @@ static hipError_t launch_variant(const FastArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int PPW>
+static hipError_t launch_db(const FastArgs &a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *) das_fast_db_kernel<PPW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFastLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int pix_per_block = (kDbThreads / 64) * PPW;
+    dim3 grid(a.batch, (a.pixel_count + pix_per_block - 1) / pix_per_block);
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((das_fast_db_kernel<PPW>), grid, dim3(kDbThreads), 2 * kFastLdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+bool fast_db_fits(const FastPlan &plan) {
+    // every 16-byte piece of a full chunk must have a thread slot
+    return (size_t) plan.chunk * 2 * plan.row_bytes <= (size_t) kDbPieces * kDbThreads * 16;
+}
+
 hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream) {
-    if (nw == 16) {  // 1024-thread workgroups, 8 waves per SIMD: 64 VGPRs
-        if (ppw == 2) return launch_variant<16, 2, 1, 8>(a, stream);
-        return launch_variant<16, 4, 1, 8>(a, stream);
+    if (nw == 32) {  // double-buffered, one 16-wave workgroup per CU
+        if (ppw == 4) return launch_db<4>(a, stream);
+        return launch_db<8>(a, stream);
     }
     if (fpi == 2) {
         if (ppw == 2) return launch_variant<8, 2, 2, 4>(a, stream);

@@ -55,6 +55,7 @@ struct FastArgs {
     const float *frames;   // [batch][n_streams][hist]
     const FastEntry *lut;  // [pixel_count][usable_pad] (+ one spare group)
     const int32_t *index;  // [usable]
+    const int32_t *row_off;  // [2*usable_pad + spare] float offset of staged row 2*s+q in a frame
     float *power;          // [batch][pixel_count]
     int32_t n_streams, hist, usable, usable_pad, pixel_count;
     int32_t wstart, wr, chunk, batch;
@@ -64,7 +65,10 @@ struct FastArgs {
 // LDS image geometry for a window of `window` samples; false if it cannot fit.
 bool fast_plan(int window, int usable, int fpi, FastPlan *plan);
 // fpi in {1,2} frames per item; ppw in {2,4,8} pixels per wave (8 only with fpi 1)
+// nw: 8 or 16 waves per workgroup (two workgroups per CU), or 32 = the double-buffered
+// 16-wave shape with one workgroup per CU (fpi 1 only)
 hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream);
+bool fast_db_fits(const FastPlan &plan);
 
 // exact-order kernel (AWPU_MATH_F32_EXACT): sub, fma, add per sample, mics in order.
 hipError_t launch_das_exact(const SweepArgs &a, hipStream_t stream);
