@@ -174,7 +174,10 @@ int build_fast_lut(awpu_hip *h, int fpi) {
     const int U = h->usable(), P = c.pixel_count;
     awpu::FastPlan plan;
     if (!awpu::fast_plan(h->window, U, fpi, &plan)) return invalid("delay window does not fit the LDS budget");
-    const size_t n = (size_t) P * plan.usable_pad + 8;  // + spare groups: the kernel prefetches one ahead
+    // rows for whole pixel tiles (the kernels sweep every pixel slot of a workgroup; slots past the
+    // grid get null rows) + spare groups: the kernels prefetch entries past the row they sweep
+    const int P_pad = (P + 127) / 128 * 128;
+    const size_t n = (size_t) P_pad * plan.usable_pad + 16;
     std::vector<awpu::FastEntry> packed(n, awpu::FastEntry{0.0f, 0u, 0.0f, 0u});
     for (int p = 0; p < P; p++) {
         const int32_t *orow = &h->off[(size_t) p * c.lut_stride];
@@ -265,6 +268,28 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         a.batch = batch;
         static const int debug = std::getenv("AWPU_FAST_DEBUG") ? std::atoi(std::getenv("AWPU_FAST_DEBUG")) : 0;
         a.debug = debug;
+        a.debug_out = nullptr;
+        if (debug & 16) {  // diagnostics: dump per-wave cycle sums of the last launch to stderr
+            static unsigned long long *d_dbg = nullptr;
+            const size_t n_waves = (size_t) 16 * batch * ((h->cfg.pixel_count + 16 * ppw - 1) / (16 * ppw));
+            if (!d_dbg) AWPU_HIP_TRY(hipMalloc(&d_dbg, n_waves * 12 * sizeof(unsigned long long)));
+            a.debug_out = d_dbg;
+            AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, s));
+            AWPU_HIP_TRY(hipStreamSynchronize(s));
+            std::vector<unsigned long long> hbuf(n_waves * 12);
+            AWPU_HIP_TRY(hipMemcpy(hbuf.data(), d_dbg, hbuf.size() * 8, hipMemcpyDeviceToHost));
+            double w = 0, al = 0, tot = 0, nb = 0;
+            double ph[5] = {0, 0, 0, 0, 0};
+            for (size_t i = 0; i < n_waves; i++) {
+                w += hbuf[12*i]; al += hbuf[12*i+1]; tot += hbuf[12*i+2]; nb += hbuf[12*i+3];
+                for (int k = 0; k < 5; k++) ph[k] += hbuf[12*i+4+k];
+            }
+            std::fprintf(stderr, "[awpu diag] per wave cycles: load-issue %.0f  sweep %.0f  tail %.0f  store %.0f  barrier %.0f\n",
+                         ph[0] / n_waves, ph[1] / n_waves, ph[2] / n_waves, ph[3] / n_waves, ph[4] / n_waves);
+            std::fprintf(stderr, "[awpu diag] waves %zu: per wave cycles total %.0f, in sweep blocks %.0f (%.1f%%), first table wait %.0f (%.1f%%); per block %.0f cycles, wait %.0f\n",
+                         n_waves, tot / n_waves, al / n_waves, 100 * al / tot, w / n_waves, 100 * w / tot, al / nb, w / nb);
+            return AWPU_OK;
+        }
         if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
         AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, s));
     }

@@ -103,17 +103,45 @@ __device__ __forceinline__ void sweep_group(Acc<FPI> &acc, const EntryGroup &e, 
 
 // The items of one wave for one staged chunk: PPW pixels x ng groups of four, one frame per
 // item, each pixel through one hand-scheduled asm block (das_fast_trip.inc).
-template <bool LOW, int PPW>
-__device__ __forceinline__ void sweep_chunk_trips(Acc<1> (&acc)[PPW], const FastEntry *lut, int pix0, int n_pix,
+// The items of one wave for one staged chunk: PPW pixels x ng groups of four, one frame per
+// item, through the hand-scheduled asm blocks (das_fast_trip.inc), four pixels per block where
+// PPW allows.  Pixels past the grid are swept too: the table has null rows for them.
+template <int PPW>
+__device__ __forceinline__ void sweep_chunk_trips(Acc<1> (&acc)[PPW], const FastEntry *lut, int pix0,
                                                   int usable_pad, int m0, int ng, unsigned lane_addr) {
+    const int stride = usable_pad * (int) sizeof(FastEntry);
+    if constexpr (PPW % 4 == 0) {
 #pragma unroll
-    for (int pp = 0; pp < PPW; pp++) {
-        const int p = pix0 + pp;
-        if (p < n_pix) {
-            const void *row = lut + (size_t) p * usable_pad + m0;
-            if (LOW) sweep_pixel_lo(acc[pp].A[0], acc[pp].Q[0], acc[pp].C[0], acc[pp].R[0], row, ng, lane_addr);
-            else sweep_pixel_hi(acc[pp].A[0], acc[pp].Q[0], acc[pp].C[0], acc[pp].R[0], row, ng, lane_addr);
+        for (int q = 0; q < PPW; q += 4) {
+            const void *row = lut + (size_t) (pix0 + q) * usable_pad + m0;
+            sweep_quad_hi(acc[q].A[0], acc[q].Q[0], acc[q].C[0], acc[q].R[0],
+                          acc[q + 1].A[0], acc[q + 1].Q[0], acc[q + 1].C[0], acc[q + 1].R[0],
+                          acc[q + 2].A[0], acc[q + 2].Q[0], acc[q + 2].C[0], acc[q + 2].R[0],
+                          acc[q + 3].A[0], acc[q + 3].Q[0], acc[q + 3].C[0], acc[q + 3].R[0], row, stride, ng, lane_addr);
         }
+    } else {
+#pragma unroll
+        for (int pp = 0; pp < PPW; pp++) {
+            const void *row = lut + (size_t) (pix0 + pp) * usable_pad + m0;
+            sweep_pixel_hi(acc[pp].A[0], acc[pp].Q[0], acc[pp].C[0], acc[pp].R[0], row, stride, ng, lane_addr);
+        }
+    }
+}
+
+template <int PPW>
+__device__ __forceinline__ void sweep_chunk_stamped(Acc<1> (&acc)[PPW], const FastEntry *lut, int pix0,
+                                                    int usable_pad, int m0, int ng, unsigned lane_addr,
+                                                    unsigned &t_wait, unsigned &t_all) {
+    static_assert(PPW % 4 == 0, "diagnostic build: quads only");
+    const int stride = usable_pad * (int) sizeof(FastEntry);
+#pragma unroll
+    for (int q = 0; q < PPW; q += 4) {
+        const void *row = lut + (size_t) (pix0 + q) * usable_pad + m0;
+        sweep_quad_stamped(acc[q].A[0], acc[q].Q[0], acc[q].C[0], acc[q].R[0],
+                           acc[q + 1].A[0], acc[q + 1].Q[0], acc[q + 1].C[0], acc[q + 1].R[0],
+                           acc[q + 2].A[0], acc[q + 2].Q[0], acc[q + 2].C[0], acc[q + 2].R[0],
+                           acc[q + 3].A[0], acc[q + 3].Q[0], acc[q + 3].C[0], acc[q + 3].R[0], row, stride, ng,
+                           lane_addr, t_wait, t_all);
     }
 }
 
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
 
         if (!(a.debug & 2)) {  // debug bit 1: no sweep (staging only)
             if constexpr (FPI == 1) {
-                sweep_chunk_trips<(WPS > 4), PPW>(acc, a.lut, pix0, a.pixel_count, a.usable_pad, m0, mc4 >> 2, lane_addr);
+                sweep_chunk_trips<PPW>(acc, a.lut, pix0, a.usable_pad, m0, mc4 >> 2, lane_addr);
             } else {
 #pragma unroll
                 for (int pp = 0; pp < PPW; pp++) {
@@ -316,7 +344,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
 constexpr int kDbThreads = 1024;
 constexpr int kDbPieces = 5;  // 16-byte pieces per thread and chunk: 5 * 1024 * 16 = 80 KiB >= one buffer
 
-template <int PPW>
+template <int PPW, bool DIAG>
 __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = kDbThreads / 64;
@@ -329,6 +357,11 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
     const int wr4 = wr >> 2;  // 16-byte pieces per row
     const float *frame_base = a.frames + (size_t) frame * a.n_streams * a.hist;
 
+    // float offset of every staged row inside a frame, kept in LDS behind the two buffers so that
+    // the per-chunk address of a piece needs no dependent global load
+    int *row_off_lds = (int *) (lds + 2 * (kFastLdsBytes / 4));
+    for (int i = threadIdx.x; i < 2 * a.usable_pad; i += kDbThreads) row_off_lds[i] = a.row_off[i];
+
     // this thread's pieces: row (= 2*mic_slot + copy) and float column inside the row
     int piece_rc[kDbPieces];  // row << 16 | column
 #pragma unroll
@@ -337,6 +370,7 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
         const int row = piece / wr4;
         piece_rc[k] = (row << 16) | ((piece - row * wr4) * 4);
     }
+    __syncthreads();
 
     Acc<1> acc[PPW];
     float tail = 0.0f;
@@ -346,34 +380,39 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
     const bool tail_lane = tail_pp < PPW && pix0 + tail_pp < a.pixel_count;
     const FastEntry *tail_row = a.lut + (size_t) (pix0 + (tail_lane ? tail_pp : 0)) * a.usable_pad;
 
-    f4 stage[kDbPieces];
-    auto load_chunk = [&](int m0, int mc) {
+    // LDS-DMA staging: lane l of a wave writes 16 bytes at (wave-uniform base) + 16*l, which is
+    // exactly piece (threadIdx.x + k*1024) of the flat image; the source address is per lane.
+    auto dma_chunk = [&](int m0, int mc, int buf) {
         const int rows = 2 * mc;
 #pragma unroll
         for (int k = 0; k < kDbPieces; k++) {
             const int row = piece_rc[k] >> 16;
             if (row < rows) {
-                // row_off[2*s + q] = index[s]*hist + wstart + q (floats); the host only picks this
-                // kernel when every 16-byte piece of every row lies inside the history
-                const int off = a.row_off[2 * m0 + row];
-                stage[k] = *(const f4u *) (frame_base + off + (piece_rc[k] & 0xffff));
+                const int off = row_off_lds[2 * m0 + row];
+                const float *src = frame_base + off + (piece_rc[k] & 0xffff);
+                float *dst = lds + buf * (kFastLdsBytes / 4) + (wave * 64 + k * kDbThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
             }
         }
     };
-    auto store_chunk = [&](int mc, int buf) {
-        const int rows = 2 * mc;
-        float *dst = lds + buf * (kFastLdsBytes / 4);
-#pragma unroll
-        for (int k = 0; k < kDbPieces; k++) {
-            if ((piece_rc[k] >> 16) < rows) *(f4 *) (dst + (threadIdx.x + k * kDbThreads) * 4) = stage[k];
-        }
-    };
 
+    unsigned t_wait = 0, t_all = 0;
+    const long long t_begin = __builtin_readcyclecounter();
     const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
-    load_chunk(0, min(a.chunk, a.usable));
-    store_chunk(min(a.chunk, a.usable), 0);
+    dma_chunk(0, min(a.chunk, a.usable), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    unsigned t_ph[5] = {0, 0, 0, 0, 0};  // diagnostics: load issue, sweep, tail, store, barrier
+    constexpr bool diag = DIAG;
+    auto stamp = [&](int k, long long &t) {
+        if (diag) {
+            const long long n = __builtin_readcyclecounter();
+            t_ph[k] += (unsigned) (n - t);
+            t = n;
+        }
+    };
     for (int c = 0; c < n_chunks; c++) {
         const int m0 = c * a.chunk;
         const int mc = min(a.chunk, a.usable - m0);
@@ -382,13 +421,20 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
         const bool more = c + 1 < n_chunks;
         const int m1 = m0 + a.chunk;
         const int mc_next = more ? min(a.chunk, a.usable - m1) : 0;
-        if (more) load_chunk(m1, mc_next);  // in flight during the sweep below
+        long long t = diag ? __builtin_readcyclecounter() : 0;
+        if (more && !(a.debug & 1)) dma_chunk(m1, mc_next, buf ^ 1);  // lands during the sweep below
+        stamp(0, t);
 
         const unsigned lane_addr = lds_base + buf * kFastLdsBytes + lane * 8;
-        sweep_chunk_trips<false, PPW>(acc, a.lut, pix0, a.pixel_count, a.usable_pad, m0, mc4 >> 2, lane_addr);
+        if constexpr (DIAG) {
+            sweep_chunk_stamped<PPW>(acc, a.lut, pix0, a.usable_pad, m0, mc4 >> 2, lane_addr, t_wait, t_all);
+        } else if (!(a.debug & 2)) {
+            sweep_chunk_trips<PPW>(acc, a.lut, pix0, a.usable_pad, m0, mc4 >> 2, lane_addr);
+        }
+        stamp(1, t);
         // the 257th sample of every window: see das_fast_kernel
         const float *buf_f = lds + buf * (kFastLdsBytes / 4);
-        for (int j0 = 0; j0 < mc4; j0 += 32) {
+        for (int j0 = 0; j0 < ((a.debug & 4) ? 0 : mc4); j0 += 32) {
             FastEntry e[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -399,10 +445,22 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
 #pragma unroll
             for (int u = 0; u < 4; u++) tail = __builtin_fmaf(e[u].g, buf_f[(e[u].addr + 1024u) >> 2], tail);
         }
-        if (more) store_chunk(mc_next, buf ^ 1);
-        __syncthreads();
+        if (diag) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(2, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next chunk are in LDS
+        stamp(3, t);
+        if (!(a.debug & 8)) __syncthreads();
+        stamp(4, t);
     }
 
+    if (DIAG && a.debug_out && lane == 0) {  // diagnostics: per-wave cycle sums
+        unsigned long long *o = a.debug_out + 12 * ((size_t) (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+        o[0] = t_wait;
+        o[1] = t_all;
+        o[2] = (unsigned long long) (__builtin_readcyclecounter() - t_begin);
+        o[3] = (unsigned long long) n_chunks * PPW;
+        for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
+    }
     tail += __shfl_xor(tail, 1);
     tail += __shfl_xor(tail, 2);
     tail += __shfl_xor(tail, 4);
@@ -455,31 +513,33 @@ static hipError_t launch_variant(const FastArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int PPW>
+template <int PPW, bool DIAG>
 static hipError_t launch_db(const FastArgs &a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *) das_fast_db_kernel<PPW>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFastLdsBytes);
+        hipError_t e = hipFuncSetAttribute((const void *) das_fast_db_kernel<PPW, DIAG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFastLdsBytes + kFastSideBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int pix_per_block = (kDbThreads / 64) * PPW;
     dim3 grid(a.batch, (a.pixel_count + pix_per_block - 1) / pix_per_block);
     if (grid.y > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((das_fast_db_kernel<PPW>), grid, dim3(kDbThreads), 2 * kFastLdsBytes, stream, a);
+    hipLaunchKernelGGL((das_fast_db_kernel<PPW, DIAG>), grid, dim3(kDbThreads), 2 * kFastLdsBytes + kFastSideBytes, stream, a);
     return hipGetLastError();
 }
 
 bool fast_db_fits(const FastPlan &plan) {
     // every 16-byte piece of a full chunk must have a thread slot
-    return (size_t) plan.chunk * 2 * plan.row_bytes <= (size_t) kDbPieces * kDbThreads * 16;
+    return (size_t) plan.chunk * 2 * plan.row_bytes <= (size_t) kDbPieces * kDbThreads * 16 &&
+           (size_t) 2 * plan.usable_pad * sizeof(int) <= (size_t) kFastSideBytes;
 }
 
 hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream) {
     if (nw == 32) {  // double-buffered, one 16-wave workgroup per CU
-        if (ppw == 4) return launch_db<4>(a, stream);
-        return launch_db<8>(a, stream);
+        if (a.debug & 16) return ppw == 4 ? launch_db<4, true>(a, stream) : launch_db<8, true>(a, stream);
+        if (ppw == 4) return launch_db<4, false>(a, stream);
+        return launch_db<8, false>(a, stream);
     }
     if (fpi == 2) {
         if (ppw == 2) return launch_variant<8, 2, 2, 4>(a, stream);

@@ -32,7 +32,8 @@ struct SweepArgs {
 };
 
 // ---- fast kernel (das_fast.hip) ---------------------------------------------------------
-constexpr int kFastLdsBytes = 79 * 1024; // per workgroup: two workgroups share a CU's 160 KiB
+constexpr int kFastLdsBytes = 78 * 1024; // one staged image; a CU holds two (+ a 4 KiB side table)
+constexpr int kFastSideBytes = 4 * 1024;
 
 // One 16-byte entry per (pixel, active mic): what one item needs, laid out so that f and g
 // start even SGPRs after an s_load_dwordx16 (packed-FMA scalar operands are aligned pairs).
@@ -59,6 +60,7 @@ struct FastArgs {
     float *power;          // [batch][pixel_count]
     int32_t n_streams, hist, usable, usable_pad, pixel_count;
     int32_t wstart, wr, chunk, batch;
+    unsigned long long *debug_out;  // diagnostics (debug bit 16): 4 words per wave
     int32_t debug;  // timing experiments only (AWPU_FAST_DEBUG): 1 = stage first chunk only, 2 = skip the sweep
 };
 

@@ -1,36 +1,51 @@
 #!/usr/bin/env python3
 """Generate beamforming-lk_amd/csrc/das_fast_trip.inc: the hand-scheduled inner loop of the
-fast sweep kernel (das_fast.hip) -- one asm block = all items of ONE pixel in the staged chunk.
+fast sweep kernel (das_fast.hip).
 
 An item (pixel x mic, one frame) costs
     v_add_u32 (LDS address) ; 2 x ds_read_b64 ; 4 x v_pk_fma_f32
-and a "trip" is 8 consecutive items whose table entries (f, addr, g, pad: 4 dwords each) sit in
-32 SGPRs.  Two SGPR sets ping-pong: while a trip runs out of one set, two s_load_dwordx16 fill
-the other with the next trip's entries.
+and a "trip" is 8 consecutive items of one pixel (or 4: a pixel's last, odd group) whose table
+entries (f, addr, g, pad: 4 dwords each) sit in 32 SGPRs.  Two SGPR sets ping-pong: while a trip
+runs out of one set, two s_load_dwordx16 fill the other with the entries of the NEXT trip -- of
+the same pixel, or the first trip of the next pixel, so that a wave meets the scalar-load latency
+once per asm block, not once per pixel.
 
-Schedule inside a trip: LDS reads run DEPTH items ahead of the FMAs that consume them; every
-wait is a counted s_waitcnt lgkmcnt(n) with n = the number of YOUNGER LDS reads of this wave.
-Scalar loads share that counter and may return out of order, but since n never budgets for them
-a pending scalar load can only make a wait longer, never let it pass early.  Each trip ends on
-lgkmcnt(0), which is also what proves the other SGPR set has landed.
+Schedule inside a trip: LDS reads run DEPTH items ahead of the FMAs that consume them; every wait
+is a counted s_waitcnt lgkmcnt(n) with n = the number of YOUNGER LDS reads of this wave.  Scalar
+loads share that counter and may return out of order, but since n never budgets for them a pending
+scalar load can only make a wait longer, never let it pass early.  Each trip ends on lgkmcnt(0),
+which is also what proves the other SGPR set has landed.
+
+Block flavours:
+  sweep_pixel_hi      one pixel per block
+  sweep_quad_hi       four pixels per block (rows `stride` bytes apart in the table)
+  sweep_quad_stamped  the same with s_memtime stamps (diagnostic builds only)
 
 Fixed registers (all in the clobber list, so hipcc keeps nothing of its own there):
-    SGPR  s[36:67] set X, s[68:99] set Y, s34 trip counter, s35 byte offset into the table row
-    VGPR  five read slots of 4 registers + 1 address temp, from `vbase`
-The block is self-contained: it begins with none of its own loads pending and ends drained, so
-the compiler never sees a register with a load in flight.
+    SGPR  s[36:67] set X, s[68:99] set Y, s28..s35 loop state
+    VGPR  DEPTH+1 read slots of 4 registers + 1 address temp, from `vbase`
+A block is self-contained: it begins with none of its own loads pending and ends drained, so the
+compiler never sees a register with a load in flight.
 """
+import os
 from pathlib import Path
 
-DEPTH = 4  # items of LDS read-ahead
+DEPTH = int(os.environ.get("TRIP_DEPTH", "4"))  # items of LDS read-ahead (2*DEPTH <= 15: lgkmcnt is 4 bits)
 SET = {"X": 36, "Y": 68}
-CNT, OFF = 34, 35
+OTHER = {"X": "Y", "Y": "X"}
+# loop state: s[28:29] stamp t0, s[30:31] temp pair, s32 row offset, s33 groups left,
+# s34 refill offset, s35 offset of the entries after the loaded ones
+S_T0, S_T1, S_ROW, S_LEFT, S_PF, S_OFF = 28, 30, 32, 33, 34, 35
 
 
-def trip(n_items, sbase, vbase, prefetch_into=None):
-    """Lines of one trip over `n_items` entries held at s[sbase...]."""
+def trip(n_items, cur, vbase, acc):
+    """One trip over `n_items` entries held in set `cur`; the other set is refilled from table
+    byte offset s{S_PF} (two s_load_dwordx16), after which s{S_OFF} = s{S_PF} + 128."""
+    sbase = SET[cur]
+    pbase = SET[OTHER[cur]]
     slots = DEPTH + 1
     addr_t = vbase + 4 * slots
+    A, Q, C, R = acc
 
     def fpair(i):
         return f"s[{sbase + 4 * i}:{sbase + 4 * i + 1}]"
@@ -47,19 +62,18 @@ def trip(n_items, sbase, vbase, prefetch_into=None):
     def fma(i):
         s = vbase + 4 * (i % slots)
         x, y = f"v[{s}:{s + 1}]", f"v[{s + 2}:{s + 3}]"
-        return [f"v_pk_fma_f32 %[A], {fpair(i)}, {x}, %[A] op_sel_hi:[0,1,1]",
-                f"v_pk_fma_f32 %[Q], {gpair(i)}, {x}, %[Q] op_sel_hi:[0,1,1]",
-                f"v_pk_fma_f32 %[C], {fpair(i)}, {y}, %[C] op_sel_hi:[0,1,1]",
-                f"v_pk_fma_f32 %[R], {gpair(i)}, {y}, %[R] op_sel_hi:[0,1,1]"]
+        return [f"v_pk_fma_f32 {A}, {fpair(i)}, {x}, {A} op_sel_hi:[0,1,1]",
+                f"v_pk_fma_f32 {Q}, {gpair(i)}, {x}, {Q} op_sel_hi:[0,1,1]",
+                f"v_pk_fma_f32 {C}, {fpair(i)}, {y}, {C} op_sel_hi:[0,1,1]",
+                f"v_pk_fma_f32 {R}, {gpair(i)}, {y}, {R} op_sel_hi:[0,1,1]"]
 
     lines = []
     for i in range(min(DEPTH, n_items)):
         lines += issue(i)
-    if prefetch_into is not None:  # next trip's entries; s35 already points at them
-        lines += [f"s_load_dwordx16 s[{prefetch_into}:{prefetch_into + 15}], %[ptr], s{OFF}",
-                  f"s_add_u32 s{OFF}, s{OFF}, 64",
-                  f"s_load_dwordx16 s[{prefetch_into + 16}:{prefetch_into + 31}], %[ptr], s{OFF}",
-                  f"s_add_u32 s{OFF}, s{OFF}, 64"]
+    lines += [f"s_load_dwordx16 s[{pbase}:{pbase + 15}], %[ptr], s{S_PF}",
+              f"s_add_u32 s{S_OFF}, s{S_PF}, 64",
+              f"s_load_dwordx16 s[{pbase + 16}:{pbase + 31}], %[ptr], s{S_OFF}",
+              f"s_add_u32 s{S_OFF}, s{S_PF}, 128"]
     for k in range(n_items):
         if k + DEPTH < n_items:
             lines += issue(k + DEPTH)
@@ -69,59 +83,92 @@ def trip(n_items, sbase, vbase, prefetch_into=None):
     return lines
 
 
-def pixel_block(name, vbase):
-    """asm block: ng groups of four items starting at table address %[ptr]."""
-    x, y = SET["X"], SET["Y"]
+def next_pixel_setup(last_pixel):
+    if last_pixel:
+        return []
+    return [f"s_add_u32 s{S_ROW}, s{S_ROW}, %[stride]",
+            f"s_mov_b32 s{S_LEFT}, %[ng]"]  # s{S_OFF} was set by the refill: new row + 128
+
+
+def pixel_code(j, n_pix, vbase, acc):
+    """State machine of pixel j.  On entry at LPj_X / LPj_Y the named set holds the pixel's next
+    entries, s{S_LEFT} = groups of four left (>= 1), s{S_OFF} = table offset of the entries after
+    those, s{S_ROW} = table offset of this pixel's row."""
+    last_pixel = j == n_pix - 1
     L = []
+    for cur in ("X", "Y"):
+        oth = OTHER[cur]
+        nxt_entry = ".Ldone_%=" if last_pixel else f".LP{j + 1}_{oth}_%="
+        L += [f".LP{j}_{cur}_%=:",
+              f"s_cmp_lt_u32 s{S_LEFT}, 2",
+              f"s_cbranch_scc1 .LP{j}_{cur}_half_%=",
+              # full trip; if it is this pixel's last, the refill comes from the next pixel's row
+              f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 2",
+              f"s_add_u32 s{S_T1}, s{S_ROW}, %[stride]",
+              f"s_cmp_eq_u32 s{S_LEFT}, 0",
+              f"s_cselect_b32 s{S_PF}, s{S_T1}, s{S_OFF}"]
+        L += trip(8, cur, vbase, acc)
+        L += [f"s_cmp_lg_u32 s{S_LEFT}, 0",
+              f"s_cbranch_scc1 .LP{j}_{oth}_%="]
+        # pixel finished on a full trip: the other set holds the next pixel's first entries
+        L += next_pixel_setup(last_pixel) + [f"s_branch {nxt_entry}"]
+        L += [f".LP{j}_{cur}_half_%=:",
+              f"s_add_u32 s{S_PF}, s{S_ROW}, %[stride]"]
+        L += trip(4, cur, vbase, acc)
+        L += next_pixel_setup(last_pixel) + [f"s_branch {nxt_entry}"]
+    return L
+
+
+def block(name, n_pix, vbase, stamp=False):
+    x = SET["X"]
+    accs = [(f"%[A{j}]", f"%[Q{j}]", f"%[C{j}]", f"%[R{j}]") for j in range(n_pix)]
+    L = []
+    if stamp:
+        L += [f"s_memtime s[{S_T0}:{S_T0 + 1}]", "s_waitcnt lgkmcnt(0)"]
     L += [f"s_load_dwordx16 s[{x}:{x + 15}], %[ptr], 0x0",
           f"s_load_dwordx16 s[{x + 16}:{x + 31}], %[ptr], 0x40",
-          f"s_lshr_b32 s{CNT}, %[ng], 1",          # full trips
-          f"s_movk_i32 s{OFF}, 0x80",               # where the next trip's entries start
-          "s_waitcnt lgkmcnt(0)",
-          f"s_cmp_eq_u32 s{CNT}, 0",
-          "s_cbranch_scc1 .Lhalf_x_%="]
-    L += [".Ltrip_x_%=:"]
-    L += trip(8, x, vbase, prefetch_into=y)
-    L += [f"s_sub_u32 s{CNT}, s{CNT}, 1",
-          f"s_cmp_eq_u32 s{CNT}, 0",
-          "s_cbranch_scc1 .Lhalf_y_%="]
-    L += trip(8, y, vbase, prefetch_into=x)
-    L += [f"s_sub_u32 s{CNT}, s{CNT}, 1",
-          f"s_cmp_lg_u32 s{CNT}, 0",
-          "s_cbranch_scc1 .Ltrip_x_%="]
-    # odd number of groups: four more items, from the set that was filled last
-    L += [".Lhalf_x_%=:",
-          "s_bitcmp0_b32 %[ng], 0",
-          "s_cbranch_scc1 .Ldone_%="]
-    L += trip(4, x, vbase)
-    L += ["s_branch .Ldone_%=",
-          ".Lhalf_y_%=:",
-          "s_bitcmp0_b32 %[ng], 0",
-          "s_cbranch_scc1 .Ldone_%="]
-    L += trip(4, y, vbase)
+          f"s_mov_b32 s{S_LEFT}, %[ng]",
+          f"s_mov_b32 s{S_ROW}, 0",
+          f"s_movk_i32 s{S_OFF}, 0x80",
+          "s_waitcnt lgkmcnt(0)"]
+    if stamp:
+        L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)",
+              f"s_sub_u32 s{S_T1}, s{S_T1}, s{S_T0}", f"s_add_u32 %[t_wait], %[t_wait], s{S_T1}"]
+    for j in range(n_pix):
+        L += pixel_code(j, n_pix, vbase, accs[j])
     L += [".Ldone_%=:"]
+    if stamp:
+        L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)",
+              f"s_sub_u32 s{S_T1}, s{S_T1}, s{S_T0}", f"s_add_u32 %[t_all], %[t_all], s{S_T1}"]
 
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
     vregs = list(range(vbase, vbase + 4 * (DEPTH + 1) + 1))
-    sregs = [CNT, OFF] + list(range(SET["X"], SET["Y"] + 32))
+    sregs = list(range(S_T0, S_OFF + 1)) + list(range(SET["X"], SET["Y"] + 32))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
-    return f'''// all items of one pixel in the staged chunk: ng groups of four (ng >= 1), entries at `row`.
-// Reads the table up to two groups past the last one it uses (the table carries spare groups).
-// temps v{vregs[0]}..v{vregs[-1]}, s{CNT}, s{OFF}, s[{SET["X"]}:{SET["Y"] + 31}]
-__device__ __forceinline__ void {name}(f2 &A, f2 &Q, f2 &C, f2 &R, const void *row, int ng, unsigned lane_addr) {{
+    acc_params = ", ".join(f"f2 &A{j}, f2 &Q{j}, f2 &C{j}, f2 &R{j}" for j in range(n_pix))
+    acc_ops = ", ".join(f'[A{j}] "+v"(A{j}), [Q{j}] "+v"(Q{j}), [C{j}] "+v"(C{j}), [R{j}] "+v"(R{j})' for j in range(n_pix))
+    stamp_params = ", unsigned &t_wait, unsigned &t_all" if stamp else ""
+    stamp_ops = ', [t_wait] "+s"(t_wait), [t_all] "+s"(t_all)' if stamp else ""
+    return f'''// {n_pix} pixel(s) of the staged chunk, ng groups of four items each (ng >= 1); pixel j's entries
+// start at `row` + j * stride bytes.  Reads the table up to one row start + two groups past the
+// last row it sweeps (the table carries spare groups).
+// temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}
+__device__ __forceinline__ void {name}({acc_params}, const void *row, int stride, int ng, unsigned lane_addr{stamp_params}) {{
     asm volatile(
 {body}
-        : [A] "+v"(A), [Q] "+v"(Q), [C] "+v"(C), [R] "+v"(R)
-        : [ptr] "s"(row), [ng] "s"(ng), [lane] "v"(lane_addr)
+        : {acc_ops}{stamp_ops}
+        : [ptr] "s"(row), [stride] "s"(stride), [ng] "s"(ng), [lane] "v"(lane_addr)
         : {clobbers});
 }}
 '''
 
 
 def main():
+    hi = 128 - (4 * (DEPTH + 1) + 1) - 3
     out = ["// GENERATED by tools/gen_trip_asm.py -- do not edit.  See that script for the schedule.", ""]
-    out.append(pixel_block("sweep_pixel_hi", 104))  # kernels with a 128-VGPR budget
-    out.append(pixel_block("sweep_pixel_lo", 40))   # low temps, for shapes with few accumulators
+    out.append(block("sweep_pixel_hi", 1, hi))
+    out.append(block("sweep_quad_hi", 4, hi))
+    out.append(block("sweep_quad_stamped", 4, hi, stamp=True))
     path = Path(__file__).resolve().parent.parent / "beamforming-lk_amd" / "csrc" / "das_fast_trip.inc"
     path.write_text("\n".join(out))
     print("wrote", path, sum(1 for _ in path.read_text().splitlines()), "lines")
