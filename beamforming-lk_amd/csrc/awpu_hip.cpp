@@ -200,8 +200,9 @@ int build_fast_lut(awpu_hip *h, int fpi) {
     return AWPU_OK;
 }
 
-// Kernel shape for a call: frames per item and pixels per wave.  AWPU_FAST_VARIANT="fpi,ppw"
-// overrides the heuristic (tuning knob, read once).
+// Kernel shape for a call.  AWPU_FAST_VARIANT="fpi,ppw[,nw]" overrides the heuristic (tuning
+// knob, read once): fpi frames per item, ppw pixels per wave, nw = 8 (8-wave workgroups, two per
+// CU) or 32 (the double-buffered 16-wave shape, one per CU).
 void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
     static int env_fpi = -1, env_ppw = -1, env_nw = 0;
     if (env_fpi == -1) {
@@ -210,19 +211,30 @@ void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
             if (std::sscanf(v, "%d,%d,%d", &env_fpi, &env_ppw, &env_nw) < 2) env_fpi = env_ppw = env_nw = 0;
         }
     }
-    // few pixels per wave while the grid is too small to fill 256 CUs twice over
-    const long blocks8 = ((long) h->cfg.pixel_count + 63) / 64 * batch;
+    // Prefer the double-buffered shape with the most pixels per wave that still gives every CU
+    // a workgroup; small grids fall back to 8-wave workgroups with fewer pixels per wave.
+    const long P = h->cfg.pixel_count;
+    auto wgs = [&](long pix_per_wg) { return (P + pix_per_wg - 1) / pix_per_wg * batch; };
     *fpi = 1;
-    *ppw = blocks8 >= 1024 ? 8 : (blocks8 >= 256 ? 4 : 2);
+    if (wgs(128) >= 256) {
+        *nw = 32;
+        *ppw = 8;
+    } else if (wgs(64) >= 256) {
+        *nw = 32;
+        *ppw = 4;
+    } else {
+        *nw = 8;
+        *ppw = wgs(32) >= 512 ? 4 : 2;
+    }
     if (env_fpi == 1 || env_fpi == 2) *fpi = env_fpi;
     if (env_ppw == 2 || env_ppw == 4 || env_ppw == 8) *ppw = env_ppw;
-    if (*fpi == 2 && *ppw == 8) *ppw = 4;
-    if (*fpi == 2 && batch < 2) *fpi = 1;
-    *nw = env_nw == 32 ? 32 : 8;
+    if (env_nw == 8 || env_nw == 32) *nw = env_nw;
     if (*nw == 32) {
         *fpi = 1;
         if (*ppw < 4) *ppw = 4;
     }
+    if (*fpi == 2 && *ppw == 8) *ppw = 4;
+    if (*fpi == 2 && batch < 2) *fpi = 1;
 }
 
 int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s) {
@@ -266,13 +278,21 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         a.wr = plan.wr;
         a.chunk = plan.chunk;
         a.batch = batch;
+        {   // frames per persistent workgroup: keep >= ~3 workgroups per CU in the grid
+            static const int env_fpw = std::getenv("AWPU_FAST_FPW") ? std::atoi(std::getenv("AWPU_FAST_FPW")) : 0;
+            const long tiles = ((long) h->cfg.pixel_count + 16 * ppw - 1) / (16 * ppw);
+            (void) tiles;
+            int fpw = 1;  // measured: persistence over frames buys nothing
+            if (env_fpw > 0) fpw = env_fpw;
+            a.frames_per_wg = std::min(fpw, batch);
+        }
         static const int debug = std::getenv("AWPU_FAST_DEBUG") ? std::atoi(std::getenv("AWPU_FAST_DEBUG")) : 0;
         a.debug = debug;
         a.debug_out = nullptr;
         if (debug & 16) {  // diagnostics: dump per-wave cycle sums of the last launch to stderr
             static unsigned long long *d_dbg = nullptr;
-            const size_t n_waves = (size_t) 16 * batch * ((h->cfg.pixel_count + 16 * ppw - 1) / (16 * ppw));
-            if (!d_dbg) AWPU_HIP_TRY(hipMalloc(&d_dbg, n_waves * 12 * sizeof(unsigned long long)));
+            const size_t n_waves = (size_t) 16 * ((batch + a.frames_per_wg - 1) / a.frames_per_wg) * ((h->cfg.pixel_count + 16 * ppw - 1) / (16 * ppw));
+            if (!d_dbg) AWPU_HIP_TRY(hipMalloc(&d_dbg, (size_t) 16 * batch * ((h->cfg.pixel_count + 63) / 64) * 12 * sizeof(unsigned long long)));
             a.debug_out = d_dbg;
             AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, s));
             AWPU_HIP_TRY(hipStreamSynchronize(s));

@@ -351,11 +351,13 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
-    const int frame = blockIdx.x;
+    // a workgroup is persistent over `frames_per_wg` consecutive frames of the batch: the chunk
+    // pipeline runs on across frame boundaries (no refill bubble, one launch/drain per group)
+    const int frame0 = blockIdx.x * a.frames_per_wg;
+    const int n_frames = min(a.frames_per_wg, a.batch - frame0);
     const int pix0 = (blockIdx.y * NW + wave) * PPW;
     const int wr = a.wr;
     const int wr4 = wr >> 2;  // 16-byte pieces per row
-    const float *frame_base = a.frames + (size_t) frame * a.n_streams * a.hist;
 
     // float offset of every staged row inside a frame, kept in LDS behind the two buffers so that
     // the per-chunk address of a piece needs no dependent global load
@@ -382,7 +384,8 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
 
     // LDS-DMA staging: lane l of a wave writes 16 bytes at (wave-uniform base) + 16*l, which is
     // exactly piece (threadIdx.x + k*1024) of the flat image; the source address is per lane.
-    auto dma_chunk = [&](int m0, int mc, int buf) {
+    auto dma_chunk = [&](int frame, int m0, int mc, int buf) {
+        const float *frame_base = a.frames + (size_t) frame * a.n_streams * a.hist;
         const int rows = 2 * mc;
 #pragma unroll
         for (int k = 0; k < kDbPieces; k++) {
@@ -400,11 +403,12 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
     unsigned t_wait = 0, t_all = 0;
     const long long t_begin = __builtin_readcyclecounter();
     const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
-    dma_chunk(0, min(a.chunk, a.usable), 0);
+    const int n_steps = n_frames * n_chunks;  // one step = one staged chunk of one frame
+    dma_chunk(frame0, 0, min(a.chunk, a.usable), 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    unsigned t_ph[5] = {0, 0, 0, 0, 0};  // diagnostics: load issue, sweep, tail, store, barrier
+    unsigned t_ph[5] = {0, 0, 0, 0, 0};  // diagnostics: dma issue, sweep, tail, dma wait, barrier
     constexpr bool diag = DIAG;
     auto stamp = [&](int k, long long &t) {
         if (diag) {
@@ -413,16 +417,19 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
             t = n;
         }
     };
-    for (int c = 0; c < n_chunks; c++) {
+    int fi = 0, c = 0;  // frame within the group, chunk within the frame
+    for (int step = 0; step < n_steps; step++) {
         const int m0 = c * a.chunk;
         const int mc = min(a.chunk, a.usable - m0);
         const int mc4 = (mc + 3) & ~3;
-        const int buf = c & 1;
-        const bool more = c + 1 < n_chunks;
-        const int m1 = m0 + a.chunk;
-        const int mc_next = more ? min(a.chunk, a.usable - m1) : 0;
+        const int buf = step & 1;
+        const bool last_chunk = c + 1 == n_chunks;
+        const int c1 = last_chunk ? 0 : c + 1;
+        const int fi1 = last_chunk ? fi + 1 : fi;
         long long t = diag ? __builtin_readcyclecounter() : 0;
-        if (more && !(a.debug & 1)) dma_chunk(m1, mc_next, buf ^ 1);  // lands during the sweep below
+        if (step + 1 < n_steps && !(a.debug & 1)) {  // lands in the other buffer during the sweep below
+            dma_chunk(frame0 + fi1, c1 * a.chunk, min(a.chunk, a.usable - c1 * a.chunk), buf ^ 1);
+        }
         stamp(0, t);
 
         const unsigned lane_addr = lds_base + buf * kFastLdsBytes + lane * 8;
@@ -451,6 +458,25 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
         stamp(3, t);
         if (!(a.debug & 8)) __syncthreads();
         stamp(4, t);
+
+        if (last_chunk) {  // this frame's sums are complete: epilogue (mimo.cpp:131-137), then start over
+            tail += __shfl_xor(tail, 1);
+            tail += __shfl_xor(tail, 2);
+            tail += __shfl_xor(tail, 4);
+#pragma unroll
+            for (int pp = 0; pp < PPW; pp++) {
+                const int p = pix0 + pp;
+                const float tl = __shfl(tail, pp * 8);
+                const float sum = finish_pixel(acc[pp].A[0], acc[pp].Q[0], acc[pp].C[0], acc[pp].R[0], tl, lane);
+                if (lane == 0 && p < a.pixel_count) {
+                    a.power[(size_t) (frame0 + fi) * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
+                }
+                acc[pp].A[0] = acc[pp].Q[0] = acc[pp].C[0] = acc[pp].R[0] = f2{0.0f, 0.0f};
+            }
+            tail = 0.0f;
+        }
+        c = c1;
+        fi = fi1;
     }
 
     if (DIAG && a.debug_out && lane == 0) {  // diagnostics: per-wave cycle sums
@@ -458,20 +484,8 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
         o[0] = t_wait;
         o[1] = t_all;
         o[2] = (unsigned long long) (__builtin_readcyclecounter() - t_begin);
-        o[3] = (unsigned long long) n_chunks * PPW;
+        o[3] = (unsigned long long) n_steps * PPW;
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
-    }
-    tail += __shfl_xor(tail, 1);
-    tail += __shfl_xor(tail, 2);
-    tail += __shfl_xor(tail, 4);
-#pragma unroll
-    for (int pp = 0; pp < PPW; pp++) {
-        const int p = pix0 + pp;
-        if (p < a.pixel_count) {
-            const float t = __shfl(tail, pp * 8);
-            const float sum = finish_pixel(acc[pp].A[0], acc[pp].Q[0], acc[pp].C[0], acc[pp].R[0], t, lane);
-            if (lane == 0) a.power[(size_t) frame * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
-        }
     }
 }
 
@@ -523,7 +537,7 @@ static hipError_t launch_db(const FastArgs &a, hipStream_t stream) {
         attr_set = true;
     }
     const int pix_per_block = (kDbThreads / 64) * PPW;
-    dim3 grid(a.batch, (a.pixel_count + pix_per_block - 1) / pix_per_block);
+    dim3 grid((a.batch + a.frames_per_wg - 1) / a.frames_per_wg, (a.pixel_count + pix_per_block - 1) / pix_per_block);
     if (grid.y > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL((das_fast_db_kernel<PPW, DIAG>), grid, dim3(kDbThreads), 2 * kFastLdsBytes + kFastSideBytes, stream, a);
     return hipGetLastError();

@@ -60,6 +60,7 @@ struct FastArgs {
     float *power;          // [batch][pixel_count]
     int32_t n_streams, hist, usable, usable_pad, pixel_count;
     int32_t wstart, wr, chunk, batch;
+    int32_t frames_per_wg;  // double-buffered shape: consecutive frames one workgroup sweeps
     unsigned long long *debug_out;  // diagnostics (debug bit 16): 4 words per wave
     int32_t debug;  // timing experiments only (AWPU_FAST_DEBUG): 1 = stage first chunk only, 2 = skip the sweep
 };
