@@ -1,0 +1,113 @@
+// mimo_worker_hip.cpp -- see mimo_worker_hip.h.  Every hot-path operation goes through the C ABI;
+// there is no CPU implementation of the sweep here.
+#include "mimo_worker_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace awpu_host {
+
+MIMOWorkerHip::MIMOWorkerHip(FrameSource *pipeline, const AntennaView &antenna, bool *running, int rows,
+                             int columns, float fov, int device, bool autostart, int math)
+    : pipeline(pipeline), antenna(antenna), running(running), rows(rows), columns(columns), fov(fov) {
+    maxIndex = rows * columns;                       // mimo.cpp:8
+    powerdB = std::vector<float>(maxIndex, 0.0f);    // mimo.cpp:10
+    const int n_sensors = pipeline->get_n_sensors();
+    signals.resize((size_t) n_sensors * AWPU_HIST);
+
+    awpu_hip_cfg cfg;
+    awpu_hip_default_cfg(&cfg);
+    cfg.device = device;
+    cfg.n_streams = n_sensors;
+    cfg.n_pixels = maxIndex;
+    cfg.lut_stride = antenna.n;
+    cfg.math = math;
+    last_status = awpu_hip_create(&engine, &cfg);
+    if (last_status != AWPU_OK) {
+        // the reference reports on std::cerr and carries on (pipeline.cpp:33-36); same here
+        std::fprintf(stderr, "MIMOWorkerHip: %s (%s)\n", awpu_hip_strerror(last_status), awpu_hip_last_error());
+        return;
+    }
+    computeDelayLUT();  // mimo.cpp:11
+    if (last_status == AWPU_OK) last_status = awpu_hip_set_active_mics(engine, antenna.index, antenna.usable);
+    if (autostart) thread_loop = std::thread(&MIMOWorkerHip::loop, this);  // mimo.cpp:12
+}
+
+MIMOWorkerHip::~MIMOWorkerHip() {
+    looping = false;
+    if (thread_loop.joinable()) thread_loop.join();
+    awpu_hip_destroy(engine);
+}
+
+// mimo.cpp:20-59: the tables are built on the host exactly as the reference does (one-off), kept in
+// the same members, and handed to the engine.
+void MIMOWorkerHip::computeDelayLUT() {
+    offsetDelays.assign((size_t) maxIndex * antenna.n, 0);
+    fractionalDelays.assign((size_t) maxIndex * antenna.n, 0.f);
+    last_status = awpu_hip_build_delay_table(antenna.points, antenna.n, rows, columns, fov, 0, rows,
+                                             offsetDelays.data(), fractionalDelays.data());
+    if (last_status == AWPU_OK)
+        last_status = awpu_hip_set_delay_table(engine, offsetDelays.data(), fractionalDelays.data());
+}
+
+// mimo.cpp:97-151.  The snapshot loop is the reference's (every stream, so that antenna.index can
+// address any of them); the pixel x mic x sample sweep and the epilogue run on the GPU.
+void MIMOWorkerHip::update() {
+    if (!engine) return;
+    const int n_sensors = pipeline->get_n_sensors();
+    for (int l = 0; l < n_sensors; l++) {
+        pipeline->read_stream((unsigned) l, &signals[(size_t) l * AWPU_HIST]);  // mimo.cpp:100-103
+    }
+    last_status = awpu_hip_process(engine, signals.data(), 1, powerdB.data());  // mimo.cpp:121-151
+}
+
+// mimo.cpp:61-95 with USE_DB 0
+void MIMOWorkerHip::populateHeatmap(uint8_t *heatmap) { awpu_hip_heatmap_u8(powerdB.data(), maxIndex, heatmap); }
+
+void MIMOWorkerHip::draw(uint8_t *heatmap) {  // worker.h:148-152
+    lock.lock();
+    populateHeatmap(heatmap);
+    lock.unlock();
+}
+
+void MIMOWorkerHip::loop() {  // worker.h:212-224
+    while (looping && pipeline->isRunning()) {
+        pipeline->barrier();
+        lock.lock();
+        update();
+        lock.unlock();
+    }
+}
+
+// aw_processing_unit.cpp:128-200, one array
+int calibrate_array(const float *X, int hist, float reference_power_level, int *index, float *correction,
+                    float *median_out) {
+    float power[AWPU_ELEMENTS];
+    for (int s = 0; s < AWPU_ELEMENTS; s++) {
+        float power_value = 0.0f;
+        for (int i = 0; i < hist; i++) power_value += X[(size_t) s * hist + i] * X[(size_t) s * hist + i];
+        power[s] = power_value / (float) hist;
+    }
+    float medians[AWPU_ELEMENTS];
+    std::memcpy(medians, power, sizeof(medians));
+    std::sort(std::begin(medians), std::end(medians));
+    // the reference averages elements 32 and 33 (aw_processing_unit.cpp:150)
+    const float median = (float) ((medians[AWPU_ELEMENTS / 2] + medians[AWPU_ELEMENTS / 2 + 1]) / 2.0);
+    int count = 0;
+    for (int s = 0; s < AWPU_ELEMENTS; s++) {
+        const float diff = std::fabs(power[s] - median);
+        if (diff > 1e-4) {                      // too far from the median
+        } else if (power[s] < median * 1e-3) {  // dead
+        } else {
+            index[count] = s;
+            correction[count] = reference_power_level / power[s];
+            count++;
+        }
+    }
+    if (median_out) *median_out = median;
+    return count;
+}
+
+}  // namespace awpu_host

@@ -1,0 +1,96 @@
+// mimo_worker_hip.h -- C++ host mirror of the reference's MIMO worker and processing unit for the
+// heatmap path, on top of the C ABI (include/awpu_hip.h).  This is the code a maintainer of
+// acoustic-warfare/beamforming-lk would drop in place of src/dsp/mimo.{h,cpp}: same constructor
+// shape, same update()/draw() roles, same state (offsetDelays, fractionalDelays, powerdB), with the
+// sweep of MIMOWorker::update (src/dsp/mimo.cpp:97-151) replaced by one awpu_hip_process call.
+//
+// The reference classes depend on Eigen (Antenna::points), OpenCV (cv::Mat) and its Pipeline; none
+// of those is available to this build, so the three touch points are narrowed to plain interfaces:
+//   FrameSource  what MIMOWorker uses of Pipeline/Streams   (src/fpga/pipeline.h:40-107,
+//                                                            src/fpga/streams.hpp:113-116)
+//   AntennaView  what it uses of Antenna                    (src/geometry/antenna.h:80-103)
+//   uint8_t*     the rows x columns CV_8UC1 heatmap         (src/dsp/mimo.cpp:61-95)
+#pragma once
+
+#include <cstdint>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "awpu_hip.h"
+
+namespace awpu_host {
+
+// src/dsp/worker.h:66-73
+enum worker_t { GENERIC, PSO, MIMO, MISO, SOUND, GRADIENT };
+
+// The slice of Pipeline + Streams the MIMO worker touches.
+class FrameSource {
+public:
+    virtual ~FrameSource() = default;
+    virtual int get_n_sensors() = 0;                          // pipeline.h:107
+    virtual int isRunning() = 0;                              // pipeline.h:71
+    virtual void barrier() = 0;                               // pipeline.h:83, blocks until a new block
+    virtual void read_stream(unsigned index, float *data) = 0;  // streams.hpp:113-116: 1024 floats, oldest first
+};
+
+// src/geometry/antenna.h:80-103 without Eigen: points is xyz[3][n] row-major by coordinate.
+struct AntennaView {
+    const float *points = nullptr;
+    int n = 0;
+    int usable = 0;              // number of usable elements
+    const int *index = nullptr;  // [usable] physical ids, as AWProcessingUnit::calibrate fills them
+};
+
+// Mirrors class MIMOWorker : public Worker  (src/dsp/mimo.h:25-92, src/dsp/worker.h:81-233).
+class MIMOWorkerHip {
+public:
+    // src/dsp/mimo.h:36.  `autostart` = the reference starts its thread in the constructor
+    // (mimo.cpp:12); tests pass false and call update() themselves.
+    MIMOWorkerHip(FrameSource *pipeline, const AntennaView &antenna, bool *running, int rows, int columns,
+                  float fov, int device = 0, bool autostart = true, int math = AWPU_MATH_F32_FAST);
+    ~MIMOWorkerHip();  // worker.h:104-107: looping = false; join
+
+    worker_t get_type() { return worker_t::MIMO; }  // mimo.h:47-49
+
+    // Worker::draw (worker.h:148-152): populateHeatmap under the worker lock.
+    void draw(uint8_t *heatmap);
+
+    // mimo.cpp:97-151.  Protected in the reference; public here so tests can step it.
+    void update();
+
+    int status() const { return last_status; }                 // last C-ABI status (0 = OK)
+    const std::vector<float> &power() const { return powerdB; }  // mimo.h:91
+    const std::vector<int32_t> &offsets() const { return offsetDelays; }
+    const std::vector<float> &fractions() const { return fractionalDelays; }
+
+private:
+    void computeDelayLUT();               // mimo.cpp:20-59
+    void populateHeatmap(uint8_t *heatmap);  // mimo.cpp:61-95
+    void loop();                          // worker.h:212-224
+
+    FrameSource *pipeline;
+    AntennaView antenna;
+    bool *running;
+    bool looping = true;
+    std::thread thread_loop;
+    std::mutex lock;
+
+    const int rows, columns;
+    const float fov;
+    int maxIndex;
+    int last_status = AWPU_OK;
+
+    std::vector<int32_t> offsetDelays;    // [maxIndex][n]  (vector<vector<int>> in mimo.h:86)
+    std::vector<float> fractionalDelays;  // [maxIndex][n]  (mimo.h:88)
+    std::vector<float> powerdB;           // mimo.h:91
+    std::vector<float> signals;           // the snapshot update() takes: [n_sensors][1024] (mimo.cpp:100-103)
+    awpu_hip_t *engine = nullptr;
+};
+
+// AWProcessingUnit::calibrate for one array (src/aw_processing_unit/aw_processing_unit.cpp:128-200):
+// X = the 64 streams [64][hist]; fills index/correction (<= 64 each), returns usable.
+int calibrate_array(const float *X, int hist, float reference_power_level, int *index, float *correction,
+                    float *median_out = nullptr);
+
+}  // namespace awpu_host

@@ -1,0 +1,193 @@
+// test_mimo_worker.cpp -- exercises the C++ host mirror (beamforming-lk_amd/host) the way the
+// reference's own process would: a producer publishes 256-sample blocks into per-mic rings, the MIMO
+// worker snapshots them and updates its heatmap.  Results are checked against the CPU oracle
+// (tests may link oracle/; the product never does).
+//
+//   test_mimo_worker          full run (needs an MI355X)
+//   test_mimo_worker --nogpu  only checks that, without a device, the worker reports the failure
+//                             and computes nothing (there is no CPU path)
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "das_oracle.h"
+#include "mimo_worker_hip.h"
+
+using namespace awpu_host;
+
+static int failures = 0;
+#define CHECK(cond, ...)                                  \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::printf(__VA_ARGS__);                     \
+            std::printf("\n");                            \
+            failures++;                                   \
+        }                                                 \
+    } while (0)
+
+// Per-mic rings with the reference's semantics (src/fpga/streams.hpp:103-116,136-139): 4 blocks of
+// 256 floats; the producer writes at `position` then forwards it; a read starts at the new position,
+// so a snapshot is oldest..newest.  Signal: the synthetic producer of src/fpga/pipeline.cpp:105-135,
+// a 9 kHz plane wave of amplitude 1e-2, here from an arbitrary direction.
+class SyntheticSource : public FrameSource {
+public:
+    SyntheticSource(const float *xyz, int n, double theta, double phi) : n(n), ring((size_t) n * 1024, 0.f), tau(n) {
+        oracle_steering_delays_f32(xyz, n, theta, phi, tau.data());
+    }
+    int get_n_sensors() override { return n; }
+    int isRunning() override { return running.load(); }
+    void barrier() override {
+        std::unique_lock<std::mutex> lk(m);
+        const int seen = published;
+        cv.wait(lk, [&] { return published != seen || !running.load(); });
+    }
+    void read_stream(unsigned index, float *data) override {
+        std::lock_guard<std::mutex> lk(m);
+        for (int i = 0; i < 1024; i++) data[i] = ring[(size_t) index * 1024 + (position + i) % 1024];
+    }
+    void publish_block() {  // Pipeline::synthetic_producer, pipeline.cpp:119-147
+        std::lock_guard<std::mutex> lk(m);
+        for (int s = 0; s < n; s++)
+            for (int i = 0; i < 256; i++) {
+                const double t = (double) (p + i) + tau[s];
+                ring[(size_t) s * 1024 + (position + i) % 1024] = (float) (1e-2 * std::sin(2.0 * M_PI * 9e3 * t / 48828.0));
+            }
+        p += 256;
+        position = (position + 256) % 1024;  // Streams::forward
+        published++;
+        cv.notify_all();
+    }
+    void stop() {
+        running = false;
+        cv.notify_all();
+    }
+
+private:
+    int n;
+    std::vector<float> ring;
+    std::vector<float> tau;
+    int position = 0, p = 0, published = 0;
+    std::atomic<int> running{1};
+    std::mutex m;
+    std::condition_variable cv;
+};
+
+static double rel_err(const std::vector<float> &got, const std::vector<float> &want) {
+    float peak = 0;
+    for (float v : want) peak = std::max(peak, v);
+    double worst = 0;
+    for (size_t i = 0; i < got.size(); i++) {
+        const double den = std::max((double) want[i], 1e-4 * peak);
+        worst = std::max(worst, std::fabs((double) got[i] - want[i]) / den);
+    }
+    return worst;
+}
+
+int main(int argc, char **argv) {
+    const bool nogpu = argc > 1 && std::strcmp(argv[1], "--nogpu") == 0;
+    const int rows = 24, cols = 24;
+    std::vector<float> xyz(3 * 64);
+    awpu_hip_create_antenna(8, 8, 0.02f, xyz.data());
+    std::vector<int> all(64);
+    for (int i = 0; i < 64; i++) all[i] = i;
+    const double theta = 0.35, phi = -2.0;
+    bool run = true;
+
+    if (nogpu) {
+        SyntheticSource src(xyz.data(), 64, theta, phi);
+        AntennaView ant{xyz.data(), 64, 64, all.data()};
+        MIMOWorkerHip w(&src, ant, &run, rows, cols, 180.f, 0, /*autostart=*/false);
+        CHECK(w.status() == AWPU_ERR_NO_DEVICE, "expected AWPU_ERR_NO_DEVICE, got %d", w.status());
+        w.update();
+        float sum = 0;
+        for (float v : w.power()) sum += v;
+        CHECK(sum == 0.0f, "power must stay untouched without a device");
+        std::printf(failures ? "FAILED\n" : "OK nogpu\n");
+        return failures ? 1 : 0;
+    }
+
+    // ---- 1. stepped worker, all 64 mics, against the oracle on the same snapshot and tables
+    {
+        SyntheticSource src(xyz.data(), 64, theta, phi);
+        AntennaView ant{xyz.data(), 64, 64, all.data()};
+        MIMOWorkerHip w(&src, ant, &run, rows, cols, 180.f, 0, false);
+        CHECK(w.status() == AWPU_OK, "create: %s", awpu_hip_last_error());
+        for (int b = 0; b < 5; b++) src.publish_block();
+        w.update();
+        CHECK(w.status() == AWPU_OK, "update: %s", awpu_hip_last_error());
+        std::vector<float> snap((size_t) 64 * 1024);
+        for (int s = 0; s < 64; s++) src.read_stream(s, &snap[(size_t) s * 1024]);
+        std::vector<int32_t> off((size_t) rows * cols * 64);
+        std::vector<float> frac(off.size()), want(rows * cols);
+        oracle_compute_delay_lut(xyz.data(), 64, rows, cols, 180.f, off.data(), frac.data());
+        CHECK(off == w.offsets() && frac == w.fractions(), "tables differ from computeDelayLUT restatement");
+        oracle_das_f32(snap.data(), 1024, off.data(), frac.data(), rows * cols, 64, all.data(), 64, want.data(), nullptr);
+        const double e = rel_err(w.power(), want);
+        CHECK(e < 1e-5, "power rel err %.3e", e);
+        const int k = (int) (std::max_element(w.power().begin(), w.power().end()) - w.power().begin());
+        const double sep = 1.0 / (rows / 2.0);
+        const int er = (int) std::lround(std::sin(theta) * std::sin(phi) / sep + rows / 2.0 - 0.5);
+        const int ec = (int) std::lround(std::sin(theta) * std::cos(phi) / sep + cols / 2.0 - 0.5);
+        CHECK(std::abs(k / cols - er) <= 1 && std::abs(k % cols - ec) <= 1, "peak at (%d,%d), source at (%d,%d)", k / cols, k % cols, er, ec);
+        std::vector<uint8_t> img(rows * cols), img_want(rows * cols);
+        w.draw(img.data());
+        oracle_heatmap_u8(w.power().data(), rows * cols, img_want.data());
+        CHECK(img == img_want && img[k] == 255, "heatmap differs from populateHeatmap restatement");
+        std::printf("1. stepped worker: rel err %.2e, peak (%d,%d)\n", e, k / cols, k % cols);
+    }
+
+    // ---- 2. calibration drops a dead and a loud mic; the worker runs on the usable list
+    {
+        SyntheticSource src(xyz.data(), 64, theta, phi);
+        for (int b = 0; b < 4; b++) src.publish_block();
+        std::vector<float> snap((size_t) 64 * 1024);
+        for (int s = 0; s < 64; s++) src.read_stream(s, &snap[(size_t) s * 1024]);
+        std::fill(snap.begin() + 9 * 1024, snap.begin() + 10 * 1024, 0.f);  // dead mic 9
+        for (int i = 0; i < 1024; i++) snap[(size_t) 40 * 1024 + i] *= 3.0f;  // loud mic 40
+        int index[64], index_o[64];
+        float corr[64], corr_o[64], med = 0, med_o = 0;
+        const int usable = calibrate_array(snap.data(), 1024, 1e-5f, index, corr, &med);
+        const int usable_o = oracle_calibrate(snap.data(), 1024, 1e-5f, index_o, corr_o, &med_o);
+        CHECK(usable == usable_o && usable == 62 && std::equal(index, index + usable, index_o) && med == med_o,
+              "calibrate: usable %d vs %d", usable, usable_o);
+        AntennaView ant{xyz.data(), 64, usable, index};
+        MIMOWorkerHip w(&src, ant, &run, rows, cols, 180.f, 0, false);
+        w.update();
+        for (int s = 0; s < 64; s++) src.read_stream(s, &snap[(size_t) s * 1024]);
+        std::vector<float> want(rows * cols);
+        oracle_das_f32(snap.data(), 1024, w.offsets().data(), w.fractions().data(), rows * cols, 64, index, usable, want.data(), nullptr);
+        const double e = rel_err(w.power(), want);
+        CHECK(e < 1e-5, "usable-subset power rel err %.3e", e);
+        std::printf("2. calibrated subset (%d mics): rel err %.2e\n", usable, e);
+    }
+
+    // ---- 3. threaded like the reference: producer -> barrier -> update under the lock; draw() from here
+    {
+        SyntheticSource src(xyz.data(), 64, theta, phi);
+        AntennaView ant{xyz.data(), 64, 64, all.data()};
+        for (int b = 0; b < 4; b++) src.publish_block();
+        std::vector<uint8_t> img(rows * cols, 0);
+        {
+            MIMOWorkerHip w(&src, ant, &run, rows, cols, 180.f, 0, /*autostart=*/true);
+            for (int b = 0; b < 6; b++) {
+                src.publish_block();
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+                w.draw(img.data());
+            }
+            src.stop();
+        }
+        const int k = (int) (std::max_element(img.begin(), img.end()) - img.begin());
+        CHECK(img[k] == 255, "threaded worker produced no heatmap");
+        std::printf("3. threaded worker: heatmap peak at (%d,%d)\n", k / cols, k % cols);
+    }
+    std::printf(failures ? "FAILED\n" : "OK\n");
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,36 @@
+"""The C++ host mirror of the reference's MIMO worker (beamforming-lk_amd/host): built with g++
+against the C ABI, run as the reference's process would run it."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+EXE = REPO / "tests" / "host" / "test_mimo_worker"
+
+
+def build(pkg, oracle):
+    pkg.binding.load()  # builds libawpu_hip.so
+    pkgdir = REPO / "beamforming-lk_amd"
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", f"-I{REPO / 'include'}", f"-I{pkgdir / 'host'}",
+           f"-I{REPO / 'oracle'}", str(REPO / "tests/host/test_mimo_worker.cpp"), str(pkgdir / "host/mimo_worker_hip.cpp"),
+           f"-L{pkgdir}", "-lawpu_hip", f"-L{REPO / 'oracle'}", "-loracle_das", "-lm",
+           f"-Wl,-rpath,{pkgdir}", f"-Wl,-rpath,{REPO / 'oracle'}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(EXE)]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+
+
+def test_host_mirror_builds_and_fails_loudly_without_gpu(pkg, oracle):
+    import torch
+
+    build(pkg, oracle)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device path is exercised on CPU-only boxes")
+    out = subprocess.run([str(EXE), "--nogpu"], capture_output=True, text=True)
+    assert out.returncode == 0 and "OK nogpu" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_host_mirror_against_oracle(pkg, oracle):
+    build(pkg, oracle)
+    out = subprocess.run([str(EXE)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
