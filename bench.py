@@ -66,6 +66,19 @@ def cpu_baseline(S, spec, xyz, off, frac, frame, seconds):
     }
 
 
+def measured_traffic(workload, batch, world):
+    """HBM bytes per launch from the committed PMC run (profiles/r01_hbm_traffic.json, collected
+    with tools/pmc_hbm.sh as MI355X_MICROARCH.md prescribes); None when it was not measured for
+    this exact workload."""
+    path = REPO / "profiles" / "r01_hbm_traffic.json"
+    if world != 1 or not path.exists():
+        return None
+    rec = json.loads(path.read_text())
+    if rec.get("workload") == workload and rec.get("frames_per_step") == batch:
+        return rec["traffic_bytes_per_launch"]
+    return None
+
+
 def main():
     args = parse_args()
     import torch
@@ -182,7 +195,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                "frac": ach_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(spec.name, B, world),
                 "kernel": "das sweep", "kernel_ms": kernel_ms, "launch_bytes": launch_bytes,
                 "note": "the sweep is fp32-VALU/LDS bound (126 flop/B >> ridge), see valu",
             },

@@ -1,0 +1,22 @@
+#!/bin/bash
+# pmc_hbm.sh -- HBM-side traffic of the sweep launch: FETCH_SIZE and WRITE_SIZE in SEPARATE passes
+# (TCC has 4 slots; FETCH_SIZE takes 3, WRITE_SIZE 2), counters only, no trace domains.
+# usage: tools/pmc_hbm.sh <outdir-under-gpurun_out> [bench args...]
+set -e
+out=gpurun_out/$1; shift
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_REQ_sum TCC_READ_sum"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --output-format csv -d $out/$tag -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 "$@" > $out/$tag.log 2>&1 || true
+done
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+tot = collections.defaultdict(float); n = collections.Counter()
+for f in glob.glob(out + "/*/*/*counter_collection.csv"):
+    for row in csv.DictReader(open(f)):
+        if "das_" not in row["Kernel_Name"]: continue
+        tot[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
+for k in sorted(tot): print(f"{k:28s} {tot[k]/n[k]:18.1f}   (avg over {n[k]} launches)")
+PY
