@@ -51,8 +51,11 @@ struct awpu_hip {
 
     // device state
     awpu::LutEntry *d_lut = nullptr;
-    awpu::FastEntry *d_fast_lut[3] = {nullptr, nullptr, nullptr};  // by frames-per-item (1, 2)
-    awpu::FastPlan fast_plan[3] = {};
+    struct FastLut {
+        awpu::FastPlan plan;
+        awpu::FastEntry *d = nullptr;
+    };
+    std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     int32_t *d_index = nullptr;
     int32_t *d_row_off = nullptr;
     float *d_frames = nullptr;
@@ -69,10 +72,9 @@ namespace {
 
 void release_device(awpu_hip *h) {
     if (h->d_lut) (void) hipFree(h->d_lut);
-    for (auto &p : h->d_fast_lut) {
-        if (p) (void) hipFree(p);
-        p = nullptr;
-    }
+    for (auto &l : h->fast_luts)
+        if (l.d) (void) hipFree(l.d);
+    h->fast_luts.clear();
     if (h->d_index) (void) hipFree(h->d_index);
     if (h->d_row_off) (void) hipFree(h->d_row_off);
     h->d_row_off = nullptr;
@@ -113,10 +115,9 @@ int prepare(awpu_hip *h) {
     if (h->d_index) (void) hipFree(h->d_index);
     h->d_lut = nullptr;
     h->d_index = nullptr;
-    for (auto &p : h->d_fast_lut) {
-        if (p) (void) hipFree(p);
-        p = nullptr;
-    }
+    for (auto &l : h->fast_luts)
+        if (l.d) (void) hipFree(l.d);
+    h->fast_luts.clear();
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
                            hipMemcpyHostToDevice));
@@ -151,7 +152,7 @@ int prepare(awpu_hip *h) {
                                hipMemcpyHostToDevice));
     } else {
         awpu::FastPlan plan;
-        if (!awpu::fast_plan(h->window, U, 1, &plan))
+        if (!awpu::fast_plan(h->window, U, 1, awpu::kFastLdsBytes, &plan))
             return invalid("delay window does not fit the LDS budget");
     }
 
@@ -169,11 +170,17 @@ int prepare(awpu_hip *h) {
 // The fast kernel's table for `fpi` frames per item: per (pixel, active mic s) the weights and
 // the LDS byte address of X[off] inside the staged image (das_fast.hip), rows padded to whole
 // groups of four with null entries (zero weights, address of a staged row).
-int build_fast_lut(awpu_hip *h, int fpi) {
+int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLut **out) {
+    for (const auto &l : h->fast_luts)
+        if (l.plan.fpi == fpi && l.plan.image_bytes == image_bytes) {
+            *out = &l;
+            return AWPU_OK;
+        }
     const auto &c = h->cfg;
     const int U = h->usable(), P = c.pixel_count;
-    awpu::FastPlan plan;
-    if (!awpu::fast_plan(h->window, U, fpi, &plan)) return invalid("delay window does not fit the LDS budget");
+    awpu_hip::FastLut lut;
+    if (!awpu::fast_plan(h->window, U, fpi, image_bytes, &lut.plan)) return invalid("delay window does not fit the LDS budget");
+    const awpu::FastPlan &plan = lut.plan;
     // rows for whole pixel tiles (the kernels sweep every pixel slot of a workgroup; slots past the
     // grid get null rows) + spare groups: the kernels prefetch entries past the row they sweep
     const int P_pad = (P + 127) / 128 * 128;
@@ -193,10 +200,11 @@ int build_fast_lut(awpu_hip *h, int fpi) {
             dst[s].addr = (uint32_t) ((j * 2 + q) * plan.row_bytes + (off_rel - q) * 4);
         }
     }
-    AWPU_HIP_TRY(hipMalloc(&h->d_fast_lut[fpi], n * sizeof(awpu::FastEntry)));
-    AWPU_HIP_TRY(hipMemcpy(h->d_fast_lut[fpi], packed.data(), n * sizeof(awpu::FastEntry),
-                           hipMemcpyHostToDevice));
-    h->fast_plan[fpi] = plan;
+    AWPU_HIP_TRY(hipMalloc(&lut.d, n * sizeof(awpu::FastEntry)));
+    AWPU_HIP_TRY(hipMemcpy(lut.d, packed.data(), n * sizeof(awpu::FastEntry), hipMemcpyHostToDevice));
+    h->fast_luts.reserve(8);
+    h->fast_luts.push_back(lut);
+    *out = &h->fast_luts.back();
     return AWPU_OK;
 }
 
@@ -228,10 +236,14 @@ void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
     }
     if (env_fpi == 1 || env_fpi == 2) *fpi = env_fpi;
     if (env_ppw == 2 || env_ppw == 4 || env_ppw == 8) *ppw = env_ppw;
-    if (env_nw == 8 || env_nw == 32) *nw = env_nw;
+    if (env_nw == 8 || env_nw == 32 || env_nw == 24) *nw = env_nw;
     if (*nw == 32) {
         *fpi = 1;
         if (*ppw < 4) *ppw = 4;
+    }
+    if (*nw == 24) {
+        *fpi = 1;
+        *ppw = 4;
     }
     if (*fpi == 2 && *ppw == 8) *ppw = 4;
     if (*fpi == 2 && batch < 2) *fpi = 1;
@@ -256,16 +268,19 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     } else {
         int fpi = 1, ppw = 8, nw = 8;
         choose_fast_variant(h, batch, &fpi, &ppw, &nw);
-        if (!h->d_fast_lut[fpi]) {
-            const int rc = build_fast_lut(h, fpi);
-            if (rc != AWPU_OK) return rc;
+        const awpu_hip::FastLut *lut = nullptr;
+        int rc = build_fast_lut(h, fpi, awpu::fast_image_bytes(nw), &lut);
+        // the double-buffered shapes read whole 16-byte pieces of every staged row
+        if (nw != 8 && (rc != AWPU_OK || !awpu::fast_db_fits(lut->plan) || h->wstart + 1 + lut->plan.wr > h->cfg.hist)) {
+            nw = 8;
+            if (ppw > 4 && fpi == 2) ppw = 4;
+            rc = build_fast_lut(h, fpi, awpu::fast_image_bytes(nw), &lut);
         }
-        const awpu::FastPlan &plan = h->fast_plan[fpi];
-        // the double-buffered shape reads whole 16-byte pieces of every staged row
-        if (nw == 32 && (!awpu::fast_db_fits(plan) || h->wstart + 1 + plan.wr > h->cfg.hist)) nw = 8;
+        if (rc != AWPU_OK) return rc;
+        const awpu::FastPlan &plan = lut->plan;
         awpu::FastArgs a{};
         a.frames = d_frames;
-        a.lut = h->d_fast_lut[fpi];
+        a.lut = lut->d;
         a.index = h->d_index;
         a.row_off = h->d_row_off;
         a.power = d_power;
@@ -291,7 +306,8 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         a.debug_out = nullptr;
         if (debug & 16) {  // diagnostics: dump per-wave cycle sums of the last launch to stderr
             static unsigned long long *d_dbg = nullptr;
-            const size_t n_waves = (size_t) 16 * ((batch + a.frames_per_wg - 1) / a.frames_per_wg) * ((h->cfg.pixel_count + 16 * ppw - 1) / (16 * ppw));
+            const int wg_waves = nw == 24 ? 12 : 16;
+            const size_t n_waves = (size_t) wg_waves * ((batch + a.frames_per_wg - 1) / a.frames_per_wg) * ((h->cfg.pixel_count + wg_waves * ppw - 1) / (wg_waves * ppw));
             if (!d_dbg) AWPU_HIP_TRY(hipMalloc(&d_dbg, (size_t) 16 * batch * ((h->cfg.pixel_count + 63) / 64) * 12 * sizeof(unsigned long long)));
             a.debug_out = d_dbg;
             AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, s));
@@ -303,6 +319,17 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
             for (size_t i = 0; i < n_waves; i++) {
                 w += hbuf[12*i]; al += hbuf[12*i+1]; tot += hbuf[12*i+2]; nb += hbuf[12*i+3];
                 for (int k = 0; k < 5; k++) ph[k] += hbuf[12*i+4+k];
+            }
+            {   // by wave slot inside the workgroup: who waits at the barrier, who is waited for
+                const int nw_wg = nw == 24 ? 12 : 16;
+                std::vector<double> sw(nw_wg, 0), ba(nw_wg, 0);
+                for (size_t i = 0; i < n_waves; i++) {
+                    sw[i % nw_wg] += hbuf[12 * i + 5];
+                    ba[i % nw_wg] += hbuf[12 * i + 8];
+                }
+                std::fprintf(stderr, "[awpu diag] wave slot: sweep / barrier kcycles:");
+                for (int k = 0; k < nw_wg; k++) std::fprintf(stderr, " %d:%.0f/%.0f", k, sw[k] * nw_wg / n_waves / 1e3, ba[k] * nw_wg / n_waves / 1e3);
+                std::fprintf(stderr, "\n");
             }
             std::fprintf(stderr, "[awpu diag] per wave cycles: load-issue %.0f  sweep %.0f  tail %.0f  store %.0f  barrier %.0f\n",
                          ph[0] / n_waves, ph[1] / n_waves, ph[2] / n_waves, ph[3] / n_waves, ph[4] / n_waves);

@@ -106,11 +106,20 @@ __device__ __forceinline__ void sweep_group(Acc<FPI> &acc, const EntryGroup &e, 
 // The items of one wave for one staged chunk: PPW pixels x ng groups of four, one frame per
 // item, through the hand-scheduled asm blocks (das_fast_trip.inc), four pixels per block where
 // PPW allows.  Pixels past the grid are swept too: the table has null rows for them.
-template <int PPW>
+template <int PPW, bool LOW = false>
 __device__ __forceinline__ void sweep_chunk_trips(Acc<1> (&acc)[PPW], const FastEntry *lut, int pix0,
                                                   int usable_pad, int m0, int ng, unsigned lane_addr) {
     const int stride = usable_pad * (int) sizeof(FastEntry);
-    if constexpr (PPW % 4 == 0) {
+    if constexpr (PPW % 4 == 0 && LOW) {
+#pragma unroll
+        for (int q = 0; q < PPW; q += 4) {
+            const void *row = lut + (size_t) (pix0 + q) * usable_pad + m0;
+            sweep_quad_lo(acc[q].A[0], acc[q].Q[0], acc[q].C[0], acc[q].R[0],
+                          acc[q + 1].A[0], acc[q + 1].Q[0], acc[q + 1].C[0], acc[q + 1].R[0],
+                          acc[q + 2].A[0], acc[q + 2].Q[0], acc[q + 2].C[0], acc[q + 2].R[0],
+                          acc[q + 3].A[0], acc[q + 3].Q[0], acc[q + 3].C[0], acc[q + 3].R[0], row, stride, ng, lane_addr);
+        }
+    } else if constexpr (PPW % 4 == 0) {
 #pragma unroll
         for (int q = 0; q < PPW; q += 4) {
             const void *row = lut + (size_t) (pix0 + q) * usable_pad + m0;
@@ -128,7 +137,7 @@ __device__ __forceinline__ void sweep_chunk_trips(Acc<1> (&acc)[PPW], const Fast
     }
 }
 
-template <int PPW>
+template <int PPW, bool LOW = false>
 __device__ __forceinline__ void sweep_chunk_stamped(Acc<1> (&acc)[PPW], const FastEntry *lut, int pix0,
                                                     int usable_pad, int m0, int ng, unsigned lane_addr,
                                                     unsigned &t_wait, unsigned &t_all) {
@@ -137,6 +146,13 @@ __device__ __forceinline__ void sweep_chunk_stamped(Acc<1> (&acc)[PPW], const Fa
 #pragma unroll
     for (int q = 0; q < PPW; q += 4) {
         const void *row = lut + (size_t) (pix0 + q) * usable_pad + m0;
+        if constexpr (LOW) {
+            sweep_quad_lo_stamped(acc[q].A[0], acc[q].Q[0], acc[q].C[0], acc[q].R[0],
+                                  acc[q + 1].A[0], acc[q + 1].Q[0], acc[q + 1].C[0], acc[q + 1].R[0],
+                                  acc[q + 2].A[0], acc[q + 2].Q[0], acc[q + 2].C[0], acc[q + 2].R[0],
+                                  acc[q + 3].A[0], acc[q + 3].Q[0], acc[q + 3].C[0], acc[q + 3].R[0], row, stride, ng,
+                                  lane_addr, t_wait, t_all);
+        } else
         sweep_quad_stamped(acc[q].A[0], acc[q].Q[0], acc[q].C[0], acc[q].R[0],
                            acc[q + 1].A[0], acc[q + 1].Q[0], acc[q + 1].C[0], acc[q + 1].R[0],
                            acc[q + 2].A[0], acc[q + 2].Q[0], acc[q + 2].C[0], acc[q + 2].R[0],
@@ -341,13 +357,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
 // Staging is by 16-byte pieces of the flat [mic][copy][wr] image: piece -> (row, column) is the
 // same for every chunk, so each thread decodes its pieces once per launch.
 // ---------------------------------------------------------------------------------------
-constexpr int kDbThreads = 1024;
-constexpr int kDbPieces = 5;  // 16-byte pieces per thread and chunk: 5 * 1024 * 16 = 80 KiB >= one buffer
-
-template <int PPW, bool DIAG>
-__global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) {
+// NW waves per workgroup, BUF bytes per LDS image (two images + the side table per workgroup),
+// WPS waves per SIMD the register budget is sized for: <16, 8, 78 KiB, 4> = one workgroup per CU,
+// <12, 4, 38 KiB, 6> = two per CU.
+template <int NW, int PPW, int BUF, int WPS, bool DIAG>
+__global__ __launch_bounds__(NW * 64, WPS) void das_fast_db_kernel(FastArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NW = kDbThreads / 64;
+    constexpr int kDbThreads = NW * 64;
+    constexpr int kDbPieces = (BUF + kDbThreads * 16 - 1) / (kDbThreads * 16);  // 16-byte pieces per thread and chunk
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
 
     // float offset of every staged row inside a frame, kept in LDS behind the two buffers so that
     // the per-chunk address of a piece needs no dependent global load
-    int *row_off_lds = (int *) (lds + 2 * (kFastLdsBytes / 4));
+    int *row_off_lds = (int *) (lds + 2 * (BUF / 4));
     for (int i = threadIdx.x; i < 2 * a.usable_pad; i += kDbThreads) row_off_lds[i] = a.row_off[i];
 
     // this thread's pieces: row (= 2*mic_slot + copy) and float column inside the row
@@ -393,7 +410,7 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
             if (row < rows) {
                 const int off = row_off_lds[2 * m0 + row];
                 const float *src = frame_base + off + (piece_rc[k] & 0xffff);
-                float *dst = lds + buf * (kFastLdsBytes / 4) + (wave * 64 + k * kDbThreads) * 4;
+                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kDbThreads) * 4;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) src,
                                                  (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
             }
@@ -432,15 +449,15 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
         }
         stamp(0, t);
 
-        const unsigned lane_addr = lds_base + buf * kFastLdsBytes + lane * 8;
+        const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
         if constexpr (DIAG) {
-            sweep_chunk_stamped<PPW>(acc, a.lut, pix0, a.usable_pad, m0, mc4 >> 2, lane_addr, t_wait, t_all);
+            sweep_chunk_stamped<PPW, (WPS > 4)>(acc, a.lut, pix0, a.usable_pad, m0, mc4 >> 2, lane_addr, t_wait, t_all);
         } else if (!(a.debug & 2)) {
-            sweep_chunk_trips<PPW>(acc, a.lut, pix0, a.usable_pad, m0, mc4 >> 2, lane_addr);
+            sweep_chunk_trips<PPW, (WPS > 4)>(acc, a.lut, pix0, a.usable_pad, m0, mc4 >> 2, lane_addr);
         }
         stamp(1, t);
         // the 257th sample of every window: see das_fast_kernel
-        const float *buf_f = lds + buf * (kFastLdsBytes / 4);
+        const float *buf_f = lds + buf * (BUF / 4);
         for (int j0 = 0; j0 < ((a.debug & 4) ? 0 : mc4); j0 += 32) {
             FastEntry e[4];
 #pragma unroll
@@ -492,14 +509,14 @@ __global__ __launch_bounds__(kDbThreads, 4) void das_fast_db_kernel(FastArgs a) 
 // ---------------------------------------------------------------------------------------
 // host side: geometry of the LDS image and the launch
 // ---------------------------------------------------------------------------------------
-bool fast_plan(int window, int usable, int fpi, FastPlan *plan) {
+bool fast_plan(int window, int usable, int fpi, int image_bytes, FastPlan *plan) {
     if (fpi != 1 && fpi != 2) return false;
     const int wr = (window + 3) & ~3;  // rows are whole 16-byte pieces (and start 16-byte aligned)
     const size_t row_bytes = (size_t) wr * sizeof(float);
-    const size_t frame_bytes = (size_t) kFastLdsBytes / fpi;
+    const size_t frame_bytes = (size_t) image_bytes / fpi;
     int chunk = (int) (frame_bytes / (2 * row_bytes));
     chunk &= ~3;  // whole entry groups per chunk
-    if (chunk > 64) chunk = 64;  // the side pass gives one lane to each mic of a chunk
+    if (chunk > 64) chunk = 64;
     if (chunk < 4) return false;
     const int usable_pad = (usable + 3) & ~3;
     if (chunk > usable_pad) chunk = usable_pad;
@@ -508,6 +525,7 @@ bool fast_plan(int window, int usable, int fpi, FastPlan *plan) {
     plan->chunk = chunk;
     plan->usable_pad = usable_pad;
     plan->row_bytes = (int) row_bytes;
+    plan->image_bytes = image_bytes;
     return true;
 }
 
@@ -527,33 +545,39 @@ static hipError_t launch_variant(const FastArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int PPW, bool DIAG>
+template <int NW, int PPW, int BUF, int WPS, bool DIAG>
 static hipError_t launch_db(const FastArgs &a, hipStream_t stream) {
     static bool attr_set = false;
+    constexpr int lds_bytes = 2 * BUF + kFastSideBytes;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *) das_fast_db_kernel<PPW, DIAG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFastLdsBytes + kFastSideBytes);
+        hipError_t e = hipFuncSetAttribute((const void *) das_fast_db_kernel<NW, PPW, BUF, WPS, DIAG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int pix_per_block = (kDbThreads / 64) * PPW;
+    const int pix_per_block = NW * PPW;
     dim3 grid((a.batch + a.frames_per_wg - 1) / a.frames_per_wg, (a.pixel_count + pix_per_block - 1) / pix_per_block);
     if (grid.y > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((das_fast_db_kernel<PPW, DIAG>), grid, dim3(kDbThreads), 2 * kFastLdsBytes + kFastSideBytes, stream, a);
+    hipLaunchKernelGGL((das_fast_db_kernel<NW, PPW, BUF, WPS, DIAG>), grid, dim3(NW * 64), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
+int fast_image_bytes(int nw) { return nw == 24 ? kFastLdsBytesSmall : kFastLdsBytes; }
+
 bool fast_db_fits(const FastPlan &plan) {
-    // every 16-byte piece of a full chunk must have a thread slot
-    return (size_t) plan.chunk * 2 * plan.row_bytes <= (size_t) kDbPieces * kDbThreads * 16 &&
-           (size_t) 2 * plan.usable_pad * sizeof(int) <= (size_t) kFastSideBytes;
+    return (size_t) 2 * plan.usable_pad * sizeof(int) <= (size_t) kFastSideBytes;
 }
 
 hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream) {
     if (nw == 32) {  // double-buffered, one 16-wave workgroup per CU
-        if (a.debug & 16) return ppw == 4 ? launch_db<4, true>(a, stream) : launch_db<8, true>(a, stream);
-        if (ppw == 4) return launch_db<4, false>(a, stream);
-        return launch_db<8, false>(a, stream);
+        if (a.debug & 16) return ppw == 4 ? launch_db<16, 4, kFastLdsBytes, 4, true>(a, stream)
+                                          : launch_db<16, 8, kFastLdsBytes, 4, true>(a, stream);
+        if (ppw == 4) return launch_db<16, 4, kFastLdsBytes, 4, false>(a, stream);
+        return launch_db<16, 8, kFastLdsBytes, 4, false>(a, stream);
+    }
+    if (nw == 24) {  // double-buffered, two 12-wave workgroups per CU, 6 waves per SIMD
+        if (a.debug & 16) return launch_db<12, 4, kFastLdsBytesSmall, 6, true>(a, stream);
+        return launch_db<12, 4, kFastLdsBytesSmall, 6, false>(a, stream);
     }
     if (fpi == 2) {
         if (ppw == 2) return launch_variant<8, 2, 2, 4>(a, stream);

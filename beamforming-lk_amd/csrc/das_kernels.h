@@ -34,6 +34,7 @@ struct SweepArgs {
 // ---- fast kernel (das_fast.hip) ---------------------------------------------------------
 constexpr int kFastLdsBytes = 78 * 1024; // one staged image; a CU holds two (+ a 4 KiB side table)
 constexpr int kFastSideBytes = 4 * 1024;
+constexpr int kFastLdsBytesSmall = 38 * 1024;  // image of the two-workgroups-per-CU double-buffered shape
 
 // One 16-byte entry per (pixel, active mic): what one item needs, laid out so that f and g
 // start even SGPRs after an s_load_dwordx16 (packed-FMA scalar operands are aligned pairs).
@@ -50,6 +51,7 @@ struct FastPlan {
     int chunk;       // mics staged per pass (multiple of 4, <= 64)
     int usable_pad;  // table row length, usable rounded up to 4 (null entries at the end)
     int row_bytes;
+    int image_bytes;  // LDS bytes of one staged image
 };
 
 struct FastArgs {
@@ -66,10 +68,11 @@ struct FastArgs {
 };
 
 // LDS image geometry for a window of `window` samples; false if it cannot fit.
-bool fast_plan(int window, int usable, int fpi, FastPlan *plan);
+bool fast_plan(int window, int usable, int fpi, int image_bytes, FastPlan *plan);
+int fast_image_bytes(int nw);
 // fpi in {1,2} frames per item; ppw in {2,4,8} pixels per wave (8 only with fpi 1)
-// nw: 8 or 16 waves per workgroup (two workgroups per CU), or 32 = the double-buffered
-// 16-wave shape with one workgroup per CU (fpi 1 only)
+// nw: 8 = 8-wave workgroups (two per CU, single image); 32 = double-buffered 16-wave workgroup, one
+// per CU; 24 = double-buffered 12-wave workgroups, two per CU (fpi 1 only for 24 and 32)
 hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream);
 bool fast_db_fits(const FastPlan &plan);
 

@@ -93,11 +93,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the sweep has no CPU path")
+    # BENCH_REHEARSAL=1: run the N > 1 code path on a box with ONE GPU (all ranks on cuda:0, gloo
+    # instead of RCCL) -- a correctness rehearsal of the sharding/broadcast logic, not a measurement.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     pkg = importlib.import_module("beamforming-lk_amd")
     sharding = importlib.import_module("beamforming-lk_amd.sharding")
@@ -110,16 +118,30 @@ def main():
     shard = sharding.shard_rows(spec.res, spec.res, world, rank)
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz, shard.row_begin, shard.row_count)
-    eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, math=math, max_batch=B,
+    hist = pkg.binding.HIST
+    win_begin = 0
+    if world > 1:
+        # Only the window [min off, max off + 257) of every mic is ever read, so that
+        # is what travels: rank 0 cuts it out of its 1024-sample snapshots each step and broadcasts
+        # [B][mics][Wc]; every rank sweeps with hist = Wc and offsets relative to the window.
+        lo = torch.tensor([int(off.min())], dtype=torch.int64, device=dev)
+        hi = torch.tensor([int(off.max())], dtype=torch.int64, device=dev)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        win_begin = int(lo.item())
+        hist = ((int(hi.item()) - win_begin + 257 + 3) // 4) * 4 + 4
+        off = off - win_begin
+    eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, hist=hist, math=math, max_batch=B,
                      device=local_rank, pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count)
     eng.set_delay_table(off, frac)
     eng.set_active_mics(None)
 
     host_frames = S.make_frames(xyz, B, seed=args.seed) if rank == 0 else None
-    bufs = tuple(torch.zeros((B, spec.n_mics, pkg.binding.HIST), dtype=torch.float32, device=dev) for _ in range(2))
-    if rank == 0:
-        for b in bufs:
-            b.copy_(torch.from_numpy(host_frames))
+    d_full = torch.from_numpy(host_frames).to(dev) if rank == 0 else None  # the ingest layout [B][mics][1024]
+    if world > 1:
+        bufs = tuple(torch.zeros((B, spec.n_mics, hist), dtype=torch.float32, device=dev) for _ in range(2))
+    else:
+        bufs = (d_full, d_full)
     d_power = torch.zeros((B, shard.pixel_count), dtype=torch.float32, device=dev)
     bcast = sharding.FrameBroadcaster(bufs, src=0)
     # a real (non-null) stream: its handle goes to the C ABI, and the torch events that time
@@ -127,16 +149,21 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
 
+    def post(k):
+        if world > 1 and rank == 0:  # cut the window out of the resident snapshots (part of the step)
+            bufs[k % 2].copy_(d_full[:, :, win_begin:win_begin + hist])
+        bcast.post(k)
+
     def run_steps(n, ev=None):
         with torch.cuda.stream(stream):
             _run_steps(n, ev)
 
     def _run_steps(n, ev):
-        bcast.post(0)
+        post(0)
         for k in range(n):
             frames = bcast.wait(k)
             if k + 1 < n:
-                bcast.post(k + 1)  # next batch travels while this one is swept
+                post(k + 1)  # next batch travels while this one is swept
             if ev is not None:
                 ev[0][k].record(stream)
             eng.process_device(frames.data_ptr(), B, d_power.data_ptr(), stream.cuda_stream)
@@ -171,9 +198,16 @@ def main():
 
         got = d_power[0].cpu().numpy()
         pick = np.linspace(0, shard.pixel_count - 1, num=min(256, shard.pixel_count)).astype(np.int64)
-        want = oracle_py.das_f32(host_frames[0], off[pick], frac[pick])
+        want = oracle_py.das_f32(host_frames[0], off[pick] + win_begin, frac[pick])
         floor = 1e-4 * want.max()
         parity = float((np.abs(got[pick] - want) / np.maximum(want, floor)).max())
+
+    # ---- N > 1: the assembled heatmap of frame 0 must equal what the shards computed
+    if world > 1:
+        full = sharding.gather_power(d_power[:1].contiguous(), sharding.all_shards(spec.res, spec.res, world), dst=0)
+        if rank == 0:
+            assert full.shape == (1, spec.n_pixels)
+            assert torch.equal(full[0, : shard.pixel_count], d_power[0])
 
     if rank == 0:
         fps = B * K / elapsed
@@ -189,8 +223,9 @@ def main():
             "config": {
                 "workload": spec.name, "mics": spec.n_mics, "grid": f"{spec.res}x{spec.res}",
                 "block_samples": 256, "frames_per_step": B, "math": args.math,
-                "sharding": f"grid rows over {world} GPU(s), frame batch broadcast from rank 0" if world > 1
-                            else "single GPU",
+                "sharding": f"grid rows over {world} GPU(s); per step rank 0 broadcasts the {hist}-sample window "
+                            f"of every mic ({B * spec.n_mics * hist * 4 / 1e6:.1f} MB), overlapped with the previous sweep"
+                            if world > 1 else "single GPU",
                 "alg_bytes_per_frame": full_bytes,
             },
             "roofline": {
@@ -205,9 +240,10 @@ def main():
             },
             "parity_max_rel_err": parity,
         }
+        if rehearsal:
+            out["rehearsal"] = "all ranks on one GPU over gloo: logic check only, not a scaling number"
         if world == 1 and args.cpu_seconds > 0:
-            off_full, frac_full = (off, frac)
-            out["cpu_baseline"] = cpu_baseline(S, spec, xyz, off_full, frac_full, host_frames[0], args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(S, spec, xyz, off, frac, host_frames[0], args.cpu_seconds)
             out["speedup_vs_cpu_1t"] = fps / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
 

@@ -169,6 +169,9 @@ def main():
     out.append(block("sweep_pixel_hi", 1, hi))
     out.append(block("sweep_quad_hi", 4, hi))
     out.append(block("sweep_quad_stamped", 4, hi, stamp=True))
+    lo = 80 - (4 * (DEPTH + 1) + 1) - 3  # shapes with an 80-VGPR budget (6 waves per SIMD)
+    out.append(block("sweep_quad_lo", 4, lo))
+    out.append(block("sweep_quad_lo_stamped", 4, lo, stamp=True))
     path = Path(__file__).resolve().parent.parent / "beamforming-lk_amd" / "csrc" / "das_fast_trip.inc"
     path.write_text("\n".join(out))
     print("wrote", path, sum(1 for _ in path.read_text().splitlines()), "lines")
