@@ -30,6 +30,7 @@ compiler never sees a register with a load in flight.
 import os
 from pathlib import Path
 
+PRIO = int(os.environ.get("TRIP_PRIO", "1"))  # alternate s_setprio per trip
 DEPTH = int(os.environ.get("TRIP_DEPTH", "4"))  # items of LDS read-ahead (2*DEPTH <= 15: lgkmcnt is 4 bits)
 SET = {"X": 36, "Y": 68}
 OTHER = {"X": "Y", "Y": "X"}
@@ -68,6 +69,13 @@ def trip(n_items, cur, vbase, acc):
                 f"v_pk_fma_f32 {R}, {gpair(i)}, {y}, {R} op_sel_hi:[0,1,1]"]
 
     lines = []
+    if PRIO:
+        # Waves of a SIMD are served oldest first; left alone, the youngest is starved and every
+        # chunk ends with that wave running alone while the others sit at the barrier (measured:
+        # sweep 196k vs 247k cycles, 63k cycles of barrier wait for the oldest).  Alternating the
+        # priority trip by trip (X trips high, Y trips low) time-slices the SIMD between waves at
+        # different phases and roughly halves that skew.
+        lines.append(f"s_setprio {1 if cur == 'X' else 0}")
     for i in range(min(DEPTH, n_items)):
         lines += issue(i)
     lines += [f"s_load_dwordx16 s[{pbase}:{pbase + 15}], %[ptr], s{S_PF}",
@@ -137,6 +145,8 @@ def block(name, n_pix, vbase, stamp=False):
     for j in range(n_pix):
         L += pixel_code(j, n_pix, vbase, accs[j])
     L += [".Ldone_%=:"]
+    if PRIO:
+        L += ["s_setprio 0"]
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)",
               f"s_sub_u32 s{S_T1}, s{S_T1}, s{S_T0}", f"s_add_u32 %[t_all], %[t_all], s{S_T1}"]
