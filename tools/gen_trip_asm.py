@@ -30,7 +30,8 @@ compiler never sees a register with a load in flight.
 import os
 from pathlib import Path
 
-PRIO = int(os.environ.get("TRIP_PRIO", "1"))  # alternate s_setprio per trip
+PRIO = int(os.environ.get("TRIP_PRIO", "2"))  # 1: alternate s_setprio per trip; 2: four levels
+PRIO_BASE = [0]  # +2 on odd pixels of a block: four levels, so that ties (decided by age) are rarer
 DEPTH = int(os.environ.get("TRIP_DEPTH", "4"))  # items of LDS read-ahead (2*DEPTH <= 15: lgkmcnt is 4 bits)
 SET = {"X": 36, "Y": 68}
 OTHER = {"X": "Y", "Y": "X"}
@@ -75,7 +76,7 @@ def trip(n_items, cur, vbase, acc):
         # sweep 196k vs 247k cycles, 63k cycles of barrier wait for the oldest).  Alternating the
         # priority trip by trip (X trips high, Y trips low) time-slices the SIMD between waves at
         # different phases and roughly halves that skew.
-        lines.append(f"s_setprio {1 if cur == 'X' else 0}")
+        lines.append(f"s_setprio {(1 if cur == 'X' else 0) + PRIO_BASE[0]}")
     for i in range(min(DEPTH, n_items)):
         lines += issue(i)
     lines += [f"s_load_dwordx16 s[{pbase}:{pbase + 15}], %[ptr], s{S_PF}",
@@ -103,6 +104,7 @@ def pixel_code(j, n_pix, vbase, acc):
     entries, s{S_LEFT} = groups of four left (>= 1), s{S_OFF} = table offset of the entries after
     those, s{S_ROW} = table offset of this pixel's row."""
     last_pixel = j == n_pix - 1
+    PRIO_BASE[0] = 2 * (j & 1) if PRIO >= 2 else 0
     L = []
     for cur in ("X", "Y"):
         oth = OTHER[cur]
