@@ -217,6 +217,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
     const int wr = a.wr;
     const AWPU_AS4 FastEntry *lut = (const AWPU_AS4 FastEntry *) (unsigned long long) a.lut;
     const AWPU_AS4 int32_t *index = (const AWPU_AS4 int32_t *) (unsigned long long) a.index;
+    const AWPU_AS4 int32_t *row_off = (const AWPU_AS4 int32_t *) (unsigned long long) a.row_off;
 
     Acc<FPI> acc[PPW];
     float tail[FPI];  // lane (8*pp + k): partial tail sum of pixel pp over the mics s = k (mod 8)
@@ -237,9 +238,25 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
         __syncthreads();                // the previous chunk is fully consumed
 
         // ---- stage [frame][mic][copy][wr] floats: copy q = the window shifted by q samples.
-        // One wave per row, two rows per trip, 16 bytes per lane per load and all loads of a
-        // trip issued before the first LDS write, so that their L2 latencies overlap.
         const int rows = (a.debug & 1) && m0 > 0 ? 0 : FPI * mc * 2;  // debug bit 0: stage once
+        const bool inside = a.wstart + 1 + wr <= a.hist;  // every 16-byte piece of every row is readable
+        if (inside && !(a.debug & 64)) {
+            // LDS-DMA, one wave per row: lane l's 16 bytes land at (row base + 1 KiB * k) + 16 l
+            for (int r = wave; r < rows; r += NW) {
+                const int b = r / (2 * mc);
+                const int jr = r - b * 2 * mc;
+                const int fb = min(frame0 + b, a.batch - 1);
+                const float *src = a.frames + (size_t) fb * a.n_streams * a.hist + row_off[2 * m0 + jr];
+                float *dst = lds + b * (FS / 4) + jr * wr;
+                for (int t0 = 0; t0 < wr; t0 += 256) {
+                    if (t0 + lane * 4 < wr) {
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + t0 + lane * 4),
+                                                         (__attribute__((address_space(3))) void *) (dst + t0), 16, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else
         for (int r = wave; r < rows; r += 2 * NW) {
             const float *src[2];
             float *dst[2];
@@ -256,8 +273,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
                 dst[u] = lds + b * (FS / 4) + (j * 2 + q) * wr;
                 valid = min(valid, a.hist - first);
             }
-            if (valid == wr) {  // the whole row lies inside the history (always, unless the
-                                // window touches the newest sample): no per-element guards
+            if (valid == wr) {  // the whole row lies inside the history: no per-element guards
                 for (int t0 = 0; t0 < wr; t0 += 512) {
                     f4 v[2][2];
 #pragma unroll
