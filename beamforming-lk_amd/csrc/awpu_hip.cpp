@@ -58,6 +58,8 @@ struct awpu_hip {
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     int32_t *d_index = nullptr;
     int32_t *d_row_off = nullptr;
+    int32_t *d_row_off_compact = nullptr;  // the same for frames uploaded as [streams][compact_hist] windows
+    int compact_hist = 0;                  // 0 = the window cannot be cut out (it touches the newest sample)
     float *d_frames = nullptr;
     float *d_power = nullptr;
     size_t frames_cap = 0, power_cap = 0;  // in floats
@@ -77,7 +79,9 @@ void release_device(awpu_hip *h) {
     h->fast_luts.clear();
     if (h->d_index) (void) hipFree(h->d_index);
     if (h->d_row_off) (void) hipFree(h->d_row_off);
+    if (h->d_row_off_compact) (void) hipFree(h->d_row_off_compact);
     h->d_row_off = nullptr;
+    h->d_row_off_compact = nullptr;
     if (h->d_frames) (void) hipFree(h->d_frames);
     if (h->d_power) (void) hipFree(h->d_power);
     h->d_lut = nullptr;
@@ -130,6 +134,19 @@ int prepare(awpu_hip *h) {
             for (int q = 0; q < 2; q++) ro[2 * s + q] = h->index[s] * c.hist + lo + q;
         AWPU_HIP_TRY(hipMalloc(&h->d_row_off, ro.size() * sizeof(int32_t)));
         AWPU_HIP_TRY(hipMemcpy(h->d_row_off, ro.data(), ro.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        // Host-buffer calls upload only the window [lo, lo + compact_hist) of every stream (the rest
+        // of the 1024-sample snapshot is never read: SURVEY 8a A10): a third of the PCIe bytes.
+        if (h->d_row_off_compact) (void) hipFree(h->d_row_off_compact);
+        h->d_row_off_compact = nullptr;
+        const int ch = ((h->window + 3) & ~3) + 4;
+        h->compact_hist = lo + ch <= c.hist ? ch : 0;
+        if (h->compact_hist) {
+            for (int s = 0; s < U; s++)
+                for (int q = 0; q < 2; q++) ro[2 * s + q] = h->index[s] * h->compact_hist + q;
+            for (size_t i = 2 * (size_t) U; i < ro.size(); i++) ro[i] = h->index[0] * h->compact_hist;
+            AWPU_HIP_TRY(hipMalloc(&h->d_row_off_compact, ro.size() * sizeof(int32_t)));
+            AWPU_HIP_TRY(hipMemcpy(h->d_row_off_compact, ro.data(), ro.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
     }
 
     if (c.math == AWPU_MATH_F32_EXACT) {
@@ -249,7 +266,10 @@ void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
     if (*fpi == 2 && batch < 2) *fpi = 1;
 }
 
-int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s) {
+// `compact`: d_frames is [batch][n_streams][compact_hist], sample 0 = history sample wstart.
+int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, bool compact = false) {
+    const int hist_eff = compact ? h->compact_hist : h->cfg.hist;
+    const int wstart_eff = compact ? 0 : h->wstart;
     if (h->cfg.math == AWPU_MATH_F32_EXACT) {
         awpu::SweepArgs a{};
         a.frames = d_frames;
@@ -257,10 +277,10 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         a.index = h->d_index;
         a.power = d_power;
         a.n_streams = h->cfg.n_streams;
-        a.hist = h->cfg.hist;
+        a.hist = hist_eff;
         a.usable = h->usable();
         a.pixel_count = h->cfg.pixel_count;
-        a.wstart = h->wstart;
+        a.wstart = wstart_eff;
         a.window = h->window;
         a.batch = batch;
         if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
@@ -271,7 +291,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         const awpu_hip::FastLut *lut = nullptr;
         int rc = build_fast_lut(h, fpi, awpu::fast_image_bytes(nw), &lut);
         // the double-buffered shapes read whole 16-byte pieces of every staged row
-        if (nw != 8 && (rc != AWPU_OK || !awpu::fast_db_fits(lut->plan) || h->wstart + 1 + lut->plan.wr > h->cfg.hist)) {
+        if (nw != 8 && (rc != AWPU_OK || !awpu::fast_db_fits(lut->plan) || wstart_eff + 1 + lut->plan.wr > hist_eff)) {
             nw = 8;
             if (ppw > 4 && fpi == 2) ppw = 4;
             rc = build_fast_lut(h, fpi, awpu::fast_image_bytes(nw), &lut);
@@ -282,14 +302,14 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         a.frames = d_frames;
         a.lut = lut->d;
         a.index = h->d_index;
-        a.row_off = h->d_row_off;
+        a.row_off = compact ? h->d_row_off_compact : h->d_row_off;
         a.power = d_power;
         a.n_streams = h->cfg.n_streams;
-        a.hist = h->cfg.hist;
+        a.hist = hist_eff;
         a.usable = h->usable();
         a.usable_pad = plan.usable_pad;
         a.pixel_count = h->cfg.pixel_count;
-        a.wstart = h->wstart;
+        a.wstart = wstart_eff;
         a.wr = plan.wr;
         a.chunk = plan.chunk;
         a.batch = batch;
@@ -477,7 +497,9 @@ int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *p
     if (!frames || !power) return invalid("null argument");
     int rc = check_ready(h, batch);
     if (rc != AWPU_OK) return rc;
-    const size_t frame_floats = (size_t) h->cfg.n_streams * h->cfg.hist;
+    const bool compact = h->compact_hist > 0;
+    const int dev_hist = compact ? h->compact_hist : h->cfg.hist;
+    const size_t frame_floats = (size_t) h->cfg.n_streams * dev_hist;
     const size_t need_frames = frame_floats * batch, need_power = (size_t) h->cfg.pixel_count * batch;
     if (h->frames_cap < need_frames) {
         if (h->d_frames) (void) hipFree(h->d_frames);
@@ -493,9 +515,15 @@ int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *p
         AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
         h->power_cap = need_power;
     }
-    AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, frames, need_frames * sizeof(float),
-                                hipMemcpyHostToDevice, h->stream));
-    rc = launch(h, h->d_frames, batch, h->d_power, h->stream);
+    if (compact) {  // rows of compact_hist floats cut out of rows of hist floats
+        AWPU_HIP_TRY(hipMemcpy2DAsync(h->d_frames, (size_t) dev_hist * sizeof(float), frames + h->wstart,
+                                      (size_t) h->cfg.hist * sizeof(float), (size_t) dev_hist * sizeof(float),
+                                      (size_t) batch * h->cfg.n_streams, hipMemcpyHostToDevice, h->stream));
+    } else {
+        AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, frames, need_frames * sizeof(float),
+                                    hipMemcpyHostToDevice, h->stream));
+    }
+    rc = launch(h, h->d_frames, batch, h->d_power, h->stream, compact);
     if (rc != AWPU_OK) return rc;
     AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_power, need_power * sizeof(float),
                                 hipMemcpyDeviceToHost, h->stream));
