@@ -243,6 +243,13 @@ class Engine:
             _check(self._lib.awpu_hip_set_active_mics(self._h, _i32(index), index.size),
                    "set_active_mics")
 
+    def set_fir_table(self, coeffs: np.ndarray) -> None:
+        """The caller's [101, 8] coefficient table of the FIR variant (src/dsp/filter.h:10-112)."""
+        coeffs = np.ascontiguousarray(coeffs, np.float32)
+        if coeffs.shape != (101, 8):
+            raise ValueError("FIR table must be [101, 8]")
+        _check(self._lib.awpu_hip_set_fir_table(self._h, _f32(coeffs)), "set_fir_table")
+
     def process(self, frames: np.ndarray) -> np.ndarray:
         """frames [batch, n_streams, hist] (or one frame [n_streams, hist]) -> power [batch, pixels]."""
         frames = np.ascontiguousarray(frames, np.float32)

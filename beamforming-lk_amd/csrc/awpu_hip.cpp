@@ -57,6 +57,8 @@ struct awpu_hip {
     };
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     int32_t *d_index = nullptr;
+    float *d_fir = nullptr;  // [101][8] coefficient table (AWPU_INTERP_FIR8)
+    bool have_fir = false;
     int32_t *d_row_off = nullptr;
     int32_t *d_row_off_compact = nullptr;  // the same for frames uploaded as [streams][compact_hist] windows
     int compact_hist = 0;                  // 0 = the window cannot be cut out (it touches the newest sample)
@@ -78,6 +80,8 @@ void release_device(awpu_hip *h) {
         if (l.d) (void) hipFree(l.d);
     h->fast_luts.clear();
     if (h->d_index) (void) hipFree(h->d_index);
+    if (h->d_fir) (void) hipFree(h->d_fir);
+    h->d_fir = nullptr;
     if (h->d_row_off) (void) hipFree(h->d_row_off);
     if (h->d_row_off_compact) (void) hipFree(h->d_row_off_compact);
     h->d_row_off = nullptr;
@@ -107,12 +111,13 @@ int prepare(awpu_hip *h) {
             hi = std::max(hi, o);
         }
     }
-    if (lo < 0 || hi + awpu::kSamples > c.hist - 1) {
+    const int reach = c.interp == AWPU_INTERP_FIR8 ? awpu::kSamples + 6 : awpu::kSamples;  // last sample read past off
+    if (lo < 0 || hi + reach > c.hist - 1) {
         g_last_error = "delay table entry reads outside the frame history";
         return AWPU_ERR_RANGE;
     }
     h->wstart = lo;
-    h->window = hi - lo + awpu::kSamples + 1;
+    h->window = hi - lo + reach + 1;
     h->tau_max = awpu::kSamples - lo;
 
     if (h->d_lut) (void) hipFree(h->d_lut);
@@ -149,7 +154,7 @@ int prepare(awpu_hip *h) {
         }
     }
 
-    if (c.math == AWPU_MATH_F32_EXACT) {
+    if (c.math == AWPU_MATH_F32_EXACT || c.interp == AWPU_INTERP_FIR8) {
         int chunk = 0;
         if (awpu::das_exact_lds_bytes(h->window, U, &chunk) == 0)
             return invalid("delay window does not fit the LDS budget");
@@ -162,6 +167,11 @@ int prepare(awpu_hip *h) {
                 const int id = h->index[s];
                 dst[s].off_rel = orow[id] - lo;
                 dst[s].frac = frow[id];
+                if (c.interp == AWPU_INTERP_FIR8) {  // delay.cpp:32-33: the coefficient row
+                    const float get_filter = frow[id] * 100.0f + 0.5f;
+                    const int32_t k = (int32_t) get_filter;
+                    std::memcpy(&dst[s].frac, &k, sizeof(k));
+                }
             }
         }
         AWPU_HIP_TRY(hipMalloc(&h->d_lut, packed.size() * sizeof(awpu::LutEntry)));
@@ -270,7 +280,7 @@ void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
 int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, bool compact = false) {
     const int hist_eff = compact ? h->compact_hist : h->cfg.hist;
     const int wstart_eff = compact ? 0 : h->wstart;
-    if (h->cfg.math == AWPU_MATH_F32_EXACT) {
+    if (h->cfg.math == AWPU_MATH_F32_EXACT || h->cfg.interp == AWPU_INTERP_FIR8) {
         awpu::SweepArgs a{};
         a.frames = d_frames;
         a.lut = h->d_lut;
@@ -284,6 +294,9 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         a.window = h->window;
         a.batch = batch;
         if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+        if (h->cfg.interp == AWPU_INTERP_FIR8) {
+            AWPU_HIP_TRY(awpu::launch_das_fir8(a, h->d_fir, s));
+        } else
         AWPU_HIP_TRY(awpu::launch_das_exact(a, s));
     } else {
         int fpi = 1, ppw = 8, nw = 8;
@@ -373,6 +386,10 @@ int check_ready(awpu_hip *h, int batch) {
         g_last_error = "delay table and active mics must be set before processing";
         return AWPU_ERR_STATE;
     }
+    if (h->cfg.interp == AWPU_INTERP_FIR8 && !h->have_fir) {
+        g_last_error = "AWPU_INTERP_FIR8 needs awpu_hip_set_fir_table";
+        return AWPU_ERR_STATE;
+    }
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     if (!h->prepared) {
         const int rc = prepare(h);
@@ -409,7 +426,7 @@ int awpu_hip_create(awpu_hip_t **out, const awpu_hip_cfg *cfg) {
         return invalid("n_streams, lut_stride, n_pixels and max_batch must be >= 1");
     if (cfg->hist < AWPU_N_SAMPLES + 1) return invalid("hist must hold at least 257 samples");
     if (cfg->max_batch > 65535) return invalid("max_batch above 65535");
-    if (cfg->interp != AWPU_INTERP_LERP) return invalid("only AWPU_INTERP_LERP is implemented");
+    if (cfg->interp != AWPU_INTERP_LERP && cfg->interp != AWPU_INTERP_FIR8) return invalid("cfg.interp");
     if (cfg->math != AWPU_MATH_F32_EXACT && cfg->math != AWPU_MATH_F32_FAST)
         return invalid("cfg.math");
     awpu_hip_cfg c = *cfg;
@@ -488,9 +505,12 @@ int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable
 }
 
 int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {
-    (void) coeffs;
-    if (!h) return invalid("null handle");
-    return invalid("AWPU_INTERP_FIR8 is not implemented");
+    if (!h || !coeffs) return invalid("null argument");
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    if (!h->d_fir) AWPU_HIP_TRY(hipMalloc(&h->d_fir, 101 * 8 * sizeof(float)));
+    AWPU_HIP_TRY(hipMemcpy(h->d_fir, coeffs, 101 * 8 * sizeof(float), hipMemcpyHostToDevice));
+    h->have_fir = true;
+    return AWPU_OK;
 }
 
 int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *power) {

@@ -79,6 +79,10 @@ bool fast_db_fits(const FastPlan &plan);
 // exact-order kernel (AWPU_MATH_F32_EXACT): sub, fma, add per sample, mics in order.
 hipError_t launch_das_exact(const SweepArgs &a, hipStream_t stream);
 
+// FIR8 variant: LutEntry.frac holds the coefficient-row index k as an int bit pattern; window
+// must cover off + 263.  d_coeffs = [101][8] floats on the device.
+hipError_t launch_das_fir8(const SweepArgs &a, const float *d_coeffs, hipStream_t stream);
+
 // LDS bytes the exact kernel asks for with the given window; 0 if the window cannot fit.
 size_t das_exact_lds_bytes(int window, int usable, int *chunk_out);
 

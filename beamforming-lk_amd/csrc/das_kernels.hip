@@ -110,6 +110,77 @@ __global__ __launch_bounds__(kExactThreads) void das_exact_kernel(SweepArgs a, i
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// FIR8 kernel (AWPU_INTERP_FIR8): the 8-tap table variant of delay(), src/dsp/delay.cpp:31-40,
+//     k = (int)(frac * 100 + 0.5);  out[n] += sum_{t<8} C[k][t] * X[off + n + t]
+// inside the same sweep and epilogue (mimo.cpp:121-151).  Not compiled in the reference's shipped
+// configuration (-mavx2 selects the linear variant); provided for completeness, same structure as
+// the exact kernel: lane l owns samples l+64k, taps accumulate in the reference's order
+// t = 0..7 (one FMA per tap where the reference has a multiply and an add).  The table entry
+// carries k (computed on the host with the reference's expression); the 8 coefficients of a
+// (pixel, mic) are wave-uniform and arrive by one scalar load.
+// ---------------------------------------------------------------------------------------
+template <int PPW>
+__global__ __launch_bounds__(kExactThreads) void das_fir8_kernel(SweepArgs a, const float *coeffs, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int W = a.window;
+    const int pix0 = (blockIdx.x * (kExactThreads / 64) + wave) * PPW;
+    const float *frame = a.frames + (size_t) b * a.n_streams * a.hist;
+
+    float acc[PPW][4];
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[pp][k] = 0.0f;
+
+    for (int m0 = 0; m0 < a.usable; m0 += chunk) {
+        const int mc = min(chunk, a.usable - m0);
+        __syncthreads();
+        for (int m = wave; m < mc; m += kExactThreads / 64) {
+            const float *src = frame + (size_t) a.index[m0 + m] * a.hist + a.wstart;
+            for (int t = lane; t < W; t += 64) lds[m * W + t] = src[t];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pp = 0; pp < PPW; pp++) {
+            const int p = pix0 + pp;
+            if (p < a.pixel_count) {
+                const LutEntry *row = a.lut + (size_t) p * a.usable + m0;
+                for (int m = 0; m < mc; m++) {
+                    const LutEntry e = row[m];
+                    const float *c = coeffs + 8 * __float_as_int(e.frac);  // .frac carries the row index k
+                    const float *x = lds + m * W + e.off_rel + lane;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+#pragma unroll
+                        for (int t = 0; t < 8; t++) acc[pp][k] = __builtin_fmaf(c[t], x[64 * k + t], acc[pp][k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) {
+        const int p = pix0 + pp;
+        if (p < a.pixel_count) {
+            const float sum = epilogue_interleaved(acc[pp], lane);
+            if (lane == 0) a.power[(size_t) b * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
+        }
+    }
+}
+
+hipError_t launch_das_fir8(const SweepArgs &a, const float *d_coeffs, hipStream_t stream) {
+    int chunk = 0;
+    const size_t lds = das_exact_lds_bytes(a.window, a.usable, &chunk);
+    if (lds == 0) return hipErrorInvalidValue;
+    const int pix_per_block = (kExactThreads / 64) * kExactPPW;
+    dim3 grid((a.pixel_count + pix_per_block - 1) / pix_per_block, a.batch);
+    hipLaunchKernelGGL(das_fir8_kernel<kExactPPW>, grid, dim3(kExactThreads), lds, stream, a, d_coeffs, chunk);
+    return hipGetLastError();
+}
+
 size_t das_exact_lds_bytes(int window, int usable, int *chunk_out) {
     const size_t row = (size_t) window * sizeof(float);
     if (row == 0 || row > kExactLdsBudget) return 0;

@@ -180,6 +180,44 @@ def das_f64(X, off, frac, index=None) -> np.ndarray:
     return power
 
 
+def das_fir8_f32(X, off, frac, coeffs, index=None, impl="oracle"):
+    """FIR8 sweep (delay.cpp:31-40 inside mimo.cpp:121-151); impl = oracle | ref (the reference's own
+    non-AVX2 build, which carries its own table: `coeffs` must then be that table)."""
+    X = np.ascontiguousarray(X, np.float32)
+    off = np.ascontiguousarray(off, np.int32)
+    frac = np.ascontiguousarray(frac, np.float32)
+    coeffs = np.ascontiguousarray(coeffs, np.float32)
+    assert coeffs.shape == (101, 8)
+    if index is None:
+        index = np.arange(X.shape[0], dtype=np.int32)
+    index = np.ascontiguousarray(index, np.int32)
+    assert off[:, index].min() >= 0 and off[:, index].max() + 263 <= X.shape[1]
+    P = off.shape[0]
+    power = np.empty(P, np.float32)
+    if impl == "oracle":
+        oracle().oracle_das_fir8_f32(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index),
+                                     index.size, _p32(coeffs), _p32(power))
+    else:
+        lib = ref("fir")
+        assert lib.ref_variant() == 2
+        lib.ref_das(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index), index.size,
+                    _p32(power), None)
+    return power
+
+
+def reference_fir_table():
+    """The reference's filter_coeffs[101][8], parsed from its header WHERE IT LIES (nothing is copied
+    into the repo); None when the reference tree is absent (GPU box)."""
+    import re
+
+    path = REFERENCE_TREE / "src/dsp/filter.h"
+    if not path.exists():
+        return None
+    nums = re.findall(r"-?\d+\.\d+(?:[eE][-+]?\d+)?", path.read_text().split("filter_coeffs")[1])
+    table = np.array(nums[: 101 * 8], dtype=np.float32).reshape(101, 8)
+    return table
+
+
 def ref_bench(X, off, frac, index=None, min_seconds=1.0):
     """frames/s of the reference-kernel loop nest on one thread over the P pixels of `off`."""
     X, off, frac, index = _sweep_args(X, off, frac, index)

@@ -261,3 +261,30 @@ def test_device_pointer_entry_with_torch(pkg, oracle):
     assert np.array_equal(got, host)
     for b in range(3):
         assert util.power_rel_err(got[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
+
+
+@pytest.mark.parametrize("table_kind", ["synthetic", "reference"])
+def test_fir8_mode_vs_oracle(pkg, oracle, table_kind):
+    """AWPU_INTERP_FIR8 (delay.cpp:31-40): GPU vs the restated FIR sweep, 64 and 256 mics, with a
+    synthetic table and -- where the reference tree is present -- the reference's own."""
+    table = util.synthetic_fir_table() if table_kind == "synthetic" else oracle.reference_fir_table()
+    if table is None:
+        pytest.skip("reference tree absent on this box")
+    for arrays, res, usable in [((1, 1), 16, 64), ((4, 1), 8, 200)]:
+        xyz = oracle.create_tiled_antenna(*arrays)
+        off, frac = oracle.compute_delay_lut(xyz, res, res)
+        n = xyz.shape[1]
+        X = util.hash_frames(n, 1024, seed=50 + usable, batch=2)
+        index = np.random.default_rng(usable).permutation(n)[:usable].astype(np.int32)
+        eng = pkg.Engine(n_pixels=off.shape[0], n_streams=n, interp=pkg.binding.INTERP_FIR8, max_batch=2)
+        with eng:
+            eng.set_delay_table(off, frac)
+            eng.set_active_mics(index)
+            with pytest.raises(pkg.AwpuError) as ei:
+                eng.process(X)
+            assert ei.value.status == pkg.binding.ERR_STATE  # table not set yet
+            eng.set_fir_table(table)
+            power = eng.process(X)
+        for b in range(2):
+            want = oracle.das_fir8_f32(X[b], off, frac, table, index)
+            assert util.power_rel_err(power[b], want) < util.POWER_RTOL

@@ -146,3 +146,34 @@ def test_unpack_exposure(oracle):
     assert block[7, 3] == np.float32(stream[3, 0]) / np.float32(8388608.0)
     assert block[8, 0] == np.float32(stream[0, 8]) / np.float32(8388608.0)
     assert block[16, 255] == np.float32(stream[255, 23]) / np.float32(8388608.0)
+
+
+def test_fir8_restatement_matches_reference_build_live(oracle):
+    """delay() FIR variant, src/dsp/delay.cpp:31-40: the reference's own non-AVX2 build (which
+    carries its filter.h table) against the restatement fed the same table, parsed from the
+    reference header where it lies."""
+    table = oracle.reference_fir_table()
+    if table is None or not oracle.ref_available("fir"):
+        pytest.skip("reference tree / oracle/_ref FIR build not available")
+    assert table.shape == (101, 8) and abs(float(table[0, 3]) - 1.0) < 1e-4
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 10, 10)
+    X = util.hash_frames(64, 1024, seed=44)[0]
+    p_o = oracle.das_fir8_f32(X, off, frac, table)
+    p_r = oracle.das_fir8_f32(X, off, frac, table, impl="ref")
+    assert util.power_rel_err(p_o, p_r) < 5e-6
+
+
+def test_fir8_at_zero_fraction_is_a_three_sample_delay(oracle):
+    """Row 0 of a fractional-delay table is (numerically) a unit tap at index 3: the FIR sweep then
+    equals the linear sweep of the same frame read 3 samples later with fraction 0 -> weight on s[i+1],
+    i.e. offsets + 2."""
+    table = np.zeros((101, 8), np.float32)
+    table[:, 3] = 1.0
+    xyz = oracle.create_antenna()
+    off, _ = oracle.compute_delay_lut(xyz, 6, 6)
+    frac = np.zeros_like(off, dtype=np.float32)
+    X = util.hash_frames(64, 1024, seed=45)[0]
+    p_fir = oracle.das_fir8_f32(X, off, frac, table)
+    p_lin = oracle.das_f32(X, off + 2, frac)
+    assert np.allclose(p_fir, p_lin, rtol=1e-6, atol=0)

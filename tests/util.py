@@ -30,3 +30,15 @@ def power_rel_err(got: np.ndarray, ref: np.ndarray) -> float:
     ref = np.asarray(ref, np.float64)
     floor = NULL_FLOOR * np.abs(ref).max(axis=-1, keepdims=True)
     return float((np.abs(got - ref) / np.maximum(np.abs(ref), floor)).max())
+
+
+def synthetic_fir_table() -> np.ndarray:
+    """A [101, 8] fractional-delay table in the spirit of the reference's (Blackman-windowed sinc,
+    centre tap 3, delays 0..1 in steps of 0.01; math_toolbox/filter_produce.m:89-101,263-264).  The
+    kernels take the table as an input, so any table exercises them."""
+    t = np.arange(8, dtype=np.float64)[None, :]
+    d = (np.arange(101, dtype=np.float64) / 100.0)[:, None]
+    x = t - 3.0 - d
+    w = 0.42 - 0.5 * np.cos(2 * np.pi * (x + 4.0) / 8.0) + 0.08 * np.cos(4 * np.pi * (x + 4.0) / 8.0)
+    h = np.sinc(x) * np.clip(w, 0.0, None)
+    return (h / h.sum(axis=1, keepdims=True)).astype(np.float32)
