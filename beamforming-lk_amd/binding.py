@@ -78,6 +78,8 @@ _SIGNATURES = {
     "awpu_hip_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "awpu_hip_synchronize": (C.c_int, [C.c_void_p]),
     "awpu_hip_heatmap_u8": (C.c_int, [_f32p, C.c_int32, _u8p]),
+    "awpu_hip_heatmap_u8_device": (
+        C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "awpu_hip_create_antenna": (C.c_int, [C.c_int32, C.c_int32, C.c_float, _f32p]),
     "awpu_hip_create_tiled_antenna": (C.c_int, [C.c_int32, C.c_int32, C.c_float, _f32p]),
     "awpu_hip_steering_delays": (C.c_int, [_f32p, C.c_int32, C.c_double, C.c_double, _f32p]),
@@ -268,6 +270,13 @@ class Engine:
         _check(self._lib.awpu_hip_process_device(self._h, C.c_void_p(d_frames_ptr), batch,
                                                  C.c_void_p(d_power_ptr), C.c_void_p(stream)),
                "awpu_hip_process_device")
+
+    def heatmap_device(self, d_power_ptr: int, n: int, batch: int, d_peak_ptr: int, d_pix_ptr: int,
+                       peak_given: bool = False, stream: int = 0) -> None:
+        """populateHeatmap (src/dsp/mimo.cpp:61-95) on device buffers, asynchronous on `stream`."""
+        _check(self._lib.awpu_hip_heatmap_u8_device(self._h, C.c_void_p(d_power_ptr), n, batch,
+                                                    C.c_void_p(d_peak_ptr), int(peak_given), C.c_void_p(d_pix_ptr),
+                                                    C.c_void_p(stream)), "awpu_hip_heatmap_u8_device")
 
     def synchronize(self) -> None:
         _check(self._lib.awpu_hip_synchronize(self._h), "awpu_hip_synchronize")

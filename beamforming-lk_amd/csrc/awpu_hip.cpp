@@ -571,6 +571,15 @@ int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch,
     return rc2;
 }
 
+int awpu_hip_heatmap_u8_device(awpu_hip_t *h, const float *d_power, int32_t n, int32_t batch, float *d_peak,
+                               int32_t peak_given, uint8_t *d_pix, void *stream) {
+    if (!h || !d_power || !d_peak || !d_pix || n < 1 || batch < 1 || batch > 65535) return invalid("bad argument");
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    AWPU_HIP_TRY(awpu::launch_heatmap(d_power, n, batch, d_peak, peak_given != 0, d_pix, s));
+    return AWPU_OK;
+}
+
 int awpu_hip_synchronize(awpu_hip_t *h) {
     if (!h) return invalid("null handle");
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));

@@ -83,6 +83,11 @@ hipError_t launch_das_exact(const SweepArgs &a, hipStream_t stream);
 // must cover off + 263.  d_coeffs = [101][8] floats on the device.
 hipError_t launch_das_fir8(const SweepArgs &a, const float *d_coeffs, hipStream_t stream);
 
+// populateHeatmap on the device: d_peak[batch] receives (or, if peak_given, supplies) the per-frame
+// maximum; d_pix[batch][n] the 8-bit image.
+hipError_t launch_heatmap(const float *d_power, int n, int batch, float *d_peak, bool peak_given, uint8_t *d_pix,
+                          hipStream_t stream);
+
 // LDS bytes the exact kernel asks for with the given window; 0 if the window cannot fit.
 size_t das_exact_lds_bytes(int window, int usable, int *chunk_out);
 

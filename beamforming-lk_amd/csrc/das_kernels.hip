@@ -181,6 +181,46 @@ hipError_t launch_das_fir8(const SweepArgs &a, const float *d_coeffs, hipStream_
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// Display step on the device: MIMOWorker::populateHeatmap with USE_DB 0, src/dsp/mimo.cpp:61-95.
+//   max_v = max(0, max_p power[p]);  pix[p] = (uint8) clip(power[p] / max_v * 255, 0, 255)
+// Two launches per call: a grid-stride maximum into one float per frame (powers are >= 0, so
+// the unsigned bit pattern orders like the value and atomicMax on it is exact), then the scaling.
+// `peak` may be supplied by the caller instead (multi-GPU: the all-reduced maximum of the tiles).
+// ---------------------------------------------------------------------------------------
+__global__ void heatmap_max_kernel(const float *power, int n, unsigned *peak_bits) {
+    const float *p = power + (size_t) blockIdx.y * n;
+    float m = 0.0f;  // mimo.cpp:62: the running maximum starts at 0
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = fmaxf(m, p[i]);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) atomicMax(peak_bits + blockIdx.y, __float_as_uint(m));
+}
+
+__global__ void heatmap_scale_kernel(const float *power, int n, const float *peak, uint8_t *pix) {
+    const float max_v = peak[blockIdx.y];
+    const float *p = power + (size_t) blockIdx.y * n;
+    uint8_t *o = pix + (size_t) blockIdx.y * n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        // mimo.cpp:85-91: float division, then double scaling and clipping, then the uchar cast
+        double level = (double) (p[i] / max_v) * 255.0;
+        level = level < 0.0 ? 0.0 : (level > 255.0 ? 255.0 : level);
+        o[i] = (uint8_t) level;
+    }
+}
+
+hipError_t launch_heatmap(const float *d_power, int n, int batch, float *d_peak, bool peak_given, uint8_t *d_pix,
+                          hipStream_t stream) {
+    const int blocks = (n + 1023) / 1024 < 64 ? (n + 1023) / 1024 : 64;
+    if (!peak_given) {
+        hipError_t e = hipMemsetAsync(d_peak, 0, sizeof(float) * batch, stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(heatmap_max_kernel, dim3(blocks, batch), dim3(256), 0, stream, d_power, n, (unsigned *) d_peak);
+    }
+    hipLaunchKernelGGL(heatmap_scale_kernel, dim3(blocks, batch), dim3(256), 0, stream, d_power, n, d_peak, d_pix);
+    return hipGetLastError();
+}
+
 size_t das_exact_lds_bytes(int window, int usable, int *chunk_out) {
     const size_t row = (size_t) window * sizeof(float);
     if (row == 0 || row > kExactLdsBudget) return 0;

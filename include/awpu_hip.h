@@ -145,6 +145,13 @@ int awpu_hip_synchronize(awpu_hip_t *h);
  * power/pix are host buffers of `n` elements (n = whole grid). */
 int awpu_hip_heatmap_u8(const float *power, int32_t n, uint8_t *pix);
 
+/* the same display step on buffers resident in device memory: d_power [batch][n]
+ * floats -> d_pix [batch][n] bytes, enqueued on `stream` (NULL = the handle's stream).  d_peak [batch]
+ * floats receives each frame's maximum; with peak_given != 0 it is an INPUT instead (multi-GPU: the
+ * all-reduced maximum over the ranks' tiles, so that every tile is scaled alike). */
+int awpu_hip_heatmap_u8_device(awpu_hip_t *h, const float *d_power, int32_t n, int32_t batch, float *d_peak,
+                               int32_t peak_given, uint8_t *d_pix, void *stream);
+
 /* ---- host-side geometry, one-off (not on the per-frame path) ------------------------- */
 
 /* create_antenna, src/geometry/antenna.cpp:60-87: xyz[3][rows*columns] */

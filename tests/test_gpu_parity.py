@@ -288,3 +288,37 @@ def test_fir8_mode_vs_oracle(pkg, oracle, table_kind):
         for b in range(2):
             want = oracle.das_fir8_f32(X[b], off, frac, table, index)
             assert util.power_rel_err(power[b], want) < util.POWER_RTOL
+
+
+def test_device_heatmap_equals_populate_heatmap(pkg, oracle):
+    """the display step on device buffers is byte-identical to the restated
+    MIMOWorker::populateHeatmap (mimo.cpp:61-95), per frame, and accepts an external peak."""
+    import torch
+
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 3, seed=9)
+    frames[2] *= 0.0  # an all-zero frame: max 0 -> 0/0 -> NaN -> clipped like the reference does
+    dev = torch.device("cuda:0")
+    with pkg.Engine(n_pixels=spec.n_pixels, max_batch=3) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        power = eng.process(frames)
+        d_power = torch.from_numpy(power).to(dev)
+        d_peak = torch.zeros(3, dtype=torch.float32, device=dev)
+        d_pix = torch.zeros((3, spec.n_pixels), dtype=torch.uint8, device=dev)
+        eng.heatmap_device(d_power.data_ptr(), spec.n_pixels, 3, d_peak.data_ptr(), d_pix.data_ptr())
+        eng.synchronize()
+        pix = d_pix.cpu().numpy()
+        assert np.array_equal(d_peak.cpu().numpy(), power.max(axis=1))
+        for b in range(2):
+            assert np.array_equal(pix[b], oracle.heatmap_u8(power[b]))
+            assert pix[b].max() == 255
+        # externally supplied peak (what a rank does with the all-reduced maximum of all tiles)
+        d_peak.fill_(float(2.0 * power[0].max()))
+        eng.heatmap_device(d_power.data_ptr(), spec.n_pixels, 1, d_peak.data_ptr(), d_pix.data_ptr(), peak_given=True)
+        eng.synchronize()
+        want = np.clip(power[0].astype(np.float32) / np.float32(2.0 * power[0].max()) * 255.0, 0, 255).astype(np.uint8)
+        assert np.array_equal(d_pix[0].cpu().numpy(), want)
