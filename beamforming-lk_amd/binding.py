@@ -16,6 +16,7 @@ from . import _build
 N_SAMPLES = 256
 HIST = 1024
 ELEMENTS = 64
+DATAGRAM_BYTES = 1032  # sizeof(message), src/fpga/receiver.h:24-30
 
 INTERP_LERP, INTERP_FIR8 = 0, 1
 MATH_F32_EXACT, MATH_F32_FAST = 0, 1
@@ -77,6 +78,9 @@ _SIGNATURES = {
     "awpu_hip_process": (C.c_int, [C.c_void_p, _f32p, C.c_int32, _f32p]),
     "awpu_hip_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "awpu_hip_synchronize": (C.c_int, [C.c_void_p]),
+    "awpu_hip_ingest_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "awpu_hip_process_ring": (C.c_int, [C.c_void_p, _f32p]),
+    "awpu_hip_ring_snapshot": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_heatmap_u8": (C.c_int, [_f32p, C.c_int32, _u8p]),
     "awpu_hip_heatmap_u8_device": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -244,6 +248,23 @@ class Engine:
             index = np.ascontiguousarray(index, np.int32)
             _check(self._lib.awpu_hip_set_active_mics(self._h, _i32(index), index.size),
                    "set_active_mics")
+
+    def ingest_block(self, datagrams) -> None:
+        """One block of 256 wire datagrams (bytes-like, 256 x 1032 B; src/fpga/receiver.h:24-30)."""
+        buf = np.frombuffer(datagrams, dtype=np.uint8)
+        if buf.size != 256 * DATAGRAM_BYTES:
+            raise ValueError("a block is 256 datagrams of 1032 bytes")
+        _check(self._lib.awpu_hip_ingest_block(self._h, buf.ctypes.data_as(C.c_void_p), DATAGRAM_BYTES), "ingest_block")
+
+    def process_ring(self) -> np.ndarray:
+        power = np.empty(self.pixel_count, np.float32)
+        _check(self._lib.awpu_hip_process_ring(self._h, _f32(power)), "process_ring")
+        return power
+
+    def ring_snapshot(self) -> np.ndarray:
+        frames = np.empty((self.cfg.n_streams, HIST), np.float32)
+        _check(self._lib.awpu_hip_ring_snapshot(self._h, _f32(frames)), "ring_snapshot")
+        return frames
 
     def set_fir_table(self, coeffs: np.ndarray) -> None:
         """The caller's [101, 8] coefficient table of the FIR variant (src/dsp/filter.h:10-112)."""

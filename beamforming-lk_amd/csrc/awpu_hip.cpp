@@ -58,6 +58,10 @@ struct awpu_hip {
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     int32_t *d_index = nullptr;
     float *d_fir = nullptr;  // [101][8] coefficient table (AWPU_INTERP_FIR8)
+    float *d_ring = nullptr;            // [n_streams][2048] history ring (awpu_hip_ingest_block)
+    unsigned char *d_datagrams = nullptr;  // staging for one block of wire datagrams
+    int32_t *d_row_off_ring = nullptr;  // row offsets for frames read out of the ring (pitch 2048)
+    int ring_pos = 0;                   // where the next block goes = start of the snapshot
     bool have_fir = false;
     int32_t *d_row_off = nullptr;
     int32_t *d_row_off_compact = nullptr;  // the same for frames uploaded as [streams][compact_hist] windows
@@ -82,6 +86,12 @@ void release_device(awpu_hip *h) {
     if (h->d_index) (void) hipFree(h->d_index);
     if (h->d_fir) (void) hipFree(h->d_fir);
     h->d_fir = nullptr;
+    if (h->d_ring) (void) hipFree(h->d_ring);
+    if (h->d_datagrams) (void) hipFree(h->d_datagrams);
+    if (h->d_row_off_ring) (void) hipFree(h->d_row_off_ring);
+    h->d_ring = nullptr;
+    h->d_datagrams = nullptr;
+    h->d_row_off_ring = nullptr;
     if (h->d_row_off) (void) hipFree(h->d_row_off);
     if (h->d_row_off_compact) (void) hipFree(h->d_row_off_compact);
     h->d_row_off = nullptr;
@@ -145,6 +155,15 @@ int prepare(awpu_hip *h) {
         h->d_row_off_compact = nullptr;
         const int ch = ((h->window + 3) & ~3) + 4;
         h->compact_hist = lo + ch <= c.hist ? ch : 0;
+        if (c.hist == AWPU_HIST) {  // frames read in place from the ingest ring: rows 2048 floats apart
+            if (h->d_row_off_ring) (void) hipFree(h->d_row_off_ring);
+            h->d_row_off_ring = nullptr;
+            std::vector<int32_t> rr(ro.size(), h->index[0] * 2048 + lo);
+            for (int s = 0; s < U; s++)
+                for (int q = 0; q < 2; q++) rr[2 * s + q] = h->index[s] * 2048 + lo + q;
+            AWPU_HIP_TRY(hipMalloc(&h->d_row_off_ring, rr.size() * sizeof(int32_t)));
+            AWPU_HIP_TRY(hipMemcpy(h->d_row_off_ring, rr.data(), rr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
         if (h->compact_hist) {
             for (int s = 0; s < U; s++)
                 for (int q = 0; q < 2; q++) ro[2 * s + q] = h->index[s] * h->compact_hist + q;
@@ -276,9 +295,13 @@ void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
     if (*fpi == 2 && batch < 2) *fpi = 1;
 }
 
-// `compact`: d_frames is [batch][n_streams][compact_hist], sample 0 = history sample wstart.
-int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, bool compact = false) {
-    const int hist_eff = compact ? h->compact_hist : h->cfg.hist;
+// layout of d_frames: kFull [batch][n_streams][hist]; kCompact [batch][n_streams][compact_hist] with
+// sample 0 = history sample wstart; kRing one frame read in place from the ingest ring (rows 2048 apart)
+enum FrameLayout { kFull = 0, kCompact = 1, kRing = 2 };
+
+int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int layout = kFull) {
+    const bool compact = layout == kCompact;
+    const int hist_eff = compact ? h->compact_hist : (layout == kRing ? 2048 : h->cfg.hist);
     const int wstart_eff = compact ? 0 : h->wstart;
     if (h->cfg.math == AWPU_MATH_F32_EXACT || h->cfg.interp == AWPU_INTERP_FIR8) {
         awpu::SweepArgs a{};
@@ -315,7 +338,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         a.frames = d_frames;
         a.lut = lut->d;
         a.index = h->d_index;
-        a.row_off = compact ? h->d_row_off_compact : h->d_row_off;
+        a.row_off = compact ? h->d_row_off_compact : (layout == kRing ? h->d_row_off_ring : h->d_row_off);
         a.power = d_power;
         a.n_streams = h->cfg.n_streams;
         a.hist = hist_eff;
@@ -543,7 +566,7 @@ int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *p
         AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, frames, need_frames * sizeof(float),
                                     hipMemcpyHostToDevice, h->stream));
     }
-    rc = launch(h, h->d_frames, batch, h->d_power, h->stream, compact);
+    rc = launch(h, h->d_frames, batch, h->d_power, h->stream, compact ? kCompact : kFull);
     if (rc != AWPU_OK) return rc;
     AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_power, need_power * sizeof(float),
                                 hipMemcpyDeviceToHost, h->stream));
@@ -569,6 +592,66 @@ int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch,
     const int rc2 = launch(h, d_frames, batch, d_power, s);
     h->timing = keep;
     return rc2;
+}
+
+int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes) {
+    if (!h || !datagrams) return invalid("null argument");
+    if (h->cfg.hist != AWPU_HIST || h->cfg.n_streams > 256) return invalid("ingest needs hist 1024 and <= 256 streams");
+    if (stride_bytes < AWPU_DATAGRAM_BYTES) return invalid("datagram stride below 1032 bytes");
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    const size_t ring_bytes = (size_t) h->cfg.n_streams * 2048 * sizeof(float);
+    if (!h->d_ring) {
+        AWPU_HIP_TRY(hipMalloc(&h->d_ring, ring_bytes));
+        AWPU_HIP_TRY(hipMemsetAsync(h->d_ring, 0, ring_bytes, h->stream));
+        AWPU_HIP_TRY(hipMalloc(&h->d_datagrams, (size_t) awpu::kSamples * AWPU_DATAGRAM_BYTES));
+        h->ring_pos = 0;
+    }
+    // tight copy of the 256 datagrams (the header travels too: 8 bytes each, ignored like the
+    // reference ignores msg.counter, pipeline.cpp:264-267)
+    AWPU_HIP_TRY(hipMemcpy2DAsync(h->d_datagrams, AWPU_DATAGRAM_BYTES, datagrams, (size_t) stride_bytes,
+                                  AWPU_DATAGRAM_BYTES, awpu::kSamples, hipMemcpyHostToDevice, h->stream));
+    AWPU_HIP_TRY(awpu::launch_unpack_block(h->d_datagrams, AWPU_DATAGRAM_BYTES, h->cfg.n_streams, h->d_ring,
+                                           h->ring_pos, h->stream));
+    h->ring_pos = (h->ring_pos + awpu::kSamples) % AWPU_HIST;  // Streams::forward
+    // the staging buffer is reused by the next call: finish the copy before returning
+    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
+    return AWPU_OK;
+}
+
+int awpu_hip_process_ring(awpu_hip_t *h, float *power) {
+    if (!power) return invalid("null argument");
+    int rc = check_ready(h, 1);
+    if (rc != AWPU_OK) return rc;
+    if (!h->d_ring) {
+        g_last_error = "no block ingested yet";
+        return AWPU_ERR_STATE;
+    }
+    const size_t need_power = (size_t) h->cfg.pixel_count;
+    if (h->power_cap < need_power) {
+        if (h->d_power) (void) hipFree(h->d_power);
+        h->d_power = nullptr;
+        h->power_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
+        h->power_cap = need_power;
+    }
+    rc = launch(h, h->d_ring + h->ring_pos, 1, h->d_power, h->stream, kRing);
+    if (rc != AWPU_OK) return rc;
+    AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_power, need_power * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
+    return AWPU_OK;
+}
+
+int awpu_hip_ring_snapshot(awpu_hip_t *h, float *frames) {
+    if (!h || !frames) return invalid("null argument");
+    if (!h->d_ring) {
+        g_last_error = "no block ingested yet";
+        return AWPU_ERR_STATE;
+    }
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    AWPU_HIP_TRY(hipMemcpy2DAsync(frames, AWPU_HIST * sizeof(float), h->d_ring + h->ring_pos, 2048 * sizeof(float),
+                                  AWPU_HIST * sizeof(float), h->cfg.n_streams, hipMemcpyDeviceToHost, h->stream));
+    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
+    return AWPU_OK;
 }
 
 int awpu_hip_heatmap_u8_device(awpu_hip_t *h, const float *d_power, int32_t n, int32_t batch, float *d_peak,

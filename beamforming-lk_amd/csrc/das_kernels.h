@@ -88,6 +88,10 @@ hipError_t launch_das_fir8(const SweepArgs &a, const float *d_coeffs, hipStream_
 hipError_t launch_heatmap(const float *d_power, int n, int batch, float *d_peak, bool peak_given, uint8_t *d_pix,
                           hipStream_t stream);
 
+// one block of 256 wire datagrams -> floats in the device ring [n_sensors][2048] at column pos (and pos+1024)
+hipError_t launch_unpack_block(const void *d_datagrams, int stride_bytes, int n_sensors, float *d_ring, int pos,
+                               hipStream_t stream);
+
 // LDS bytes the exact kernel asks for with the given window; 0 if the window cannot fit.
 size_t das_exact_lds_bytes(int window, int usable, int *chunk_out);
 

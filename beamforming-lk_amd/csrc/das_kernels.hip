@@ -221,6 +221,55 @@ hipError_t launch_heatmap(const float *d_power, int n, int batch, float *d_peak,
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// Ingest on the device: Pipeline::receive_exposure, src/fpga/pipeline.cpp:260-297.
+// Input: one block = 256 datagrams as they come off the wire, each
+//     { u16 frequency; u8 n_arrays; u8 version; u32 counter; i32 stream[256]; }  (src/fpga/receiver.h:24-30)
+// Output: for sensor s and sample i   x = (float) stream_i[flip(s)] / 8388608.0f   (pipeline.cpp:277-290,
+// arrays are daisy-chained, every other group of 8 columns is mirrored) written into the per-mic
+// history ring at `pos + i`.  The ring is [n_sensors][2048]: every block is written twice, 1024
+// floats apart, so that any 1024-sample snapshot is contiguous -- the reference gets the same
+// effect by mapping one page twice (src/fpga/streams.hpp:152-182).
+// A 64 x 64 tile goes through LDS so that both the datagram reads (along s) and the ring writes
+// (along i) are coalesced.
+// ---------------------------------------------------------------------------------------
+__global__ void unpack_block_kernel(const unsigned char *datagrams, int stride_bytes, int n_sensors, float *ring,
+                                    int pos) {
+    __shared__ float tile[64][65];
+    const int s0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 rows per pass
+    for (int r = ty; r < 64; r += 4) {
+        const int s = s0 + tx, i = i0 + r;
+        float v = 0.0f;
+        if (s < n_sensors) {
+            // pipeline.cpp:277-287: `inverted` toggles at every multiple of 8, starting inverted
+            const bool inverted = ((s >> 3) & 1) == 0;
+            const int idx = inverted ? 8 * (1 + (s >> 3)) - 1 - (s & 7) : s;
+            const int32_t raw = *(const int32_t *) (datagrams + (size_t) i * stride_bytes + 8 + 4 * idx);
+            v = (float) raw / 8388608.0f;  // MAX_VALUE_FLOAT, src/fpga/pipeline.h:25
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int s = s0 + r, i = i0 + tx;
+        if (s < n_sensors) {
+            const float v = tile[tx][r];
+            float *row = ring + (size_t) s * 2048;
+            row[pos + i] = v;
+            row[(pos + i + 1024) & 2047] = v;
+        }
+    }
+}
+
+hipError_t launch_unpack_block(const void *d_datagrams, int stride_bytes, int n_sensors, float *d_ring, int pos,
+                               hipStream_t stream) {
+    dim3 grid((n_sensors + 63) / 64, kSamples / 64);
+    hipLaunchKernelGGL(unpack_block_kernel, grid, dim3(256), 0, stream, (const unsigned char *) d_datagrams,
+                       stride_bytes, n_sensors, d_ring, pos);
+    return hipGetLastError();
+}
+
 size_t das_exact_lds_bytes(int window, int usable, int *chunk_out) {
     const size_t row = (size_t) window * sizeof(float);
     if (row == 0 || row > kExactLdsBudget) return 0;

@@ -152,6 +152,25 @@ int awpu_hip_heatmap_u8(const float *power, int32_t n, uint8_t *pix);
 int awpu_hip_heatmap_u8_device(awpu_hip_t *h, const float *d_power, int32_t n, int32_t batch, float *d_peak,
                                int32_t peak_given, uint8_t *d_pix, void *stream);
 
+/* ---- wire-format ingest on the device -------------------------------------- */
+
+#define AWPU_DATAGRAM_BYTES 1032 /* sizeof(message), src/fpga/receiver.h:24-30: 8-byte header + 256 x i32 */
+
+/* replaces: Pipeline::receive_exposure + Streams::write_stream/forward for one block,
+ * src/fpga/pipeline.cpp:260-297, src/fpga/streams.hpp:103-105,136-139.  `datagrams` = 256 consecutive
+ * wire datagrams (host memory, `stride_bytes` apart, normally AWPU_DATAGRAM_BYTES): sample i of
+ * sensor s is stream_i[flip(s)] / 2^23.  The block is appended to a per-handle history ring in device
+ * memory (cfg.hist must be AWPU_HIST, cfg.n_streams <= 256).  The ring starts zeroed. */
+int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes);
+
+/* the body of MIMOWorker::update (src/dsp/mimo.cpp:97-151) on the snapshot the ring currently holds
+ * (oldest..newest, what Streams::read_stream would return for every stream): power [pixel_count]. */
+int awpu_hip_process_ring(awpu_hip_t *h, float *power);
+
+/* copies the current 1024-sample snapshot of every stream to host memory [n_streams][1024] (debug /
+ * calibration: AWProcessingUnit::calibrate reads exactly this, aw_processing_unit.cpp:116-122) */
+int awpu_hip_ring_snapshot(awpu_hip_t *h, float *frames);
+
 /* ---- host-side geometry, one-off (not on the per-frame path) ------------------------- */
 
 /* create_antenna, src/geometry/antenna.cpp:60-87: xyz[3][rows*columns] */

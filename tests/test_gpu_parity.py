@@ -322,3 +322,61 @@ def test_device_heatmap_equals_populate_heatmap(pkg, oracle):
         eng.synchronize()
         want = np.clip(power[0].astype(np.float32) / np.float32(2.0 * power[0].max()) * 255.0, 0, 255).astype(np.uint8)
         assert np.array_equal(d_pix[0].cpu().numpy(), want)
+
+
+def make_datagrams(stream_block, counter0=0, n_arrays=1):
+    """256 wire datagrams (src/fpga/receiver.h:24-30: u16 frequency, u8 n_arrays, u8 version, u32 counter,
+    i32 stream[256], packed) from stream_block[256 samples][256 channels] int32."""
+    msg = np.zeros(256, dtype=np.dtype([("frequency", "<u2"), ("n_arrays", "u1"), ("version", "u1"),
+                                        ("counter", "<u4"), ("stream", "<i4", (256,))]))
+    assert msg.dtype.itemsize == 1032
+    msg["frequency"] = 48828
+    msg["n_arrays"] = n_arrays
+    msg["version"] = 2
+    msg["counter"] = counter0 + np.arange(256)
+    msg["stream"] = stream_block
+    return msg.tobytes()
+
+
+def test_wire_ingest_and_ring_sweep(pkg, oracle):
+    """SURVEY 8f N1: Pipeline::receive_exposure (pipeline.cpp:260-297) + the stream ring on the device.
+    Five blocks of raw datagrams go in -- the last two over a real UDP socket on loopback, as from
+    the FPGA / udpreplay --; the ring snapshot must equal the restated unpacking bit for bit, and the
+    sweep on it the oracle's."""
+    import socket
+
+    rng = np.random.default_rng(77)
+    n = 64
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 12, 12)
+    ring = np.zeros((n, 1024), np.float32)  # host model of the per-mic rings, oldest..newest after each roll
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.bind(("127.0.0.1", 0))
+    rx.settimeout(5.0)
+    tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    with pkg.Engine(n_pixels=off.shape[0], n_streams=n) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        with pytest.raises(pkg.AwpuError):
+            eng.process_ring()  # nothing ingested yet
+        for b in range(5):
+            stream = rng.integers(-(1 << 21), 1 << 21, size=(256, 256), dtype=np.int32)  # 24-bit samples
+            wire = make_datagrams(stream, counter0=256 * b)
+            if b >= 3:  # through the network stack, one datagram at a time like receive_message()
+                got = bytearray()
+                for i in range(256):
+                    tx.sendto(wire[1032 * i:1032 * (i + 1)], rx.getsockname())
+                    pkt = rx.recv(2048)
+                    assert len(pkt) == 1032
+                    got += pkt
+                wire = bytes(got)
+            eng.ingest_block(wire)
+            block = oracle.unpack_exposure(stream, n)
+            ring = np.concatenate([ring[:, 256:], block], axis=1)
+            assert np.array_equal(eng.ring_snapshot(), ring), f"ring differs after block {b}"
+        power = eng.process_ring()
+        assert util.power_rel_err(power, oracle.das_f32(ring, off, frac)) < util.POWER_RTOL
+        # the ring path and the host-buffer path agree bit for bit on the same snapshot
+        assert np.array_equal(power, eng.process(ring))
+    rx.close()
+    tx.close()
