@@ -59,6 +59,8 @@ struct awpu_hip {
     int32_t *d_index = nullptr;
     float *d_fir = nullptr;  // [101][8] coefficient table (AWPU_INTERP_FIR8)
     float *d_ring = nullptr;            // [n_streams][2048] history ring (awpu_hip_ingest_block)
+    float *d_pack = nullptr;            // [pairs][usable][wp][2] sample-interleaved frame pairs
+    size_t pack_cap = 0;                // floats
     unsigned char *d_datagrams = nullptr;  // staging for one block of wire datagrams
     int32_t *d_row_off_ring = nullptr;  // row offsets for frames read out of the ring (pitch 2048)
     int ring_pos = 0;                   // where the next block goes = start of the snapshot
@@ -87,6 +89,9 @@ void release_device(awpu_hip *h) {
     if (h->d_fir) (void) hipFree(h->d_fir);
     h->d_fir = nullptr;
     if (h->d_ring) (void) hipFree(h->d_ring);
+    if (h->d_pack) (void) hipFree(h->d_pack);
+    h->d_pack = nullptr;
+    h->pack_cap = 0;
     if (h->d_datagrams) (void) hipFree(h->d_datagrams);
     if (h->d_row_off_ring) (void) hipFree(h->d_row_off_ring);
     h->d_ring = nullptr;
@@ -225,7 +230,9 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
     const auto &c = h->cfg;
     const int U = h->usable(), P = c.pixel_count;
     awpu_hip::FastLut lut;
-    if (!awpu::fast_plan(h->window, U, fpi, image_bytes, &lut.plan)) return invalid("delay window does not fit the LDS budget");
+    const bool pairs = image_bytes < 0;  // frame-pair layout: one image row per mic, 8-byte elements
+    if (!(pairs ? awpu::pair_plan(h->window, U, &lut.plan) : awpu::fast_plan(h->window, U, fpi, image_bytes, &lut.plan)))
+        return invalid("delay window does not fit the LDS budget");
     const awpu::FastPlan &plan = lut.plan;
     // rows for whole pixel tiles (the kernels sweep every pixel slot of a workgroup; slots past the
     // grid get null rows) + spare groups: the kernels prefetch entries past the row they sweep
@@ -243,7 +250,8 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
             const int j = s % plan.chunk;  // mic slot inside its chunk
             dst[s].f = frow[id];
             dst[s].g = 1.0f - frow[id];
-            dst[s].addr = (uint32_t) ((j * 2 + q) * plan.row_bytes + (off_rel - q) * 4);
+            dst[s].addr = pairs ? (uint32_t) (j * plan.row_bytes + off_rel * 8)
+                                : (uint32_t) ((j * 2 + q) * plan.row_bytes + (off_rel - q) * 4);
         }
     }
     AWPU_HIP_TRY(hipMalloc(&lut.d, n * sizeof(awpu::FastEntry)));
@@ -322,6 +330,44 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         } else
         AWPU_HIP_TRY(awpu::launch_das_exact(a, s));
     } else {
+        // ---- frame-pair shape: batches on grids that fill the chip (AWPU_FAST_PAIRS=0/1 overrides)
+        static const int env_pairs = std::getenv("AWPU_FAST_PAIRS") ? std::atoi(std::getenv("AWPU_FAST_PAIRS")) : -1;
+        static const int debug_flags = std::getenv("AWPU_FAST_DEBUG") ? std::atoi(std::getenv("AWPU_FAST_DEBUG")) : 0;
+        const long pair_wgs = ((long) h->cfg.pixel_count + 63) / 64 * ((batch + 1) / 2);
+        if (layout != kRing && batch >= 2 && env_pairs != 0 && (pair_wgs >= 256 || env_pairs == 1)) {
+            const awpu_hip::FastLut *plut = nullptr;
+            if (build_fast_lut(h, 2, -1, &plut) == AWPU_OK) {
+                const awpu::FastPlan &pp = plut->plan;
+                const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * h->usable() * pp.wr * 2;
+                if (h->pack_cap < need) {
+                    if (h->d_pack) (void) hipFree(h->d_pack);
+                    h->d_pack = nullptr;
+                    h->pack_cap = 0;
+                    AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
+                    h->pack_cap = need;
+                }
+                awpu::PairArgs pa{};
+                pa.packed = h->d_pack;
+                pa.lut = plut->d;
+                pa.power = d_power;
+                pa.usable = h->usable();
+                pa.usable_pad = pp.usable_pad;
+                pa.pixel_count = h->cfg.pixel_count;
+                pa.wp = pp.wr;
+                pa.chunk = pp.chunk;
+                pa.batch = batch;
+                pa.debug = debug_flags;
+                pa.debug_out = nullptr;
+                if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+                AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index,
+                                                     h->usable(), pp.wr, batch, h->d_pack, s));
+                AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
+                if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_end, s));
+                h->stats.launches += 1;
+                h->stats.frames += (uint64_t) batch;
+                return AWPU_OK;
+            }
+        }
         int fpi = 1, ppw = 8, nw = 8;
         choose_fast_variant(h, batch, &fpi, &ppw, &nw);
         const awpu_hip::FastLut *lut = nullptr;

@@ -523,6 +523,204 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_db_kernel(FastArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Frame-pair shape (the default for batches): two frames are packed sample-interleaved,
+// (x_a[t], x_b[t]) = one 8-byte element, by pack_pairs_kernel; the sweep then puts the two FRAMES in
+// the two lanes of every v_pk_fma_f32 instead of two neighbouring samples:
+//   * any integer delay is 8-byte aligned -- no parity copies; the LDS image of a chunk,
+//     [mic][W] elements, has the footprint the two copies had and holds two frames;
+//   * lane l owns samples l, l+64, l+128, l+192; an item = 1 address add + 4 ds_read_b64 +
+//     8 v_pk_fma_f32 (A_k += f x_k, Q_k += g x_k), so 8 of 9 VALU instructions are FMAs (4 of 5
+//     before) and a table entry serves two frames;
+//   * the packed rows of a chunk are contiguous in HBM: staging is one linear LDS-DMA stream.
+// One 16-wave workgroup per CU, two LDS images (chunk c+1 lands while chunk c is swept), 4 pixels
+// per wave; grid = (frame pairs, 64-pixel tiles).
+// ---------------------------------------------------------------------------------------
+__global__ void pack_pairs_kernel(const float *frames, int n_streams, int hist, int wstart, const int32_t *index,
+                                  int usable, int wp, int batch, float *packed) {
+    const int pair = blockIdx.y, s = blockIdx.x;
+    const int fa = min(2 * pair, batch - 1), fb = min(2 * pair + 1, batch - 1);
+    const float *xa = frames + ((size_t) fa * n_streams + index[s]) * hist + wstart;
+    const float *xb = frames + ((size_t) fb * n_streams + index[s]) * hist + wstart;
+    f2 *dst = (f2 *) packed + ((size_t) pair * usable + s) * wp;
+    const int valid = min(wp, hist - wstart);
+    for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = t < valid ? f2{xa[t], xb[t]} : f2{0.0f, 0.0f};
+}
+
+// out[] of one pixel (both frames at once) from the skewed accumulators, then mimo.cpp:131-137.
+// P[0..3] = A_k: f-terms of samples l+64k; P[4..7] = Q_k: g-terms, belonging to samples l+64k-1.
+__device__ __forceinline__ f2 finish_pixel_pair(const f2 (&P)[8], f2 tail, int lane) {
+    f2 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        f2 qn;
+        qn.x = __shfl_down(P[4 + k].x, 1);
+        qn.y = __shfl_down(P[4 + k].y, 1);
+        f2 wrap = tail;  // sample 255 takes X[off+256]'s term
+        if (k < 3) {
+            wrap.x = __shfl(P[5 + (k < 3 ? k : 0)].x, 0);
+            wrap.y = __shfl(P[5 + (k < 3 ? k : 0)].y, 0);
+        }
+        if (lane == 63) qn = wrap;
+        o[k] = P[k] + qn;  // out[l + 64k]
+    }
+    f2 sum = f2{0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        f2 prev, next, wp_, wn_;
+        prev.x = __shfl_up(o[k].x, 1);
+        prev.y = __shfl_up(o[k].y, 1);
+        next.x = __shfl_down(o[k].x, 1);
+        next.y = __shfl_down(o[k].y, 1);
+        wp_.x = __shfl(o[k > 0 ? k - 1 : 0].x, 63);
+        wp_.y = __shfl(o[k > 0 ? k - 1 : 0].y, 63);
+        wn_.x = __shfl(o[k < 3 ? k + 1 : 3].x, 0);
+        wn_.y = __shfl(o[k < 3 ? k + 1 : 3].y, 0);
+        if (lane == 0) prev = wp_;
+        if (lane == 63) next = wn_;
+        const int i = lane + 64 * k;
+        const f2 ma = o[k] * 0.5f - 0.25f * (next + prev);
+        if (i >= 1 && i <= kSamples - 2) sum += ma * ma;
+    }
+    sum.x = wave_sum(sum.x);
+    sum.y = wave_sum(sum.y);
+    return sum;
+}
+
+// tell the compiler a pointer / int is wave-uniform (it is: built from block and wave ids)
+__device__ __forceinline__ const void *uniform_ptr(const void *p) {
+    const unsigned long long v = (unsigned long long) p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned) (v >> 32));
+    return (const void *) (((unsigned long long) hi << 32) | lo);
+}
+
+template <int PPW, bool DIAG>
+__global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
+    static_assert(PPW % 2 == 0 && PPW <= 8, "pixels go through the asm blocks two at a time");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
+    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int pair = blockIdx.x;
+    const int pix0 = (blockIdx.y * NW + wave) * PPW;
+    const size_t row_floats = (size_t) a.wp * 2;
+    const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
+
+    f2 acc[PPW][8];
+    f2 tail = f2{0.0f, 0.0f};
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[pp][k] = f2{0.0f, 0.0f};
+    const int tail_pp = lane >> 3;
+    const bool tail_lane = tail_pp < PPW && pix0 + tail_pp < a.pixel_count;
+    const FastEntry *tail_row = a.lut + (size_t) (pix0 + (tail_lane ? tail_pp : 0)) * a.usable_pad;
+
+    // one chunk = rows m0 .. m0+mc of this pair, contiguous in HBM and in the LDS image
+    auto dma_chunk = [&](int m0, int mc, int buf) {
+        const float *src = pair_base + (size_t) m0 * row_floats;
+        const int n_pieces = (int) ((size_t) mc * row_floats / 4);
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            const int piece = threadIdx.x + k * kThreads;
+            if (piece < n_pieces) {
+                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + (size_t) piece * 4),
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+            }
+        }
+    };
+
+    unsigned t_wait = 0, t_all = 0;
+    const long long t_begin = __builtin_readcyclecounter();
+    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
+    dma_chunk(0, min(a.chunk, a.usable), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    unsigned t_ph[5] = {0, 0, 0, 0, 0};
+    auto stamp = [&](int k, long long &t) {
+        if (DIAG) {
+            const long long n = __builtin_readcyclecounter();
+            t_ph[k] += (unsigned) (n - t);
+            t = n;
+        }
+    };
+    const int stride = a.usable_pad * (int) sizeof(FastEntry);
+    for (int c = 0; c < n_chunks; c++) {
+        const int m0 = c * a.chunk;
+        const int mc = min(a.chunk, a.usable - m0);
+        const int mc4 = (mc + 3) & ~3;
+        const int buf = c & 1;
+        long long t = DIAG ? __builtin_readcyclecounter() : 0;
+        if (c + 1 < n_chunks) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
+        stamp(0, t);
+
+        const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
+#pragma unroll
+        for (int q = 0; q < PPW; q += 2) {
+            const void *row = uniform_ptr(a.lut + (size_t) (pix0 + q) * a.usable_pad + m0);
+            const int ng = __builtin_amdgcn_readfirstlane(mc4 >> 2);
+            if constexpr (DIAG) sweep_duo_pairs_stamped(acc[q], acc[q + 1], row, stride, ng, lane_addr, t_wait, t_all);
+            else sweep_duo_pairs(acc[q], acc[q + 1], row, stride, ng, lane_addr);
+        }
+        stamp(1, t);
+        // the 257th sample of every window, both frames: lane 8*pp + k takes the mics s = k (mod 8)
+        const char *img = (const char *) (lds + buf * (BUF / 4));
+        for (int j0 = 0; j0 < mc4; j0 += 32) {
+            FastEntry e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 8 * u + ((lane - m0) & 7);
+                e[u] = tail_row[m0 + min(j, mc4 - 1)];
+                if (!tail_lane || j >= mc4) e[u].g = 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const f2 x = *(const f2 *) (img + e[u].addr + 256 * 8);
+                tail = __builtin_elementwise_fma(f2{e[u].g, e[u].g}, x, tail);
+            }
+        }
+        if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(2, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3, t);
+        __syncthreads();
+        stamp(4, t);
+    }
+
+    if (DIAG && a.debug_out && lane == 0) {
+        unsigned long long *o = a.debug_out + 12 * ((size_t) (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+        o[0] = t_wait;
+        o[1] = t_all;
+        o[2] = (unsigned long long) (__builtin_readcyclecounter() - t_begin);
+        o[3] = (unsigned long long) n_chunks * PPW;
+        for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
+    }
+    tail.x += __shfl_xor(tail.x, 1);
+    tail.y += __shfl_xor(tail.y, 1);
+    tail.x += __shfl_xor(tail.x, 2);
+    tail.y += __shfl_xor(tail.y, 2);
+    tail.x += __shfl_xor(tail.x, 4);
+    tail.y += __shfl_xor(tail.y, 4);
+    const float norm = (float) (kSamples * a.usable);
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) {
+        const int p = pix0 + pp;
+        f2 tl;
+        tl.x = __shfl(tail.x, pp * 8);
+        tl.y = __shfl(tail.y, pp * 8);
+        const f2 sum = finish_pixel_pair(acc[pp], tl, lane);
+        if (lane == 0 && p < a.pixel_count) {
+            a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
+            if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // host side: geometry of the LDS image and the launch
 // ---------------------------------------------------------------------------------------
 bool fast_plan(int window, int usable, int fpi, int image_bytes, FastPlan *plan) {
@@ -576,6 +774,52 @@ static hipError_t launch_db(const FastArgs &a, hipStream_t stream) {
     if (grid.y > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL((das_fast_db_kernel<NW, PPW, BUF, WPS, DIAG>), grid, dim3(NW * 64), lds_bytes, stream, a);
     return hipGetLastError();
+}
+
+bool pair_plan(int window, int usable, FastPlan *plan) {
+    const int wp = (window + 1) & ~1;  // rows of 8-byte elements, whole 16-byte pieces
+    const size_t row_bytes = (size_t) wp * 8;
+    int chunk = (int) ((size_t) kFastLdsBytes / row_bytes);
+    chunk &= ~3;
+    if (chunk > 64) chunk = 64;
+    if (chunk < 4) return false;
+    const int usable_pad = (usable + 3) & ~3;
+    if (chunk > usable_pad) chunk = usable_pad;
+    plan->fpi = 2;
+    plan->wr = wp;
+    plan->chunk = chunk;
+    plan->usable_pad = usable_pad;
+    plan->row_bytes = (int) row_bytes;
+    plan->image_bytes = -1;  // marks the frame-pair layout
+    return true;
+}
+
+hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index,
+                             int usable, int wp, int batch, float *d_packed, hipStream_t stream) {
+    dim3 grid(usable, (batch + 1) / 2);
+    hipLaunchKernelGGL(pack_pairs_kernel, grid, dim3(128), 0, stream, d_frames, n_streams, hist, wstart, d_index,
+                       usable, wp, batch, d_packed);
+    return hipGetLastError();
+}
+
+template <int PPW, bool DIAG>
+static hipError_t launch_pair_variant(const PairArgs &a, hipStream_t stream) {
+    static bool attr_set = false;
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *) das_pair_kernel<PPW, DIAG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid((a.batch + 1) / 2, (a.pixel_count + 16 * PPW - 1) / (16 * PPW));
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((das_pair_kernel<PPW, DIAG>), grid, dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {
+    return launch_pair_variant<4, false>(a, stream);
 }
 
 int fast_image_bytes(int nw) { return nw == 24 ? kFastLdsBytesSmall : kFastLdsBytes; }

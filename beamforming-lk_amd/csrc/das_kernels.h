@@ -67,6 +67,20 @@ struct FastArgs {
     int32_t debug;  // timing experiments only (AWPU_FAST_DEBUG): 1 = stage first chunk only, 2 = skip the sweep
 };
 
+// ---- frame-pair shape: frames packed two by two, sample-interleaved
+struct PairArgs {
+    const float *packed;   // [pairs][usable][wp][2]: (frame 2k, frame 2k+1) samples of the window, active-mic order
+    const FastEntry *lut;  // [P_pad][usable_pad]; addr = slot * wp * 8 + (off - wstart) * 8
+    float *power;          // [batch][pixel_count]
+    int32_t usable, usable_pad, pixel_count, wp, chunk, batch;
+    unsigned long long *debug_out;
+    int32_t debug;
+};
+bool pair_plan(int window, int usable, FastPlan *plan);
+hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index,
+                             int usable, int wp, int batch, float *d_packed, hipStream_t stream);
+hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream);
+
 // LDS image geometry for a window of `window` samples; false if it cannot fit.
 bool fast_plan(int window, int usable, int fpi, int image_bytes, FastPlan *plan);
 int fast_image_bytes(int nw);

@@ -123,8 +123,9 @@ def test_batch_equals_single_frames(pkg, oracle, math):
     rev, _ = run_engine(pkg, frames[::-1][:4], off, frac, math=math, max_batch=7)
     assert np.array_equal(rev, batch[::-1][:4])
     for b in range(5):
+        # a single-frame call may run another kernel shape (the epilogue sums in another order)
         single, _ = run_engine(pkg, frames[b], off, frac, math=math)
-        assert np.array_equal(batch[b], single)
+        assert util.power_rel_err(batch[b], single) < 2e-6
         assert util.power_rel_err(batch[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
 
 

@@ -92,6 +92,58 @@ def trip(n_items, cur, vbase, acc):
     return lines
 
 
+def trip2(n_items, cur, vbase, acc, depth):
+    """Frame-pair flavour of trip(): the LDS image holds (frame a, frame b) sample-interleaved, so one
+    ds_read_b64 returns one sample of both frames and the two lanes of a packed FMA are the two frames.
+    Lane l owns samples l, l+64, l+128, l+192: per item one address add, FOUR ds_read_b64 (512 bytes
+    apart) and EIGHT v_pk_fma_f32 into acc = (A0..A3, Q0..Q3):  A_k += f * x_k  (-> out[l+64k]),
+    Q_k += g * x_k  (-> out[l+64k-1]; the one-sample skew is undone once per pixel)."""
+    sbase = SET[cur]
+    pbase = SET[OTHER[cur]]
+    slots = depth + 1
+    addr_t = vbase + 8 * slots
+
+    def fpair(i):
+        return f"s[{sbase + 4 * i}:{sbase + 4 * i + 1}]"
+
+    def gpair(i):
+        return f"s[{sbase + 4 * i + 2}:{sbase + 4 * i + 3}]"
+
+    def issue(i):
+        s = vbase + 8 * (i % slots)
+        L = [f"v_add_u32 v{addr_t}, s{sbase + 4 * i + 1}, %[lane]"]
+        for k in range(4):
+            off = f" offset:{512 * k}" if k else ""
+            L.append(f"ds_read_b64 v[{s + 2 * k}:{s + 2 * k + 1}], v{addr_t}{off}")
+        return L
+
+    def fma(i):
+        s = vbase + 8 * (i % slots)
+        L = []
+        for k in range(4):
+            x = f"v[{s + 2 * k}:{s + 2 * k + 1}]"
+            L.append(f"v_pk_fma_f32 {acc[k]}, {fpair(i)}, {x}, {acc[k]} op_sel_hi:[0,1,1]")
+            L.append(f"v_pk_fma_f32 {acc[4 + k]}, {gpair(i)}, {x}, {acc[4 + k]} op_sel_hi:[0,1,1]")
+        return L
+
+    lines = []
+    if PRIO:
+        lines.append(f"s_setprio {(1 if cur == 'X' else 0) + PRIO_BASE[0]}")
+    for i in range(min(depth, n_items)):
+        lines += issue(i)
+    lines += [f"s_load_dwordx16 s[{pbase}:{pbase + 15}], %[ptr], s{S_PF}",
+              f"s_add_u32 s{S_OFF}, s{S_PF}, 64",
+              f"s_load_dwordx16 s[{pbase + 16}:{pbase + 31}], %[ptr], s{S_OFF}",
+              f"s_add_u32 s{S_OFF}, s{S_PF}, 128"]
+    for k in range(n_items):
+        if k + depth < n_items:
+            lines += issue(k + depth)
+        younger = min(depth, n_items - 1 - k)
+        lines.append(f"s_waitcnt lgkmcnt({4 * younger})")
+        lines += fma(k)
+    return lines
+
+
 def next_pixel_setup(last_pixel):
     if last_pixel:
         return []
@@ -99,7 +151,7 @@ def next_pixel_setup(last_pixel):
             f"s_mov_b32 s{S_LEFT}, %[ng]"]  # s{S_OFF} was set by the refill: new row + 128
 
 
-def pixel_code(j, n_pix, vbase, acc):
+def pixel_code(j, n_pix, vbase, acc, pair_depth=0):
     """State machine of pixel j.  On entry at LPj_X / LPj_Y the named set holds the pixel's next
     entries, s{S_LEFT} = groups of four left (>= 1), s{S_OFF} = table offset of the entries after
     those, s{S_ROW} = table offset of this pixel's row."""
@@ -117,21 +169,24 @@ def pixel_code(j, n_pix, vbase, acc):
               f"s_add_u32 s{S_T1}, s{S_ROW}, %[stride]",
               f"s_cmp_eq_u32 s{S_LEFT}, 0",
               f"s_cselect_b32 s{S_PF}, s{S_T1}, s{S_OFF}"]
-        L += trip(8, cur, vbase, acc)
+        L += trip2(8, cur, vbase, acc, pair_depth) if pair_depth else trip(8, cur, vbase, acc)
         L += [f"s_cmp_lg_u32 s{S_LEFT}, 0",
               f"s_cbranch_scc1 .LP{j}_{oth}_%="]
         # pixel finished on a full trip: the other set holds the next pixel's first entries
         L += next_pixel_setup(last_pixel) + [f"s_branch {nxt_entry}"]
         L += [f".LP{j}_{cur}_half_%=:",
               f"s_add_u32 s{S_PF}, s{S_ROW}, %[stride]"]
-        L += trip(4, cur, vbase, acc)
+        L += trip2(4, cur, vbase, acc, pair_depth) if pair_depth else trip(4, cur, vbase, acc)
         L += next_pixel_setup(last_pixel) + [f"s_branch {nxt_entry}"]
     return L
 
 
-def block(name, n_pix, vbase, stamp=False):
+def block(name, n_pix, vbase, stamp=False, pair_depth=0):
     x = SET["X"]
-    accs = [(f"%[A{j}]", f"%[Q{j}]", f"%[C{j}]", f"%[R{j}]") for j in range(n_pix)]
+    if pair_depth:  # frame-pair flavour: 8 accumulators per pixel, named A0..A3, Q0..Q3 per pixel
+        accs = [tuple(f"%[P{j}{n}{k}]" for n in "AQ" for k in range(4)) for j in range(n_pix)]
+    else:
+        accs = [(f"%[A{j}]", f"%[Q{j}]", f"%[C{j}]", f"%[R{j}]") for j in range(n_pix)]
     L = []
     if stamp:
         L += [f"s_memtime s[{S_T0}:{S_T0 + 1}]", "s_waitcnt lgkmcnt(0)"]
@@ -145,7 +200,7 @@ def block(name, n_pix, vbase, stamp=False):
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)",
               f"s_sub_u32 s{S_T1}, s{S_T1}, s{S_T0}", f"s_add_u32 %[t_wait], %[t_wait], s{S_T1}"]
     for j in range(n_pix):
-        L += pixel_code(j, n_pix, vbase, accs[j])
+        L += pixel_code(j, n_pix, vbase, accs[j], pair_depth)
     L += [".Ldone_%=:"]
     if PRIO:
         L += ["s_setprio 0"]
@@ -154,11 +209,15 @@ def block(name, n_pix, vbase, stamp=False):
               f"s_sub_u32 s{S_T1}, s{S_T1}, s{S_T0}", f"s_add_u32 %[t_all], %[t_all], s{S_T1}"]
 
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
-    vregs = list(range(vbase, vbase + 4 * (DEPTH + 1) + 1))
+    vregs = list(range(vbase, vbase + (8 * (pair_depth + 1) + 1 if pair_depth else 4 * (DEPTH + 1) + 1)))
     sregs = list(range(S_T0, S_OFF + 1)) + list(range(SET["X"], SET["Y"] + 32))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
-    acc_params = ", ".join(f"f2 &A{j}, f2 &Q{j}, f2 &C{j}, f2 &R{j}" for j in range(n_pix))
-    acc_ops = ", ".join(f'[A{j}] "+v"(A{j}), [Q{j}] "+v"(Q{j}), [C{j}] "+v"(C{j}), [R{j}] "+v"(R{j})' for j in range(n_pix))
+    if pair_depth:
+        acc_params = ", ".join(f"f2 (&P{j})[8]" for j in range(n_pix))
+        acc_ops = ", ".join(f'[P{j}{n}{k}] "+v"(P{j}[{4 * "AQ".index(n) + k}])' for j in range(n_pix) for n in "AQ" for k in range(4))
+    else:
+        acc_params = ", ".join(f"f2 &A{j}, f2 &Q{j}, f2 &C{j}, f2 &R{j}" for j in range(n_pix))
+        acc_ops = ", ".join(f'[A{j}] "+v"(A{j}), [Q{j}] "+v"(Q{j}), [C{j}] "+v"(C{j}), [R{j}] "+v"(R{j})' for j in range(n_pix))
     stamp_params = ", unsigned &t_wait, unsigned &t_all" if stamp else ""
     stamp_ops = ', [t_wait] "+s"(t_wait), [t_all] "+s"(t_all)' if stamp else ""
     return f'''// {n_pix} pixel(s) of the staged chunk, ng groups of four items each (ng >= 1); pixel j's entries
@@ -181,6 +240,9 @@ def main():
     out.append(block("sweep_pixel_hi", 1, hi))
     out.append(block("sweep_quad_hi", 4, hi))
     out.append(block("sweep_quad_stamped", 4, hi, stamp=True))
+    pd = 2  # frame-pair items: 2 items (8 reads) of read-ahead; +4 being issued +2 scalar loads <= 15 (lgkmcnt is 4 bits)
+    out.append(block("sweep_duo_pairs", 2, 128 - (8 * (pd + 1) + 1) - 3, pair_depth=pd))
+    out.append(block("sweep_duo_pairs_stamped", 2, 128 - (8 * (pd + 1) + 1) - 3, stamp=True, pair_depth=pd))
     lo = 80 - (4 * (DEPTH + 1) + 1) - 3  # shapes with an 80-VGPR budget (6 waves per SIMD)
     out.append(block("sweep_quad_lo", 4, lo))
     out.append(block("sweep_quad_lo_stamped", 4, lo, stamp=True))
