@@ -361,6 +361,30 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
                 if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
                 AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index,
                                                      h->usable(), pp.wr, batch, h->d_pack, s));
+                if (debug_flags & 16) {  // diagnostics: per-wave cycle sums of this launch to stderr
+                    static unsigned long long *d_dbg = nullptr;
+                    const size_t n_waves = (size_t) 16 * ((batch + 1) / 2) * ((h->cfg.pixel_count + 63) / 64);
+                    if (!d_dbg) AWPU_HIP_TRY(hipMalloc(&d_dbg, n_waves * 12 * sizeof(unsigned long long)));
+                    pa.debug_out = d_dbg;
+                    AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
+                    AWPU_HIP_TRY(hipStreamSynchronize(s));
+                    std::vector<unsigned long long> hb(n_waves * 12);
+                    AWPU_HIP_TRY(hipMemcpy(hb.data(), d_dbg, hb.size() * 8, hipMemcpyDeviceToHost));
+                    double v[12] = {0};
+                    std::vector<double> sw(16, 0), ba(16, 0);
+                    for (size_t i = 0; i < n_waves; i++) {
+                        for (int k = 0; k < 9; k++) v[k] += hb[12 * i + k];
+                        sw[i % 16] += hb[12 * i + 5];
+                        ba[i % 16] += hb[12 * i + 8];
+                    }
+                    std::fprintf(stderr, "[awpu diag pairs] per wave cycles: total %.0f | dma-issue %.0f sweep %.0f (in blocks %.0f, first table wait %.0f) tail %.0f dma-wait %.0f barrier %.0f | per pixel-chunk %.0f\n",
+                                 v[2] / n_waves, v[4] / n_waves, v[5] / n_waves, v[1] / n_waves, v[0] / n_waves, v[6] / n_waves,
+                                 v[7] / n_waves, v[8] / n_waves, v[1] / v[3]);
+                    std::fprintf(stderr, "[awpu diag pairs] wave slot sweep/barrier kcycles:");
+                    for (int k = 0; k < 16; k++) std::fprintf(stderr, " %d:%.0f/%.0f", k, sw[k] * 16 / n_waves / 1e3, ba[k] * 16 / n_waves / 1e3);
+                    std::fprintf(stderr, "\n");
+                    return AWPU_OK;
+                }
                 AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
                 if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_end, s));
                 h->stats.launches += 1;

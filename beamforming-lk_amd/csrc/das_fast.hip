@@ -146,18 +146,21 @@ __device__ __forceinline__ void sweep_chunk_stamped(Acc<1> (&acc)[PPW], const Fa
 #pragma unroll
     for (int q = 0; q < PPW; q += 4) {
         const void *row = lut + (size_t) (pix0 + q) * usable_pad + m0;
+        unsigned dw = 0, da = 0;
         if constexpr (LOW) {
             sweep_quad_lo_stamped(acc[q].A[0], acc[q].Q[0], acc[q].C[0], acc[q].R[0],
                                   acc[q + 1].A[0], acc[q + 1].Q[0], acc[q + 1].C[0], acc[q + 1].R[0],
                                   acc[q + 2].A[0], acc[q + 2].Q[0], acc[q + 2].C[0], acc[q + 2].R[0],
                                   acc[q + 3].A[0], acc[q + 3].Q[0], acc[q + 3].C[0], acc[q + 3].R[0], row, stride, ng,
-                                  lane_addr, t_wait, t_all);
+                                  lane_addr, dw, da);
         } else
         sweep_quad_stamped(acc[q].A[0], acc[q].Q[0], acc[q].C[0], acc[q].R[0],
                            acc[q + 1].A[0], acc[q + 1].Q[0], acc[q + 1].C[0], acc[q + 1].R[0],
                            acc[q + 2].A[0], acc[q + 2].Q[0], acc[q + 2].C[0], acc[q + 2].R[0],
                            acc[q + 3].A[0], acc[q + 3].Q[0], acc[q + 3].C[0], acc[q + 3].R[0], row, stride, ng,
-                           lane_addr, t_wait, t_all);
+                           lane_addr, dw, da);
+        t_wait += dw;
+        t_all += da;
     }
 }
 
@@ -649,6 +652,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         }
     };
     const int stride = a.usable_pad * (int) sizeof(FastEntry);
+    const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
     for (int c = 0; c < n_chunks; c++) {
         const int m0 = c * a.chunk;
         const int mc = min(a.chunk, a.usable - m0);
@@ -658,29 +662,48 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         if (c + 1 < n_chunks) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
         stamp(0, t);
 
+        // table entries of the tail pass below: requested now, consumed after the sweep
+        struct AddrG {
+            unsigned addr;
+            float g;
+        };
+        AddrG te[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = 8 * u + ((lane - m0) & 7);
+            te[u] = *(const AddrG *) ((const char *) (tail_row + m0 + min(j, mc4 - 1)) + 4);  // fields addr, g
+            if (!tail_lane || j >= mc4) te[u].g = 0.0f;
+        }
         const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
 #pragma unroll
         for (int q = 0; q < PPW; q += 2) {
             const void *row = uniform_ptr(a.lut + (size_t) (pix0 + q) * a.usable_pad + m0);
             const int ng = __builtin_amdgcn_readfirstlane(mc4 >> 2);
-            if constexpr (DIAG) sweep_duo_pairs_stamped(acc[q], acc[q + 1], row, stride, ng, lane_addr, t_wait, t_all);
-            else sweep_duo_pairs(acc[q], acc[q + 1], row, stride, ng, lane_addr);
+            if constexpr (DIAG) {
+                unsigned dw = 0, da = 0;
+                sweep_duo_pairs_stamped(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank, dw, da);
+                t_wait += dw;
+                t_all += da;
+            } else {
+                sweep_duo_pairs(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
+            }
         }
         stamp(1, t);
         // the 257th sample of every window, both frames: lane 8*pp + k takes the mics s = k (mod 8)
         const char *img = (const char *) (lds + buf * (BUF / 4));
-        for (int j0 = 0; j0 < mc4; j0 += 32) {
-            FastEntry e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // mics 0..31 of the chunk (prefetched above)
+            const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
+            tail = __builtin_elementwise_fma(f2{te[u].g, te[u].g}, x, tail);
+        }
+        for (int j0 = 32; j0 < mc4; j0 += 32) {  // chunks of more than 32 mics (narrow windows)
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int j = j0 + 8 * u + ((lane - m0) & 7);
-                e[u] = tail_row[m0 + min(j, mc4 - 1)];
-                if (!tail_lane || j >= mc4) e[u].g = 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const f2 x = *(const f2 *) (img + e[u].addr + 256 * 8);
-                tail = __builtin_elementwise_fma(f2{e[u].g, e[u].g}, x, tail);
+                AddrG e = *(const AddrG *) ((const char *) (tail_row + m0 + min(j, mc4 - 1)) + 4);
+                if (!tail_lane || j >= mc4) e.g = 0.0f;
+                const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
+                tail = __builtin_elementwise_fma(f2{e.g, e.g}, x, tail);
             }
         }
         if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -819,6 +842,7 @@ static hipError_t launch_pair_variant(const PairArgs &a, hipStream_t stream) {
 }
 
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {
+    if (a.debug & 16) return launch_pair_variant<4, true>(a, stream);
     return launch_pair_variant<4, false>(a, stream);
 }
 

@@ -30,7 +30,7 @@ compiler never sees a register with a load in flight.
 import os
 from pathlib import Path
 
-PRIO = int(os.environ.get("TRIP_PRIO", "2"))  # 1: alternate s_setprio per trip; 2: four levels
+PRIO = int(os.environ.get("TRIP_PRIO", "5"))  # pair blocks: 3 rotation, 4 youngest-first, 5 alternate the two; others: 2 = four levels
 PRIO_BASE = [0]  # +2 on odd pixels of a block: four levels, so that ties (decided by age) are rarer
 DEPTH = int(os.environ.get("TRIP_DEPTH", "4"))  # items of LDS read-ahead (2*DEPTH <= 15: lgkmcnt is 4 bits)
 SET = {"X": 36, "Y": 68}
@@ -38,6 +38,45 @@ OTHER = {"X": "Y", "Y": "X"}
 # loop state: s[28:29] stamp t0, s[30:31] temp pair, s32 row offset, s33 groups left,
 # s34 refill offset, s35 offset of the entries after the loaded ones
 S_T0, S_T1, S_ROW, S_LEFT, S_PF, S_OFF = 28, 30, 32, 33, 34, 35
+S_PRIO = 27  # PRIO 3: rotating priority counter (starts at the wave's age rank on its SIMD)
+
+
+S_RANK = 26  # the wave's age rank on its SIMD (0 = oldest), constant
+
+
+def select_prio(sel, step):
+    """s_setprio takes an immediate, so the priority is chosen by a 4-way branch on s{sel} & 3 after
+    adding `step` to it."""
+    L = []
+    if step:
+        L += [f"s_add_u32 s{sel}, s{sel}, {step}", f"s_and_b32 s{sel}, s{sel}, 3"]
+    for k in range(3):
+        L += [f"s_cmp_eq_u32 s{sel}, {k}", f"s_cbranch_scc1 .Lprio{k}_%=_{COUNTER[0]}"]
+    L += ["s_setprio 3", f"s_branch .Lprio_done_%=_{COUNTER[0]}"]
+    for k in range(3):
+        L += [f".Lprio{k}_%=_{COUNTER[0]}:", f"s_setprio {k}"]
+        if k < 2:
+            L += [f"s_branch .Lprio_done_%=_{COUNTER[0]}"]
+    L += [f".Lprio_done_%=_{COUNTER[0]}:"]
+    COUNTER[0] += 1
+    return L
+
+
+def trip_prio(cur):
+    """Waves of a SIMD are served by priority, then oldest first.  Left alone (measured, 4 waves per
+    SIMD, one barrier per chunk) the oldest wave sweeps a chunk in 123k cycles and the youngest in
+    217k, so every chunk ends with one starved wave running alone.  Equal-time rotation of the top
+    priority (each trip the next wave) still leaves the oldest ahead (157k vs 206k), a static
+    youngest-first order overshoots (228k vs 136k); alternating the two -- X trips rotate, Y trips
+    youngest-first -- lands near balance."""
+    if PRIO == 4:
+        return select_prio(S_RANK, 0)
+    if PRIO == 3 or cur == "X":
+        return select_prio(S_PRIO, 1)
+    return select_prio(S_RANK, 0)
+
+
+COUNTER = [0]
 
 
 def trip(n_items, cur, vbase, acc):
@@ -127,7 +166,9 @@ def trip2(n_items, cur, vbase, acc, depth):
         return L
 
     lines = []
-    if PRIO:
+    if PRIO >= 3:
+        lines += trip_prio(cur)
+    elif PRIO:
         lines.append(f"s_setprio {(1 if cur == 'X' else 0) + PRIO_BASE[0]}")
     for i in range(min(depth, n_items)):
         lines += issue(i)
@@ -190,6 +231,8 @@ def block(name, n_pix, vbase, stamp=False, pair_depth=0):
     L = []
     if stamp:
         L += [f"s_memtime s[{S_T0}:{S_T0 + 1}]", "s_waitcnt lgkmcnt(0)"]
+    if PRIO >= 3 and pair_depth:
+        L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
     L += [f"s_load_dwordx16 s[{x}:{x + 15}], %[ptr], 0x0",
           f"s_load_dwordx16 s[{x + 16}:{x + 31}], %[ptr], 0x40",
           f"s_mov_b32 s{S_LEFT}, %[ng]",
@@ -198,7 +241,7 @@ def block(name, n_pix, vbase, stamp=False, pair_depth=0):
           "s_waitcnt lgkmcnt(0)"]
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)",
-              f"s_sub_u32 s{S_T1}, s{S_T1}, s{S_T0}", f"s_add_u32 %[t_wait], %[t_wait], s{S_T1}"]
+              f"s_sub_u32 %[t_wait], s{S_T1}, s{S_T0}"]
     for j in range(n_pix):
         L += pixel_code(j, n_pix, vbase, accs[j], pair_depth)
     L += [".Ldone_%=:"]
@@ -206,11 +249,11 @@ def block(name, n_pix, vbase, stamp=False, pair_depth=0):
         L += ["s_setprio 0"]
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)",
-              f"s_sub_u32 s{S_T1}, s{S_T1}, s{S_T0}", f"s_add_u32 %[t_all], %[t_all], s{S_T1}"]
+              f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
 
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
     vregs = list(range(vbase, vbase + (8 * (pair_depth + 1) + 1 if pair_depth else 4 * (DEPTH + 1) + 1)))
-    sregs = list(range(S_T0, S_OFF + 1)) + list(range(SET["X"], SET["Y"] + 32))
+    sregs = [S_RANK, S_PRIO] + list(range(S_T0, S_OFF + 1)) + list(range(SET["X"], SET["Y"] + 32))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
     if pair_depth:
         acc_params = ", ".join(f"f2 (&P{j})[8]" for j in range(n_pix))
@@ -219,16 +262,16 @@ def block(name, n_pix, vbase, stamp=False, pair_depth=0):
         acc_params = ", ".join(f"f2 &A{j}, f2 &Q{j}, f2 &C{j}, f2 &R{j}" for j in range(n_pix))
         acc_ops = ", ".join(f'[A{j}] "+v"(A{j}), [Q{j}] "+v"(Q{j}), [C{j}] "+v"(C{j}), [R{j}] "+v"(R{j})' for j in range(n_pix))
     stamp_params = ", unsigned &t_wait, unsigned &t_all" if stamp else ""
-    stamp_ops = ', [t_wait] "+s"(t_wait), [t_all] "+s"(t_all)' if stamp else ""
+    stamp_ops = ', [t_wait] "=&s"(t_wait), [t_all] "=&s"(t_all)' if stamp else ""  # this call's cycles
     return f'''// {n_pix} pixel(s) of the staged chunk, ng groups of four items each (ng >= 1); pixel j's entries
 // start at `row` + j * stride bytes.  Reads the table up to one row start + two groups past the
 // last row it sweeps (the table carries spare groups).
 // temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}
-__device__ __forceinline__ void {name}({acc_params}, const void *row, int stride, int ng, unsigned lane_addr{stamp_params}) {{
+__device__ __forceinline__ void {name}({acc_params}, const void *row, int stride, int ng, unsigned lane_addr{", int rank" if pair_depth else ""}{stamp_params}) {{
     asm volatile(
 {body}
         : {acc_ops}{stamp_ops}
-        : [ptr] "s"(row), [stride] "s"(stride), [ng] "s"(ng), [lane] "v"(lane_addr)
+        : [ptr] "s"(row), [stride] "s"(stride), [ng] "s"(ng), [lane] "v"(lane_addr){', [rank] "s"(rank)' if pair_depth else ""}
         : {clobbers});
 }}
 '''
