@@ -55,24 +55,54 @@ class FrameBroadcaster:
     post(k) starts the broadcast of batch k into buffer k % 2 (async); wait(k) returns that
     buffer once the batch has landed.  The sweep of batch k runs while batch k+1 is in flight.
     With world size 1 (or no process group) it degenerates to handing out the local buffer.
+
+    mode "broadcast": one dist.broadcast per batch (a ring on xGMI: the root's outgoing link sets
+    the rate).  mode "scatter_allgather": the root scatters 1/world of the batch to every rank over
+    its point-to-point links, then an all-gather completes every rank's copy -- the bandwidth-optimal
+    broadcast on a fully connected mesh, one more collective launch per batch.  The batch dimension
+    must divide by the world size for it; otherwise it falls back to "broadcast".
     """
 
     def __init__(self, buffers: Tuple[torch.Tensor, torch.Tensor], src: int = 0,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, mode: str = "broadcast"):
         self.buffers = buffers
         self.src = src
         self.group = group
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self._work = [None, None]
+        self._mine = [None, None]
+        self.mode = mode
+        if self.active:
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+            if mode == "scatter_allgather" and buffers[0].shape[0] % self.world != 0:
+                self.mode = "broadcast"
+        if mode not in ("broadcast", "scatter_allgather"):
+            raise ValueError("mode must be 'broadcast' or 'scatter_allgather'")
 
     def post(self, k: int) -> None:
-        if self.active:
-            self._work[k % 2] = dist.broadcast(self.buffers[k % 2], src=self.src, group=self.group, async_op=True)
+        if not self.active:
+            return
+        buf = self.buffers[k % 2]
+        if self.mode == "broadcast":
+            self._work[k % 2] = [dist.broadcast(buf, src=self.src, group=self.group, async_op=True)]
+            return
+        per = buf.shape[0] // self.world
+        if self._mine[k % 2] is None:  # this rank's 1/world of the batch, outside `buf` (no aliasing)
+            self._mine[k % 2] = torch.empty_like(buf[:per])
+        mine = self._mine[k % 2]
+        chunks = [buf[r * per:(r + 1) * per].contiguous() for r in range(self.world)] if self.rank == self.src else None
+        w1 = dist.scatter(mine, chunks, src=self.src, group=self.group, async_op=True)
+        if dist.get_backend(self.group) == "gloo":
+            w1.wait()  # gloo runs async ops on several threads, not in issue order (NCCL/RCCL is stream-ordered)
+        w2 = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True)
+        self._work[k % 2] = [w1, w2]
 
     def wait(self, k: int) -> torch.Tensor:
-        w = self._work[k % 2]
-        if w is not None:
-            w.wait()  # on CUDA this orders the current stream after the collective
+        works = self._work[k % 2]
+        if works is not None:
+            for w in works:
+                w.wait()  # on CUDA this orders the current stream after the collective
             self._work[k % 2] = None
         return self.buffers[k % 2]
 

@@ -143,7 +143,7 @@ def main():
     else:
         bufs = (d_full, d_full)
     d_power = torch.zeros((B, shard.pixel_count), dtype=torch.float32, device=dev)
-    bcast = sharding.FrameBroadcaster(bufs, src=0)
+    bcast = sharding.FrameBroadcaster(bufs, src=0, mode=os.environ.get("BENCH_BCAST", "broadcast"))
     # a real (non-null) stream: its handle goes to the C ABI, and the torch events that time
     # the sweep are recorded on the same stream
     stream = torch.cuda.Stream(device=dev)

@@ -33,7 +33,7 @@ def test_shard_rows_tile_the_grid(pkg):
         sh.shard_rows(4, 4, 8, 0)
 
 
-def _worker(rank, world, port, res, batch, steps, out_dir):
+def _worker(rank, world, port, res, batch, steps, out_dir, mode="broadcast"):
     import sys
     from pathlib import Path
 
@@ -51,7 +51,7 @@ def _worker(rank, world, port, res, batch, steps, out_dir):
     sl = slice(shard.pixel_begin, shard.pixel_begin + shard.pixel_count)
     rng = np.random.default_rng(100)
     bufs = tuple(torch.zeros((batch, 64, 1024), dtype=torch.float32) for _ in range(2))
-    bc = sh.FrameBroadcaster(bufs, src=0)
+    bc = sh.FrameBroadcaster(bufs, src=0, mode=mode)
     assert bc.active
     results = []
     all_frames = [rng.uniform(-0.01, 0.01, size=(batch, 64, 1024)).astype(np.float32) for _ in range(steps)]
@@ -79,10 +79,10 @@ def _worker(rank, world, port, res, batch, steps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,res", [(2, 10), (2, 7)])
-def test_broadcast_and_gather_world2(tmp_path, world, res):
+@pytest.mark.parametrize("world,res,mode", [(2, 10, "broadcast"), (2, 7, "broadcast"), (2, 6, "scatter_allgather")])
+def test_broadcast_and_gather_world2(tmp_path, world, res, mode):
     port = free_port()
-    mp.spawn(_worker, args=(world, port, res, 2, 3, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, res, 2, 3, str(tmp_path), mode), nprocs=world, join=True)
     assert np.load(tmp_path / "ok.npy")[0]
 
 
