@@ -1,0 +1,56 @@
+"""Randomised parity sweep, run as a child process by tests/test_gpu_random.py so that the kernel
+shape can be forced through the environment (the library reads its tuning knobs once per process).
+
+Random, NOT geometry-derived tables: arbitrary integer offsets inside the legal range, arbitrary
+fractions, arbitrary active-mic subsets, ragged pixel counts, odd batches, short histories."""
+import importlib
+import sys
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+import util  # noqa: E402
+from oracle import oracle_py  # noqa: E402
+
+pkg = importlib.import_module("beamforming-lk_amd")
+
+
+def main(seed: int, cases: int) -> int:
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for case in range(cases):
+        n_streams = int(rng.choice([64, 128, 192, 256]))
+        lut_stride = n_streams + int(rng.choice([0, 0, 7]))
+        hist = int(rng.choice([600, 777, 1024]))
+        P = int(rng.choice([1, 5, 63, 64, 65, 130, 257]))
+        batch = int(rng.integers(1, 8))
+        usable = int(rng.integers(1, n_streams + 1))
+        spread = int(rng.choice([0, 3, 40, 120, hist - 257]))  # window width control
+        base = int(rng.integers(0, hist - 257 - spread + 1))
+        off = rng.integers(base, base + spread + 1, size=(P, lut_stride)).astype(np.int32)
+        frac = rng.uniform(0, 1, size=(P, lut_stride)).astype(np.float32)
+        frac[rng.uniform(size=frac.shape) < 0.05] = 0.0
+        index = rng.permutation(n_streams)[:usable].astype(np.int32)
+        X = util.hash_frames(n_streams, hist, seed=1000 + case, batch=batch)
+        eng = pkg.Engine(n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch)
+        with eng:
+            eng.set_delay_table(off, frac)
+            eng.set_active_mics(index)
+            power = eng.process(X)
+        for b in range(batch):
+            want = oracle_py.das_f32(X[b], off, frac, index)
+            err = util.power_rel_err(power[b], want)
+            worst = max(worst, err)
+            if not err < util.POWER_RTOL:
+                print(f"FAIL case {case}: streams {n_streams} stride {lut_stride} hist {hist} P {P} batch {batch} "
+                      f"usable {usable} window {spread + 257} frame {b}: rel err {err:.3e}")
+                return 1
+    print(f"OK {cases} cases, worst rel err {worst:.2e}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(int(sys.argv[1]), int(sys.argv[2])))

@@ -1,0 +1,23 @@
+"""Randomised GPU-vs-oracle parity with the kernel shape forced each way (one child process per
+shape, because the library reads AWPU_FAST_* once per process)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("env", [
+    {"AWPU_FAST_PAIRS": "1"},                                  # frame-pair sweep on every batch >= 2
+    {"AWPU_FAST_PAIRS": "0", "AWPU_FAST_VARIANT": "1,8,32"},   # double-buffered single-frame shape
+    {"AWPU_FAST_PAIRS": "0", "AWPU_FAST_VARIANT": "1,2,8"},    # 8-wave shape, 2 pixels per wave
+    {"AWPU_FAST_PAIRS": "0", "AWPU_FAST_VARIANT": "2,4,8"},    # two frames per item, compiler-scheduled
+], ids=["pairs", "db", "small", "fpi2"])
+def test_random_tables(env):
+    out = subprocess.run([sys.executable, str(REPO / "tests" / "gpu_random_check.py"), "2024", "14"],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK 14 cases" in out.stdout, out.stdout + out.stderr[-2000:]
