@@ -381,3 +381,30 @@ def test_wire_ingest_and_ring_sweep(pkg, oracle):
         assert np.array_equal(power, eng.process(ring))
     rx.close()
     tx.close()
+
+
+@pytest.mark.parametrize("wl,batch", [("headline", 4), ("c3", 2)])
+def test_full_size_properties(pkg, oracle, wl, batch):
+    """BASELINE's full sizes (256 mics x 128x128, 512 mics x 128x128), where the oracle would take
+    minutes: size-independent properties on the whole grid plus an oracle check on a sample of pixels.
+      * frame 1 = 4 x frame 0  ->  power exactly 16 x (power-of-two scaling is exact in fp32)
+      * the peak pixel looks at the plane-wave source
+      * 200 sampled pixels agree with the oracle to 1e-5."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS[wl]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, batch, seed=3)
+    frames[1] = 4.0 * frames[0]
+    power, st = run_engine(pkg, frames, off, frac)
+    assert st.usable == spec.n_mics
+    assert np.array_equal(power[1], 16.0 * power[0])
+    r, c = divmod(int(power[0].argmax()), spec.res)
+    er, ec = S.source_pixel(spec)
+    assert abs(r - er) <= 1 and abs(c - ec) <= 1
+    pick = np.random.default_rng(1).choice(spec.n_pixels, 200, replace=False)
+    for b in (0, batch - 1):
+        want = oracle.das_f32(frames[b], off[pick], frac[pick])
+        got = power[b][pick]
+        floor = util.NULL_FLOOR * float(power[b].max())
+        assert float((np.abs(got - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
