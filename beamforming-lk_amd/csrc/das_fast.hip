@@ -606,8 +606,11 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
-    const int pair = blockIdx.x;
-    const int pix0 = (blockIdx.y * NW + wave) * PPW;
+    // dispatch order: the pairs of a tile are consecutive (they share the tile's table rows in L2);
+    // debug bit 256 swaps the roles (tiles of a pair consecutive: they share the pair's samples)
+    const int pair = (a.debug & 256) ? blockIdx.y : blockIdx.x;
+    const int tile = (a.debug & 256) ? blockIdx.x : blockIdx.y;
+    const int pix0 = (tile * NW + wave) * PPW;
     const size_t row_floats = (size_t) a.wp * 2;
     const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
 
@@ -836,6 +839,7 @@ static hipError_t launch_pair_variant(const PairArgs &a, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid((a.batch + 1) / 2, (a.pixel_count + 16 * PPW - 1) / (16 * PPW));
+    if (a.debug & 256) grid = dim3(grid.y, grid.x);
     if (grid.y > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL((das_pair_kernel<PPW, DIAG>), grid, dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
