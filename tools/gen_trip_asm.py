@@ -22,7 +22,7 @@ Block flavours:
   sweep_quad_stamped  the same with s_memtime stamps (diagnostic builds only)
 
 Fixed registers (all in the clobber list, so hipcc keeps nothing of its own there):
-    SGPR  s[36:67] set X, s[68:99] set Y, s28..s35 loop state
+    SGPR  s[36:67] set X, s[68:99] set Y, s23..s31 and s35 loop state (s32..s34 are left alone: SP/FP/BP)
     VGPR  DEPTH+1 read slots of 4 registers + 1 address temp, from `vbase`
 A block is self-contained: it begins with none of its own loads pending and ends drained, so the
 compiler never sees a register with a load in flight.
@@ -35,9 +35,9 @@ PRIO_BASE = [0]  # +2 on odd pixels of a block: four levels, so that ties (decid
 DEPTH = int(os.environ.get("TRIP_DEPTH", "4"))  # items of LDS read-ahead (2*DEPTH <= 15: lgkmcnt is 4 bits)
 SET = {"X": 36, "Y": 68}
 OTHER = {"X": "Y", "Y": "X"}
-# loop state: s[28:29] stamp t0, s[30:31] temp pair, s32 row offset, s33 groups left,
-# s34 refill offset, s35 offset of the entries after the loaded ones
-S_T0, S_T1, S_ROW, S_LEFT, S_PF, S_OFF = 28, 30, 32, 33, 34, 35
+# loop state: s[28:29] stamp t0, s[30:31] temp pair, s23 row offset, s24 groups left,
+# s25 refill offset, s35 offset of the entries after the loaded ones
+S_T0, S_T1, S_ROW, S_LEFT, S_PF, S_OFF = 28, 30, 23, 24, 25, 35  # not s32..s34: stack/frame/base pointer registers
 S_PRIO = 27  # PRIO 3: rotating priority counter (starts at the wave's age rank on its SIMD)
 
 
@@ -253,7 +253,7 @@ def block(name, n_pix, vbase, stamp=False, pair_depth=0):
 
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
     vregs = list(range(vbase, vbase + (8 * (pair_depth + 1) + 1 if pair_depth else 4 * (DEPTH + 1) + 1)))
-    sregs = [S_RANK, S_PRIO] + list(range(S_T0, S_OFF + 1)) + list(range(SET["X"], SET["Y"] + 32))
+    sregs = sorted({S_RANK, S_PRIO, S_ROW, S_LEFT, S_PF, S_OFF, S_T0, S_T0 + 1, S_T1, S_T1 + 1}) + list(range(SET["X"], SET["Y"] + 32))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
     if pair_depth:
         acc_params = ", ".join(f"f2 (&P{j})[8]" for j in range(n_pix))
