@@ -283,7 +283,7 @@ def main():
     out.append(block("sweep_pixel_hi", 1, hi))
     out.append(block("sweep_quad_hi", 4, hi))
     out.append(block("sweep_quad_stamped", 4, hi, stamp=True))
-    pd = 2  # frame-pair items: 2 items (8 reads) of read-ahead; +4 being issued +2 scalar loads <= 15 (lgkmcnt is 4 bits)
+    pd = int(os.environ.get("PAIR_DEPTH", "2"))  # frame-pair items: 2 items (8 reads) of read-ahead; +4 being issued +2 scalar loads <= 15 (lgkmcnt is 4 bits)
     out.append(block("sweep_duo_pairs", 2, 128 - (8 * (pd + 1) + 1) - 3, pair_depth=pd))
     out.append(block("sweep_duo_pairs_stamped", 2, 128 - (8 * (pd + 1) + 1) - 3, stamp=True, pair_depth=pd))
     lo = 80 - (4 * (DEPTH + 1) + 1) - 3  # shapes with an 80-VGPR budget (6 waves per SIMD)
