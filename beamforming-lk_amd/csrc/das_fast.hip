@@ -1,30 +1,36 @@
-// das_fast.hip -- the LDS-tiled, packed-FMA sweep kernel (AWPU_MATH_F32_FAST) for gfx950.
+// das_fast.hip -- the LDS-tiled, packed-FMA sweep kernels (AWPU_MATH_F32_FAST) for gfx950.
 //
-// Replaces the loop nest of MIMOWorker::update, src/dsp/mimo.cpp:121-151, around delay(),
+// They replace the loop nest of MIMOWorker::update, src/dsp/mimo.cpp:121-151, around delay(),
 // src/dsp/delay.cpp:16-26, with the interpolation written as two FMAs per sample:
 //     out[i] += f * X[off+i] + g * X[off+i+1],   g = 1 - f
 // (the reference computes X[off+i+1] + f * (X[off+i] - X[off+i+1]); the two differ by fp32
-// rounding only).
+// rounding only).  One (pixel, mic) pair = one "item" of 256 samples.
 //
-// Mapping (one (pixel, mic) pair = one "item" of 256 samples):
-//   * A workgroup = 8 waves; wave w sweeps PPW pixels; a launch covers the pixel tiles x the
-//     frame groups of a batch (FPI frames share one item's address and coefficients).
-//   * The touched window of a chunk of mics is staged once per workgroup in LDS, TWICE: copy q
-//     holds the window shifted by q floats, so that for any integer delay the run a lane needs
-//     starts 8-byte aligned in copy (off & 1) -- ds_read_b64 runs at twice the per-byte rate of
-//     ds_read_b32 but faults to a 64-cycle replay when misaligned.
-//   * An item's (f, g, LDS address) are wave-uniform and arrive by scalar loads (s_load_dwordx16
-//     = 4 items) into SGPRs; the only per-item VALU work besides the FMAs is one address add.
-//   * Lane l owns samples {2l, 2l+1} (run A) and {128+2l, 129+2l} (run B): two conflict-free
-//     ds_read_b64 per frame (64 lanes x 8 B = every bank once per half-wave) feed four
-//     v_pk_fma_f32 -- the only way to reach the fp32 peak on this chip (a plain v_fma_f32
-//     issues at half the lane rate, measured in tools/ubench.hip):
+// Three kernels, one idea:
+//   das_pair_kernel      frames packed two by two, sample-interleaved; the two lanes of every packed
+//                        FMA are the two FRAMES.  Default for batches.  (bottom of this file)
+//   das_fast_db_kernel   one frame per item, 16-wave workgroup per CU, two LDS images filled by
+//                        LDS-DMA while the other is swept.  Single-frame calls on full grids.
+//   das_fast_kernel      one (or two) frames per item, 8-wave workgroups, two per CU.  Small grids.
+// Common to all:
+//   * the touched window of a chunk of mics is staged once per workgroup in LDS; the accumulators
+//     of a wave's pixels stay in registers across chunks;
+//   * an item's (f, g, LDS address) are wave-uniform and arrive by scalar loads (s_load_dwordx16 =
+//     4 items) into SGPRs; besides the FMAs the only per-item VALU instruction is the address add;
+//   * every inner FMA is a v_pk_fma_f32 -- the only way to reach the fp32 peak on this chip (a
+//     plain v_fma_f32 issues at half the lane rate, tools/ubench.hip) -- fed by conflict-free
+//     ds_read_b64 (64 lanes x 8 B = every bank once per half-wave);
+//   * the inner loops of the two big kernels are hand-scheduled asm (das_fast_trip.inc, generated
+//     by tools/gen_trip_asm.py);
+//   * the g-terms land one sample low (g * X[t] belongs to out[t-1]); that skew is undone once per
+//     pixel with lane shifts, and the 257th sample X[off+256] (owned by no lane) is gathered in a
+//     side pass, one lane per mic;
+//   * epilogue (mimo.cpp:131-137): MA filter via lane shifts, squares, wave reduction.
+// Single-frame kernels only: lane l owns samples {2l,2l+1} and {128+2l,129+2l}, and the window is
+// staged TWICE, copy q shifted by q floats, so that any integer delay starts 8-byte aligned in copy
+// (off & 1) -- a misaligned ds_read_b64 is a 64-cycle replay:
 //         A += f*x   -> out[2l], out[2l+1]          Q += g*x   -> out[2l-1], out[2l]
 //         C += f*y   -> out[128+2l], out[129+2l]    R += g*y   -> out[127+2l], out[128+2l]
-//     The one-sample skew of the g terms is undone once per pixel (wave shifts), not per mic.
-//   * The 257th sample of a window (X[off+256], weight g, lands in out[255]) is owned by no
-//     lane; it is gathered in a side pass with one lane per mic and wave-reduced per pixel.
-//   * Epilogue (mimo.cpp:131-137): MA filter via lane shifts, squares, wave reduction.
 #include "das_kernels.h"
 
 namespace awpu {
