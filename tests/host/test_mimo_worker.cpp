@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "das_oracle.h"
+#include "aw_processing_unit_hip.h"
 #include "mimo_worker_hip.h"
 
 using namespace awpu_host;
@@ -187,6 +188,33 @@ int main(int argc, char **argv) {
         const int k = (int) (std::max_element(img.begin(), img.end()) - img.begin());
         CHECK(img[k] == 255, "threaded worker produced no heatmap");
         std::printf("3. threaded worker: heatmap peak at (%d,%d)\n", k / cols, k % cols);
+    }
+    // ---- 4. the processing unit as AWControlUnit drives it: construct (calibrates), start(MIMO), draw, stop
+    {
+        SyntheticSource src(xyz.data(), 64, theta, phi);
+        std::thread producer([&] {
+            for (int b = 0; b < 40 && src.isRunning(); b++) {
+                src.publish_block();
+                std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            }
+        });
+        AWProcessingUnitHip awpu(&src, 180.f, rows, /*verbose=*/0);
+        CHECK(awpu.n_antennas() == 1 && awpu.usable() == 64, "calibrate kept %d mics", awpu.usable());
+        CHECK(!awpu.start(GRADIENT), "only the MIMO worker is on this path");
+        CHECK(awpu.start(MIMO), "start(MIMO): %s", awpu_hip_last_error());
+        awpu.resume();
+        std::this_thread::sleep_for(std::chrono::milliseconds(80));
+        std::vector<uint8_t> small(rows * cols, 0), big(96 * 96, 0);
+        awpu.draw(small.data(), big.data(), 96);
+        const int k = (int) (std::max_element(small.begin(), small.end()) - small.begin());
+        const int kb = (int) (std::max_element(big.begin(), big.end()) - big.begin());
+        CHECK(small[k] == 255 && awpu.status() == AWPU_OK, "no heatmap from the processing unit");
+        CHECK(std::abs(kb / 96 - (k / cols) * 4) <= 6 && std::abs(kb % 96 - (k % cols) * 4) <= 6, "upscaled peak moved");
+        CHECK(awpu.targets().empty(), "MIMO has no targets");
+        CHECK(awpu.stop(MIMO) && !awpu.stop(MIMO), "stop(MIMO) once");
+        src.stop();
+        producer.join();
+        std::printf("4. processing unit: heatmap peak at (%d,%d), upscaled (%d,%d)\n", k / cols, k % cols, kb / 96, kb % 96);
     }
     std::printf(failures ? "FAILED\n" : "OK\n");
     return failures ? 1 : 0;
