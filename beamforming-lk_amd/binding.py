@@ -82,6 +82,14 @@ _SIGNATURES = {
     "awpu_hip_process_ring": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_ring_snapshot": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_heatmap_u8": (C.c_int, [_f32p, C.c_int32, _u8p]),
+    "awpu_hip_set_mic_gains": (C.c_int, [C.c_void_p, _f32p]),
+    "awpu_hip_calibrate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, _i32p, _f32p,
+                                            C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p]),
+    "awpu_hip_calibrate_ring": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, _i32p, _f32p, C.POINTER(C.c_float),
+                                          C.POINTER(C.c_int32)]),
+    "awpu_hip_upscale_u8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                             C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "awpu_hip_resize_linear_u8": (C.c_int, [_u8p, C.c_int32, C.c_int32, _u8p, C.c_int32, C.c_int32]),
     "awpu_hip_heatmap_u8_device": (
         C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "awpu_hip_create_antenna": (C.c_int, [C.c_int32, C.c_int32, C.c_float, _f32p]),
@@ -177,6 +185,18 @@ def build_delay_table(xyz: np.ndarray, rows: int, columns: int, fov_deg: float =
     _check(load().awpu_hip_build_delay_table(_f32(xyz), n, rows, columns, fov_deg, row_begin,
                                              row_count, _i32(off), _f32(frac)), "build_delay_table")
     return off, frac
+
+
+def resize_linear_u8(pix: np.ndarray, out_rows: int, out_cols: int) -> np.ndarray:
+    """cv::resize(..., INTER_LINEAR) of AWProcessingUnit::draw, src/aw_processing_unit/aw_processing_unit.cpp:252
+    (8-bit single channel, upscaling only), on the host."""
+    pix = np.ascontiguousarray(pix, np.uint8)
+    if pix.ndim != 2:
+        raise ValueError("pix must be [rows][cols]")
+    out = np.empty((out_rows, out_cols), np.uint8)
+    _check(load().awpu_hip_resize_linear_u8(pix.ctypes.data_as(_u8p), pix.shape[0], pix.shape[1],
+                                            out.ctypes.data_as(_u8p), out_rows, out_cols), "resize_linear_u8")
+    return out
 
 
 def heatmap_u8(power: np.ndarray) -> np.ndarray:
@@ -298,6 +318,44 @@ class Engine:
         _check(self._lib.awpu_hip_heatmap_u8_device(self._h, C.c_void_p(d_power_ptr), n, batch,
                                                     C.c_void_p(d_peak_ptr), int(peak_given), C.c_void_p(d_pix_ptr),
                                                     C.c_void_p(stream)), "awpu_hip_heatmap_u8_device")
+
+    def set_mic_gains(self, gains: Optional[np.ndarray]) -> None:
+        """Optional per-mic gain (the reference's unused power_correction_mask, aw_processing_unit.cpp:190-200);
+        gains [n_streams] by stream id, None = off."""
+        if gains is None:
+            _check(self._lib.awpu_hip_set_mic_gains(self._h, None), "set_mic_gains")
+            return
+        gains = np.ascontiguousarray(gains, np.float32)
+        if gains.shape != (self.cfg.n_streams,):
+            raise ValueError("gains must be [n_streams]")
+        _check(self._lib.awpu_hip_set_mic_gains(self._h, _f32(gains)), "set_mic_gains")
+
+    def _calibrated(self, call):
+        index = np.empty(64, np.int32)
+        corr = np.empty(64, np.float32)
+        med, n = C.c_float(0), C.c_int32(0)
+        call(index, corr, med, n)
+        return index[: n.value].copy(), corr[: n.value].copy(), med.value
+
+    def calibrate_device(self, d_frame_ptr: int, array: int = 0, reference_power_level: float = 1e-5, stream: int = 0):
+        """AWProcessingUnit::calibrate (aw_processing_unit.cpp:102-212) for one array of a snapshot in
+        device memory -> (index, correction, median)."""
+        return self._calibrated(lambda i, c, m, n: _check(self._lib.awpu_hip_calibrate_device(
+            self._h, C.c_void_p(d_frame_ptr), array, reference_power_level, _i32(i), _f32(c), C.byref(m), C.byref(n),
+            C.c_void_p(stream)), "awpu_hip_calibrate_device"))
+
+    def calibrate_ring(self, array: int = 0, reference_power_level: float = 1e-5):
+        """The same on the current snapshot of the ingest ring."""
+        return self._calibrated(lambda i, c, m, n: _check(self._lib.awpu_hip_calibrate_ring(
+            self._h, array, reference_power_level, _i32(i), _f32(c), C.byref(m), C.byref(n)), "awpu_hip_calibrate_ring"))
+
+    def upscale_device(self, d_pix_ptr: int, rows: int, cols: int, batch: int, d_out_ptr: int, out_rows: int,
+                       out_cols: int, d_colormap_ptr: int = 0, stream: int = 0) -> None:
+        """The display upscale (aw_processing_unit.cpp:252), optionally through a 256x3 colour table
+        (main.cpp:345), on device buffers; asynchronous on `stream`."""
+        _check(self._lib.awpu_hip_upscale_u8_device(self._h, C.c_void_p(d_pix_ptr), rows, cols, batch,
+                                                    C.c_void_p(d_colormap_ptr), C.c_void_p(d_out_ptr), out_rows,
+                                                    out_cols, C.c_void_p(stream)), "awpu_hip_upscale_u8_device")
 
     def synchronize(self) -> None:
         _check(self._lib.awpu_hip_synchronize(self._h), "awpu_hip_synchronize")

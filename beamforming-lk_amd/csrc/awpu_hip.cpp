@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +48,7 @@ struct awpu_hip {
     std::vector<int32_t> off;   // [pixel_count][lut_stride]  offsetDelays
     std::vector<float> frac;    // [pixel_count][lut_stride]  fractionalDelays
     std::vector<int32_t> index; // [usable]                   antenna.index
+    std::vector<float> gain;    // [n_streams] optional per-mic gain (awpu_hip_set_mic_gains); empty = none
     bool have_table = false, have_mics = false, prepared = false;
 
     // device state
@@ -57,8 +59,12 @@ struct awpu_hip {
     };
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     int32_t *d_index = nullptr;
+    float *d_gain = nullptr;  // [usable] gains in active-mic order, or null
+    float *d_calib = nullptr; // [64] per-mic mean squares (calibration)
     float *d_fir = nullptr;  // [101][8] coefficient table (AWPU_INTERP_FIR8)
     float *d_ring = nullptr;            // [n_streams][2048] history ring (awpu_hip_ingest_block)
+    awpu::ResizeTap *d_taps = nullptr;  // column + row taps of the display upscale, for taps_key
+    int taps_key[4] = {0, 0, 0, 0};     // {srows, scols, drows, dcols}
     float *d_pack = nullptr;            // [pairs][usable][wp][2] sample-interleaved frame pairs
     size_t pack_cap = 0;                // floats
     unsigned char *d_datagrams = nullptr;  // staging for one block of wire datagrams
@@ -86,11 +92,17 @@ void release_device(awpu_hip *h) {
         if (l.d) (void) hipFree(l.d);
     h->fast_luts.clear();
     if (h->d_index) (void) hipFree(h->d_index);
+    if (h->d_gain) (void) hipFree(h->d_gain);
+    h->d_gain = nullptr;
+    if (h->d_calib) (void) hipFree(h->d_calib);
+    h->d_calib = nullptr;
     if (h->d_fir) (void) hipFree(h->d_fir);
     h->d_fir = nullptr;
     if (h->d_ring) (void) hipFree(h->d_ring);
     if (h->d_pack) (void) hipFree(h->d_pack);
     h->d_pack = nullptr;
+    if (h->d_taps) (void) hipFree(h->d_taps);
+    h->d_taps = nullptr;
     h->pack_cap = 0;
     if (h->d_datagrams) (void) hipFree(h->d_datagrams);
     if (h->d_row_off_ring) (void) hipFree(h->d_row_off_ring);
@@ -145,6 +157,14 @@ int prepare(awpu_hip *h) {
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
                            hipMemcpyHostToDevice));
+    if (h->d_gain) (void) hipFree(h->d_gain);
+    h->d_gain = nullptr;
+    if (!h->gain.empty()) {
+        std::vector<float> compact(U);
+        for (int s = 0; s < U; s++) compact[s] = h->gain[h->index[s]];
+        AWPU_HIP_TRY(hipMalloc(&h->d_gain, (size_t) U * sizeof(float)));
+        AWPU_HIP_TRY(hipMemcpy(h->d_gain, compact.data(), (size_t) U * sizeof(float), hipMemcpyHostToDevice));
+    }
     {   // float offset, inside one frame, of staged row 2*s+q (copy q of active mic s)
         if (h->d_row_off) (void) hipFree(h->d_row_off);
         h->d_row_off = nullptr;
@@ -250,6 +270,10 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
             const int j = s % plan.chunk;  // mic slot inside its chunk
             dst[s].f = frow[id];
             dst[s].g = 1.0f - frow[id];
+            if (!h->gain.empty()) {  // the per-mic gain rides on the two weights
+                dst[s].f *= h->gain[id];
+                dst[s].g *= h->gain[id];
+            }
             dst[s].addr = pairs ? (uint32_t) (j * plan.row_bytes + off_rel * 8)
                                 : (uint32_t) ((j * 2 + q) * plan.row_bytes + (off_rel - q) * 4);
         }
@@ -317,6 +341,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         a.lut = h->d_lut;
         a.index = h->d_index;
         a.power = d_power;
+        a.gain = h->d_gain;
         a.n_streams = h->cfg.n_streams;
         a.hist = hist_eff;
         a.usable = h->usable();
@@ -597,6 +622,79 @@ int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable
     return AWPU_OK;
 }
 
+int awpu_hip_set_mic_gains(awpu_hip_t *h, const float *gains) {
+    if (!h) return invalid("null handle");
+    if (!gains) {
+        h->gain.clear();
+    } else {
+        for (int s = 0; s < h->cfg.n_streams; s++)
+            if (!std::isfinite(gains[s])) return invalid("gain not finite");
+        h->gain.assign(gains, gains + h->cfg.n_streams);
+    }
+    h->prepared = false;
+    return AWPU_OK;
+}
+
+namespace {
+
+// aw_processing_unit.cpp:145-200 on the 64 mean squares of one array
+int usable_from_power(const float *power, float reference_power_level, int32_t *index, float *correction,
+                      float *median_out) {
+    float sorted[AWPU_ELEMENTS];
+    std::copy(power, power + AWPU_ELEMENTS, sorted);
+    std::sort(sorted, sorted + AWPU_ELEMENTS);
+    // the reference averages elements 32 and 33 of the sorted list (.cpp:150), in double, then rounds
+    const float median = (float) ((sorted[AWPU_ELEMENTS / 2] + sorted[AWPU_ELEMENTS / 2 + 1]) / 2.0);
+    int count = 0;
+    for (int s = 0; s < AWPU_ELEMENTS; s++) {
+        const bool far_off = std::fabs(power[s] - median) > 1e-4;  // float promoted against a double bound
+        const bool dead = power[s] < median * 1e-3;
+        if (far_off || dead) continue;
+        index[count] = s;
+        correction[count] = reference_power_level / power[s];
+        count++;
+    }
+    if (median_out) *median_out = median;
+    return count;
+}
+
+int calibrate_rows(awpu_hip *h, const float *d_rows, int pitch, int hist, float reference_power_level, int32_t *index,
+                   float *correction, float *median, int32_t *usable, hipStream_t s) {
+    if (!h->d_calib) AWPU_HIP_TRY(hipMalloc(&h->d_calib, AWPU_ELEMENTS * sizeof(float)));
+    AWPU_HIP_TRY(awpu::launch_stream_power(d_rows, pitch, hist, AWPU_ELEMENTS, h->d_calib, s));
+    float power[AWPU_ELEMENTS];
+    AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_calib, sizeof(power), hipMemcpyDeviceToHost, s));
+    AWPU_HIP_TRY(hipStreamSynchronize(s));
+    *usable = usable_from_power(power, reference_power_level, index, correction, median);
+    return AWPU_OK;
+}
+
+}  // namespace
+
+int awpu_hip_calibrate_device(awpu_hip_t *h, const float *d_frame, int32_t array, float reference_power_level,
+                              int32_t *index, float *correction, float *median, int32_t *usable, void *stream) {
+    if (!h || !d_frame || !index || !correction || !usable) return invalid("null argument");
+    if (array < 0 || (array + 1) * AWPU_ELEMENTS > h->cfg.n_streams) return invalid("array outside the streams");
+    if (h->cfg.hist > 16384) return invalid("history too long for the calibration kernel");
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    return calibrate_rows(h, d_frame + (size_t) array * AWPU_ELEMENTS * h->cfg.hist, h->cfg.hist, h->cfg.hist,
+                          reference_power_level, index, correction, median, usable, s);
+}
+
+int awpu_hip_calibrate_ring(awpu_hip_t *h, int32_t array, float reference_power_level, int32_t *index,
+                            float *correction, float *median, int32_t *usable) {
+    if (!h || !index || !correction || !usable) return invalid("null argument");
+    if (array < 0 || (array + 1) * AWPU_ELEMENTS > h->cfg.n_streams) return invalid("array outside the streams");
+    if (!h->d_ring) {
+        g_last_error = "no block ingested yet";
+        return AWPU_ERR_STATE;
+    }
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    return calibrate_rows(h, h->d_ring + (size_t) array * AWPU_ELEMENTS * 2048 + h->ring_pos, 2048, AWPU_HIST,
+                          reference_power_level, index, correction, median, usable, h->stream);
+}
+
 int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {
     if (!h || !coeffs) return invalid("null argument");
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
@@ -730,6 +828,59 @@ int awpu_hip_heatmap_u8_device(awpu_hip_t *h, const float *d_power, int32_t n, i
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     AWPU_HIP_TRY(awpu::launch_heatmap(d_power, n, batch, d_peak, peak_given != 0, d_pix, s));
+    return AWPU_OK;
+}
+
+int awpu_hip_upscale_u8_device(awpu_hip_t *h, const uint8_t *d_pix, int32_t rows, int32_t cols, int32_t batch,
+                               const uint8_t *d_colormap, uint8_t *d_out, int32_t out_rows, int32_t out_cols,
+                               void *stream) {
+    if (!h || !d_pix || !d_out || rows < 1 || cols < 1 || batch < 1 || batch > 65535) return invalid("bad argument");
+    if (out_rows < rows || out_cols < cols || out_rows > 65535) return invalid("upscale only: out >= in, out_rows <= 65535");
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    const int key[4] = {rows, cols, out_rows, out_cols};
+    if (!h->d_taps || std::memcmp(key, h->taps_key, sizeof(key)) != 0) {
+        std::vector<awpu::ResizeTap> taps((size_t) out_cols + out_rows);
+        awpu::resize_taps(cols, out_cols, true, taps.data());
+        awpu::resize_taps(rows, out_rows, false, taps.data() + out_cols);
+        AWPU_HIP_TRY(hipStreamSynchronize(s));  // an earlier launch may still read the old taps
+        if (h->d_taps) (void) hipFree(h->d_taps);
+        h->d_taps = nullptr;
+        AWPU_HIP_TRY(hipMalloc(&h->d_taps, taps.size() * sizeof(awpu::ResizeTap)));
+        AWPU_HIP_TRY(hipMemcpy(h->d_taps, taps.data(), taps.size() * sizeof(awpu::ResizeTap), hipMemcpyHostToDevice));
+        std::memcpy(h->taps_key, key, sizeof(key));
+    }
+    AWPU_HIP_TRY(awpu::launch_upscale(d_pix, rows, cols, batch, h->d_taps, d_colormap, d_out, out_rows, out_cols, s));
+    return AWPU_OK;
+}
+
+int awpu_hip_resize_linear_u8(const uint8_t *pix, int32_t rows, int32_t cols, uint8_t *out, int32_t out_rows,
+                              int32_t out_cols) {
+    if (!pix || !out || rows < 1 || cols < 1) return invalid("bad argument");
+    if (out_rows < rows || out_cols < cols) return invalid("upscale only: out >= in");
+    std::vector<awpu::ResizeTap> taps((size_t) out_cols + out_rows);
+    awpu::resize_taps(cols, out_cols, true, taps.data());
+    awpu::resize_taps(rows, out_rows, false, taps.data() + out_cols);
+    std::vector<int> sums((size_t) 2 * out_cols);  // the two source rows of the current output row, widened
+    int have0 = -1, have1 = -1;
+    for (int dy = 0; dy < out_rows; dy++) {
+        const awpu::ResizeTap ty = taps[(size_t) out_cols + dy];
+        const int r0 = std::min(std::max(ty.src, 0), rows - 1), r1 = std::min(std::max(ty.src + 1, 0), rows - 1);
+        const int want[2] = {r0, r1};
+        int *have[2] = {&have0, &have1};
+        for (int k = 0; k < 2; k++) {
+            if (*have[k] == want[k]) continue;
+            const uint8_t *row = pix + (size_t) want[k] * cols;
+            int *line = sums.data() + (size_t) k * out_cols;
+            for (int dx = 0; dx < out_cols; dx++) {
+                const awpu::ResizeTap tx = taps[dx];
+                line[dx] = row[tx.src] * tx.w0 + row[std::min(tx.src + 1, cols - 1)] * tx.w1;
+            }
+            *have[k] = want[k];
+        }
+        for (int dx = 0; dx < out_cols; dx++)
+            out[(size_t) dy * out_cols + dx] = awpu::resize_combine(sums[dx], sums[(size_t) out_cols + dx], ty.w0, ty.w1);
+    }
     return AWPU_OK;
 }
 

@@ -22,6 +22,7 @@ struct SweepArgs {
     const LutEntry *lut;   // [pixel_count][usable], compact active-mic order
     const int32_t *index;  // [usable] stream id per active mic
     float *power;          // [batch][pixel_count]
+    const float *gain;     // [usable] per-mic gain applied while staging, or nullptr (the reference has none)
     int32_t n_streams;
     int32_t hist;
     int32_t usable;
@@ -101,6 +102,28 @@ hipError_t launch_das_fir8(const SweepArgs &a, const float *d_coeffs, hipStream_
 // maximum; d_pix[batch][n] the 8-bit image.
 hipError_t launch_heatmap(const float *d_power, int n, int batch, float *d_peak, bool peak_given, uint8_t *d_pix,
                           hipStream_t stream);
+
+// mean square of `hist` samples of each of `n` rows (pitch floats apart), summed in sample order
+// (calibration, aw_processing_unit.cpp:133-143)
+hipError_t launch_stream_power(const float *d_rows, int pitch, int hist, int n, float *d_out, hipStream_t stream);
+
+// One axis of the 8-bit bilinear upscale: for output coordinate d, the first source coordinate
+// (may be -1 / size-1: the kernel clamps) and the two 11-bit weights (w0 + w1 = 2048).
+struct ResizeTap {
+    int32_t src;
+    int16_t w0, w1;
+};
+// fills taps[dsize]; `zero_frac_at_border`: columns zero the fraction at the borders, rows only clamp
+void resize_taps(int ssize, int dsize, bool zero_frac_at_border, ResizeTap *taps);
+// one output pixel from the two horizontally interpolated sums
+inline __host__ __device__ uint8_t resize_combine(int S0, int S1, int b0, int b1) {
+    return (uint8_t) ((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// d_src [batch][srows][scols] u8 -> d_dst [batch][drows][dcols] u8, or [batch][drows][dcols][3] through
+// d_colormap[256][3] when it is not null.  d_taps = dcols column taps followed by drows row taps.
+hipError_t launch_upscale(const uint8_t *d_src, int srows, int scols, int batch, const ResizeTap *d_taps,
+                          const uint8_t *d_colormap, uint8_t *d_dst, int drows, int dcols, hipStream_t stream);
 
 // one block of 256 wire datagrams -> floats in the device ring [n_sensors][2048] at column pos (and pos+1024)
 hipError_t launch_unpack_block(const void *d_datagrams, int stride_bytes, int n_sensors, float *d_ring, int pos,

@@ -73,6 +73,10 @@ __global__ __launch_bounds__(kExactThreads) void das_exact_kernel(SweepArgs a, i
         __syncthreads();  // previous chunk fully consumed
         for (int m = wave; m < mc; m += kExactThreads / 64) {
             const float *src = frame + (size_t) a.index[m0 + m] * a.hist + a.wstart;
+            if (a.gain) {  // optional per-mic gain (awpu_hip_set_mic_gains); absent in the reference
+                const float gm = a.gain[m0 + m];
+                for (int t = lane; t < W; t += 64) lds[m * W + t] = src[t] * gm;
+            } else
             for (int t = lane; t < W; t += 64) lds[m * W + t] = src[t];
         }
         __syncthreads();
@@ -141,6 +145,10 @@ __global__ __launch_bounds__(kExactThreads) void das_fir8_kernel(SweepArgs a, co
         __syncthreads();
         for (int m = wave; m < mc; m += kExactThreads / 64) {
             const float *src = frame + (size_t) a.index[m0 + m] * a.hist + a.wstart;
+            if (a.gain) {  // optional per-mic gain (awpu_hip_set_mic_gains); absent in the reference
+                const float gm = a.gain[m0 + m];
+                for (int t = lane; t < W; t += 64) lds[m * W + t] = src[t] * gm;
+            } else
             for (int t = lane; t < W; t += 64) lds[m * W + t] = src[t];
         }
         __syncthreads();
@@ -218,6 +226,86 @@ hipError_t launch_heatmap(const float *d_power, int n, int batch, float *d_peak,
         hipLaunchKernelGGL(heatmap_max_kernel, dim3(blocks, batch), dim3(256), 0, stream, d_power, n, (unsigned *) d_peak);
     }
     hipLaunchKernelGGL(heatmap_scale_kernel, dim3(blocks, batch), dim3(256), 0, stream, d_power, n, d_peak, d_pix);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Calibration on the device: the per-mic mean square of AWProcessingUnit::calibrate,
+// src/aw_processing_unit/aw_processing_unit.cpp:133-143:  power = (sum_i x_i * x_i) / hist,
+// accumulated in float in sample order (multiply, then add: no FMA), so the 64 values -- and the
+// median / usable-mic decisions the host takes on them -- equal the scalar loop bit for bit.  One
+// workgroup per mic: the row is fetched coalesced into LDS, then one lane walks it.  A one-off
+// call on 256 KiB; latency-bound by design (about 1024 dependent adds).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_power_kernel(const float *rows, int pitch, int hist, float *out) {
+    extern __shared__ float samples[];
+    const float *row = rows + (size_t) blockIdx.x * pitch;
+    for (int i = threadIdx.x; i < hist; i += blockDim.x) samples[i] = row[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma clang fp contract(off)  // hipcc contracts a*b+c by default; the scalar loop it mirrors does not
+        float sum = 0.0f;
+        for (int i = 0; i < hist; i++) {
+            const float square = samples[i] * samples[i];
+            sum = sum + square;
+        }
+        out[blockIdx.x] = __fdiv_rn(sum, (float) hist);
+    }
+}
+
+hipError_t launch_stream_power(const float *d_rows, int pitch, int hist, int n, float *d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(stream_power_kernel, dim3(n), dim3(256), sizeof(float) * hist, stream, d_rows, pitch, hist, d_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// The display upscale, cv::resize(compact, normal, ..., INTER_LINEAR) in AWProcessingUnit::draw
+// (src/aw_processing_unit/aw_processing_unit.cpp:252), with an optional colour table
+// (cv::applyColorMap, src/aw_processing_unit/main.cpp:345) fused into the store.  Arithmetic is OpenCV's
+// 8-bit fixed-point path (11-bit weights, horizontal sums in int, vertical (b*(S>>4))>>16) so that the
+// image equals what the reference's GUI thread would show.  The compact image is a few KiB and stays
+// in cache; the kernel is bound by the writes of the large image (one thread per output pixel, rows
+// contiguous across lanes).
+// ---------------------------------------------------------------------------------------
+void resize_taps(int ssize, int dsize, bool zero_frac_at_border, ResizeTap *taps) {
+    const double scale = 1.0 / ((double) dsize / ssize);
+    for (int d = 0; d < dsize; d++) {
+        float frac = (float) ((d + 0.5) * scale - 0.5);
+        int first = (int) std::floor(frac);
+        frac -= (float) first;
+        if (zero_frac_at_border && first < 0) frac = 0.f, first = 0;
+        if (zero_frac_at_border && first >= ssize - 1) frac = 0.f, first = ssize - 1;
+        taps[d].src = first;
+        taps[d].w0 = (int16_t) std::lrint((1.f - frac) * 2048.f);
+        taps[d].w1 = (int16_t) std::lrint(frac * 2048.f);
+    }
+}
+
+__global__ void upscale_kernel(const uint8_t *src, int srows, int scols, const ResizeTap *taps, const uint8_t *colormap,
+                               uint8_t *dst, int drows, int dcols) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dcols) return;
+    const uint8_t *img = src + (size_t) blockIdx.z * srows * scols;
+    const ResizeTap tx = taps[dx], ty = taps[dcols + dy];
+    const int c0 = tx.src, c1 = min(tx.src + 1, scols - 1);
+    const int r0 = min(max(ty.src, 0), srows - 1), r1 = min(max(ty.src + 1, 0), srows - 1);
+    const int S0 = img[r0 * scols + c0] * tx.w0 + img[r0 * scols + c1] * tx.w1;
+    const int S1 = img[r1 * scols + c0] * tx.w0 + img[r1 * scols + c1] * tx.w1;
+    const uint8_t v = resize_combine(S0, S1, ty.w0, ty.w1);
+    const size_t o = ((size_t) blockIdx.z * drows + dy) * dcols + dx;
+    if (colormap) {
+        dst[3 * o + 0] = colormap[3 * v + 0];
+        dst[3 * o + 1] = colormap[3 * v + 1];
+        dst[3 * o + 2] = colormap[3 * v + 2];
+    } else {
+        dst[o] = v;
+    }
+}
+
+hipError_t launch_upscale(const uint8_t *d_src, int srows, int scols, int batch, const ResizeTap *d_taps,
+                          const uint8_t *d_colormap, uint8_t *d_dst, int drows, int dcols, hipStream_t stream) {
+    hipLaunchKernelGGL(upscale_kernel, dim3((dcols + 255) / 256, drows, batch), dim3(256), 0, stream, d_src, srows,
+                       scols, d_taps, d_colormap, d_dst, drows, dcols);
     return hipGetLastError();
 }
 

@@ -2,7 +2,6 @@
 // src/aw_processing_unit/aw_processing_unit.cpp.
 #include "aw_processing_unit_hip.h"
 
-#include <cmath>
 #include <cstdio>
 
 namespace awpu_host {
@@ -85,21 +84,8 @@ int AWProcessingUnitHip::status() const { return workers.empty() ? AWPU_ERR_STAT
 void AWProcessingUnitHip::draw(uint8_t *compact, uint8_t *normal, int normal_res) const {
     for (auto &w : workers)
         if (w->get_type() == MIMO) w->draw(compact);
-    // cv::resize(..., INTER_LINEAR) stand-in: plain bilinear with pixel-centre alignment
-    const float scale = (float) small_res / (float) normal_res;
-    for (int y = 0; y < normal_res; y++) {
-        const float fy = std::fmax(0.f, (y + 0.5f) * scale - 0.5f);
-        const int y0 = (int) fy, y1 = y0 + 1 < small_res ? y0 + 1 : y0;
-        const float wy = fy - y0;
-        for (int x = 0; x < normal_res; x++) {
-            const float fx = std::fmax(0.f, (x + 0.5f) * scale - 0.5f);
-            const int x0 = (int) fx, x1 = x0 + 1 < small_res ? x0 + 1 : x0;
-            const float wx = fx - x0;
-            const float top = compact[y0 * small_res + x0] * (1 - wx) + compact[y0 * small_res + x1] * wx;
-            const float bot = compact[y1 * small_res + x0] * (1 - wx) + compact[y1 * small_res + x1] * wx;
-            normal[(size_t) y * normal_res + x] = (uint8_t) std::lround(top * (1 - wy) + bot * wy);
-        }
-    }
+    // cv::resize(*compact, *normal, normal->size(), 0, 0, cv::INTER_LINEAR), .cpp:252
+    if (normal && normal_res >= small_res) awpu_hip_resize_linear_u8(compact, small_res, small_res, normal, normal_res, normal_res);
 }
 
 }  // namespace awpu_host

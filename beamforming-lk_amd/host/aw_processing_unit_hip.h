@@ -48,7 +48,8 @@ public:
     void stop_audio() {}
     void calibrate(const float reference_power_level = 1e-5);  // .cpp:102-212
     std::vector<Target> targets() { return {}; }               // MIMO tracks nothing
-    // .cpp:245-259: compact = the MIMO heatmap; normal = compact resized (bilinear) to normal_res^2
+    // .cpp:245-259: compact = the MIMO heatmap; normal = compact resized (cv::resize INTER_LINEAR
+    // arithmetic) to normal_res^2, normal_res >= small_res
     void draw(uint8_t *compact, uint8_t *normal, int normal_res) const;
 
     int n_antennas() const { return (int) antennas.size(); }

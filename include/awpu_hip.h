@@ -121,6 +121,25 @@ int awpu_hip_set_delay_table(awpu_hip_t *h, const int32_t *off, const float *fra
  * (mimo.cpp:125-127).  index == NULL means identity 0..usable-1. */
 int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable);
 
+/* Optional per-mic gain: the reference computes antenna.power_correction_mask
+ * (aw_processing_unit.cpp:190-200) and never applies it; with gains set, the sweep behaves as if every
+ * stream s of the snapshot had been multiplied by gains[s] first.  gains [n_streams], indexed by
+ * stream id like the table columns; NULL switches it off (the default, = the reference). */
+int awpu_hip_set_mic_gains(awpu_hip_t *h, const float *gains);
+
+/* replaces: AWProcessingUnit::calibrate for one array, src/aw_processing_unit/aw_processing_unit.cpp:102-212
+ * (SURVEY 8f N4), with the per-mic mean squares computed on the device: mean square of every mic of
+ * array `array` (streams array*64 .. +63) over the snapshot, the median (elements 32 and 33 of the
+ * sorted list, as the reference takes it), then the usable mics: those within 1e-4 of the median and
+ * not below median*1e-3.  Outputs (host): index[64] (mic ids inside the array, ascending),
+ * correction[64] (reference_power_level / power), *median, *usable (entries filled).
+ * _device: d_frame [n_streams][hist] in device memory, on `stream` (NULL = the handle's); returns
+ * after the result has reached the host.  _ring: on the current snapshot of the ingest ring. */
+int awpu_hip_calibrate_device(awpu_hip_t *h, const float *d_frame, int32_t array, float reference_power_level,
+                              int32_t *index, float *correction, float *median, int32_t *usable, void *stream);
+int awpu_hip_calibrate_ring(awpu_hip_t *h, int32_t array, float reference_power_level, int32_t *index,
+                            float *correction, float *median, int32_t *usable);
+
 /* FIR8 coefficient table, the caller's copy of filter_coeffs[101][8] (src/dsp/filter.h:10-112) */
 int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs);
 
@@ -151,6 +170,21 @@ int awpu_hip_heatmap_u8(const float *power, int32_t n, uint8_t *pix);
  * all-reduced maximum over the ranks' tiles, so that every tile is scaled alike). */
 int awpu_hip_heatmap_u8_device(awpu_hip_t *h, const float *d_power, int32_t n, int32_t batch, float *d_peak,
                                int32_t peak_given, uint8_t *d_pix, void *stream);
+
+/* replaces: cv::resize(*compact, *normal, normal->size(), 0, 0, cv::INTER_LINEAR) in AWProcessingUnit::draw,
+ * src/aw_processing_unit/aw_processing_unit.cpp:252 (and, with a colour table, cv::applyColorMap in the
+ * GUI loop, src/aw_processing_unit/main.cpp:345), on images resident in device memory: d_pix
+ * [batch][rows][cols] bytes -> d_out [batch][out_rows][out_cols] bytes, or [batch][out_rows][out_cols][3]
+ * through d_colormap[256][3] (device memory; entry v = the three output bytes for level v) when
+ * d_colormap is not NULL.  Same 8-bit fixed-point arithmetic as OpenCV's generic path.  Upscaling only
+ * (out >= in): AWPU_ERR_INVALID otherwise.  Enqueued on `stream` (NULL = the handle's stream). */
+int awpu_hip_upscale_u8_device(awpu_hip_t *h, const uint8_t *d_pix, int32_t rows, int32_t cols, int32_t batch,
+                               const uint8_t *d_colormap, uint8_t *d_out, int32_t out_rows, int32_t out_cols,
+                               void *stream);
+
+/* the same resize on host buffers (one image), for callers that already hold the compact image on the host */
+int awpu_hip_resize_linear_u8(const uint8_t *pix, int32_t rows, int32_t cols, uint8_t *out, int32_t out_rows,
+                              int32_t out_cols);
 
 /* ---- wire-format ingest on the device -------------------------------------- */
 

@@ -261,6 +261,59 @@ void oracle_heatmap_u8(const float *power, int P, uint8_t *pix) {
     }
 }
 
+/* cv::resize(compact, normal, size, 0, 0, cv::INTER_LINEAR) on CV_8UC1, the step after populateHeatmap in
+ * AWProcessingUnit::draw (src/aw_processing_unit/aw_processing_unit.cpp:252).  OpenCV itself is a
+ * third-party dependency that is absent from the reference tree and from this image (the reference's
+ * CMakeLists finds the system OpenCV 4), so this restates OpenCV 4.x's published generic 8-bit path
+ * (modules/imgproc/src/resize.cpp: resize -> ResizeFunc with HResizeLinear<uchar,int,short,2048> and
+ * VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>): 11-bit fixed-point coefficients,
+ * horizontal pass into ints, vertical pass ((b*(S>>4))>>16 summed, +2, >>2).  PARITY UNPINNED for this
+ * one function: there is no OpenCV here to check it against; the tests pin hand-computed vectors only.
+ * Upscaling only (dst >= src in both directions; the decimation special cases are not restated). */
+static void resize_coeffs(int ssize, int dsize, int clamp_frac, int *ofs, short *coef) {
+    const double inv_scale = (double) dsize / ssize;
+    const double scale = 1.0 / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float) ((d + 0.5) * scale - 0.5);
+        int s0 = (int) floorf(f);
+        f -= s0;
+        if (clamp_frac) { /* columns: the fraction is zeroed at the borders; rows are clamped instead */
+            if (s0 < 0) { f = 0.f; s0 = 0; }
+            if (s0 >= ssize - 1) { f = 0.f; s0 = ssize - 1; }
+        }
+        ofs[d] = s0;
+        coef[2 * d] = (short) lrintf((1.f - f) * 2048.f);
+        coef[2 * d + 1] = (short) lrintf(f * 2048.f);
+    }
+}
+
+int oracle_resize_linear_u8(const uint8_t *src, int srows, int scols, uint8_t *dst, int drows, int dcols) {
+    if (drows < srows || dcols < scols || srows < 1 || scols < 1) return -1;
+    int *xofs = (int *) malloc(sizeof(int) * (size_t) (dcols + drows));
+    short *alpha = (short *) malloc(sizeof(short) * 2 * (size_t) (dcols + drows));
+    if (!xofs || !alpha) { free(xofs); free(alpha); return -1; }
+    int *yofs = xofs + dcols;
+    short *beta = alpha + 2 * dcols;
+    resize_coeffs(scols, dcols, 1, xofs, alpha);
+    resize_coeffs(srows, drows, 0, yofs, beta);
+    for (int dy = 0; dy < drows; dy++) {
+        int r0 = yofs[dy], r1 = yofs[dy] + 1;
+        r0 = r0 < 0 ? 0 : (r0 < srows ? r0 : srows - 1);
+        r1 = r1 < 0 ? 0 : (r1 < srows ? r1 : srows - 1);
+        const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+        for (int dx = 0; dx < dcols; dx++) {
+            const int sx = xofs[dx], sx1 = sx + 1 < scols ? sx + 1 : sx;
+            const int a0 = alpha[2 * dx], a1 = alpha[2 * dx + 1];
+            const int S0 = src[r0 * scols + sx] * a0 + src[r0 * scols + sx1] * a1;
+            const int S1 = src[r1 * scols + sx] * a0 + src[r1 * scols + sx1] * a1;
+            dst[(size_t) dy * dcols + dx] = (uint8_t) ((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+        }
+    }
+    free(xofs);
+    free(alpha);
+    return 0;
+}
+
 /* --------------------------------------------------------------- calibration */
 
 static int cmp_float(const void *a, const void *b) {

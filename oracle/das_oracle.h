@@ -86,6 +86,8 @@ void oracle_das_fir8_f32(const float *X, int hist, const int32_t *off, const flo
 
 /* MIMOWorker::populateHeatmap with USE_DB 0, src/dsp/mimo.cpp:61-95. */
 void oracle_heatmap_u8(const float *power, int P, uint8_t *pix);
+/* cv::resize(..., INTER_LINEAR) on an 8-bit single-channel image (aw_processing_unit.cpp:252), upscaling only */
+int oracle_resize_linear_u8(const uint8_t *src, int srows, int scols, uint8_t *dst, int drows, int dcols);
 
 /* AWProcessingUnit::calibrate per-array mic selection,
  * src/aw_processing_unit/aw_processing_unit.cpp:128-200.  X is the 64 streams

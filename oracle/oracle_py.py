@@ -55,6 +55,8 @@ def oracle() -> C.CDLL:
         lib.oracle_das_f64.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f64p]
         lib.oracle_das_fir8_f32.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
         lib.oracle_heatmap_u8.argtypes = [_f32p, C.c_int, _u8p]
+        lib.oracle_resize_linear_u8.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
+        lib.oracle_resize_linear_u8.restype = C.c_int
         lib.oracle_calibrate.argtypes = [_f32p, C.c_int, C.c_float, _i32p, _f32p, _f32p]
         lib.oracle_calibrate.restype = C.c_int
         lib.oracle_unpack_exposure.argtypes = [_i32p, C.c_int, C.c_int, _f32p]
@@ -234,6 +236,16 @@ def heatmap_u8(power) -> np.ndarray:
     pix = np.empty(power.shape, np.uint8)
     oracle().oracle_heatmap_u8(_p32(power), power.size, pix.ctypes.data_as(_u8p))
     return pix
+
+
+def resize_linear_u8(pix, out_rows: int, out_cols: int) -> np.ndarray:
+    pix = np.ascontiguousarray(pix, np.uint8)
+    out = np.empty((out_rows, out_cols), np.uint8)
+    rc = oracle().oracle_resize_linear_u8(pix.ctypes.data_as(_u8p), pix.shape[0], pix.shape[1],
+                                          out.ctypes.data_as(_u8p), out_rows, out_cols)
+    if rc != 0:
+        raise ValueError("oracle_resize_linear_u8: upscaling only")
+    return out
 
 
 def calibrate(X, reference_power_level=1e-5):

@@ -95,6 +95,16 @@ def test_delay_table_equals_oracle(pkg, oracle, arrays, res, fov):
     assert np.array_equal(np.concatenate([a[0], b[0]]), off) and np.array_equal(np.concatenate([a[1], b[1]]), frac)
 
 
+def test_host_resize_equals_oracle(pkg, oracle):
+    """awpu_hip_resize_linear_u8 (host, no device needed) against the restated cv::resize."""
+    rng = np.random.default_rng(8)
+    for (r, c, R, C_) in [(2, 2, 4, 4), (16, 16, 64, 64), (12, 20, 50, 33), (64, 64, 256, 256), (5, 1, 5, 9), (9, 9, 9, 9)]:
+        img = rng.integers(0, 256, (r, c), dtype=np.uint8)
+        assert np.array_equal(pkg.resize_linear_u8(img, R, C_), oracle.resize_linear_u8(img, R, C_)), (r, c, R, C_)
+    with pytest.raises(Exception):
+        pkg.resize_linear_u8(rng.integers(0, 256, (8, 8), dtype=np.uint8), 4, 8)
+
+
 def test_heatmap_equals_oracle(pkg, oracle):
     rng = np.random.default_rng(0)
     p = rng.uniform(0, 3e-5, 4096).astype(np.float32)

@@ -325,6 +325,82 @@ def test_device_heatmap_equals_populate_heatmap(pkg, oracle):
         assert np.array_equal(d_pix[0].cpu().numpy(), want)
 
 
+def test_device_upscale_and_colour_table(pkg, oracle):
+    """SURVEY 8f N2, second half: the display upscale of AWProcessingUnit::draw (aw_processing_unit.cpp:252)
+    and the colour table of the GUI loop (main.cpp:345) on device images; bit-exact against the restated
+    cv::resize arithmetic."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(91)
+    lut = torch.from_numpy(rng.integers(0, 256, (256, 3), dtype=np.uint8)).to(dev)
+    with pkg.Engine(n_streams=64, n_pixels=64, lut_stride=64) as eng:
+        for (r, c, R, C_, batch) in [(16, 16, 64, 64, 3), (128, 128, 1024, 1024, 2), (12, 20, 50, 33, 1), (64, 64, 64, 64, 1)]:
+            img = rng.integers(0, 256, (batch, r, c), dtype=np.uint8)
+            d_img = torch.from_numpy(img).to(dev)
+            d_out = torch.zeros((batch, R, C_), dtype=torch.uint8, device=dev)
+            eng.upscale_device(d_img.data_ptr(), r, c, batch, d_out.data_ptr(), R, C_)
+            d_rgb = torch.zeros((batch, R, C_, 3), dtype=torch.uint8, device=dev)
+            eng.upscale_device(d_img.data_ptr(), r, c, batch, d_rgb.data_ptr(), R, C_, d_colormap_ptr=lut.data_ptr())
+            eng.synchronize()
+            for b in range(batch):
+                want = oracle.resize_linear_u8(img[b], R, C_)
+                assert np.array_equal(d_out[b].cpu().numpy(), want), (r, c, R, C_, b)
+                assert np.array_equal(d_rgb[b].cpu().numpy(), lut.cpu().numpy()[want]), (r, c, R, C_, b)
+        with pytest.raises(pkg.AwpuError):
+            eng.upscale_device(d_img.data_ptr(), 64, 64, 1, d_out.data_ptr(), 32, 64)
+
+
+def test_device_calibration_equals_restated_loop(pkg, oracle):
+    """SURVEY 8f N4: AWProcessingUnit::calibrate (aw_processing_unit.cpp:102-212) with the mean squares
+    computed on the device: same usable mics, bit-identical correction mask and median."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    X = util.hash_frames(128, 1024, seed=21, scale=2.0 ** -7)[0].copy()
+    X[5] = 0.0            # dead
+    X[17] *= 64.0         # far too loud
+    X[64 + 9] *= 40.0     # second array: another loud one
+    X[64 + 63] = 0.0
+    d_X = torch.from_numpy(X).to(dev)
+    with pkg.Engine(n_streams=128, n_pixels=64, lut_stride=128) as eng:
+        for array in range(2):
+            index, corr, median = eng.calibrate_device(d_X.data_ptr(), array=array)
+            want_index, want_corr, want_median = oracle.calibrate(X[64 * array: 64 * array + 64])
+            assert np.array_equal(index, want_index) and index.size == 62
+            assert np.array_equal(corr, want_corr) and median == want_median
+        with pytest.raises(pkg.AwpuError):
+            eng.calibrate_device(d_X.data_ptr(), array=2)
+        with pytest.raises(pkg.AwpuError) as ei:
+            eng.calibrate_ring()
+        assert ei.value.status == pkg.binding.ERR_STATE
+
+
+def test_mic_gains_equal_prescaled_frames(pkg, oracle):
+    """The optional per-mic gain (the reference's unused power_correction_mask): a sweep with gains
+    equals the oracle's sweep of frames scaled stream by stream, in every kernel shape."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, spec.res, spec.res)
+    frames = S.make_frames(xyz, 4, seed=31)
+    rng = np.random.default_rng(13)
+    gains = rng.uniform(0.5, 2.0, 64).astype(np.float32)
+    index = np.array([s for s in range(64) if s not in (3, 40)], np.int32)
+    want = np.stack([oracle.das_f32(f * gains[:, None], off, frac, index) for f in frames])
+    for math in (pkg.MATH_F32_EXACT, pkg.MATH_F32_FAST):
+        with pkg.Engine(n_pixels=spec.n_pixels, math=math, max_batch=4) as eng:
+            eng.set_delay_table(off, frac)
+            eng.set_active_mics(index)
+            eng.set_mic_gains(gains)
+            for batch in (1, 4):  # single-frame and frame-pair shapes
+                got = eng.process(frames[:batch])
+                assert util.power_rel_err(got, want[:batch]) <= util.POWER_RTOL, (math, batch)
+            eng.set_mic_gains(None)  # off again = the reference
+            plain = np.stack([oracle.das_f32(f, off, frac, index) for f in frames[:1]])
+            assert util.power_rel_err(eng.process(frames[:1]), plain) <= util.POWER_RTOL
+
+
 def make_datagrams(stream_block, counter0=0, n_arrays=1):
     """256 wire datagrams (src/fpga/receiver.h:24-30: u16 frequency, u8 n_arrays, u8 version, u32 counter,
     i32 stream[256], packed) from stream_block[256 samples][256 channels] int32."""
@@ -379,6 +455,11 @@ def test_wire_ingest_and_ring_sweep(pkg, oracle):
         assert util.power_rel_err(power, oracle.das_f32(ring, off, frac)) < util.POWER_RTOL
         # the ring path and the host-buffer path agree bit for bit on the same snapshot
         assert np.array_equal(power, eng.process(ring))
+        # calibration straight off the ring (aw_processing_unit.cpp:102-212): random int24 noise is far
+        # above the 1e-4 band, so what matters here is that all decisions equal the scalar loop's
+        index, corr, median = eng.calibrate_ring()
+        want_index, want_corr, want_median = oracle.calibrate(ring)
+        assert np.array_equal(index, want_index) and np.array_equal(corr, want_corr) and median == want_median
     rx.close()
     tx.close()
 

@@ -126,6 +126,27 @@ def test_heatmap_u8(oracle):
     assert pix.tolist() == [0, 25, 127, 255]
 
 
+def test_resize_linear_u8_known_answers(oracle):
+    """cv::resize INTER_LINEAR on 8-bit (aw_processing_unit.cpp:252).  OpenCV is absent here (parity
+    unpinned for this function): the expected 2x2 -> 4x4 image below was worked out by hand from
+    OpenCV's fixed-point recipe (weights 2048/1536/512, ((b*(S>>4))>>16 summed, +2, >>2)."""
+    src = np.array([[0, 100], [200, 40]], np.uint8)
+    want = [[0, 25, 75, 100], [50, 59, 76, 85], [150, 126, 79, 55], [200, 160, 80, 40]]
+    assert oracle.resize_linear_u8(src, 4, 4).tolist() == want
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (16, 16), dtype=np.uint8)
+    assert np.array_equal(oracle.resize_linear_u8(img, 16, 16), img)              # same size: identity
+    assert np.all(oracle.resize_linear_u8(np.full((7, 9), 201, np.uint8), 40, 31) == 201)  # constants survive
+    big = oracle.resize_linear_u8(img, 64, 64)
+    assert big.min() >= img.min() and big.max() <= img.max()                      # a convex combination
+    assert np.array_equal(big[[0, -1]][:, [0, -1]], img[[0, -1]][:, [0, -1]])      # corners replicate
+    ramp = np.tile(np.arange(0, 256, 8, dtype=np.uint8), (4, 1))
+    up = oracle.resize_linear_u8(ramp, 4, 128).astype(int)
+    assert np.all(np.diff(up, axis=1) >= 0)                                       # monotone stays monotone
+    with pytest.raises(ValueError):
+        oracle.resize_linear_u8(img, 8, 8)
+
+
 def test_calibrate_restatement(oracle):
     """aw_processing_unit.cpp:128-200: a dead mic and a loud mic are dropped."""
     X = util.hash_frames(64, 1024, seed=21, scale=2.0 ** -7)[0].copy()
