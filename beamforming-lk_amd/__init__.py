@@ -19,11 +19,12 @@ from .binding import (  # noqa: F401
     create_tiled_antenna,
     heatmap_u8,
     resize_linear_u8,
+    steer_table,
     steering_delays,
 )
 
 __all__ = [
     "Engine", "AwpuError", "MATH_F32_EXACT", "MATH_F32_FAST", "build_delay_table",
-    "create_antenna", "create_tiled_antenna", "steering_delays", "heatmap_u8", "resize_linear_u8", "binding",
+    "create_antenna", "create_tiled_antenna", "steering_delays", "heatmap_u8", "resize_linear_u8", "steer_table", "binding",
     "synthetic", "_build",
 ]

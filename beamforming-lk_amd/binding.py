@@ -82,6 +82,9 @@ _SIGNATURES = {
     "awpu_hip_process_ring": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_ring_snapshot": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_heatmap_u8": (C.c_int, [_f32p, C.c_int32, _u8p]),
+    "awpu_hip_steer_table": (C.c_int, [_f32p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
+                                       _i32p, _f32p]),
+    "awpu_hip_beams": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int32, _f32p, _f32p]),
     "awpu_hip_set_mic_gains": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_calibrate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, _i32p, _f32p,
                                             C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p]),
@@ -184,6 +187,22 @@ def build_delay_table(xyz: np.ndarray, rows: int, columns: int, fov_deg: float =
     frac = np.empty((row_count * columns, n), np.float32)
     _check(load().awpu_hip_build_delay_table(_f32(xyz), n, rows, columns, fov_deg, row_begin,
                                              row_count, _i32(off), _f32(frac)), "build_delay_table")
+    return off, frac
+
+
+def steer_table(xyz: np.ndarray, theta, phi):
+    """Particle::steer (src/dsp/particle.cpp:37-49) for a batch of directions -> (off, frac) [n_dir, n]."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    theta = np.ascontiguousarray(np.atleast_1d(theta), np.float64)
+    phi = np.ascontiguousarray(np.atleast_1d(phi), np.float64)
+    if theta.shape != phi.shape or theta.ndim != 1:
+        raise ValueError("theta and phi must be 1-D and alike")
+    n = xyz.shape[1]
+    off = np.empty((theta.size, n), np.int32)
+    frac = np.empty((theta.size, n), np.float32)
+    dp = C.POINTER(C.c_double)
+    _check(load().awpu_hip_steer_table(_f32(xyz), n, theta.ctypes.data_as(dp), phi.ctypes.data_as(dp), theta.size,
+                                       _i32(off), _f32(frac)), "steer_table")
     return off, frac
 
 
@@ -318,6 +337,20 @@ class Engine:
         _check(self._lib.awpu_hip_heatmap_u8_device(self._h, C.c_void_p(d_power_ptr), n, batch,
                                                     C.c_void_p(d_peak_ptr), int(peak_given), C.c_void_p(d_pix_ptr),
                                                     C.c_void_p(stream)), "awpu_hip_heatmap_u8_device")
+
+    def beams(self, off: np.ndarray, frac: np.ndarray, d_frame_ptr: int = 0, want_beams: bool = True):
+        """Particle::beam / Particle::das (src/dsp/particle.cpp:51-103) for off/frac [n_dir, lut_stride];
+        d_frame_ptr 0 = the ingest ring's snapshot -> (power [n_dir], beams [n_dir, 256] or None)."""
+        off = np.ascontiguousarray(off, np.int32)
+        frac = np.ascontiguousarray(frac, np.float32)
+        if off.ndim != 2 or off.shape[1] != self.cfg.lut_stride or frac.shape != off.shape:
+            raise ValueError("off/frac must be [n_dir, lut_stride]")
+        n = off.shape[0]
+        power = np.empty(n, np.float32)
+        out = np.empty((n, 256), np.float32) if want_beams else None
+        _check(self._lib.awpu_hip_beams(self._h, C.c_void_p(d_frame_ptr), _i32(off), _f32(frac), n, _f32(power),
+                                        _f32(out) if want_beams else None), "awpu_hip_beams")
+        return power, out
 
     def set_mic_gains(self, gains: Optional[np.ndarray]) -> None:
         """Optional per-mic gain (the reference's unused power_correction_mask, aw_processing_unit.cpp:190-200);

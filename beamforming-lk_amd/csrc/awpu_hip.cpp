@@ -61,6 +61,9 @@ struct awpu_hip {
     int32_t *d_index = nullptr;
     float *d_gain = nullptr;  // [usable] gains in active-mic order, or null
     float *d_calib = nullptr; // [64] per-mic mean squares (calibration)
+    awpu::LutEntry *d_beam_lut = nullptr;  // [beam_cap][usable] entries of awpu_hip_beams
+    float *d_beam_out = nullptr;           // [beam_cap] powers then [beam_cap][256] beams
+    size_t beam_cap = 0, beam_lut_cap = 0;
     float *d_fir = nullptr;  // [101][8] coefficient table (AWPU_INTERP_FIR8)
     float *d_ring = nullptr;            // [n_streams][2048] history ring (awpu_hip_ingest_block)
     awpu::ResizeTap *d_taps = nullptr;  // column + row taps of the display upscale, for taps_key
@@ -96,6 +99,11 @@ void release_device(awpu_hip *h) {
     h->d_gain = nullptr;
     if (h->d_calib) (void) hipFree(h->d_calib);
     h->d_calib = nullptr;
+    if (h->d_beam_lut) (void) hipFree(h->d_beam_lut);
+    if (h->d_beam_out) (void) hipFree(h->d_beam_out);
+    h->d_beam_lut = nullptr;
+    h->d_beam_out = nullptr;
+    h->beam_cap = h->beam_lut_cap = 0;
     if (h->d_fir) (void) hipFree(h->d_fir);
     h->d_fir = nullptr;
     if (h->d_ring) (void) hipFree(h->d_ring);
@@ -693,6 +701,67 @@ int awpu_hip_calibrate_ring(awpu_hip_t *h, int32_t array, float reference_power_
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     return calibrate_rows(h, h->d_ring + (size_t) array * AWPU_ELEMENTS * 2048 + h->ring_pos, 2048, AWPU_HIST,
                           reference_power_level, index, correction, median, usable, h->stream);
+}
+
+int awpu_hip_beams(awpu_hip_t *h, const float *d_frame, const int32_t *off, const float *frac, int32_t n_dir,
+                   float *power, float *beams) {
+    if (!h || !off || !frac || (!power && !beams)) return invalid("null argument");
+    if (n_dir < 1 || n_dir > 65535) return invalid("n_dir outside [1, 65535]");
+    if (!h->have_mics) {
+        g_last_error = "active mics not set";
+        return AWPU_ERR_STATE;
+    }
+    int pitch = h->cfg.hist;
+    const float *frame = d_frame;
+    if (!frame) {  // the current snapshot of the ingest ring
+        if (!h->d_ring) {
+            g_last_error = "no block ingested yet";
+            return AWPU_ERR_STATE;
+        }
+        frame = h->d_ring + h->ring_pos;
+        pitch = 2048;
+    }
+    const int U = h->usable(), stride = h->cfg.lut_stride;
+    std::vector<awpu::LutEntry> entries((size_t) n_dir * U);
+    for (int d = 0; d < n_dir; d++) {
+        for (int s = 0; s < U; s++) {
+            const int id = h->index[s];
+            const int o = off[(size_t) d * stride + id];
+            const float f = frac[(size_t) d * stride + id];
+            if (o < 0 || o + awpu::kSamples > h->cfg.hist - 1) {  // delay() reads X[off .. off+256]
+                g_last_error = "delay table entry reads outside the frame history";
+                return AWPU_ERR_RANGE;
+            }
+            if (!(f >= 0.0f && f <= 1.0f)) return invalid("fraction outside [0, 1]");
+            entries[(size_t) d * U + s] = awpu::LutEntry{id * pitch + o, f};
+        }
+    }
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->beam_lut_cap < entries.size()) {
+        if (h->d_beam_lut) (void) hipFree(h->d_beam_lut);
+        h->d_beam_lut = nullptr;
+        h->beam_lut_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_beam_lut, entries.size() * sizeof(awpu::LutEntry)));
+        h->beam_lut_cap = entries.size();
+    }
+    if (h->beam_cap < (size_t) n_dir) {
+        if (h->d_beam_out) (void) hipFree(h->d_beam_out);
+        h->d_beam_out = nullptr;
+        h->beam_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_beam_out, (size_t) n_dir * (1 + awpu::kSamples) * sizeof(float)));
+        h->beam_cap = n_dir;
+    }
+    float *d_power = h->d_beam_out, *d_beams = h->d_beam_out + h->beam_cap;
+    AWPU_HIP_TRY(hipMemcpyAsync(h->d_beam_lut, entries.data(), entries.size() * sizeof(awpu::LutEntry),
+                                hipMemcpyHostToDevice, h->stream));
+    AWPU_HIP_TRY(awpu::launch_das_beams(frame, h->d_beam_lut, U, n_dir, d_power, beams ? d_beams : nullptr, h->stream));
+    if (power)
+        AWPU_HIP_TRY(hipMemcpyAsync(power, d_power, (size_t) n_dir * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (beams)
+        AWPU_HIP_TRY(hipMemcpyAsync(beams, d_beams, (size_t) n_dir * awpu::kSamples * sizeof(float),
+                                    hipMemcpyDeviceToHost, h->stream));
+    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));  // `entries` must outlive the upload
+    return AWPU_OK;
 }
 
 int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {

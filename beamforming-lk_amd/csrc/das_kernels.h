@@ -103,6 +103,11 @@ hipError_t launch_das_fir8(const SweepArgs &a, const float *d_coeffs, hipStream_
 hipError_t launch_heatmap(const float *d_power, int n, int batch, float *d_peak, bool peak_given, uint8_t *d_pix,
                           hipStream_t stream);
 
+// Few-beam delay-and-sum (Particle::beam / Particle::das): entries [n_dir][usable] with off_rel = float
+// offset of X[off] from `frame` (row start + off); d_power [n_dir], d_beams [n_dir][256] or null.
+hipError_t launch_das_beams(const float *d_frame, const LutEntry *d_entries, int usable, int n_dir, float *d_power,
+                            float *d_beams, hipStream_t stream);
+
 // mean square of `hist` samples of each of `n` rows (pitch floats apart), summed in sample order
 // (calibration, aw_processing_unit.cpp:133-143)
 hipError_t launch_stream_power(const float *d_rows, int pitch, int hist, int n, float *d_out, hipStream_t stream);

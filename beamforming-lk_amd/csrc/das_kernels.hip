@@ -230,6 +230,54 @@ hipError_t launch_heatmap(const float *d_power, int n, int batch, float *d_peak,
 }
 
 // ---------------------------------------------------------------------------------------
+// Few-beam delay-and-sum for the trackers: Particle::beam and Particle::das,
+// src/dsp/particle.cpp:51-82 and :88-103, for a batch of steered directions in one launch (the
+// reference runs 4 monopulse directions x (seekers + trackers) one after the other,
+// gradient_ascend.cpp:30-81).  One workgroup per direction, thread i owns output sample i; mics are
+// visited in the reference's order with delay()'s operation order (d = cur - next; t = fma(frac, d,
+// next); out += t), so the 256-sample beam -- the signal MISOWorker hands to the audio path,
+// miso.cpp:46 -- is bit-identical to the reference's.  A direction reads 64 x 257 floats that all
+// directions share, straight from L2: no LDS staging at this size.  power = sum MA^2 / N_SAMPLES
+// (particle.cpp:68-77: not divided by the mic count, unlike the MIMO sweep).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSamples) void das_beam_kernel(const float *frame, const LutEntry *entries, int usable,
+                                                            float *power, float *beams) {
+    __shared__ float line[kSamples];
+    __shared__ float partial[kSamples / 64];
+    const int i = threadIdx.x;
+    const LutEntry *row = entries + (size_t) blockIdx.x * usable;
+    float out = 0.0f;
+    for (int s = 0; s < usable; s++) {
+        const LutEntry e = row[s];  // uniform: scalar load
+        const float *x = frame + e.off_rel + i;
+        const float cur = x[0], nxt = x[1];
+        const float d = cur - nxt;
+        const float t = __builtin_fmaf(e.frac, d, nxt);
+        out = out + t;
+    }
+    if (beams) beams[(size_t) blockIdx.x * kSamples + i] = out;
+    line[i] = out;
+    __syncthreads();
+    float sq = 0.0f;
+    if (i >= 1 && i <= kSamples - 2) {
+        const float ma = out * 0.5f - 0.25f * (line[i + 1] + line[i - 1]);
+        sq = ma * ma;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) sq += __shfl_xor(sq, s);
+    if ((i & 63) == 0) partial[i >> 6] = sq;
+    __syncthreads();
+    if (i == 0 && power) power[blockIdx.x] = (partial[0] + partial[1] + partial[2] + partial[3]) / (float) kSamples;
+}
+
+hipError_t launch_das_beams(const float *d_frame, const LutEntry *d_entries, int usable, int n_dir, float *d_power,
+                            float *d_beams, hipStream_t stream) {
+    hipLaunchKernelGGL(das_beam_kernel, dim3(n_dir), dim3(kSamples), 0, stream, d_frame, d_entries, usable, d_power,
+                       d_beams);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // Calibration on the device: the per-mic mean square of AWProcessingUnit::calibrate,
 // src/aw_processing_unit/aw_processing_unit.cpp:133-143:  power = (sum_i x_i * x_i) / hist,
 // accumulated in float in sample order (multiply, then add: no FMA), so the 64 values -- and the

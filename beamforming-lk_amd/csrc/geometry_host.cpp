@@ -103,6 +103,21 @@ int awpu_hip_steering_delays(const float *xyz, int32_t n, double theta, double p
     return AWPU_OK;
 }
 
+int awpu_hip_steer_table(const float *xyz, int32_t n, const double *theta, const double *phi, int32_t n_dir,
+                         int32_t *off, float *frac) {
+    if (!xyz || !theta || !phi || !off || !frac || n <= 0 || n_dir <= 0) return AWPU_ERR_INVALID;
+    std::vector<float> tau(n);
+    for (int d = 0; d < n_dir; d++) {
+        steering_delays(xyz, n, theta[d], phi[d], tau.data());
+        for (int i = 0; i < n; i++) {  // particle.cpp:39-47, the same split as mimo.cpp:46-54
+            double whole;
+            frac[(size_t) d * n + i] = static_cast<float>(std::modf(static_cast<double>(tau[i]), &whole));
+            off[(size_t) d * n + i] = AWPU_N_SAMPLES - static_cast<int>(whole);
+        }
+    }
+    return AWPU_OK;
+}
+
 int awpu_hip_build_delay_table(const float *xyz, int32_t n, int32_t rows, int32_t columns,
                                float fov_deg, int32_t row_begin, int32_t row_count, int32_t *off,
                                float *frac) {

@@ -140,6 +140,24 @@ int awpu_hip_calibrate_device(awpu_hip_t *h, const float *d_frame, int32_t array
 int awpu_hip_calibrate_ring(awpu_hip_t *h, int32_t array, float reference_power_level, int32_t *index,
                             float *correction, float *median, int32_t *usable);
 
+/* ---- few-beam delay-and-sum for the trackers --------------------------------- */
+
+/* replaces: Particle::steer for a batch of directions, src/dsp/particle.cpp:37-49 (the same modf split as
+ * the MIMO table): off/frac [n_dir][n] from element positions xyz[3][n] and angles theta/phi [n_dir]. */
+int awpu_hip_steer_table(const float *xyz, int32_t n, const double *theta, const double *phi, int32_t n_dir,
+                         int32_t *off, float *frac);
+
+/* replaces: Particle::beam (src/dsp/particle.cpp:51-82) and Particle::das (:88-103) for n_dir steered
+ * directions in one launch -- what GradientParticle::step (gradient_ascend.cpp:30-81) asks four times
+ * per particle and MISOWorker::update (miso.cpp:40-46) once per block.  off/frac: host tables
+ * [n_dir][lut_stride] as from awpu_hip_steer_table, read at the handle's active mics.  d_frame: one
+ * snapshot [n_streams][hist] in device memory, or NULL = the current snapshot of the ingest ring.
+ * power [n_dir] (host, may be NULL): sum MA^2 / 256 -- NOT divided by the mic count, as in the reference.
+ * beams [n_dir][256] (host, may be NULL): the delayed-and-summed signal, bit-identical to the reference's.
+ * Needs awpu_hip_set_active_mics; does not touch the heatmap table.  Synchronous. */
+int awpu_hip_beams(awpu_hip_t *h, const float *d_frame, const int32_t *off, const float *frac, int32_t n_dir,
+                   float *power, float *beams);
+
 /* FIR8 coefficient table, the caller's copy of filter_coeffs[101][8] (src/dsp/filter.h:10-112) */
 int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs);
 

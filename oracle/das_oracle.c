@@ -205,6 +205,31 @@ void oracle_das_f32(const float *X, int hist, const int32_t *off, const float *f
     }
 }
 
+/* Particle::beam and Particle::das, src/dsp/particle.cpp:51-82 and :88-103 (USE_BANDPASS 1,
+ * particle.h:17), for n_dir steered directions with tables as Particle::steer fills them
+ * (particle.cpp:37-49: same split as the MIMO table).  Differences from the MIMO sweep: the power is
+ * divided by N_SAMPLES only (`norm` is computed and never used), and the 256-sample beam itself is a
+ * result (MISOWorker hands it to the audio path, src/dsp/miso.cpp:46). */
+void oracle_particle_beams(const float *X, int hist, const int32_t *off, const float *frac, int n_dir,
+                           int lut_stride, const int32_t *index, int usable, float *power, float *beams) {
+    for (int m = 0; m < n_dir; m++) {
+        float out[ORACLE_N_SAMPLES] = {0.0f};
+        for (int s = 0; s < usable; s++) {
+            const int i = index[s];
+            oracle_delay_lerp(out, X + (size_t) i * hist + off[(size_t) m * lut_stride + i],
+                              frac[(size_t) m * lut_stride + i]);
+        }
+        float power_accumulator = 0.0f;
+        for (int i = 1; i < ORACLE_N_SAMPLES - 1; i++) {
+            const float MA = out[i] * 0.5f - 0.25f * (out[i + 1] + out[i - 1]);
+            power_accumulator += MA * MA;
+        }
+        power_accumulator /= (float) ORACLE_N_SAMPLES;
+        if (power) power[m] = power_accumulator;
+        if (beams) memcpy(beams + (size_t) m * ORACLE_N_SAMPLES, out, sizeof(out));
+    }
+}
+
 void oracle_das_fir8_f32(const float *X, int hist, const int32_t *off, const float *frac, int P,
                          int lut_stride, const int32_t *index, int usable, const float *coeffs,
                          float *power) {

@@ -85,6 +85,9 @@ void oracle_das_fir8_f32(const float *X, int hist, const int32_t *off, const flo
                          float *power);
 
 /* MIMOWorker::populateHeatmap with USE_DB 0, src/dsp/mimo.cpp:61-95. */
+/* Particle::beam / Particle::das (src/dsp/particle.cpp:51-103) for n_dir directions; power and beams may be NULL */
+void oracle_particle_beams(const float *X, int hist, const int32_t *off, const float *frac, int n_dir,
+                           int lut_stride, const int32_t *index, int usable, float *power, float *beams);
 void oracle_heatmap_u8(const float *power, int P, uint8_t *pix);
 /* cv::resize(..., INTER_LINEAR) on an 8-bit single-channel image (aw_processing_unit.cpp:252), upscaling only */
 int oracle_resize_linear_u8(const uint8_t *src, int srows, int scols, uint8_t *dst, int drows, int dcols);

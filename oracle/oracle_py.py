@@ -54,6 +54,8 @@ def oracle() -> C.CDLL:
         lib.oracle_das_f32.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
         lib.oracle_das_f64.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f64p]
         lib.oracle_das_fir8_f32.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
+        lib.oracle_particle_beams.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
+        lib.oracle_particle_beams.restype = None
         lib.oracle_heatmap_u8.argtypes = [_f32p, C.c_int, _u8p]
         lib.oracle_resize_linear_u8.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
         lib.oracle_resize_linear_u8.restype = C.c_int
@@ -87,6 +89,8 @@ def ref(variant: str = "avx2") -> C.CDLL:
         lib.ref_delay.restype = None
         lib.ref_das.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
         lib.ref_das.restype = None
+        lib.ref_particle_beams.argtypes = lib.ref_das.argtypes
+        lib.ref_particle_beams.restype = None
         lib.ref_das_bench.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p,
                                       C.c_double, C.POINTER(C.c_int)]
         lib.ref_das_bench.restype = C.c_double
@@ -171,6 +175,17 @@ def das_f32(X, off, frac, index=None, want_out=False, impl="oracle"):
     fn(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index), index.size,
        _p32(power), _p32(out) if want_out else None)
     return (power, out) if want_out else power
+
+
+def particle_beams(X, off, frac, index=None, impl="oracle"):
+    """Particle::beam / Particle::das (particle.cpp:51-103) for off/frac [n_dir, stride] -> (power[n_dir], beams[n_dir, 256])."""
+    X, off, frac, index = _sweep_args(X, off, frac, index)
+    n = off.shape[0]
+    power = np.empty(n, np.float32)
+    beams = np.empty((n, 256), np.float32)
+    fn = oracle().oracle_particle_beams if impl == "oracle" else ref("avx2").ref_particle_beams
+    fn(_p32(X), X.shape[1], _pi(off), _p32(frac), n, off.shape[1], _pi(index), index.size, _p32(power), _p32(beams))
+    return power, beams
 
 
 def das_f64(X, off, frac, index=None) -> np.ndarray:

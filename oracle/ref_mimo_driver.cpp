@@ -59,6 +59,26 @@ void ref_das(const float *X, int hist, const int32_t *off, const float *frac, in
     }
 }
 
+/* src/dsp/particle.cpp:51-82 / :88-103 (Particle::beam, Particle::das) around the reference delay() */
+void ref_particle_beams(const float *X, int hist, const int32_t *off, const float *frac, int n_dir, int lut_stride,
+                        const int32_t *index, int usable, float *power, float *beams) {
+    for (int m = 0; m < n_dir; m++) {
+        float out[N_SAMPLES] = {0.0};
+        for (int s = 0; s < usable; s++) {
+            int i = index[s];
+            delay(&out[0], &X[(size_t) i * hist + off[(size_t) m * lut_stride + i]], frac[(size_t) m * lut_stride + i]);
+        }
+        float power_accumulator = 0.0f;
+        for (int i = 1; i < N_SAMPLES - 1; i++) {
+            float MA = out[i] * 0.5f - 0.25f * (out[i + 1] + out[i - 1]);
+            power_accumulator += MA * MA;
+        }
+        power_accumulator /= static_cast<float>(N_SAMPLES);
+        if (power) power[m] = power_accumulator;
+        if (beams) memcpy(beams + (size_t) m * N_SAMPLES, out, sizeof(out));
+    }
+}
+
 /* frames/s of ref_das on one thread: runs whole frames until `min_seconds`
  * elapsed (at least one), returns frames / seconds. */
 double ref_das_bench(const float *X, int hist, const int32_t *off, const float *frac, int P,

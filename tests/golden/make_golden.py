@@ -64,9 +64,41 @@ def sweep_case(name, arrays_x, arrays_y, res, pixels, seed, index=None, hist=102
     print(f"{name}.npz", off.shape, "power range", power.min(), power.max())
 
 
+def steer_split(xyz, theta, phi):
+    """Particle::steer, src/dsp/particle.cpp:37-49, on the restated steering vector."""
+    off = np.empty((len(theta), xyz.shape[1]), np.int32)
+    frac = np.empty(off.shape, np.float32)
+    for d, (t, p) in enumerate(zip(theta, phi)):
+        tau = O.steering_delays_f32(xyz, float(t), float(p)).astype(np.float64)
+        whole = np.trunc(tau)
+        frac[d] = (tau - whole).astype(np.float32)
+        off[d] = 256 - whole.astype(np.int32)
+    return off, frac
+
+
+def beams_case(name, seed, index=None):
+    """Particle::beam / Particle::das (particle.cpp:51-103) around the reference delay(): a monopulse
+    quadruple around each of a few directions, as GradientParticle::step asks for them."""
+    xyz = O.create_antenna()
+    rng = np.random.Generator(np.random.PCG64(seed))
+    centre_t = rng.uniform(0.05, 1.2, 6)
+    centre_p = rng.uniform(-np.pi, np.pi, 6)
+    theta = np.concatenate([[t - 0.05, t + 0.05, t, t] for t in centre_t] + [[0.0, np.pi / 2]])
+    phi = np.concatenate([[p, p, p - 0.05, p + 0.05] for p in centre_p] + [[0.0, 3.0]])
+    off, frac = steer_split(xyz, theta, phi)
+    X = util.hash_frames(64, 1024, seed=seed)[0]
+    power, beams = O.particle_beams(X, off, frac, index, impl="ref")
+    np.savez_compressed(HERE / f"{name}.npz", seed=seed, theta=theta, phi=phi, off=off, frac=frac,
+                        index=np.arange(64, dtype=np.int32) if index is None else index.astype(np.int32),
+                        power=power, beams=beams)
+    print(f"{name}.npz", beams.shape, "power range", power.min(), power.max())
+
+
 def main():
     O.build(ref=True)
     delay_kat()
+    beams_case("beams_c1", seed=106)
+    beams_case("beams_c1_ragged", seed=107, index=np.array([s for s in range(64) if s % 9 != 4], np.int32))
     rng = np.random.Generator(np.random.PCG64(2024))
     # c1 geometry (one 8x8 array, 32x32 grid, fov 180): every 7th pixel, all 64 mics
     sweep_case("sweep_c1", 1, 1, 32, np.arange(0, 1024, 7), seed=101)

@@ -351,6 +351,49 @@ def test_device_upscale_and_colour_table(pkg, oracle):
             eng.upscale_device(d_img.data_ptr(), 64, 64, 1, d_out.data_ptr(), 32, 64)
 
 
+def test_few_beam_das_for_trackers(pkg, oracle):
+    """SURVEY 8f N3: Particle::beam / Particle::das (particle.cpp:51-103) for a batch of steered directions
+    in one launch.  Golden beams (made by the reference's delay()) bit-exact, powers to rounding; the
+    same from a device snapshot and from the ingest ring."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    for name in ("beams_c1", "beams_c1_ragged"):
+        g = np.load(GOLDEN / f"{name}.npz")
+        X = util.hash_frames(64, 1024, seed=int(g["seed"]))[0]
+        d_X = torch.from_numpy(X).to(dev)
+        with pkg.Engine(n_pixels=16) as eng:
+            with pytest.raises(pkg.AwpuError) as ei:
+                eng.beams(g["off"], g["frac"], d_X.data_ptr())
+            assert ei.value.status == pkg.binding.ERR_STATE  # active mics not set
+            eng.set_active_mics(g["index"])
+            power, beams = eng.beams(g["off"], g["frac"], d_X.data_ptr())
+            assert np.array_equal(beams, g["beams"])
+            assert util.power_rel_err(power, g["power"]) < 2e-6
+            p_only, none = eng.beams(g["off"][:3], g["frac"][:3], d_X.data_ptr(), want_beams=False)
+            assert none is None and np.array_equal(p_only, power[:3])
+            bad = g["off"].copy()
+            bad[1, int(g["index"][0])] = 1024 - 256
+            with pytest.raises(pkg.AwpuError) as ei:
+                eng.beams(bad, g["frac"], d_X.data_ptr())
+            assert ei.value.status == pkg.binding.ERR_RANGE
+    # off the ingest ring: random int24 samples through the wire path, 100 random directions
+    rng = np.random.default_rng(3)
+    xyz = oracle.create_antenna()
+    off, frac = pkg.steer_table(xyz, rng.uniform(0, 1.5, 100), rng.uniform(-np.pi, np.pi, 100))
+    with pkg.Engine(n_pixels=16) as eng:
+        eng.set_active_mics(None)
+        ring = np.zeros((64, 1024), np.float32)
+        for b in range(5):
+            stream = rng.integers(-(1 << 23), 1 << 23, (256, 256), dtype=np.int32)
+            eng.ingest_block(make_datagrams(stream))
+            ring = np.concatenate([ring[:, 256:], oracle.unpack_exposure(stream, 64)], axis=1)
+        power, beams = eng.beams(off, frac)
+        want_p, want_b = oracle.particle_beams(ring, off, frac)
+        assert np.array_equal(beams, want_b)
+        assert util.power_rel_err(power, want_p) < 2e-6
+
+
 def test_device_calibration_equals_restated_loop(pkg, oracle):
     """SURVEY 8f N4: AWProcessingUnit::calibrate (aw_processing_unit.cpp:102-212) with the mean squares
     computed on the device: same usable mics, bit-identical correction mask and median."""

@@ -40,6 +40,23 @@ def test_sweep_golden(oracle, name):
     assert util.power_rel_err(power, g["power"]) < 2e-6
 
 
+@pytest.mark.parametrize("name", ["beams_c1", "beams_c1_ragged"])
+def test_particle_beams_golden(oracle, pkg, name):
+    """Particle::beam / Particle::das, src/dsp/particle.cpp:51-103 (SURVEY 8f N3): the beams the reference's
+    delay() produced are reproduced bit for bit, the powers to rounding (its -Ofast epilogue order is
+    the compiler's); the stored tables are what the library's Particle::steer mirror gives."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    X = util.hash_frames(64, 1024, seed=int(g["seed"]))[0]
+    power, beams = oracle.particle_beams(X, g["off"], g["frac"], g["index"])
+    assert np.array_equal(beams, g["beams"])
+    assert util.power_rel_err(power, g["power"]) < 2e-6
+    off, frac = pkg.steer_table(oracle.create_antenna(), g["theta"], g["phi"])
+    assert np.array_equal(off, g["off"]) and np.array_equal(frac, g["frac"])
+    if oracle.ref_available():
+        p_r, b_r = oracle.particle_beams(X, g["off"], g["frac"], g["index"], impl="ref")
+        assert np.array_equal(b_r, g["beams"]) and np.array_equal(p_r, g["power"])
+
+
 @pytest.mark.parametrize("name", SWEEPS)
 def test_golden_tables_match_lut_restatement(oracle, name):
     """The stored tables are what the restated computeDelayLUT (mimo.cpp:20-59) gives today."""
