@@ -668,7 +668,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         const int mc4 = (mc + 3) & ~3;
         const int buf = c & 1;
         long long t = DIAG ? __builtin_readcyclecounter() : 0;
-        if (c + 1 < n_chunks) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
+        if (c + 1 < n_chunks && !(a.debug & 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
         stamp(0, t);
 
         // table entries of the tail pass below: requested now, consumed after the sweep
@@ -700,6 +700,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         stamp(1, t);
         // the 257th sample of every window, both frames: lane 8*pp + k takes the mics s = k (mod 8)
         const char *img = (const char *) (lds + buf * (BUF / 4));
+        if (!(a.debug & 4))
 #pragma unroll
         for (int u = 0; u < 4; u++) {  // mics 0..31 of the chunk (prefetched above)
             const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         stamp(2, t);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(3, t);
-        __syncthreads();
+        if (!(a.debug & 8)) __syncthreads();
         stamp(4, t);
     }
 
