@@ -74,9 +74,11 @@ def measured_traffic(workload, batch, world):
     if world != 1 or not path.exists():
         return None
     rec = json.loads(path.read_text())
-    if rec.get("workload") == workload and batch % 2 == 0:
-        # measured at 64 frames per launch; the sweep's traffic is proportional to the frame pairs
-        return int(rec["traffic_bytes_per_launch"] * batch / rec["frames_per_step"])
+    if rec.get("workload") != workload:
+        return None
+    for m in rec["measurements"]:  # not proportional to the batch (L2 residency changes): exact matches only
+        if m["frames_per_step"] == batch:
+            return int(m["traffic_bytes_per_launch"])
     return None
 
 
