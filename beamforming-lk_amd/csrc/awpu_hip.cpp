@@ -36,6 +36,12 @@ int invalid(const char *why) {
     return AWPU_ERR_INVALID;
 }
 
+template <class T>
+void dev_free(T *&p) {  // hipFree + forget
+    if (p) (void) hipFree(p);
+    p = nullptr;
+}
+
 }  // namespace
 
 struct awpu_hip {
@@ -90,44 +96,25 @@ struct awpu_hip {
 namespace {
 
 void release_device(awpu_hip *h) {
-    if (h->d_lut) (void) hipFree(h->d_lut);
-    for (auto &l : h->fast_luts)
-        if (l.d) (void) hipFree(l.d);
+    dev_free(h->d_lut);
+    for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
-    if (h->d_index) (void) hipFree(h->d_index);
-    if (h->d_gain) (void) hipFree(h->d_gain);
-    h->d_gain = nullptr;
-    if (h->d_calib) (void) hipFree(h->d_calib);
-    h->d_calib = nullptr;
-    if (h->d_beam_lut) (void) hipFree(h->d_beam_lut);
-    if (h->d_beam_out) (void) hipFree(h->d_beam_out);
-    h->d_beam_lut = nullptr;
-    h->d_beam_out = nullptr;
-    h->beam_cap = h->beam_lut_cap = 0;
-    if (h->d_fir) (void) hipFree(h->d_fir);
-    h->d_fir = nullptr;
-    if (h->d_ring) (void) hipFree(h->d_ring);
-    if (h->d_pack) (void) hipFree(h->d_pack);
-    h->d_pack = nullptr;
-    if (h->d_taps) (void) hipFree(h->d_taps);
-    h->d_taps = nullptr;
-    h->pack_cap = 0;
-    if (h->d_datagrams) (void) hipFree(h->d_datagrams);
-    if (h->d_row_off_ring) (void) hipFree(h->d_row_off_ring);
-    h->d_ring = nullptr;
-    h->d_datagrams = nullptr;
-    h->d_row_off_ring = nullptr;
-    if (h->d_row_off) (void) hipFree(h->d_row_off);
-    if (h->d_row_off_compact) (void) hipFree(h->d_row_off_compact);
-    h->d_row_off = nullptr;
-    h->d_row_off_compact = nullptr;
-    if (h->d_frames) (void) hipFree(h->d_frames);
-    if (h->d_power) (void) hipFree(h->d_power);
-    h->d_lut = nullptr;
-    h->d_index = nullptr;
-    h->d_frames = nullptr;
-    h->d_power = nullptr;
-    h->frames_cap = h->power_cap = 0;
+    dev_free(h->d_index);
+    dev_free(h->d_gain);
+    dev_free(h->d_calib);
+    dev_free(h->d_beam_lut);
+    dev_free(h->d_beam_out);
+    dev_free(h->d_fir);
+    dev_free(h->d_ring);
+    dev_free(h->d_pack);
+    dev_free(h->d_taps);
+    dev_free(h->d_datagrams);
+    dev_free(h->d_row_off_ring);
+    dev_free(h->d_row_off);
+    dev_free(h->d_row_off_compact);
+    dev_free(h->d_frames);
+    dev_free(h->d_power);
+    h->beam_cap = h->beam_lut_cap = h->pack_cap = h->frames_cap = h->power_cap = 0;
 }
 
 // Pack the reference-format tables into the kernels' layout once both the tables and the
@@ -155,18 +142,15 @@ int prepare(awpu_hip *h) {
     h->window = hi - lo + reach + 1;
     h->tau_max = awpu::kSamples - lo;
 
-    if (h->d_lut) (void) hipFree(h->d_lut);
-    if (h->d_index) (void) hipFree(h->d_index);
-    h->d_lut = nullptr;
-    h->d_index = nullptr;
-    for (auto &l : h->fast_luts)
-        if (l.d) (void) hipFree(l.d);
+    // (hipFree waits for the device: launches still reading the old tables finish first)
+    dev_free(h->d_lut);
+    dev_free(h->d_index);
+    for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
                            hipMemcpyHostToDevice));
-    if (h->d_gain) (void) hipFree(h->d_gain);
-    h->d_gain = nullptr;
+    dev_free(h->d_gain);
     if (!h->gain.empty()) {
         std::vector<float> compact(U);
         for (int s = 0; s < U; s++) compact[s] = h->gain[h->index[s]];
@@ -174,8 +158,7 @@ int prepare(awpu_hip *h) {
         AWPU_HIP_TRY(hipMemcpy(h->d_gain, compact.data(), (size_t) U * sizeof(float), hipMemcpyHostToDevice));
     }
     {   // float offset, inside one frame, of staged row 2*s+q (copy q of active mic s)
-        if (h->d_row_off) (void) hipFree(h->d_row_off);
-        h->d_row_off = nullptr;
+        dev_free(h->d_row_off);
         const int upad = (U + 3) & ~3;
         std::vector<int32_t> ro((size_t) 2 * upad + 8, h->index[0] * c.hist + lo);
         for (int s = 0; s < U; s++)
@@ -184,13 +167,11 @@ int prepare(awpu_hip *h) {
         AWPU_HIP_TRY(hipMemcpy(h->d_row_off, ro.data(), ro.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         // Host-buffer calls upload only the window [lo, lo + compact_hist) of every stream (the rest
         // of the 1024-sample snapshot is never read: SURVEY 8a A10): a third of the PCIe bytes.
-        if (h->d_row_off_compact) (void) hipFree(h->d_row_off_compact);
-        h->d_row_off_compact = nullptr;
+        dev_free(h->d_row_off_compact);
         const int ch = ((h->window + 3) & ~3) + 4;
         h->compact_hist = lo + ch <= c.hist ? ch : 0;
         if (c.hist == AWPU_HIST) {  // frames read in place from the ingest ring: rows 2048 floats apart
-            if (h->d_row_off_ring) (void) hipFree(h->d_row_off_ring);
-            h->d_row_off_ring = nullptr;
+            dev_free(h->d_row_off_ring);
             std::vector<int32_t> rr(ro.size(), h->index[0] * 2048 + lo);
             for (int s = 0; s < U; s++)
                 for (int q = 0; q < 2; q++) rr[2 * s + q] = h->index[s] * 2048 + lo + q;
@@ -373,8 +354,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
                 const awpu::FastPlan &pp = plut->plan;
                 const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * h->usable() * pp.wr * 2;
                 if (h->pack_cap < need) {
-                    if (h->d_pack) (void) hipFree(h->d_pack);
-                    h->d_pack = nullptr;
+                    dev_free(h->d_pack);
                     h->pack_cap = 0;
                     AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
                     h->pack_cap = need;
@@ -738,15 +718,13 @@ int awpu_hip_beams(awpu_hip_t *h, const float *d_frame, const int32_t *off, cons
     }
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     if (h->beam_lut_cap < entries.size()) {
-        if (h->d_beam_lut) (void) hipFree(h->d_beam_lut);
-        h->d_beam_lut = nullptr;
+        dev_free(h->d_beam_lut);
         h->beam_lut_cap = 0;
         AWPU_HIP_TRY(hipMalloc(&h->d_beam_lut, entries.size() * sizeof(awpu::LutEntry)));
         h->beam_lut_cap = entries.size();
     }
     if (h->beam_cap < (size_t) n_dir) {
-        if (h->d_beam_out) (void) hipFree(h->d_beam_out);
-        h->d_beam_out = nullptr;
+        dev_free(h->d_beam_out);
         h->beam_cap = 0;
         AWPU_HIP_TRY(hipMalloc(&h->d_beam_out, (size_t) n_dir * (1 + awpu::kSamples) * sizeof(float)));
         h->beam_cap = n_dir;
@@ -782,15 +760,13 @@ int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *p
     const size_t frame_floats = (size_t) h->cfg.n_streams * dev_hist;
     const size_t need_frames = frame_floats * batch, need_power = (size_t) h->cfg.pixel_count * batch;
     if (h->frames_cap < need_frames) {
-        if (h->d_frames) (void) hipFree(h->d_frames);
-        h->d_frames = nullptr;
+        dev_free(h->d_frames);
         h->frames_cap = 0;
         AWPU_HIP_TRY(hipMalloc(&h->d_frames, need_frames * sizeof(float)));
         h->frames_cap = need_frames;
     }
     if (h->power_cap < need_power) {
-        if (h->d_power) (void) hipFree(h->d_power);
-        h->d_power = nullptr;
+        dev_free(h->d_power);
         h->power_cap = 0;
         AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
         h->power_cap = need_power;
@@ -865,8 +841,7 @@ int awpu_hip_process_ring(awpu_hip_t *h, float *power) {
     }
     const size_t need_power = (size_t) h->cfg.pixel_count;
     if (h->power_cap < need_power) {
-        if (h->d_power) (void) hipFree(h->d_power);
-        h->d_power = nullptr;
+        dev_free(h->d_power);
         h->power_cap = 0;
         AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
         h->power_cap = need_power;
@@ -913,8 +888,7 @@ int awpu_hip_upscale_u8_device(awpu_hip_t *h, const uint8_t *d_pix, int32_t rows
         awpu::resize_taps(cols, out_cols, true, taps.data());
         awpu::resize_taps(rows, out_rows, false, taps.data() + out_cols);
         AWPU_HIP_TRY(hipStreamSynchronize(s));  // an earlier launch may still read the old taps
-        if (h->d_taps) (void) hipFree(h->d_taps);
-        h->d_taps = nullptr;
+        dev_free(h->d_taps);
         AWPU_HIP_TRY(hipMalloc(&h->d_taps, taps.size() * sizeof(awpu::ResizeTap)));
         AWPU_HIP_TRY(hipMemcpy(h->d_taps, taps.data(), taps.size() * sizeof(awpu::ResizeTap), hipMemcpyHostToDevice));
         std::memcpy(h->taps_key, key, sizeof(key));

@@ -107,6 +107,62 @@ class FrameBroadcaster:
         return self.buffers[k % 2]
 
 
+def global_peak(local_peak: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Display-time normalisation across tiles: MIMOWorker::populateHeatmap scales by the maximum over the
+    WHOLE grid (src/dsp/mimo.cpp:62-73), so every rank's per-frame tile maximum [batch] is all-reduced
+    (MAX, in place; one float per frame) before the tiles are scaled with peak_given (awpu_hip_heatmap_u8_device)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(local_peak, op=dist.ReduceOp.MAX, group=group)
+    return local_peak
+
+
+def shard_frames(batch: int, world: int, rank: int) -> Tuple[int, int]:
+    """The other decomposition: whole frames per rank (frame k of a batch goes to one GPU, which sweeps
+    the full grid).  Throughput-only -- a frame's latency is that of one GPU -- but each frame crosses
+    xGMI once instead of world-1 times.  Returns (first frame, frame count) of this rank's contiguous,
+    balanced share."""
+    if not (0 <= rank < world):
+        raise ValueError("rank outside world")
+    base, extra = divmod(batch, world)
+    return rank * base + min(rank, extra), base + (1 if rank < extra else 0)
+
+
+class FrameScatterer:
+    """Double-buffered scatter for the frame-sharded decomposition (shard_frames): post(k) sends slice r
+    of the source's full batch buffer k % 2 to rank r's local buffer k % 2 (async); wait(k) returns the
+    local buffer once it has landed.  The batch must divide by the world size.  Without a process
+    group the local buffers are handed out as they are."""
+
+    def __init__(self, local: Tuple[torch.Tensor, torch.Tensor], full: Optional[Tuple[torch.Tensor, torch.Tensor]],
+                 src: int = 0, group: Optional[dist.ProcessGroup] = None):
+        self.local = local
+        self.full = full
+        self.src = src
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self._work = [None, None]
+        if self.active:
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+            if self.rank == src and (full is None or full[0].shape[0] != local[0].shape[0] * self.world):
+                raise ValueError("the source needs full buffers of world x the local batch")
+
+    def post(self, k: int) -> None:
+        if not self.active:
+            return
+        chunks = None
+        if self.rank == self.src:
+            per = self.local[0].shape[0]
+            chunks = [self.full[k % 2][r * per:(r + 1) * per] for r in range(self.world)]  # contiguous slices
+        self._work[k % 2] = dist.scatter(self.local[k % 2], chunks, src=self.src, group=self.group, async_op=True)
+
+    def wait(self, k: int) -> torch.Tensor:
+        if self._work[k % 2] is not None:
+            self._work[k % 2].wait()
+            self._work[k % 2] = None
+        return self.local[k % 2]
+
+
 def gather_power(local: torch.Tensor, shards: List[RowShard], dst: int = 0,
                  group: Optional[dist.ProcessGroup] = None) -> Optional[torch.Tensor]:
     """Assemble the [batch, P] heatmap on `dst` from per-rank [batch, pixel_count] tiles.

@@ -72,6 +72,14 @@ def _worker(rank, world, port, res, batch, steps, out_dir, mode="broadcast"):
             results.append(full.numpy())
         else:
             assert full is None
+        # display step across tiles: all-reduce(MAX) of the tile maxima, then every rank scales
+        # its tile alike; the assembled image must be the single-process populateHeatmap of the full grid
+        peak = sh.global_peak(torch.from_numpy(local.max(axis=1).copy()))
+        whole = np.stack([oracle_py.das_f32(got[b], off, frac) for b in range(batch)])
+        assert np.array_equal(peak.numpy(), whole.max(axis=1))
+        for b in range(batch):  # the host heatmap takes its own maximum: hand it the global one as an extra pixel
+            tile = pkg.heatmap_u8(np.concatenate([local[b], peak.numpy()[b:b + 1]]))[:-1]
+            assert np.array_equal(tile, oracle_py.heatmap_u8(whole[b])[sl])
     if rank == 0:
         want = np.stack([np.stack([oracle_py.das_f32(all_frames[k][b], off, frac) for b in range(batch)]) for k in range(steps)])
         np.save(os.path.join(out_dir, "ok.npy"), np.array([np.array_equal(np.stack(results), want)]))
@@ -86,6 +94,57 @@ def test_broadcast_and_gather_world2(tmp_path, world, res, mode):
     assert np.load(tmp_path / "ok.npy")[0]
 
 
+def _scatter_worker(rank, world, port, steps, out_dir):
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = importlib.import_module("beamforming-lk_amd.sharding")
+    batch, per = 6, 6 // world
+    first, count = sh.shard_frames(batch, world, rank)
+    assert count == per
+    rng = np.random.default_rng(7)
+    all_frames = [rng.standard_normal((batch, 4, 32)).astype(np.float32) for _ in range(steps)]
+    local = tuple(torch.zeros((per, 4, 32)) for _ in range(2))
+    full = tuple(torch.zeros((batch, 4, 32)) for _ in range(2)) if rank == 0 else None
+    sc = sh.FrameScatterer(local, full, src=0)
+    if rank == 0:
+        full[0].copy_(torch.from_numpy(all_frames[0]))
+    sc.post(0)
+    ok = True
+    for k in range(steps):
+        mine = sc.wait(k)
+        if k + 1 < steps:
+            if rank == 0:
+                full[(k + 1) % 2].copy_(torch.from_numpy(all_frames[k + 1]))
+            sc.post(k + 1)
+        ok &= np.array_equal(mine.numpy(), all_frames[k][first:first + count])
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "ok.npy"), flag.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_scatter_world2(tmp_path):
+    """The frame-sharded decomposition: every rank receives exactly its frames of rank 0's batches."""
+    mp.spawn(_scatter_worker, args=(2, free_port(), 4, str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "ok.npy")[0] == 1
+
+
+def test_shard_frames_is_a_balanced_partition(pkg):
+    sh = importlib.import_module("beamforming-lk_amd.sharding")
+    for batch, world in [(128, 8), (10, 4), (3, 8), (64, 1)]:
+        parts = [sh.shard_frames(batch, world, r) for r in range(world)]
+        assert parts[0][0] == 0 and sum(n for _, n in parts) == batch
+        for (a, n), (b, _) in zip(parts, parts[1:]):
+            assert a + n == b
+        assert max(n for _, n in parts) - min(n for _, n in parts) <= 1
+
+
 def test_broadcaster_is_a_noop_without_a_group(pkg):
     sh = importlib.import_module("beamforming-lk_amd.sharding")
     bufs = (torch.ones(3), torch.zeros(3))
@@ -95,3 +154,4 @@ def test_broadcaster_is_a_noop_without_a_group(pkg):
     assert bc.wait(0) is bufs[0] and bc.wait(1) is bufs[1]
     t = torch.arange(6.0).reshape(2, 3)
     assert sh.gather_power(t, sh.all_shards(3, 1, 1)) is t
+    assert sh.global_peak(t) is t
