@@ -1,5 +1,6 @@
 """Parity of the gfx950 sweep (through the C ABI) with the oracle, the reference-generated
 golden vectors and size-independent properties.  Everything here needs a real MI355X."""
+import importlib
 from pathlib import Path
 
 import numpy as np
@@ -532,3 +533,38 @@ def test_full_size_properties(pkg, oracle, wl, batch):
         got = power[b][pick]
         floor = util.NULL_FLOOR * float(power[b].max())
         assert float((np.abs(got - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+
+
+def test_c4_rank_slab_of_eight(pkg, oracle):
+    """BASELINE configs[3]/[4]: 512 mics x 256x256 sharded over 8 GPUs -- here the slab rank 5 would own
+    (rows 160..191, 8192 pixels), a batch of 6 frames as one rank of a batched run would see them.
+    Same size-independent properties as above plus an oracle check on 150 sampled pixels; the second
+    handle (rank 6's slab) shows that neighbouring slabs continue each other."""
+    sharding = importlib.import_module("beamforming-lk_amd.sharding")
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c4"]
+    xyz = S.geometry(spec)
+    frames = S.make_frames(xyz, 6, seed=9)
+    frames[3] = -2.0 * frames[0]
+    powers = []
+    for rank in (5, 6):
+        shard = sharding.shard_rows(spec.res, spec.res, 8, rank)
+        assert (shard.row_count, shard.pixel_count) == (32, 8192)
+        off, frac = S.delay_table(spec, xyz, shard.row_begin, shard.row_count)
+        eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, lut_stride=spec.n_mics, max_batch=6,
+                         pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count)
+        with eng:
+            eng.set_delay_table(off, frac)
+            eng.set_active_mics(None)
+            power = eng.process(frames)
+        assert power.shape == (6, 8192)
+        assert np.array_equal(power[3], 4.0 * power[0])
+        pick = np.random.default_rng(rank).choice(shard.pixel_count, 150, replace=False)
+        for b in (0, 5):
+            want = oracle.das_f32(frames[b], off[pick], frac[pick])
+            floor = util.NULL_FLOOR * float(power[b].max())
+            assert float((np.abs(power[b][pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+        powers.append(power)
+    # the last row of one slab and the first row of the next are neighbouring grid rows: smooth across the seam
+    seam = np.abs(powers[0][0, -256:] - powers[1][0, :256]) / powers[0][0].max()
+    assert seam.max() < 0.25
