@@ -568,3 +568,24 @@ def test_c4_rank_slab_of_eight(pkg, oracle):
     # the last row of one slab and the first row of the next are neighbouring grid rows: smooth across the seam
     seam = np.abs(powers[0][0, -256:] - powers[1][0, :256]) / powers[0][0].max()
     assert seam.max() < 0.25
+
+
+def test_1024_frames_in_flight(pkg, oracle):
+    """BASELINE configs[4] batches 1024 frames per step: one call, 512 frame pairs (c1 geometry so that the
+    oracle can check whole frames): first, last and two middle frames against the oracle, and repeated frames
+    against each other."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = np.tile(util.hash_frames(64, 1024, seed=40, batch=8), (128, 1, 1))  # 8 distinct frames, repeated
+    assert frames.shape == (1024, 64, 1024)
+    power, _ = run_engine(pkg, frames, off, frac)
+    for b in (0, 511, 512, 1023):
+        want = oracle.das_f32(frames[b], off, frac)
+        assert util.power_rel_err(power[b], want) < util.POWER_RTOL
+    # frames repeat every 8: the same frame gives the same bits wherever it sits in the batch ...
+    assert np.array_equal(power[8:16], power[:8]) and np.array_equal(power[1016:], power[:8])
+    # ... and agrees with the small-batch call (a different kernel shape: other summation order)
+    few, _ = run_engine(pkg, frames[:8], off, frac)
+    assert util.power_rel_err(power[:8], few) < 2e-6
