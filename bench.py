@@ -86,6 +86,8 @@ def measured_traffic(workload, batch, world):
 
 def main():
     args = parse_args()
+    # dmabuf IPC for RCCL between processes; read when the HSA runtime starts, so before torch touches the GPU
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -106,7 +108,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
