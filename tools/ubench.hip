@@ -57,12 +57,12 @@ __global__ void k_pkfma(float *out, int iters, float f) {
 
 // ---- LDS reads only.  WIDTH = 4, 8, 16 bytes per lane, conflict-free consecutive lanes
 template <int WIDTH>
-__global__ void k_lds(float *out, int iters) {
+__global__ void k_lds(float *out, int iters, int skew = 0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = i;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    unsigned addr = lane * WIDTH;
+    unsigned addr = lane * (WIDTH == 17 ? 8 : WIDTH) + skew;
     float acc = 0;
     for (int it = 0; it < iters; it++) {
         if (WIDTH == 4) {
@@ -80,6 +80,15 @@ __global__ void k_lds(float *out, int iters) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < 16; j++) asm volatile("" ::"v"(v[j]));
+            acc += v[0].x;
+        } else if (WIDTH == 17) {  // 16 bytes per lane as two 8-byte reads 512 bytes apart in ONE instruction
+            f4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v[j]) : "v"(addr), "n"(2 * j), "n"(2 * j + 1));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; j++) asm volatile("" ::"v"(v[j]));
             acc += v[0].x;
         } else {
             f4 v[16];
@@ -260,6 +269,12 @@ int main() {
             ms = time_ms([&] { hipLaunchKernelGGL(k_lds<8>, dim3(blocks), dim3(256), 32768, 0, out, it2); });
             bytes = (double) blocks * 256 * it2 * 16 * 8;
             printf("ds_b64    wps %d: %8.3f ms  %.1f B/clk/CU @2.4GHz\n", wps, ms, bytes / (ms * 1e-3) / (ghz * 1e9) / cus);
+            ms = time_ms([&] { hipLaunchKernelGGL(k_lds<17>, dim3(blocks), dim3(256), 32768, 0, out, it2); });
+            bytes = (double) blocks * 256 * it2 * 8 * 16;
+            printf("ds_2st64  wps %d: %8.3f ms  %.1f B/clk/CU @2.4GHz\n", wps, ms, bytes / (ms * 1e-3) / (ghz * 1e9) / cus);
+            ms = time_ms([&] { hipLaunchKernelGGL(k_lds<16>, dim3(blocks), dim3(256), 32768, 0, out, it2, 8); });
+            bytes = (double) blocks * 256 * it2 * 16 * 16;
+            printf("ds_b128+8 wps %d: %8.3f ms  %.1f B/clk/CU @2.4GHz  (8-byte aligned only)\n", wps, ms, bytes / (ms * 1e-3) / (ghz * 1e9) / cus);
             if (wps <= 4) {
                 ms = time_ms([&] { hipLaunchKernelGGL(k_lds<16>, dim3(blocks), dim3(256), 32768, 0, out, it2); });
                 bytes = (double) blocks * 256 * it2 * 16 * 16;
