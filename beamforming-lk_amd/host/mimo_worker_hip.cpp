@@ -32,6 +32,10 @@ MIMOWorkerHip::MIMOWorkerHip(FrameSource *pipeline, const AntennaView &antenna, 
     }
     computeDelayLUT();  // mimo.cpp:11
     if (last_status == AWPU_OK) last_status = awpu_hip_set_active_mics(engine, antenna.index, antenna.usable);
+    if (last_status == AWPU_OK && pipeline->feeds_device_ring()) {
+        from_ring = true;
+        pipeline->attach(engine, &lock);  // blocks arrive in the engine's ring from now on
+    }
     if (autostart) thread_loop = std::thread(&MIMOWorkerHip::loop, this);  // mimo.cpp:12
 }
 
@@ -56,6 +60,10 @@ void MIMOWorkerHip::computeDelayLUT() {
 // address any of them); the pixel x mic x sample sweep and the epilogue run on the GPU.
 void MIMOWorkerHip::update() {
     if (!engine) return;
+    if (from_ring) {  // the snapshot is already in device memory (awpu_hip_ingest_block)
+        last_status = awpu_hip_process_ring(engine, powerdB.data());
+        return;
+    }
     const int n_sensors = pipeline->get_n_sensors();
     for (int l = 0; l < n_sensors; l++) {
         pipeline->read_stream((unsigned) l, &signals[(size_t) l * AWPU_HIST]);  // mimo.cpp:100-103

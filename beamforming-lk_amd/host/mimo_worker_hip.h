@@ -32,6 +32,13 @@ public:
     virtual int isRunning() = 0;                              // pipeline.h:71
     virtual void barrier() = 0;                               // pipeline.h:83, blocks until a new block
     virtual void read_stream(unsigned index, float *data) = 0;  // streams.hpp:113-116: 1024 floats, oldest first
+    // A source that can deliver its blocks straight into an engine's device ring (PipelineHip) says so;
+    // the worker then attaches its engine and sweeps with awpu_hip_process_ring, no host snapshot.
+    virtual bool feeds_device_ring() { return false; }
+    virtual void attach(awpu_hip_t *engine, std::mutex *guard) {
+        (void) engine;
+        (void) guard;
+    }
 };
 
 // src/geometry/antenna.h:80-103 without Eigen: points is xyz[3][n] row-major by coordinate.
@@ -73,6 +80,7 @@ private:
     AntennaView antenna;
     bool *running;
     bool looping = true;
+    bool from_ring = false;  // the source fills the engine's device ring
     std::thread thread_loop;
     std::mutex lock;
 

@@ -20,6 +20,11 @@
 #include "das_oracle.h"
 #include "aw_processing_unit_hip.h"
 #include "mimo_worker_hip.h"
+#include "pipeline_hip.h"
+
+#include <arpa/inet.h>
+#include <sys/socket.h>
+#include <unistd.h>
 
 using namespace awpu_host;
 
@@ -215,6 +220,64 @@ int main(int argc, char **argv) {
         src.stop();
         producer.join();
         std::printf("4. processing unit: heatmap peak at (%d,%d), upscaled (%d,%d)\n", k / cols, k % cols, kb / 96, kb % 96);
+    }
+    // ---- 5. the live path: wire datagrams over UDP (loopback) -> PipelineHip -> device ring -> sweep.
+    // The sender plays the FPGA / udpreplay: one datagram per sample time, 24-bit samples of the plane
+    // wave in wire order (src/fpga/receiver.h:24-30; every other group of 8 columns mirrored).
+    {
+        const int port = 21000 + (int) (getpid() % 4000);
+        std::vector<float> tau(64);
+        oracle_steering_delays_f32(xyz.data(), 64, theta, phi, tau.data());
+        std::atomic<bool> sending{true};
+        std::thread sender([&] {
+            const int tx = socket(AF_INET, SOCK_DGRAM, IPPROTO_UDP);
+            struct sockaddr_in to;
+            std::memset(&to, 0, sizeof(to));
+            to.sin_family = AF_INET;
+            to.sin_port = htons((uint16_t) port);
+            to.sin_addr.s_addr = inet_addr("127.0.0.1");
+            WireMessage msg{};
+            msg.frequency = 48828;
+            msg.n_arrays = 1;
+            msg.version = 2;
+            for (uint32_t p = 0; sending.load(); p++) {
+                msg.counter = p;
+                for (int sensor = 0; sensor < 64; sensor++) {
+                    const bool inverted = ((sensor / 8) % 2) == 0;
+                    const int wire = inverted ? 8 * (1 + sensor / 8) - 1 - sensor % 8 : sensor;
+                    const double v = 1e-2 * std::sin(2.0 * M_PI * 9e3 * ((double) p + tau[sensor]) / 48828.0);
+                    msg.stream[wire] = (int32_t) std::lround(v * 8388608.0);
+                }
+                (void) sendto(tx, &msg, sizeof(msg), 0, (struct sockaddr *) &to, sizeof(to));
+                if (p % 64 == 63) std::this_thread::sleep_for(std::chrono::microseconds(700));  // ~2x real time
+            }
+            close(tx);
+        });
+        PipelineHip pipeline("127.0.0.1", port);
+        CHECK(pipeline.connect() == 0, "connect");
+        CHECK(pipeline.get_n_sensors() == 64, "n_sensors %d", pipeline.get_n_sensors());
+        {
+            AWProcessingUnitHip awpu(&pipeline, 180.f, rows, /*verbose=*/0);  // calibrates on the host copy of the ring
+            CHECK(awpu.usable() == 64, "calibrate kept %d mics", awpu.usable());
+            CHECK(awpu.start(MIMO), "start(MIMO): %s", awpu_hip_last_error());
+            awpu.resume();
+            const int seen = pipeline.mostRecent();
+            for (int spin = 0; spin < 400 && pipeline.mostRecent() < seen + 6; spin++)
+                std::this_thread::sleep_for(std::chrono::milliseconds(5));  // a full ring of blocks after the attach
+            CHECK(pipeline.mostRecent() >= seen + 6, "no blocks arrived");
+            std::this_thread::sleep_for(std::chrono::milliseconds(30));
+            std::vector<uint8_t> img(rows * cols, 0);
+            awpu.draw_heatmap(img.data());
+            const int k = (int) (std::max_element(img.begin(), img.end()) - img.begin());
+            CHECK(awpu.status() == AWPU_OK && pipeline.last_status() == AWPU_OK, "status %d / %d: %s", awpu.status(),
+                  pipeline.last_status(), awpu_hip_last_error());
+            CHECK(img[k] == 255 && k / cols == 8 && k % cols == 10, "live heatmap peak at (%d,%d), expected (8,10)", k / cols, k % cols);
+            std::printf("5. UDP -> device ring -> sweep: heatmap peak at (%d,%d) after %d blocks\n", k / cols, k % cols,
+                        pipeline.mostRecent());
+        }
+        sending = false;
+        sender.join();
+        CHECK(pipeline.disconnect() == 0, "disconnect");
     }
     std::printf(failures ? "FAILED\n" : "OK\n");
     return failures ? 1 : 0;

@@ -13,7 +13,7 @@ def build(pkg, oracle):
     pkg.binding.load()  # builds libawpu_hip.so
     pkgdir = REPO / "beamforming-lk_amd"
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", f"-I{REPO / 'include'}", f"-I{pkgdir / 'host'}",
-           f"-I{REPO / 'oracle'}", str(REPO / "tests/host/test_mimo_worker.cpp"), str(pkgdir / "host/mimo_worker_hip.cpp"), str(pkgdir / "host/aw_processing_unit_hip.cpp"),
+           f"-I{REPO / 'oracle'}", str(REPO / "tests/host/test_mimo_worker.cpp"), str(pkgdir / "host/mimo_worker_hip.cpp"), str(pkgdir / "host/aw_processing_unit_hip.cpp"), str(pkgdir / "host/pipeline_hip.cpp"),
            f"-L{pkgdir}", "-lawpu_hip", f"-L{REPO / 'oracle'}", "-loracle_das", "-lm",
            f"-Wl,-rpath,{pkgdir}", f"-Wl,-rpath,{REPO / 'oracle'}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(EXE)]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
