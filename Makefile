@@ -1,0 +1,34 @@
+# Makefile -- the same builds __graft_entry__.build() drives from Python, for C++ integrators.
+#   make lib         beamforming-lk_amd/libawpu_hip.so   (hipcc, gfx950 only; there is no CPU fallback)
+#   make oracle      oracle/liboracle_das.so (+ oracle/_ref from the reference tree when it is present)
+#   make host-test   tests/host/test_mimo_worker: the C++ mirror (MIMOWorkerHip, AWProcessingUnitHip,
+#                    PipelineHip) against the oracle; needs an MI355X to run (--nogpu checks the failure path)
+HIPCC ?= /opt/rocm/bin/hipcc
+PKG := beamforming-lk_amd
+CSRC := $(PKG)/csrc
+LIB := $(PKG)/libawpu_hip.so
+KERNEL_SRC := $(CSRC)/das_kernels.hip $(CSRC)/das_fast.hip $(CSRC)/awpu_hip.cpp $(CSRC)/geometry_host.cpp
+HOST_SRC := $(PKG)/host/mimo_worker_hip.cpp $(PKG)/host/aw_processing_unit_hip.cpp $(PKG)/host/pipeline_hip.cpp
+
+.PHONY: lib oracle host-test trips clean
+lib: $(LIB)
+
+$(LIB): $(KERNEL_SRC) $(CSRC)/das_kernels.h $(CSRC)/das_fast_trip.inc include/awpu_hip.h
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-result -x hip \
+	    -Iinclude -I$(CSRC) $(KERNEL_SRC) -o $@
+
+# the hand-scheduled inner loops are generated (tools/gen_trip_asm.py documents the schedule and its knobs)
+trips:
+	python3 tools/gen_trip_asm.py
+
+oracle:
+	$(MAKE) -C oracle
+
+host-test: $(LIB) oracle
+	g++ -O2 -std=c++17 -pthread -Iinclude -I$(PKG)/host -Ioracle tests/host/test_mimo_worker.cpp $(HOST_SRC) \
+	    -L$(PKG) -lawpu_hip -Loracle -loracle_das -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -Wl,-rpath,'$$ORIGIN/../../oracle' -Wl,-rpath,/opt/rocm/lib \
+	    -o tests/host/test_mimo_worker
+
+clean:
+	rm -f $(LIB) tests/host/test_mimo_worker
+	$(MAKE) -C oracle clean
