@@ -82,6 +82,8 @@ _SIGNATURES = {
     "awpu_hip_process_ring": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_ring_snapshot": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_heatmap_u8": (C.c_int, [_f32p, C.c_int32, _u8p]),
+    "awpu_hip_live_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _f32p, C.c_int32, C.c_int32, _u8p, C.c_int32,
+                                      C.c_int32, C.c_void_p, _u8p]),
     "awpu_hip_steer_table": (C.c_int, [_f32p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
                                        _i32p, _f32p]),
     "awpu_hip_beams": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _f32p, C.c_int32, _f32p, _f32p]),
@@ -351,6 +353,22 @@ class Engine:
         _check(self._lib.awpu_hip_beams(self._h, C.c_void_p(d_frame_ptr), _i32(off), _f32(frac), n, _f32(power),
                                         _f32(out) if want_beams else None), "awpu_hip_beams")
         return power, out
+
+    def live_block(self, wire: bytes, rows: int, cols: int, out_rows: int = 0, out_cols: int = 0,
+                   d_colormap_ptr: int = 0, want_power: bool = True):
+        """Block in, images out (awpu_hip_live_block): ingest 256 raw datagrams, sweep the new snapshot, 8-bit
+        heatmap, optional upscale -> (power or None, image [rows, cols], big image or None)."""
+        if len(wire) != 256 * 1032:
+            raise ValueError("wire must be 256 datagrams of 1032 bytes")
+        power = np.empty(self.cfg.n_pixels, np.float32) if want_power else None
+        image = np.empty((rows, cols), np.uint8)
+        big = None
+        if out_rows:
+            big = np.empty((out_rows, out_cols, 3) if d_colormap_ptr else (out_rows, out_cols), np.uint8)
+        _check(self._lib.awpu_hip_live_block(self._h, wire, 1032, _f32(power) if want_power else None, rows, cols,
+                                             image.ctypes.data_as(_u8p), out_rows, out_cols, C.c_void_p(d_colormap_ptr),
+                                             big.ctypes.data_as(_u8p) if big is not None else None), "awpu_hip_live_block")
+        return power, image, big
 
     def set_mic_gains(self, gains: Optional[np.ndarray]) -> None:
         """Optional per-mic gain (the reference's unused power_correction_mask, aw_processing_unit.cpp:190-200);

@@ -72,6 +72,8 @@ struct awpu_hip {
     size_t beam_cap = 0, beam_lut_cap = 0;
     float *d_fir = nullptr;  // [101][8] coefficient table (AWPU_INTERP_FIR8)
     float *d_ring = nullptr;            // [n_streams][2048] history ring (awpu_hip_ingest_block)
+    uint8_t *d_display = nullptr;       // awpu_hip_live_block: peak (one float), compact image, upscaled image
+    size_t display_cap = 0;             // bytes
     awpu::ResizeTap *d_taps = nullptr;  // column + row taps of the display upscale, for taps_key
     int taps_key[4] = {0, 0, 0, 0};     // {srows, scols, drows, dcols}
     float *d_pack = nullptr;            // [pairs][usable][wp][2] sample-interleaved frame pairs
@@ -108,6 +110,8 @@ void release_device(awpu_hip *h) {
     dev_free(h->d_ring);
     dev_free(h->d_pack);
     dev_free(h->d_taps);
+    dev_free(h->d_display);
+    h->display_cap = 0;
     dev_free(h->d_datagrams);
     dev_free(h->d_row_off_ring);
     dev_free(h->d_row_off);
@@ -807,7 +811,10 @@ int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch,
     return rc2;
 }
 
-int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes) {
+namespace {
+
+// H2D of one block of raw datagrams + the unpack launch, enqueued on the handle's stream (no wait)
+int enqueue_ingest(awpu_hip *h, const void *datagrams, int32_t stride_bytes) {
     if (!h || !datagrams) return invalid("null argument");
     if (h->cfg.hist != AWPU_HIST || h->cfg.n_streams > 256) return invalid("ingest needs hist 1024 and <= 256 streams");
     if (stride_bytes < AWPU_DATAGRAM_BYTES) return invalid("datagram stride below 1032 bytes");
@@ -826,7 +833,65 @@ int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_b
     AWPU_HIP_TRY(awpu::launch_unpack_block(h->d_datagrams, AWPU_DATAGRAM_BYTES, h->cfg.n_streams, h->d_ring,
                                            h->ring_pos, h->stream));
     h->ring_pos = (h->ring_pos + awpu::kSamples) % AWPU_HIST;  // Streams::forward
+    return AWPU_OK;
+}
+
+int ensure_power(awpu_hip *h, size_t need_power) {
+    if (h->power_cap < need_power) {
+        dev_free(h->d_power);
+        h->power_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
+        h->power_cap = need_power;
+    }
+    return AWPU_OK;
+}
+
+}  // namespace
+
+int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes) {
+    const int rc = enqueue_ingest(h, datagrams, stride_bytes);
+    if (rc != AWPU_OK) return rc;
     // the staging buffer is reused by the next call: finish the copy before returning
+    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
+    return AWPU_OK;
+}
+
+int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes, float *power, int32_t rows,
+                        int32_t cols, uint8_t *image, int32_t out_rows, int32_t out_cols, const uint8_t *d_colormap,
+                        uint8_t *big_image) {
+    int rc = check_ready(h, 1);
+    if (rc != AWPU_OK) return rc;
+    const int n = h->cfg.n_pixels;
+    if (h->cfg.pixel_count != n) return invalid("the display step needs the whole grid on this handle");
+    if ((image || big_image) && (rows < 1 || cols < 1 || rows * cols != n)) return invalid("rows x cols must be the grid");
+    if (big_image && (out_rows < rows || out_cols < cols || out_rows > 65535)) return invalid("upscale only: out >= in");
+    rc = enqueue_ingest(h, datagrams, stride_bytes);
+    if (rc != AWPU_OK) return rc;
+    rc = ensure_power(h, (size_t) n);
+    if (rc != AWPU_OK) return rc;
+    rc = launch(h, h->d_ring + h->ring_pos, 1, h->d_power, h->stream, kRing);
+    if (rc != AWPU_OK) return rc;
+    if (power) AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_power, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (image || big_image) {
+        const size_t channels = d_colormap ? 3 : 1;
+        const size_t need = sizeof(float) + (size_t) n + (big_image ? (size_t) out_rows * out_cols * channels : 0);
+        if (h->display_cap < need) {
+            dev_free(h->d_display);
+            h->display_cap = 0;
+            AWPU_HIP_TRY(hipMalloc(&h->d_display, need));
+            h->display_cap = need;
+        }
+        float *d_peak = reinterpret_cast<float *>(h->d_display);
+        uint8_t *d_small = h->d_display + sizeof(float), *d_big = d_small + n;
+        AWPU_HIP_TRY(awpu::launch_heatmap(h->d_power, n, 1, d_peak, false, d_small, h->stream));
+        if (image) AWPU_HIP_TRY(hipMemcpyAsync(image, d_small, (size_t) n, hipMemcpyDeviceToHost, h->stream));
+        if (big_image) {
+            rc = awpu_hip_upscale_u8_device(h, d_small, rows, cols, 1, d_colormap, d_big, out_rows, out_cols, h->stream);
+            if (rc != AWPU_OK) return rc;
+            AWPU_HIP_TRY(hipMemcpyAsync(big_image, d_big, (size_t) out_rows * out_cols * channels, hipMemcpyDeviceToHost,
+                                        h->stream));
+        }
+    }
     AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
     return AWPU_OK;
 }
@@ -840,12 +905,8 @@ int awpu_hip_process_ring(awpu_hip_t *h, float *power) {
         return AWPU_ERR_STATE;
     }
     const size_t need_power = (size_t) h->cfg.pixel_count;
-    if (h->power_cap < need_power) {
-        dev_free(h->d_power);
-        h->power_cap = 0;
-        AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
-        h->power_cap = need_power;
-    }
+    rc = ensure_power(h, need_power);
+    if (rc != AWPU_OK) return rc;
     rc = launch(h, h->d_ring + h->ring_pos, 1, h->d_power, h->stream, kRing);
     if (rc != AWPU_OK) return rc;
     AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_power, need_power * sizeof(float), hipMemcpyDeviceToHost, h->stream));

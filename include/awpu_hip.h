@@ -215,6 +215,17 @@ int awpu_hip_resize_linear_u8(const uint8_t *pix, int32_t rows, int32_t cols, ui
  * memory (cfg.hist must be AWPU_HIST, cfg.n_streams <= 256).  The ring starts zeroed. */
 int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes);
 
+/* One display step of the live path in one call and one wait -- what the reference spreads over
+ * Pipeline::receive_exposure (src/fpga/pipeline.cpp:260-297), MIMOWorker::update (src/dsp/mimo.cpp:97-151),
+ * populateHeatmap (mimo.cpp:61-95) and cv::resize in AWProcessingUnit::draw (aw_processing_unit.cpp:252):
+ * ingest the block, sweep the ring's new snapshot, scale to 8 bits, upscale, and bring back what the
+ * caller asks for.  Every output is a host buffer and may be NULL: power [n_pixels], image [rows*cols],
+ * big_image [out_rows*out_cols] (x3 through d_colormap[256][3], device memory, when that is not NULL).
+ * Needs the whole grid on this handle (pixel_count == n_pixels) and rows*cols == n_pixels. */
+int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes, float *power, int32_t rows,
+                        int32_t cols, uint8_t *image, int32_t out_rows, int32_t out_cols, const uint8_t *d_colormap,
+                        uint8_t *big_image);
+
 /* the body of MIMOWorker::update (src/dsp/mimo.cpp:97-151) on the snapshot the ring currently holds
  * (oldest..newest, what Streams::read_stream would return for every stream): power [pixel_count]. */
 int awpu_hip_process_ring(awpu_hip_t *h, float *power);

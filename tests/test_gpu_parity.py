@@ -589,3 +589,30 @@ def test_1024_frames_in_flight(pkg, oracle):
     # ... and agrees with the small-batch call (a different kernel shape: other summation order)
     few, _ = run_engine(pkg, frames[:8], off, frac)
     assert util.power_rel_err(power[:8], few) < 2e-6
+
+
+def test_live_block_equals_the_separate_steps(pkg, oracle):
+    """awpu_hip_live_block = ingest_block + process_ring + populateHeatmap + cv::resize in one call: same
+    power bits, same images as the separate entry points (and therefore as the restatements)."""
+    import torch
+
+    rng = np.random.default_rng(55)
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 16, 16)
+    blocks = [make_datagrams(rng.integers(-(1 << 23), 1 << 23, (256, 256), dtype=np.int32), counter0=256 * b) for b in range(6)]
+    lut = torch.from_numpy(rng.integers(0, 256, (256, 3), dtype=np.uint8)).to("cuda:0")
+    with pkg.Engine(n_pixels=256) as one, pkg.Engine(n_pixels=256) as sep:
+        for eng in (one, sep):
+            eng.set_delay_table(off, frac)
+            eng.set_active_mics(None)
+        for b, wire in enumerate(blocks):
+            power, image, big = one.live_block(wire, 16, 16, 64, 48)
+            sep.ingest_block(wire)
+            want_power = sep.process_ring()
+            assert np.array_equal(power, want_power), b
+            assert np.array_equal(image.ravel(), oracle.heatmap_u8(want_power)), b
+            assert np.array_equal(big, oracle.resize_linear_u8(image, 64, 48)), b
+        _, image, rgb = one.live_block(blocks[0], 16, 16, 32, 32, d_colormap_ptr=lut.data_ptr(), want_power=False)
+        assert np.array_equal(rgb, lut.cpu().numpy()[oracle.resize_linear_u8(image, 32, 32)])
+        with pytest.raises(pkg.AwpuError):
+            one.live_block(blocks[0], 8, 16)  # rows x cols is not the grid

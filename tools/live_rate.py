@@ -38,3 +38,9 @@ for name in sys.argv[1:] or ["c1", "headline"]:
         dt = (time.perf_counter() - t0) / n
         print(f"{spec.name}: ingest + sweep + readback {dt * 1e3:.3f} ms per block -> {1 / dt:.0f} blocks/s "
               f"= {1 / dt / (48828 / 256):.0f} x real time")
+        t0 = time.perf_counter()
+        for _ in range(n):  # the whole display step in one call: + 8-bit heatmap + upscale to 1024 x 1024, images read back
+            eng.live_block(wire, spec.res, spec.res, 1024, 1024, want_power=False)
+        dt = (time.perf_counter() - t0) / n
+        print(f"{spec.name}: live_block (block in, {spec.res}x{spec.res} and 1024x1024 images out) {dt * 1e3:.3f} ms per block "
+              f"-> {1 / dt:.0f} blocks/s")
