@@ -269,7 +269,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
         for (int r = wave; r < rows; r += 2 * NW) {
             const float *src[2];
             float *dst[2];
-            int valid = wr;
+            int valid[2];  // floats of each row that lie inside the history (the shifted copy has one less)
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int rr = min(r + u * NW, rows - 1);  // a duplicate row rewrites the same bytes
@@ -280,9 +280,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
                 const int first = a.wstart + q;
                 src[u] = a.frames + ((size_t) fb * a.n_streams + index[m0 + j]) * a.hist + first;
                 dst[u] = lds + b * (FS / 4) + (j * 2 + q) * wr;
-                valid = min(valid, a.hist - first);
+                valid[u] = min(wr, a.hist - first);
             }
-            if (valid == wr) {  // the whole row lies inside the history: no per-element guards
+            if (valid[0] == wr && valid[1] == wr) {  // both rows lie inside the history: no per-element guards
                 for (int t0 = 0; t0 < wr; t0 += 512) {
                     f4 v[2][2];
 #pragma unroll
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
             } else {
 #pragma unroll
                 for (int u = 0; u < 2; u++)
-                    for (int t = lane; t < wr; t += 64) dst[u][t] = t < valid ? src[u][t] : 0.0f;
+                    for (int t = lane; t < wr; t += 64) dst[u][t] = t < valid[u] ? src[u][t] : 0.0f;
             }
         }
         __syncthreads();

@@ -16,13 +16,16 @@ import util  # noqa: E402
 from oracle import oracle_py  # noqa: E402
 
 pkg = importlib.import_module("beamforming-lk_amd")
+import os  # noqa: E402
+
+MATH = pkg.MATH_F32_EXACT if os.environ.get("AWPU_TEST_MATH") == "exact" else pkg.MATH_F32_FAST
 
 
 def main(seed: int, cases: int) -> int:
     rng = np.random.default_rng(seed)
     worst = 0.0
     for case in range(cases):
-        n_streams = int(rng.choice([64, 128, 192, 256]))
+        n_streams = int(rng.choice([64, 128, 192, 256, 512]))
         lut_stride = n_streams + int(rng.choice([0, 0, 7]))
         hist = int(rng.choice([600, 777, 1024]))
         P = int(rng.choice([1, 5, 63, 64, 65, 130, 257]))
@@ -35,7 +38,7 @@ def main(seed: int, cases: int) -> int:
         frac[rng.uniform(size=frac.shape) < 0.05] = 0.0
         index = rng.permutation(n_streams)[:usable].astype(np.int32)
         X = util.hash_frames(n_streams, hist, seed=1000 + case, batch=batch)
-        eng = pkg.Engine(n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch)
+        eng = pkg.Engine(n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch, math=MATH)
         with eng:
             eng.set_delay_table(off, frac)
             eng.set_active_mics(index)

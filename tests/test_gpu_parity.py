@@ -172,6 +172,20 @@ def test_extreme_offsets_and_fractions(pkg, oracle, math):
     power, st = run_engine(pkg, X, off, frac, math=math)
     assert st.window == hist
     assert util.power_rel_err(power, oracle.das_f32(X, off, frac)) < util.POWER_RTOL
+    # the same with a ragged mic list and a history that is not a multiple of 4 (regression: the guarded
+    # staging of the last, odd group of rows used to clip the unshifted copy to the shifted copy's length,
+    # losing the newest sample for entries at the largest legal offset)
+    hist = 777
+    off = rng.integers(0, hist - 256, size=(P, M)).astype(np.int32)
+    off[1, :] = hist - 257
+    off[5, ::3] = hist - 257
+    index = np.array([s for s in range(M) if s not in (7, 30, 55)], np.int32)
+    frames = util.hash_frames(M, hist, seed=78, batch=3)
+    for batch in (1, 3):
+        power, st = run_engine(pkg, frames[:batch], off, frac, index=index, math=math)
+        assert st.window == hist
+        want = np.stack([oracle.das_f32(f, off, frac, index) for f in frames[:batch]])
+        assert util.power_rel_err(power, want) < util.POWER_RTOL, batch
 
 
 @pytest.mark.parametrize("math", MATHS)
