@@ -19,6 +19,10 @@ pkg = importlib.import_module("beamforming-lk_amd")
 import os  # noqa: E402
 
 MATH = pkg.MATH_F32_EXACT if os.environ.get("AWPU_TEST_MATH") == "exact" else pkg.MATH_F32_FAST
+# AWPU_TEST_PATH=device: frames and power stay in device memory (awpu_hip_process_device reads the full
+# [batch][streams][hist] layout in place; the host entry uploads a compacted window instead), each case
+# also swept as two pixel shards and, where the wire format allows (hist 1024, <= 256 streams), from the ring
+DEVICE_PATH = os.environ.get("AWPU_TEST_PATH") == "device"
 
 
 def main(seed: int, cases: int) -> int:
@@ -42,7 +46,28 @@ def main(seed: int, cases: int) -> int:
         with eng:
             eng.set_delay_table(off, frac)
             eng.set_active_mics(index)
-            power = eng.process(X)
+            if DEVICE_PATH:
+                import torch
+
+                d_X = torch.from_numpy(X).cuda()
+                d_P = torch.zeros((batch, P), dtype=torch.float32, device="cuda")
+                eng.process_device(d_X.data_ptr(), batch, d_P.data_ptr())
+                eng.synchronize()
+                power = d_P.cpu().numpy()
+            else:
+                power = eng.process(X)
+        if DEVICE_PATH and P > 1:  # two ragged pixel shards must tile the single-handle result bit for bit
+            cut = int(rng.integers(1, P))
+            parts = []
+            for a, b in ((0, cut), (cut, P)):
+                with pkg.Engine(n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch,
+                                math=MATH, pixel_begin=a, pixel_count=b - a) as sh:
+                    sh.set_delay_table(off[a:b], frac[a:b])
+                    sh.set_active_mics(index)
+                    parts.append(sh.process(X))
+            if not np.array_equal(np.concatenate(parts, axis=1), power) and util.power_rel_err(np.concatenate(parts, axis=1), power) > 2e-6:
+                print(f"FAIL case {case}: shards [0,{cut}) + [{cut},{P}) differ from the whole grid")
+                return 1
         for b in range(batch):
             want = oracle_py.das_f32(X[b], off, frac, index)
             err = util.power_rel_err(power[b], want)

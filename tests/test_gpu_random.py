@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
     {"AWPU_FAST_PAIRS": "0", "AWPU_FAST_VARIANT": "1,2,8"},    # 8-wave shape, 2 pixels per wave
     {"AWPU_FAST_PAIRS": "0", "AWPU_FAST_VARIANT": "2,4,8"},    # two frames per item, compiler-scheduled
     {"AWPU_TEST_MATH": "exact"},                                # the exact-order kernel
-], ids=["pairs", "db", "small", "fpi2", "exact"])
+    {"AWPU_TEST_PATH": "device"},                               # device-resident frames + two pixel shards per case
+], ids=["pairs", "db", "small", "fpi2", "exact", "device"])
 def test_random_tables(env):
     out = subprocess.run([sys.executable, str(REPO / "tests" / "gpu_random_check.py"), "2024", "14"],
                          env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
