@@ -23,6 +23,11 @@ MATH = pkg.MATH_F32_EXACT if os.environ.get("AWPU_TEST_MATH") == "exact" else pk
 # [batch][streams][hist] layout in place; the host entry uploads a compacted window instead), each case
 # also swept as two pixel shards and, where the wire format allows (hist 1024, <= 256 streams), from the ring
 DEVICE_PATH = os.environ.get("AWPU_TEST_PATH") == "device"
+# AWPU_TEST_INTERP=fir8: the 8-tap table variant of delay() (reads 6 samples further); AWPU_TEST_REUSE=1:
+# every case re-targets ONE handle per geometry (new table, new mic list, gains on and off) instead of a
+# fresh handle, so stale device tables or caches would show
+FIR8 = os.environ.get("AWPU_TEST_INTERP") == "fir8"
+REUSE = os.environ.get("AWPU_TEST_REUSE") == "1"
 
 
 def main(seed: int, cases: int) -> int:
@@ -35,13 +40,50 @@ def main(seed: int, cases: int) -> int:
         P = int(rng.choice([1, 5, 63, 64, 65, 130, 257]))
         batch = int(rng.integers(1, 8))
         usable = int(rng.integers(1, n_streams + 1))
-        spread = int(rng.choice([0, 3, 40, 120, hist - 257]))  # window width control
-        base = int(rng.integers(0, hist - 257 - spread + 1))
+        reach = 257 + (6 if FIR8 else 0)
+        spread = int(rng.choice([0, 3, 40, 120, hist - reach]))  # window width control
+        base = int(rng.integers(0, hist - reach - spread + 1))
         off = rng.integers(base, base + spread + 1, size=(P, lut_stride)).astype(np.int32)
         frac = rng.uniform(0, 1, size=(P, lut_stride)).astype(np.float32)
         frac[rng.uniform(size=frac.shape) < 0.05] = 0.0
         index = rng.permutation(n_streams)[:usable].astype(np.int32)
         X = util.hash_frames(n_streams, hist, seed=1000 + case, batch=batch)
+        if FIR8:
+            table = util.synthetic_fir_table()
+            with pkg.Engine(n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch,
+                            interp=pkg.binding.INTERP_FIR8) as eng:
+                eng.set_delay_table(off, frac)
+                eng.set_active_mics(index)
+                eng.set_fir_table(table)
+                power = eng.process(X)
+            for b in range(batch):
+                err = util.power_rel_err(power[b], oracle_py.das_fir8_f32(X[b], off, frac, table, index))
+                worst = max(worst, err)
+                if not err < util.POWER_RTOL:
+                    print(f"FAIL case {case} (fir8): streams {n_streams} hist {hist} P {P} batch {batch} usable {usable} "
+                          f"window {spread + reach} frame {b}: rel err {err:.3e}")
+                    return 1
+            continue
+        if REUSE:
+            with pkg.Engine(n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch, math=MATH) as eng:
+                for turn in range(3):  # same handle: other table, other mics, gains on / off
+                    off_t = rng.integers(base, base + spread + 1, size=(P, lut_stride)).astype(np.int32)
+                    frac_t = rng.uniform(0, 1, size=(P, lut_stride)).astype(np.float32)
+                    index_t = rng.permutation(n_streams)[: int(rng.integers(1, n_streams + 1))].astype(np.int32)
+                    gains = rng.uniform(0.5, 2.0, n_streams).astype(np.float32) if turn == 1 else None
+                    eng.set_delay_table(off_t, frac_t)
+                    eng.set_active_mics(index_t)
+                    eng.set_mic_gains(gains)
+                    power = eng.process(X)
+                    for b in range(batch):
+                        Xb = X[b] * gains[:, None] if gains is not None else X[b]
+                        err = util.power_rel_err(power[b], oracle_py.das_f32(Xb, off_t, frac_t, index_t))
+                        worst = max(worst, err)
+                        if not err < util.POWER_RTOL:
+                            print(f"FAIL case {case} turn {turn} (reuse): streams {n_streams} hist {hist} P {P} batch {batch} "
+                                  f"usable {index_t.size} frame {b}: rel err {err:.3e}")
+                            return 1
+            continue
         eng = pkg.Engine(n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch, math=MATH)
         with eng:
             eng.set_delay_table(off, frac)

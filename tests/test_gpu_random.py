@@ -18,7 +18,9 @@ pytestmark = pytest.mark.gpu
     {"AWPU_FAST_PAIRS": "0", "AWPU_FAST_VARIANT": "2,4,8"},    # two frames per item, compiler-scheduled
     {"AWPU_TEST_MATH": "exact"},                                # the exact-order kernel
     {"AWPU_TEST_PATH": "device"},                               # device-resident frames + two pixel shards per case
-], ids=["pairs", "db", "small", "fpi2", "exact", "device"])
+    {"AWPU_TEST_INTERP": "fir8"},                               # the 8-tap variant of delay()
+    {"AWPU_TEST_REUSE": "1"},                                   # one handle re-targeted: tables, mic lists, gains
+], ids=["pairs", "db", "small", "fpi2", "exact", "device", "fir8", "reuse"])
 def test_random_tables(env):
     out = subprocess.run([sys.executable, str(REPO / "tests" / "gpu_random_check.py"), "2024", "14"],
                          env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
