@@ -630,3 +630,32 @@ def test_live_block_equals_the_separate_steps(pkg, oracle):
         assert np.array_equal(rgb, lut.cpu().numpy()[oracle.resize_linear_u8(image, 32, 32)])
         with pytest.raises(pkg.AwpuError):
             one.live_block(blocks[0], 8, 16)  # rows x cols is not the grid
+
+
+@pytest.mark.parametrize("n_streams,usable,P", [(128, 128, 100), (256, 256, 4096), (256, 201, 333), (192, 64, 65)])
+def test_ring_sweep_wider_arrays(pkg, oracle, n_streams, usable, P):
+    """The device ring with 2..4 arrays on the wire (the datagram carries up to 256 sensors), ragged mic
+    lists and grids on both sides of the kernel-shape thresholds, random tables that reach both ends of the
+    history: snapshot bit-exact after every block (ring wrap-around included: 9 blocks), sweep within
+    tolerance, second-array calibration equal to the scalar loop."""
+    rng = np.random.default_rng(n_streams + P)
+    off = rng.integers(0, 1024 - 256, size=(P, n_streams)).astype(np.int32)
+    off[0, :] = 1024 - 257
+    off[-1, :] = 0
+    frac = rng.uniform(0, 1, size=(P, n_streams)).astype(np.float32)
+    index = np.sort(rng.permutation(n_streams)[:usable]).astype(np.int32)
+    ring = np.zeros((n_streams, 1024), np.float32)
+    with pkg.Engine(n_pixels=P, n_streams=n_streams) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(index)
+        for b in range(9):
+            stream = rng.integers(-(1 << 23), 1 << 23, size=(256, 256), dtype=np.int32)
+            eng.ingest_block(make_datagrams(stream, counter0=256 * b, n_arrays=n_streams // 64))
+            ring = np.concatenate([ring[:, 256:], oracle.unpack_exposure(stream, n_streams)], axis=1)
+            if b in (0, 3, 4, 8):
+                assert np.array_equal(eng.ring_snapshot(), ring), b
+                power = eng.process_ring()
+                assert util.power_rel_err(power, oracle.das_f32(ring, off, frac, index)) < util.POWER_RTOL, b
+        got = eng.calibrate_ring(array=1)
+        want = oracle.calibrate(ring[64:128])
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
