@@ -776,15 +776,25 @@ bool fast_plan(int window, int usable, int fpi, int image_bytes, FastPlan *plan)
     return true;
 }
 
+// Kernels that ask for more than 64 KiB of dynamic LDS need the limit raised once per function AND
+// per device (a process may hold handles on several GPUs); `done` is the caller's per-function flags.
+static hipError_t allow_lds(const void *kernel, int bytes, bool (&done)[64]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+    return hipSuccess;
+}
+
 template <int NW, int PPW, int FPI, int WPS>
 static hipError_t launch_variant(const FastArgs &a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *) das_fast_kernel<NW, PPW, FPI, WPS>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kFastLdsBytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static bool attr_set[64] = {};
+    if (hipError_t e = allow_lds((const void *) das_fast_kernel<NW, PPW, FPI, WPS>, kFastLdsBytes, attr_set); e != hipSuccess)
+        return e;
     const int pix_per_block = NW * PPW;
     dim3 grid((a.batch + FPI - 1) / FPI, (a.pixel_count + pix_per_block - 1) / pix_per_block);
     if (grid.y > 65535) return hipErrorInvalidValue;
@@ -794,14 +804,10 @@ static hipError_t launch_variant(const FastArgs &a, hipStream_t stream) {
 
 template <int NW, int PPW, int BUF, int WPS, bool DIAG>
 static hipError_t launch_db(const FastArgs &a, hipStream_t stream) {
-    static bool attr_set = false;
+    static bool attr_set[64] = {};
     constexpr int lds_bytes = 2 * BUF + kFastSideBytes;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *) das_fast_db_kernel<NW, PPW, BUF, WPS, DIAG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_lds((const void *) das_fast_db_kernel<NW, PPW, BUF, WPS, DIAG>, lds_bytes, attr_set); e != hipSuccess)
+        return e;
     const int pix_per_block = NW * PPW;
     dim3 grid((a.batch + a.frames_per_wg - 1) / a.frames_per_wg, (a.pixel_count + pix_per_block - 1) / pix_per_block);
     if (grid.y > 65535) return hipErrorInvalidValue;
@@ -837,14 +843,9 @@ hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int
 
 template <int PPW, bool DIAG>
 static hipError_t launch_pair_variant(const PairArgs &a, hipStream_t stream) {
-    static bool attr_set = false;
+    static bool attr_set[64] = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *) das_pair_kernel<PPW, DIAG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_lds((const void *) das_pair_kernel<PPW, DIAG>, lds_bytes, attr_set); e != hipSuccess) return e;
     dim3 grid((a.batch + 1) / 2, (a.pixel_count + 16 * PPW - 1) / (16 * PPW));
     if (a.debug & 256) grid = dim3(grid.y, grid.x);
     if (grid.y > 65535) return hipErrorInvalidValue;
