@@ -668,9 +668,6 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         const int mc4 = (mc + 3) & ~3;
         const int buf = c & 1;
         long long t = DIAG ? __builtin_readcyclecounter() : 0;
-        if (c + 1 < n_chunks && !(a.debug & 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
-        stamp(0, t);
-
         // table entries of the tail pass below: requested now, consumed after the sweep
         struct AddrG {
             unsigned addr;
@@ -683,6 +680,11 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
             te[u] = *(const AddrG *) ((const char *) (tail_row + m0 + min(j, mc4 - 1)) + 4);  // fields addr, g
             if (!tail_lane || j >= mc4) te[u].g = 0.0f;
         }
+        // The refill of the other image goes out AFTER the requests above: hipcc guards the reuse of their
+        // destination registers with s_waitcnt vmcnt(0), which in the other order waited for the DMA just
+        // issued -- every wave idle at the head of every chunk until its pieces had landed.
+        if (c + 1 < n_chunks && !(a.debug & 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
+        stamp(0, t);
         const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
 #pragma unroll
         for (int q = 0; q < PPW; q += 2) {
