@@ -659,3 +659,49 @@ def test_ring_sweep_wider_arrays(pkg, oracle, n_streams, usable, P):
         got = eng.calibrate_ring(array=1)
         want = oracle.calibrate(ring[64:128])
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+
+
+def test_random_display_and_beam_shapes(pkg, oracle):
+    """Randomised sizes through the neighbours of the sweep: device heatmap + upscale against the
+    restatements for odd image shapes and batches, and few-beam sweeps with ragged mic lists, table strides
+    wider than the stream count and offsets at both ends of the history."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(808)
+    with pkg.Engine(n_pixels=64) as eng:
+        for _ in range(12):
+            r, c = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+            R, C_ = r + int(rng.integers(0, 200)), c + int(rng.integers(0, 200))
+            batch = int(rng.integers(1, 5))
+            power = rng.uniform(0, 1e-4, (batch, r * c)).astype(np.float32)
+            power[0, rng.integers(0, r * c)] = 0.0
+            d_power = torch.from_numpy(power).to(dev)
+            d_peak = torch.zeros(batch, dtype=torch.float32, device=dev)
+            d_pix = torch.zeros((batch, r * c), dtype=torch.uint8, device=dev)
+            d_big = torch.zeros((batch, R, C_), dtype=torch.uint8, device=dev)
+            eng.heatmap_device(d_power.data_ptr(), r * c, batch, d_peak.data_ptr(), d_pix.data_ptr())
+            eng.upscale_device(d_pix.data_ptr(), r, c, batch, d_big.data_ptr(), R, C_)
+            eng.synchronize()
+            for b in range(batch):
+                small = oracle.heatmap_u8(power[b])
+                assert np.array_equal(d_pix[b].cpu().numpy(), small), (r, c, b)
+                assert np.array_equal(d_big[b].cpu().numpy(), oracle.resize_linear_u8(small.reshape(r, c), R, C_)), (r, c, R, C_, b)
+    for _ in range(8):
+        n_streams = int(rng.choice([64, 128, 256]))
+        stride = n_streams + int(rng.choice([0, 5]))
+        hist = int(rng.choice([513, 800, 1024]))
+        n_dir = int(rng.integers(1, 130))
+        usable = int(rng.integers(1, n_streams + 1))
+        off = rng.integers(0, hist - 256, size=(n_dir, stride)).astype(np.int32)
+        off[0, :] = hist - 257
+        frac = rng.uniform(0, 1, size=(n_dir, stride)).astype(np.float32)
+        index = rng.permutation(n_streams)[:usable].astype(np.int32)
+        X = util.hash_frames(n_streams, hist, seed=int(rng.integers(1, 1 << 30)))[0]
+        d_X = torch.from_numpy(X).to(dev)
+        with pkg.Engine(n_pixels=4, n_streams=n_streams, lut_stride=stride, hist=hist) as eng:
+            eng.set_active_mics(index)
+            power, beams = eng.beams(off, frac, d_X.data_ptr())
+        want_p, want_b = oracle.particle_beams(X, off, frac, index)
+        assert np.array_equal(beams, want_b), (n_streams, hist, n_dir, usable)
+        assert util.power_rel_err(power, want_p) < 2e-6
