@@ -61,11 +61,18 @@ def cpu_baseline(S, spec, xyz, off, frac, frame, seconds):
             if time.perf_counter() - t0 >= seconds:
                 break
         fps = frames / (time.perf_counter() - t0)
-    return {
+    out = {
         "value": fps, "unit": "frames/s", "cores": 1, "kind": kind,
         "sample": f"{frames} whole frames of the same workload ({spec.name}), 1 thread, "
                   f"{os.cpu_count()} host cores present",
     }
+    if kind == "reference":  # beside it: the same kernel with the pixels dealt to the box's CPU share
+        threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()))
+        fps_mt, frames_mt, _ = oracle_py.ref_bench_mt(frame, off, frac, threads, min_seconds=max(2.0, seconds / 4))
+        out["multi_thread"] = {"value": fps_mt, "unit": "frames/s", "cores": threads,
+                               "sample": f"{frames_mt} whole frames, pixels dealt to {threads} threads (the reference's "
+                                         f"MIMO worker itself is one thread)"}
+    return out
 
 
 def measured_traffic(workload, batch, world):

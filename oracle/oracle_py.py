@@ -94,6 +94,9 @@ def ref(variant: str = "avx2") -> C.CDLL:
         lib.ref_das_bench.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p,
                                       C.c_double, C.POINTER(C.c_int)]
         lib.ref_das_bench.restype = C.c_double
+        lib.ref_das_bench_mt.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p,
+                                         C.c_double, C.c_int, C.POINTER(C.c_int)]
+        lib.ref_das_bench_mt.restype = C.c_double
         _refs[variant] = lib
     return _refs[variant]
 
@@ -244,6 +247,18 @@ def ref_bench(X, off, frac, index=None, min_seconds=1.0):
     fps = ref("avx2").ref_das_bench(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1],
                                     _pi(index), index.size, _p32(power), float(min_seconds), C.byref(done))
     return fps, done.value
+
+
+def ref_bench_mt(X, off, frac, threads, index=None, min_seconds=1.0):
+    """frames/s of the same loop nest with the pixels dealt to `threads` host threads (the reference itself
+    runs one); also returns the power it computed, for a check against the one-thread result."""
+    X, off, frac, index = _sweep_args(X, off, frac, index)
+    P = off.shape[0]
+    power = np.empty(P, np.float32)
+    done = C.c_int(0)
+    fps = ref("avx2").ref_das_bench_mt(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index),
+                                       index.size, _p32(power), float(min_seconds), int(threads), C.byref(done))
+    return fps, done.value, power
 
 
 def heatmap_u8(power) -> np.ndarray:

@@ -14,6 +14,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #ifndef N_SAMPLES
 #define N_SAMPLES 256
@@ -57,6 +59,34 @@ void ref_das(const float *X, int hist, const int32_t *off, const float *frac, in
         p /= static_cast<float>(N_SAMPLES * count);
         power[m] = p;
     }
+}
+
+/* The same loop nest with the pixels dealt to `threads` host threads (contiguous slabs): NOT something the
+ * reference does -- its MIMO worker is one thread (src/dsp/mimo.cpp:12) -- but the honest "what could the
+ * host do" figure next to the one-thread number.  Whole frames until `min_seconds` have passed. */
+double ref_das_bench_mt(const float *X, int hist, const int32_t *off, const float *frac, int P, int lut_stride,
+                        const int32_t *index, int usable, float *power, double min_seconds, int threads,
+                        int *frames_done) {
+    using clk = std::chrono::steady_clock;
+    if (threads < 1) threads = 1;
+    const auto t0 = clk::now();
+    int frames = 0;
+    double el = 0.0;
+    do {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) {
+            const int a = (int) ((long long) P * t / threads), b = (int) ((long long) P * (t + 1) / threads);
+            pool.emplace_back([=] {
+                ref_das(X, hist, off + (size_t) a * lut_stride, frac + (size_t) a * lut_stride, b - a, lut_stride, index,
+                        usable, power + a, nullptr);
+            });
+        }
+        for (auto &th : pool) th.join();
+        frames++;
+        el = std::chrono::duration<double>(clk::now() - t0).count();
+    } while (el < min_seconds);
+    if (frames_done) *frames_done = frames;
+    return frames / el;
 }
 
 /* src/dsp/particle.cpp:51-82 / :88-103 (Particle::beam, Particle::das) around the reference delay() */
