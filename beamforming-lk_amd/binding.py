@@ -37,7 +37,8 @@ class Cfg(C.Structure):
         ("max_batch", C.c_int32),
         ("pixel_begin", C.c_int32),
         ("pixel_count", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("grid_columns", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -236,11 +237,13 @@ class Engine:
 
     def __init__(self, n_pixels: int, n_streams: int = ELEMENTS, lut_stride: Optional[int] = None,
                  hist: int = HIST, math: int = MATH_F32_FAST, interp: int = INTERP_LERP,
-                 max_batch: int = 1, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0):
+                 max_batch: int = 1, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0,
+                 grid_columns: int = 0):
         lib = load()
         cfg = Cfg()
         lib.awpu_hip_default_cfg(C.byref(cfg))
         cfg.device = device
+        cfg.grid_columns = grid_columns
         cfg.n_streams = n_streams
         cfg.hist = hist
         cfg.n_pixels = n_pixels

@@ -89,6 +89,7 @@ struct awpu_hip {
     float *d_power = nullptr;
     size_t frames_cap = 0, power_cap = 0;  // in floats
     int wstart = 0, window = 0, tau_max = 0;
+    int pair_cols = 0;  // frame-pair sweep: > 0 = waves take vertically adjacent pixels (grid row length), 0 = consecutive
 
     awpu_hip_stats stats{};
 
@@ -220,6 +221,32 @@ int prepare(awpu_hip *h) {
             return invalid("delay window does not fit the LDS budget");
     }
 
+    // Pairing of pixels inside a wave of the frame-pair sweep: the shared-read block saves a mic's LDS reads
+    // when the two pixels' integer delays coincide.  With the grid's row length known, compare consecutive
+    // pixels against vertically adjacent ones on a sample of the table and take the better.
+    h->pair_cols = 0;
+    {
+        const int cols = c.grid_columns;
+        if (cols > 0 && P % cols == 0 && c.pixel_begin % cols == 0 && P / cols >= 2) {
+            long same_h = 0, same_v = 0, seen = 0;
+            const int step = std::max(1, (P - cols) / 4096);
+            for (int p = 0; p + cols < P; p += step) {
+                if ((p % cols) + 1 >= cols) continue;
+                const int32_t *o0 = &h->off[(size_t) p * c.lut_stride];
+                const int32_t *oh = &h->off[(size_t) (p + 1) * c.lut_stride];
+                const int32_t *ov = &h->off[(size_t) (p + cols) * c.lut_stride];
+                for (int s = 0; s < U; s++) {
+                    const int id = h->index[s];
+                    same_h += o0[id] == oh[id];
+                    same_v += o0[id] == ov[id];
+                    seen++;
+                }
+            }
+            if (seen > 0 && same_v > same_h) h->pair_cols = cols;
+            if (const char *e = std::getenv("AWPU_FAST_PAIRCOLS")) h->pair_cols = std::atoi(e) ? cols : 0;  // tests force either
+        }
+    }
+
     auto &st = h->stats;
     st.tau_max = h->tau_max;
     st.window = h->window;
@@ -249,7 +276,8 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
     const awpu::FastPlan &plan = lut.plan;
     // rows for whole pixel tiles (the kernels sweep every pixel slot of a workgroup; slots past the
     // grid get null rows) + spare groups: the kernels prefetch entries past the row they sweep
-    const int P_pad = (P + 127) / 128 * 128;
+    // (with vertical pixel pairs the partner of a pixel in the last row lies one grid row past the table)
+    const int P_pad = (P + (pairs ? h->pair_cols : 0) + 127) / 128 * 128;
     const size_t n = (size_t) P_pad * plan.usable_pad + 16;
     std::vector<awpu::FastEntry> packed(n, awpu::FastEntry{0.0f, 0u, 0.0f, 0u});
     for (int p = 0; p < P; p++) {
@@ -351,7 +379,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         // ---- frame-pair shape: batches on grids that fill the chip (AWPU_FAST_PAIRS=0/1 overrides)
         static const int env_pairs = std::getenv("AWPU_FAST_PAIRS") ? std::atoi(std::getenv("AWPU_FAST_PAIRS")) : -1;
         static const int debug_flags = std::getenv("AWPU_FAST_DEBUG") ? std::atoi(std::getenv("AWPU_FAST_DEBUG")) : 0;
-        const long pair_wgs = ((long) h->cfg.pixel_count + 63) / 64 * ((batch + 1) / 2);
+        const long pair_wgs = (long) awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols) * ((batch + 1) / 2);
         if (layout != kRing && batch >= 2 && env_pairs != 0 && (pair_wgs >= 256 || env_pairs == 1)) {
             const awpu_hip::FastLut *plut = nullptr;
             if (build_fast_lut(h, 2, -1, &plut) == AWPU_OK) {
@@ -373,6 +401,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
                 pa.wp = pp.wr;
                 pa.chunk = pp.chunk;
                 pa.batch = batch;
+                pa.cols = h->pair_cols;
                 pa.debug = debug_flags;
                 pa.debug_out = nullptr;
                 if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
@@ -380,7 +409,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
                                                      h->usable(), pp.wr, batch, h->d_pack, s));
                 if (debug_flags & 16) {  // diagnostics: per-wave cycle sums of this launch to stderr
                     static unsigned long long *d_dbg = nullptr;
-                    const size_t n_waves = (size_t) 16 * ((batch + 1) / 2) * ((h->cfg.pixel_count + 63) / 64);
+                    const size_t n_waves = (size_t) 16 * ((batch + 1) / 2) * awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols);
                     if (!d_dbg) AWPU_HIP_TRY(hipMalloc(&d_dbg, n_waves * 12 * sizeof(unsigned long long)));
                     pa.debug_out = d_dbg;
                     AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));

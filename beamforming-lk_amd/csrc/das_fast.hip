@@ -603,7 +603,9 @@ __device__ __forceinline__ const void *uniform_ptr(const void *p) {
     return (const void *) (((unsigned long long) hi << 32) | lo);
 }
 
-template <int PPW, bool DIAG>
+// SHARE: the two pixels of a block are swept in mic-major order and share a mic's sample reads whenever
+// their table entries carry the same LDS address (sweep_duo_shared); same sums bit for bit.
+template <int PPW, bool DIAG, bool SHARE>
 __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
     static_assert(PPW % 2 == 0 && PPW <= 8, "pixels go through the asm blocks two at a time");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -616,7 +618,33 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
     // debug bit 256 swaps the roles (tiles of a pair consecutive: they share the pair's samples)
     const int pair = (a.debug & 256) ? blockIdx.y : blockIdx.x;
     const int tile = (a.debug & 256) ? blockIdx.x : blockIdx.y;
-    const int pix0 = (tile * NW + wave) * PPW;
+    // Which pixels this wave sweeps.  Neighbouring pixels in a grid column usually differ less in delay than
+    // neighbours in a row (arrays are wider than tall), and the shared-read block profits from pixels whose
+    // integer delays coincide, so when the grid's row length is known (a.cols > 0) a workgroup takes 32
+    // columns x 2 rows and a wave two vertical pairs; otherwise 4 consecutive pixels (two horizontal pairs).
+    int pix[PPW];   // pixel of slot q (slots 2j, 2j+1 form a pair: the two pixels of one asm block)
+    bool live[PPW];  // false: outside the grid, swept on another pixel's (or a null) row and not stored
+    int pair_rows;  // table rows between the two pixels of a pair
+    if (a.cols > 0) {
+        static_assert(PPW == 4, "vertical pairing: 2 columns x 2 rows per wave");
+        const int tiles_per_rowpair = (a.cols + 2 * NW - 1) / (2 * NW);
+        const int row2 = tile / tiles_per_rowpair, col0 = (tile - row2 * tiles_per_rowpair) * 2 * NW + 2 * wave;
+        const int rows = a.pixel_count / a.cols;
+#pragma unroll
+        for (int q = 0; q < PPW; q++) {
+            const int row = 2 * row2 + (q & 1), col = col0 + (q >> 1);
+            live[q] = row < rows && col < a.cols;
+            pix[q] = min(2 * row2 * a.cols + col, a.pixel_count - 1) + (q & 1) * a.cols;  // B's row = A's + cols rows
+        }
+        pair_rows = a.cols;
+    } else {
+#pragma unroll
+        for (int q = 0; q < PPW; q++) {
+            pix[q] = (tile * NW + wave) * PPW + q;
+            live[q] = pix[q] < a.pixel_count;
+        }
+        pair_rows = 1;
+    }
     const size_t row_floats = (size_t) a.wp * 2;
     const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
 
@@ -627,8 +655,16 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
 #pragma unroll
         for (int k = 0; k < 8; k++) acc[pp][k] = f2{0.0f, 0.0f};
     const int tail_pp = lane >> 3;
-    const bool tail_lane = tail_pp < PPW && pix0 + tail_pp < a.pixel_count;
-    const FastEntry *tail_row = a.lut + (size_t) (pix0 + (tail_lane ? tail_pp : 0)) * a.usable_pad;
+    int tail_pix = pix[0];
+    bool tail_lane = false;
+#pragma unroll
+    for (int q = 0; q < PPW; q++)
+        if (tail_pp == q) {
+            tail_pix = pix[q];
+            tail_lane = live[q];
+        }
+    if (!tail_lane) tail_pix = pix[0];
+    const FastEntry *tail_row = a.lut + (size_t) tail_pix * a.usable_pad;
 
     // one chunk = rows m0 .. m0+mc of this pair, contiguous in HBM and in the LDS image
     auto dma_chunk = [&](int m0, int mc, int buf) {
@@ -660,7 +696,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
             t = n;
         }
     };
-    const int stride = a.usable_pad * (int) sizeof(FastEntry);
+    const int stride = pair_rows * a.usable_pad * (int) sizeof(FastEntry);  // from pixel A's row to pixel B's
     const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
     for (int c = 0; c < n_chunks; c++) {
         const int m0 = c * a.chunk;
@@ -688,15 +724,17 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
 #pragma unroll
         for (int q = 0; q < PPW; q += 2) {
-            const void *row = uniform_ptr(a.lut + (size_t) (pix0 + q) * a.usable_pad + m0);
+            const void *row = uniform_ptr(a.lut + (size_t) pix[q] * a.usable_pad + m0);
             const int ng = __builtin_amdgcn_readfirstlane(mc4 >> 2);
             if constexpr (DIAG) {
                 unsigned dw = 0, da = 0;
-                sweep_duo_pairs_stamped(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank, dw, da);
+                if constexpr (SHARE) sweep_duo_shared_stamped(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank, dw, da);
+                else sweep_duo_pairs_stamped(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank, dw, da);
                 t_wait += dw;
                 t_all += da;
             } else {
-                sweep_duo_pairs(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
+                if constexpr (SHARE) sweep_duo_shared(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
+                else sweep_duo_pairs(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
             }
         }
         stamp(1, t);
@@ -743,12 +781,12 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
     const float norm = (float) (kSamples * a.usable);
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++) {
-        const int p = pix0 + pp;
+        const int p = pix[pp];
         f2 tl;
         tl.x = __shfl(tail.x, pp * 8);
         tl.y = __shfl(tail.y, pp * 8);
         const f2 sum = finish_pixel_pair(acc[pp], tl, lane);
-        if (lane == 0 && p < a.pixel_count) {
+        if (lane == 0 && live[pp]) {
             a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
             if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
         }
@@ -843,21 +881,23 @@ hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int
     return hipGetLastError();
 }
 
-template <int PPW, bool DIAG>
+template <int PPW, bool DIAG, bool SHARE>
 static hipError_t launch_pair_variant(const PairArgs &a, hipStream_t stream) {
     static bool attr_set[64] = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
-    if (hipError_t e = allow_lds((const void *) das_pair_kernel<PPW, DIAG>, lds_bytes, attr_set); e != hipSuccess) return e;
-    dim3 grid((a.batch + 1) / 2, (a.pixel_count + 16 * PPW - 1) / (16 * PPW));
+    if (hipError_t e = allow_lds((const void *) das_pair_kernel<PPW, DIAG, SHARE>, lds_bytes, attr_set); e != hipSuccess) return e;
+    static_assert(16 * PPW == 64, "pair_tiles() counts 64-pixel tiles");
+    dim3 grid((a.batch + 1) / 2, pair_tiles(a.pixel_count, a.cols));
     if (a.debug & 256) grid = dim3(grid.y, grid.x);
     if (grid.y > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((das_pair_kernel<PPW, DIAG>), grid, dim3(1024), lds_bytes, stream, a);
+    hipLaunchKernelGGL((das_pair_kernel<PPW, DIAG, SHARE>), grid, dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {
-    if (a.debug & 16) return launch_pair_variant<4, true>(a, stream);
-    return launch_pair_variant<4, false>(a, stream);
+    const bool share = (a.debug & 4096) == 0;  // bit 4096: the pixel-major block without read sharing
+    if (a.debug & 16) return share ? launch_pair_variant<4, true, true>(a, stream) : launch_pair_variant<4, true, false>(a, stream);
+    return share ? launch_pair_variant<4, false, true>(a, stream) : launch_pair_variant<4, false, false>(a, stream);
 }
 
 int fast_image_bytes(int nw) { return nw == 24 ? kFastLdsBytesSmall : kFastLdsBytes; }

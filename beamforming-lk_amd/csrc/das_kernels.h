@@ -74,9 +74,14 @@ struct PairArgs {
     const FastEntry *lut;  // [P_pad][usable_pad]; addr = slot * wp * 8 + (off - wstart) * 8
     float *power;          // [batch][pixel_count]
     int32_t usable, usable_pad, pixel_count, wp, chunk, batch;
+    int32_t cols;  // > 0: the grid's row length; a wave then sweeps vertical pixel pairs (pixel_count % cols == 0)
     unsigned long long *debug_out;
     int32_t debug;
 };
+// 64-pixel tiles of the frame-pair sweep: consecutive pixels, or 2 rows x 32 columns when cols > 0
+inline int pair_tiles(int pixel_count, int cols) {
+    return cols > 0 ? ((pixel_count / cols + 1) / 2) * ((cols + 31) / 32) : (pixel_count + 63) / 64;
+}
 bool pair_plan(int window, int usable, FastPlan *plan);
 hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index,
                              int usable, int wp, int batch, float *d_packed, hipStream_t stream);

@@ -23,6 +23,7 @@ MIMOWorkerHip::MIMOWorkerHip(FrameSource *pipeline, const AntennaView &antenna, 
     cfg.n_streams = n_sensors;
     cfg.n_pixels = maxIndex;
     cfg.lut_stride = antenna.n;
+    cfg.grid_columns = columns;  // lets the batched sweep pair vertically adjacent pixels (results unchanged)
     cfg.math = math;
     last_status = awpu_hip_create(&engine, &cfg);
     if (last_status != AWPU_OK) {

@@ -145,7 +145,8 @@ def main():
         hist = ((int(hi.item()) - win_begin + 257 + 3) // 4) * 4 + 4
         off = off - win_begin
     eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, hist=hist, math=math, max_batch=B,
-                     device=local_rank, pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count)
+                     device=local_rank, pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count,
+                     grid_columns=0 if os.environ.get("BENCH_NO_GRID_HINT") else spec.res)
     eng.set_delay_table(off, frac)
     eng.set_active_mics(None)
 
@@ -230,7 +231,7 @@ def main():
         first, _ = sharding.shard_frames(B, world, rank)
         off_all, frac_all = S.delay_table(spec, xyz, 0, spec.res)
         eng2 = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, hist=hist, math=math, max_batch=per,
-                          device=local_rank)
+                          device=local_rank, grid_columns=spec.res)
         eng2.set_delay_table(off_all - win_begin, frac_all)
         eng2.set_active_mics(None)
         mine = tuple(torch.zeros((per, spec.n_mics, hist), dtype=torch.float32, device=dev) for _ in range(2))

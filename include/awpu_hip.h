@@ -83,7 +83,12 @@ typedef struct {
      * to awpu_hip_set_delay_table and the power rows written cover exactly these pixels */
     int32_t pixel_begin;
     int32_t pixel_count; /* 0 = all n_pixels */
-    int32_t reserved[5];
+    /* optional hint: pixels per row of the steering grid (MIMOWorker's `columns`, mimo.cpp:8), 0 = unknown.
+     * Results do not depend on it; the batched sweep uses it to give a wave vertically adjacent pixels,
+     * whose integer delays coincide for most mics (one sample read then serves both).  Ignored unless
+     * pixel_begin and pixel_count are whole rows. */
+    int32_t grid_columns;
+    int32_t reserved[4];
 } awpu_hip_cfg;
 
 typedef struct {

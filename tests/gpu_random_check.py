@@ -38,6 +38,11 @@ def main(seed: int, cases: int) -> int:
         lut_stride = n_streams + int(rng.choice([0, 0, 7]))
         hist = int(rng.choice([600, 777, 1024]))
         P = int(rng.choice([1, 5, 63, 64, 65, 130, 257]))
+        grid_columns = 0
+        if os.environ.get("AWPU_TEST_GRID") == "1":  # a real rows x cols grid, row length passed as the hint
+            cols = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 100]))
+            P = cols * int(rng.choice([1, 2, 3, 5, 8]))
+            grid_columns = cols
         batch = int(rng.integers(1, 8))
         usable = int(rng.integers(1, n_streams + 1))
         reach = 257 + (6 if FIR8 else 0)
@@ -84,7 +89,8 @@ def main(seed: int, cases: int) -> int:
                                   f"usable {index_t.size} frame {b}: rel err {err:.3e}")
                             return 1
             continue
-        eng = pkg.Engine(n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch, math=MATH)
+        eng = pkg.Engine(n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch, math=MATH,
+                         grid_columns=grid_columns)
         with eng:
             eng.set_delay_table(off, frac)
             eng.set_active_mics(index)

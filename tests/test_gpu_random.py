@@ -20,7 +20,9 @@ pytestmark = pytest.mark.gpu
     {"AWPU_TEST_PATH": "device"},                               # device-resident frames + two pixel shards per case
     {"AWPU_TEST_INTERP": "fir8"},                               # the 8-tap variant of delay()
     {"AWPU_TEST_REUSE": "1"},                                   # one handle re-targeted: tables, mic lists, gains
-], ids=["pairs", "db", "small", "fpi2", "exact", "device", "fir8", "reuse"])
+    {"AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_FAST_PAIRCOLS": "1"},  # frame pairs, vertical pixel pairs
+    {"AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_FAST_DEBUG": "4096"},   # the block without read sharing
+], ids=["pairs", "db", "small", "fpi2", "exact", "device", "fir8", "reuse", "pairs_vertical", "pairs_unshared"])
 def test_random_tables(env):
     out = subprocess.run([sys.executable, str(REPO / "tests" / "gpu_random_check.py"), "2024", "14"],
                          env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)

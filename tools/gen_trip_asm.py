@@ -277,6 +277,117 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row, int stride
 '''
 
 
+def block_shared(name, vbase, stamp=False):
+    """Frame-pair sweep of TWO pixels in mic-major order with the sample reads shared at run time: for
+    every mic the block handles pixel A's item, then pixel B's; when B's entry carries the same LDS
+    address as A's (the two pixels' integer delays coincide: most mics for neighbouring pixels) B's
+    eight packed FMAs take their samples from the registers A's item loaded, and B issues neither an
+    address add nor LDS reads.  Same items, same per-pixel order as sweep_duo_pairs, so the sums are
+    bit-identical; the table format is unchanged.
+
+    Trips of 4 mics.  SGPR sets: A0/B0 (entries of pixel A / B for this trip) and A1/B1 (the next trip's,
+    being fetched), 16 SGPRs each.  VGPR slots: two for A's samples (this mic / next mic), ONE for B's.
+    Stage s of a trip:  issue A[s+1];  wait until at most A[s+1]'s four reads are in flight (LDS returns
+    in order: A[s] and B[s] are then in);  8 FMAs of A[s];  8 FMAs of B[s] from A's slot or B's;  issue
+    B[s+1] unless shared.  At most 4 + 4 + 4 LDS reads and 2 scalar loads are in flight (lgkmcnt <= 15)."""
+    setA, setB = (36, 68), (52, 84)
+    accA = tuple(f"%[P0{n}{k}]" for n in "AQ" for k in range(4))
+    accB = tuple(f"%[P1{n}{k}]" for n in "AQ" for k in range(4))
+    slotA = (vbase, vbase + 8)
+    slotB = vbase + 16
+    addr_t = vbase + 24
+
+    def reads(slot, addr_sgpr):
+        L = [f"v_add_u32 v{addr_t}, s{addr_sgpr}, %[lane]"]
+        for k in range(4):
+            off = f" offset:{512 * k}" if k else ""
+            L.append(f"ds_read_b64 v[{slot + 2 * k}:{slot + 2 * k + 1}], v{addr_t}{off}")
+        return L
+
+    def fmas(acc, base, i, slot):
+        L = []
+        for k in range(4):
+            x = f"v[{slot + 2 * k}:{slot + 2 * k + 1}]"
+            L.append(f"v_pk_fma_f32 {acc[k]}, s[{base + 4 * i}:{base + 4 * i + 1}], {x}, {acc[k]} op_sel_hi:[0,1,1]")
+            L.append(f"v_pk_fma_f32 {acc[4 + k]}, s[{base + 4 * i + 2}:{base + 4 * i + 3}], {x}, {acc[4 + k]} op_sel_hi:[0,1,1]")
+        return L
+
+    def uid():
+        COUNTER[0] += 1
+        return f"%=_{COUNTER[0]}"
+
+    def issue_b(sA, sB, i):
+        u = uid()
+        return ([f"s_cmp_eq_u32 s{sA + 4 * i + 1}, s{sB + 4 * i + 1}", f"s_cbranch_scc1 .Lnoread{u}"]
+                + reads(slotB, sB + 4 * i + 1) + [f".Lnoread{u}:"])
+
+    def trip_s(par):
+        sA, sB = setA[par], setB[par]
+        nA, nB = setA[1 - par], setB[1 - par]
+        L = trip_prio("X" if par == 0 else "Y") if PRIO >= 3 else []
+        L += reads(slotA[0], sA + 1)
+        L += issue_b(sA, sB, 0)
+        L += [f"s_load_dwordx16 s[{nA}:{nA + 15}], %[ptr], s{S_PF}",
+              f"s_add_u32 s{S_OFF}, s{S_PF}, %[stride]",
+              f"s_load_dwordx16 s[{nB}:{nB + 15}], %[ptr], s{S_OFF}",
+              f"s_add_u32 s{S_PF}, s{S_PF}, 64"]
+        for st in range(4):
+            if st < 3:
+                L += reads(slotA[(st + 1) % 2], sA + 4 * (st + 1) + 1)
+            L.append(f"s_waitcnt lgkmcnt({4 if st < 3 else 0})")
+            L += fmas(accA, sA, st, slotA[st % 2])
+            u = uid()
+            L += [f"s_cmp_eq_u32 s{sA + 4 * st + 1}, s{sB + 4 * st + 1}", f"s_cbranch_scc1 .Lshared{u}"]
+            L += fmas(accB, sB, st, slotB) + [f"s_branch .Lfmadone{u}", f".Lshared{u}:"]
+            L += fmas(accB, sB, st, slotA[st % 2]) + [f".Lfmadone{u}:"]
+            if st < 3:
+                L += issue_b(sA, sB, st + 1)
+        return L
+
+    L = []
+    if stamp:
+        L += [f"s_memtime s[{S_T0}:{S_T0 + 1}]", "s_waitcnt lgkmcnt(0)"]
+    if PRIO >= 3:
+        L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    L += [f"s_load_dwordx16 s[{setA[0]}:{setA[0] + 15}], %[ptr], 0x0",
+          f"s_load_dwordx16 s[{setB[0]}:{setB[0] + 15}], %[ptr], %[stride]",
+          f"s_mov_b32 s{S_LEFT}, %[ng]",
+          f"s_movk_i32 s{S_PF}, 0x40",
+          "s_waitcnt lgkmcnt(0)"]
+    if stamp:
+        L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)",
+              f"s_sub_u32 %[t_wait], s{S_T1}, s{S_T0}"]
+    L += [".LT0_%=:"] + trip_s(0)
+    L += [f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_cmp_eq_u32 s{S_LEFT}, 0", "s_cbranch_scc1 .Ldone_%="]
+    L += trip_s(1)
+    L += [f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_cmp_lg_u32 s{S_LEFT}, 0", "s_cbranch_scc1 .LT0_%="]
+    L += [".Ldone_%=:"]
+    if PRIO:
+        L += ["s_setprio 0"]
+    if stamp:
+        L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)",
+              f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
+    body = "\n".join(f'        "{l}\\n\\t"' for l in L)
+    vregs = list(range(vbase, vbase + 25))
+    sregs = sorted({S_RANK, S_PRIO, S_LEFT, S_PF, S_OFF, S_T0, S_T0 + 1, S_T1, S_T1 + 1}) + list(range(36, 100))
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
+    acc_ops = ", ".join(f'[P{j}{n}{k}] "+v"(P{j}[{4 * "AQ".index(n) + k}])' for j in range(2) for n in "AQ" for k in range(4))
+    stamp_params = ", unsigned &t_wait, unsigned &t_all" if stamp else ""
+    stamp_ops = ', [t_wait] "=&s"(t_wait), [t_all] "=&s"(t_all)' if stamp else ""
+    return f'''// Two pixels of the staged chunk in mic-major order, ng groups of four mics each (ng >= 1); pixel A's
+// entries start at `row`, pixel B's at `row` + stride bytes.  Sample reads are shared whenever the two
+// entries of a mic carry the same LDS address.  Reads the table up to one group past each row's end.
+// temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}
+__device__ __forceinline__ void {name}(f2 (&P0)[8], f2 (&P1)[8], const void *row, int stride, int ng, unsigned lane_addr, int rank{stamp_params}) {{
+    asm volatile(
+{body}
+        : {acc_ops}{stamp_ops}
+        : [ptr] "s"(row), [stride] "s"(stride), [ng] "s"(ng), [lane] "v"(lane_addr), [rank] "s"(rank)
+        : {clobbers});
+}}
+'''
+
+
 def main():
     hi = 128 - (4 * (DEPTH + 1) + 1) - 3
     out = ["// GENERATED by tools/gen_trip_asm.py -- do not edit.  See that script for the schedule.", ""]
@@ -286,6 +397,8 @@ def main():
     pd = int(os.environ.get("PAIR_DEPTH", "2"))  # frame-pair items: 2 items (8 reads) of read-ahead; +4 being issued +2 scalar loads <= 15 (lgkmcnt is 4 bits)
     out.append(block("sweep_duo_pairs", 2, 128 - (8 * (pd + 1) + 1) - 3, pair_depth=pd))
     out.append(block("sweep_duo_pairs_stamped", 2, 128 - (8 * (pd + 1) + 1) - 3, stamp=True, pair_depth=pd))
+    out.append(block_shared("sweep_duo_shared", 128 - 25 - 3))
+    out.append(block_shared("sweep_duo_shared_stamped", 128 - 25 - 3, stamp=True))
     lo = 80 - (4 * (DEPTH + 1) + 1) - 3  # shapes with an 80-VGPR budget (6 waves per SIMD)
     out.append(block("sweep_quad_lo", 4, lo))
     out.append(block("sweep_quad_lo_stamped", 4, lo, stamp=True))
