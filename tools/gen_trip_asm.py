@@ -316,10 +316,12 @@ def block_shared(name, vbase, stamp=False):
         COUNTER[0] += 1
         return f"%=_{COUNTER[0]}"
 
+    cold = []  # the not-shared paths, kept out of line so that the common path takes no branch
+
     def issue_b(sA, sB, i):
         u = uid()
-        return ([f"s_cmp_eq_u32 s{sA + 4 * i + 1}, s{sB + 4 * i + 1}", f"s_cbranch_scc1 .Lnoread{u}"]
-                + reads(slotB, sB + 4 * i + 1) + [f".Lnoread{u}:"])
+        cold.extend([f".Lread{u}:"] + reads(slotB, sB + 4 * i + 1) + [f"s_branch .Lreadback{u}"])
+        return [f"s_cmp_lg_u32 s{sA + 4 * i + 1}, s{sB + 4 * i + 1}", f"s_cbranch_scc1 .Lread{u}", f".Lreadback{u}:"]
 
     def trip_s(par):
         sA, sB = setA[par], setB[par]
@@ -337,8 +339,8 @@ def block_shared(name, vbase, stamp=False):
             L.append(f"s_waitcnt lgkmcnt({4 if st < 3 else 0})")
             L += fmas(accA, sA, st, slotA[st % 2])
             u = uid()
-            L += [f"s_cmp_eq_u32 s{sA + 4 * st + 1}, s{sB + 4 * st + 1}", f"s_cbranch_scc1 .Lshared{u}"]
-            L += fmas(accB, sB, st, slotB) + [f"s_branch .Lfmadone{u}", f".Lshared{u}:"]
+            cold.extend([f".Lown{u}:"] + fmas(accB, sB, st, slotB) + [f"s_branch .Lfmadone{u}"])
+            L += [f"s_cmp_lg_u32 s{sA + 4 * st + 1}, s{sB + 4 * st + 1}", f"s_cbranch_scc1 .Lown{u}"]
             L += fmas(accB, sB, st, slotA[st % 2]) + [f".Lfmadone{u}:"]
             if st < 3:
                 L += issue_b(sA, sB, st + 1)
@@ -361,7 +363,7 @@ def block_shared(name, vbase, stamp=False):
     L += [f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_cmp_eq_u32 s{S_LEFT}, 0", "s_cbranch_scc1 .Ldone_%="]
     L += trip_s(1)
     L += [f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_cmp_lg_u32 s{S_LEFT}, 0", "s_cbranch_scc1 .LT0_%="]
-    L += [".Ldone_%=:"]
+    L += ["s_branch .Ldone_%="] + cold + [".Ldone_%=:"]
     if PRIO:
         L += ["s_setprio 0"]
     if stamp:
