@@ -8,7 +8,10 @@
 //
 // Three kernels, one idea:
 //   das_pair_kernel      frames packed two by two, sample-interleaved; the two lanes of every packed
-//                        FMA are the two FRAMES.  Default for batches.  (bottom of this file)
+//                        FMA are the two FRAMES; the two pixels of a block are swept in mic-major order
+//                        and share a mic's sample reads when their integer delays coincide (vertically
+//                        adjacent pixels when the grid's row length is known).  Default for batches.
+//                        (bottom of this file)
 //   das_fast_db_kernel   one frame per item, 16-wave workgroup per CU, two LDS images filled by
 //                        LDS-DMA while the other is swept.  Single-frame calls on full grids.
 //   das_fast_kernel      one (or two) frames per item, 8-wave workgroups, two per CU.  Small grids.
