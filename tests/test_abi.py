@@ -109,3 +109,48 @@ def test_heatmap_equals_oracle(pkg, oracle):
     rng = np.random.default_rng(0)
     p = rng.uniform(0, 3e-5, 4096).astype(np.float32)
     assert np.array_equal(pkg.heatmap_u8(p), oracle.heatmap_u8(p))
+
+
+def test_null_arguments_are_refused_not_dereferenced(pkg):
+    """Every entry point of the C ABI with a null handle / null buffers: a negative status, no crash
+    (no device needed: argument checks come first).  awpu_hip_destroy(NULL) is a no-op like free(NULL)."""
+    B = pkg.binding
+    lib = B.load()
+    f, i, u = np.zeros(16, np.float32), np.zeros(16, np.int32), np.zeros(16, np.uint8)
+    fp, ip, up = f.ctypes.data_as(B._f32p), i.ctypes.data_as(B._i32p), u.ctypes.data_as(B._u8p)
+    seen = []
+
+    def call(name, *args):
+        status = getattr(lib, name)(*args)
+        seen.append(name)
+        assert status < 0, (name, status)
+
+    assert lib.awpu_hip_destroy(None) == 0
+    call("awpu_hip_set_delay_table", None, ip, fp)
+    call("awpu_hip_set_active_mics", None, ip, 4)
+    call("awpu_hip_set_fir_table", None, fp)
+    call("awpu_hip_set_mic_gains", None, fp)
+    call("awpu_hip_process", None, fp, 1, fp)
+    call("awpu_hip_process_device", None, None, 1, None, None)
+    call("awpu_hip_synchronize", None)
+    call("awpu_hip_ingest_block", None, None, 1032)
+    call("awpu_hip_process_ring", None, fp)
+    call("awpu_hip_ring_snapshot", None, fp)
+    call("awpu_hip_live_block", None, None, 1032, fp, 4, 4, up, 8, 8, None, up)
+    call("awpu_hip_heatmap_u8", None, 4, up)
+    call("awpu_hip_heatmap_u8_device", None, None, 4, 1, None, 0, None, None)
+    call("awpu_hip_upscale_u8_device", None, None, 4, 4, 1, None, None, 8, 8, None)
+    call("awpu_hip_resize_linear_u8", None, 4, 4, up, 8, 8)
+    call("awpu_hip_calibrate_device", None, None, 0, 1e-5, ip, fp, None, None, None)
+    call("awpu_hip_calibrate_ring", None, 0, 1e-5, ip, fp, None, None)
+    call("awpu_hip_beams", None, None, ip, fp, 1, fp, fp)
+    call("awpu_hip_steer_table", None, 4, None, None, 1, ip, fp)
+    call("awpu_hip_create_antenna", 8, 8, 0.02, None)
+    call("awpu_hip_create_tiled_antenna", 0, 1, 0.02, fp)
+    call("awpu_hip_steering_delays", None, 4, 0.1, 0.2, fp)
+    call("awpu_hip_build_delay_table", None, 4, 2, 2, 180.0, 0, 2, ip, fp)
+    call("awpu_hip_get_stats", None, None)
+    call("awpu_hip_create", None, None)
+    untested = set(B.EXPORTED_SYMBOLS) - set(seen) - {"awpu_hip_destroy", "awpu_hip_default_cfg", "awpu_hip_strerror",
+                                                      "awpu_hip_last_error", "awpu_hip_abi_version"}
+    assert not untested, untested
