@@ -535,9 +535,11 @@ def test_full_size_properties(pkg, oracle, wl, batch):
     off, frac = S.delay_table(spec, xyz)
     frames = S.make_frames(xyz, batch, seed=3)
     frames[1] = 4.0 * frames[0]
-    power, st = run_engine(pkg, frames, off, frac)
+    power, st = run_engine(pkg, frames, off, frac, grid_columns=spec.res)  # vertical pixel pairs in the batched sweep
     assert st.usable == spec.n_mics
     assert np.array_equal(power[1], 16.0 * power[0])
+    plain, _ = run_engine(pkg, frames, off, frac)  # without the hint: consecutive pixels paired, same bits
+    assert np.array_equal(plain, power)
     r, c = divmod(int(power[0].argmax()), spec.res)
     er, ec = S.source_pixel(spec)
     assert abs(r - er) <= 1 and abs(c - ec) <= 1
@@ -566,7 +568,7 @@ def test_c4_rank_slab_of_eight(pkg, oracle):
         assert (shard.row_count, shard.pixel_count) == (32, 8192)
         off, frac = S.delay_table(spec, xyz, shard.row_begin, shard.row_count)
         eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, lut_stride=spec.n_mics, max_batch=6,
-                         pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count)
+                         pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count, grid_columns=spec.res)
         with eng:
             eng.set_delay_table(off, frac)
             eng.set_active_mics(None)
