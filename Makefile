@@ -1,6 +1,7 @@
 # Makefile -- the same builds __graft_entry__.build() drives from Python, for C++ integrators.
 #   make lib         beamforming-lk_amd/libawpu_hip.so   (hipcc, gfx950 only; there is no CPU fallback)
 #   make oracle      oracle/liboracle_das.so (+ oracle/_ref from the reference tree when it is present)
+#   make example     examples/heatmap_min: the C ABI from plain C (needs an MI355X to do more than report its absence)
 #   make host-test   tests/host/test_mimo_worker: the C++ mirror (MIMOWorkerHip, AWProcessingUnitHip,
 #                    PipelineHip) against the oracle; needs an MI355X to run (--nogpu checks the failure path)
 HIPCC ?= /opt/rocm/bin/hipcc
@@ -10,7 +11,7 @@ LIB := $(PKG)/libawpu_hip.so
 KERNEL_SRC := $(CSRC)/das_kernels.hip $(CSRC)/das_fast.hip $(CSRC)/awpu_hip.cpp $(CSRC)/geometry_host.cpp
 HOST_SRC := $(PKG)/host/mimo_worker_hip.cpp $(PKG)/host/aw_processing_unit_hip.cpp $(PKG)/host/pipeline_hip.cpp
 
-.PHONY: lib oracle host-test trips clean
+.PHONY: lib oracle host-test example trips clean
 lib: $(LIB)
 
 $(LIB): $(KERNEL_SRC) $(CSRC)/das_kernels.h $(CSRC)/das_fast_trip.inc include/awpu_hip.h
@@ -29,6 +30,10 @@ host-test: $(LIB) oracle
 	    -L$(PKG) -lawpu_hip -Loracle -loracle_das -Wl,-rpath,'$$ORIGIN/../../$(PKG)' -Wl,-rpath,'$$ORIGIN/../../oracle' -Wl,-rpath,/opt/rocm/lib \
 	    -o tests/host/test_mimo_worker
 
+example: $(LIB)
+	gcc -O2 -Wall -Iinclude examples/heatmap_min.c -L$(PKG) -lawpu_hip -lm -Wl,-rpath,'$$ORIGIN/../$(PKG)' \
+	    -Wl,-rpath,/opt/rocm/lib -o examples/heatmap_min
+
 clean:
-	rm -f $(LIB) tests/host/test_mimo_worker
+	rm -f $(LIB) tests/host/test_mimo_worker examples/heatmap_min
 	$(MAKE) -C oracle clean

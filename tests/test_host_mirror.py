@@ -34,3 +34,34 @@ def test_host_mirror_against_oracle(pkg, oracle):
     build(pkg, oracle)
     out = subprocess.run([str(EXE)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+def build_example(pkg):
+    pkg.binding.load()
+    exe = REPO / "examples" / "heatmap_min"
+    pkgdir = REPO / "beamforming-lk_amd"
+    subprocess.run(["gcc", "-O2", "-Wall", f"-I{REPO / 'include'}", str(REPO / "examples/heatmap_min.c"), f"-L{pkgdir}",
+                    "-lawpu_hip", "-lm", f"-Wl,-rpath,{pkgdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+                   check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_c_example_reports_the_missing_device(pkg):
+    """examples/heatmap_min.c is plain C against include/awpu_hip.h; without a GPU it must say so (exit 2)."""
+    import torch
+
+    exe = build_example(pkg)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 2 and "no gfx950" in out.stderr, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_finds_the_source(pkg):
+    out = subprocess.run([str(build_example(pkg))], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    S = pkg.synthetic
+    er, ec = S.source_pixel(S.WORKLOADS["c1"])
+    r, c = (int(v) for v in out.stdout.split("(")[1].split(")")[0].split(","))
+    assert abs(r - er) <= 1 and abs(c - ec) <= 1 and "image value there 255" in out.stdout, out.stdout
