@@ -17,7 +17,7 @@ CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libawpu_hip.so"
 
 SOURCES = [CSRC / "das_kernels.hip", CSRC / "das_fast.hip", CSRC / "awpu_hip.cpp", CSRC / "geometry_host.cpp"]
-HEADERS = [CSRC / "das_kernels.h", REPO / "include" / "awpu_hip.h"]
+HEADERS = [CSRC / "das_kernels.h", CSRC / "das_fast_trip.inc", REPO / "include" / "awpu_hip.h"]
 
 
 def hipcc_path() -> str:
@@ -38,6 +38,19 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP kernels and the C ABI into beamforming-lk_amd/libawpu_hip.so."""
     if not force and not stale():
         return LIB_PATH
+    # several ranks of one job may get here at once (torch.distributed.run starts them together): one builds,
+    # the others wait for the lock and then find the library fresh
+    import fcntl
+
+    with open(PKG_DIR / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not stale():
+            return LIB_PATH
+        return _compile(verbose)
+
+
+def _compile(verbose: bool) -> Path:
+    tmp = LIB_PATH.with_suffix(f".so.tmp{os.getpid()}")
     cmd = [
         hipcc_path(),
         "--offload-arch=gfx950",
@@ -51,15 +64,17 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         f"-I{REPO / 'include'}",
         f"-I{CSRC}",
         *[str(s) for s in SOURCES],
-        "-o", str(LIB_PATH),
+        "-o", str(tmp),
     ]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
+        tmp.unlink(missing_ok=True)
         raise RuntimeError(f"hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
     if verbose and proc.stderr.strip():
         print(proc.stderr)
+    os.replace(tmp, LIB_PATH)  # a process that is loading the old file keeps its mapping
     return LIB_PATH
 
 
