@@ -218,11 +218,15 @@ def main():
         parity = float((np.abs(got[pick] - want) / np.maximum(want, floor)).max())
 
     # ---- N > 1: the assembled heatmap of frame 0 must equal what the shards computed
+    gather_check = None
     if world > 1:
-        full = sharding.gather_power(d_power[:1].contiguous(), sharding.all_shards(spec.res, spec.res, world), dst=0)
-        if rank == 0:
-            assert full.shape == (1, spec.n_pixels)
-            assert torch.equal(full[0, : shard.pixel_count], d_power[0])
+        try:  # a failure here must not cost the run its result line
+            full = sharding.gather_power(d_power[:1].contiguous(), sharding.all_shards(spec.res, spec.res, world), dst=0)
+            if rank == 0:
+                ok = full.shape == (1, spec.n_pixels) and torch.equal(full[0, : shard.pixel_count], d_power[0])
+                gather_check = "ok" if ok else "MISMATCH: the assembled heatmap differs from rank 0's tile"
+        except Exception as e:  # noqa: BLE001
+            gather_check = f"failed: {type(e).__name__}: {e}"
 
     # ---- N > 1, second measurement: the frame-sharded decomposition (whole frames per rank, full grid;
     # each frame crosses xGMI once).  Reported beside the headline number, not instead of it.
@@ -309,6 +313,8 @@ def main():
             },
             "parity_max_rel_err": parity,
         }
+        if gather_check is not None:
+            out["gather_check"] = gather_check
         if alt is not None:
             out["alt_sharding"] = alt
         if rehearsal:
