@@ -7,6 +7,7 @@ loaded, importing a compute entry point raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
@@ -93,6 +94,9 @@ _SIGNATURES = {
                                             C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p]),
     "awpu_hip_calibrate_ring": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, _i32p, _f32p, C.POINTER(C.c_float),
                                           C.POINTER(C.c_int32)]),
+    "awpu_hip_calibrate_host": (C.c_int, [C.c_void_p, _f32p, C.c_int32, C.c_float, _i32p, _f32p, C.POINTER(C.c_float),
+                                          C.POINTER(C.c_int32)]),
+    "awpu_hip_last_error_of": (C.c_char_p, [C.c_void_p]),
     "awpu_hip_upscale_u8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                              C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "awpu_hip_resize_linear_u8": (C.c_int, [_u8p, C.c_int32, C.c_int32, _u8p, C.c_int32, C.c_int32]),
@@ -119,6 +123,10 @@ def load(build: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # AWPU_NO_BUILD=1: never start a compiler from this process (set by the profiling scripts: under rocprofv3
+    # a child process inherits the profiler's preloaded library, see tools/pmc.sh)
+    if os.environ.get("AWPU_NO_BUILD") == "1":
+        build = False
     path = _build.build_library() if build else _build.LIB_PATH
     # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; a process that uses both torch and
     # this library must run on ONE HIP runtime, and the first one loaded wins the SONAME.  Load
@@ -397,6 +405,18 @@ class Engine:
         return self._calibrated(lambda i, c, m, n: _check(self._lib.awpu_hip_calibrate_device(
             self._h, C.c_void_p(d_frame_ptr), array, reference_power_level, _i32(i), _f32(c), C.byref(m), C.byref(n),
             C.c_void_p(stream)), "awpu_hip_calibrate_device"))
+
+    def calibrate_host(self, frame: np.ndarray, array: int = 0, reference_power_level: float = 1e-5):
+        """The same for a snapshot [n_streams, hist] in host memory."""
+        frame = np.ascontiguousarray(frame, np.float32)
+        if frame.shape != (self.cfg.n_streams, self.cfg.hist):
+            raise ValueError("frame must be [n_streams, hist]")
+        return self._calibrated(lambda i, c, m, n: _check(self._lib.awpu_hip_calibrate_host(
+            self._h, _f32(frame), array, reference_power_level, _i32(i), _f32(c), C.byref(m), C.byref(n)),
+            "awpu_hip_calibrate_host"))
+
+    def last_error(self) -> str:
+        return self._lib.awpu_hip_last_error_of(self._h).decode()
 
     def calibrate_ring(self, array: int = 0, reference_power_level: float = 1e-5):
         """The same on the current snapshot of the ingest ring."""

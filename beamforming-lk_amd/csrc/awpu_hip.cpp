@@ -19,9 +19,20 @@
 namespace {
 
 thread_local std::string g_last_error;
+// the handle the calling thread is working on: errors are also kept in the handle, so that a thread
+// other than the one that ran into the error (a GUI thread asking about a worker's engine) can read them
+thread_local awpu_hip *g_ctx = nullptr;
+void note_error(const std::string &text);
+
+struct CtxScope {
+    awpu_hip *saved;
+    explicit CtxScope(awpu_hip *h) : saved(g_ctx) { g_ctx = h; }
+    ~CtxScope() { g_ctx = saved; }
+};
+#define AWPU_CTX(h) CtxScope ctx_scope_(h)
 
 int hip_fail(hipError_t e, const char *what) {
-    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    note_error(std::string(what) + ": " + hipGetErrorString(e));
     return AWPU_ERR_HIP;
 }
 
@@ -32,8 +43,13 @@ int hip_fail(hipError_t e, const char *what) {
     } while (0)
 
 int invalid(const char *why) {
-    g_last_error = why;
+    note_error(why);
     return AWPU_ERR_INVALID;
+}
+
+int fail(int status, const char *why) {
+    note_error(why);
+    return status;
 }
 
 template <class T>
@@ -92,11 +108,30 @@ struct awpu_hip {
     int pair_cols = 0;  // frame-pair sweep: > 0 = waves take vertically adjacent pixels (grid row length), 0 = consecutive
 
     awpu_hip_stats stats{};
+    std::string last_error;                  // awpu_hip_last_error_of
+    unsigned long long *d_diag = nullptr;    // AWPU_FAST_DEBUG=16 cycle stamps of the last launch
+    size_t diag_cap = 0;                     // in 64-bit words
 
     int usable() const { return static_cast<int>(index.size()); }
 };
 
 namespace {
+
+void note_error(const std::string &text) {
+    g_last_error = text;
+    if (g_ctx) g_ctx->last_error = text;
+}
+
+// diagnostics buffer of `words` 64-bit words, grown on demand (one per handle: handles on different
+// devices, or launches of different sizes, must not share it)
+int ensure_diag(awpu_hip *h, size_t words) {
+    if (h->diag_cap >= words) return AWPU_OK;
+    dev_free(h->d_diag);
+    h->diag_cap = 0;
+    AWPU_HIP_TRY(hipMalloc(&h->d_diag, words * sizeof(unsigned long long)));
+    h->diag_cap = words;
+    return AWPU_OK;
+}
 
 void release_device(awpu_hip *h) {
     dev_free(h->d_lut);
@@ -119,6 +154,8 @@ void release_device(awpu_hip *h) {
     dev_free(h->d_row_off_compact);
     dev_free(h->d_frames);
     dev_free(h->d_power);
+    dev_free(h->d_diag);
+    h->diag_cap = 0;
     h->beam_cap = h->beam_lut_cap = h->pack_cap = h->frames_cap = h->power_cap = 0;
 }
 
@@ -140,8 +177,7 @@ int prepare(awpu_hip *h) {
     }
     const int reach = c.interp == AWPU_INTERP_FIR8 ? awpu::kSamples + 6 : awpu::kSamples;  // last sample read past off
     if (lo < 0 || hi + reach > c.hist - 1) {
-        g_last_error = "delay table entry reads outside the frame history";
-        return AWPU_ERR_RANGE;
+        return fail(AWPU_ERR_RANGE, "delay table entry reads outside the frame history");
     }
     h->wstart = lo;
     h->window = hi - lo + reach + 1;
@@ -310,14 +346,26 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
 // Kernel shape for a call.  AWPU_FAST_VARIANT="fpi,ppw[,nw]" overrides the heuristic (tuning
 // knob, read once): fpi frames per item, ppw pixels per wave, nw = 8 (8-wave workgroups, two per
 // CU) or 32 (the double-buffered 16-wave shape, one per CU).
-void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
-    static int env_fpi = -1, env_ppw = -1, env_nw = 0;
-    if (env_fpi == -1) {
-        env_fpi = env_ppw = 0;
-        if (const char *v = std::getenv("AWPU_FAST_VARIANT")) {
-            if (std::sscanf(v, "%d,%d,%d", &env_fpi, &env_ppw, &env_nw) < 2) env_fpi = env_ppw = env_nw = 0;
-        }
+struct EnvKnobs {  // tuning / test knobs, read once per process
+    int fpi = 0, ppw = 0, nw = 0;  // AWPU_FAST_VARIANT
+    int pairs = -1;                // AWPU_FAST_PAIRS
+    int debug = 0;                 // AWPU_FAST_DEBUG
+    int fpw = 0;                   // AWPU_FAST_FPW
+    EnvKnobs() {
+        if (const char *v = std::getenv("AWPU_FAST_VARIANT"))
+            if (std::sscanf(v, "%d,%d,%d", &fpi, &ppw, &nw) < 2) fpi = ppw = nw = 0;
+        if (const char *v = std::getenv("AWPU_FAST_PAIRS")) pairs = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FAST_DEBUG")) debug = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FAST_FPW")) fpw = std::atoi(v);
     }
+};
+const EnvKnobs &env() {
+    static const EnvKnobs knobs;  // initialised once, thread-safe
+    return knobs;
+}
+
+void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
+    const int env_fpi = env().fpi, env_ppw = env().ppw, env_nw = env().nw;
     // Prefer the double-buffered shape with the most pixels per wave that still gives every CU
     // a workgroup; small grids fall back to 8-wave workgroups with fewer pixels per wave.
     const long P = h->cfg.pixel_count;
@@ -352,182 +400,174 @@ void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
 // sample 0 = history sample wstart; kRing one frame read in place from the ingest ring (rows 2048 apart)
 enum FrameLayout { kFull = 0, kCompact = 1, kRing = 2 };
 
-int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int layout = kFull) {
-    const bool compact = layout == kCompact;
-    const int hist_eff = compact ? h->compact_hist : (layout == kRing ? 2048 : h->cfg.hist);
-    const int wstart_eff = compact ? 0 : h->wstart;
-    if (h->cfg.math == AWPU_MATH_F32_EXACT || h->cfg.interp == AWPU_INTERP_FIR8) {
-        awpu::SweepArgs a{};
-        a.frames = d_frames;
-        a.lut = h->d_lut;
-        a.index = h->d_index;
-        a.power = d_power;
-        a.gain = h->d_gain;
-        a.n_streams = h->cfg.n_streams;
-        a.hist = hist_eff;
-        a.usable = h->usable();
-        a.pixel_count = h->cfg.pixel_count;
-        a.wstart = wstart_eff;
-        a.window = h->window;
-        a.batch = batch;
-        if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-        if (h->cfg.interp == AWPU_INTERP_FIR8) {
-            AWPU_HIP_TRY(awpu::launch_das_fir8(a, h->d_fir, s));
-        } else
-        AWPU_HIP_TRY(awpu::launch_das_exact(a, s));
-    } else {
-        // ---- frame-pair shape: batches on grids that fill the chip (AWPU_FAST_PAIRS=0/1 overrides)
-        static const int env_pairs = std::getenv("AWPU_FAST_PAIRS") ? std::atoi(std::getenv("AWPU_FAST_PAIRS")) : -1;
-        static const int debug_flags = std::getenv("AWPU_FAST_DEBUG") ? std::atoi(std::getenv("AWPU_FAST_DEBUG")) : 0;
-        const long pair_wgs = (long) awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols) * ((batch + 1) / 2);
-        if (layout != kRing && batch >= 2 && env_pairs != 0 && (pair_wgs >= 256 || env_pairs == 1)) {
-            const awpu_hip::FastLut *plut = nullptr;
-            if (build_fast_lut(h, 2, -1, &plut) == AWPU_OK) {
-                const awpu::FastPlan &pp = plut->plan;
-                const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * h->usable() * pp.wr * 2;
-                if (h->pack_cap < need) {
-                    dev_free(h->d_pack);
-                    h->pack_cap = 0;
-                    AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
-                    h->pack_cap = need;
-                }
-                awpu::PairArgs pa{};
-                pa.packed = h->d_pack;
-                pa.lut = plut->d;
-                pa.power = d_power;
-                pa.usable = h->usable();
-                pa.usable_pad = pp.usable_pad;
-                pa.pixel_count = h->cfg.pixel_count;
-                pa.wp = pp.wr;
-                pa.chunk = pp.chunk;
-                pa.batch = batch;
-                pa.cols = h->pair_cols;
-                pa.debug = debug_flags;
-                pa.debug_out = nullptr;
-                if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-                AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index,
-                                                     h->usable(), pp.wr, batch, h->d_pack, s));
-                if (debug_flags & 16) {  // diagnostics: per-wave cycle sums of this launch to stderr
-                    static unsigned long long *d_dbg = nullptr;
-                    const size_t n_waves = (size_t) 16 * ((batch + 1) / 2) * awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols);
-                    if (!d_dbg) AWPU_HIP_TRY(hipMalloc(&d_dbg, n_waves * 12 * sizeof(unsigned long long)));
-                    pa.debug_out = d_dbg;
-                    AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
-                    AWPU_HIP_TRY(hipStreamSynchronize(s));
-                    std::vector<unsigned long long> hb(n_waves * 12);
-                    AWPU_HIP_TRY(hipMemcpy(hb.data(), d_dbg, hb.size() * 8, hipMemcpyDeviceToHost));
-                    double v[12] = {0};
-                    std::vector<double> sw(16, 0), ba(16, 0);
-                    for (size_t i = 0; i < n_waves; i++) {
-                        for (int k = 0; k < 9; k++) v[k] += hb[12 * i + k];
-                        sw[i % 16] += hb[12 * i + 5];
-                        ba[i % 16] += hb[12 * i + 8];
-                    }
-                    std::fprintf(stderr, "[awpu diag pairs] per wave cycles: total %.0f | dma-issue %.0f sweep %.0f (in blocks %.0f, first table wait %.0f) tail %.0f dma-wait %.0f barrier %.0f | per pixel-chunk %.0f\n",
-                                 v[2] / n_waves, v[4] / n_waves, v[5] / n_waves, v[1] / n_waves, v[0] / n_waves, v[6] / n_waves,
-                                 v[7] / n_waves, v[8] / n_waves, v[1] / v[3]);
-                    std::fprintf(stderr, "[awpu diag pairs] wave slot sweep/barrier kcycles:");
-                    for (int k = 0; k < 16; k++) std::fprintf(stderr, " %d:%.0f/%.0f", k, sw[k] * 16 / n_waves / 1e3, ba[k] * 16 / n_waves / 1e3);
-                    std::fprintf(stderr, "\n");
-                    return AWPU_OK;
-                }
-                AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
-                if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_end, s));
-                h->stats.launches += 1;
-                h->stats.frames += (uint64_t) batch;
-                return AWPU_OK;
-            }
-        }
-        int fpi = 1, ppw = 8, nw = 8;
-        choose_fast_variant(h, batch, &fpi, &ppw, &nw);
-        const awpu_hip::FastLut *lut = nullptr;
-        int rc = build_fast_lut(h, fpi, awpu::fast_image_bytes(nw), &lut);
-        // the double-buffered shapes read whole 16-byte pieces of every staged row
-        if (nw != 8 && (rc != AWPU_OK || !awpu::fast_db_fits(lut->plan) || wstart_eff + 1 + lut->plan.wr > hist_eff)) {
-            nw = 8;
-            if (ppw > 4 && fpi == 2) ppw = 4;
-            rc = build_fast_lut(h, fpi, awpu::fast_image_bytes(nw), &lut);
-        }
-        if (rc != AWPU_OK) return rc;
-        const awpu::FastPlan &plan = lut->plan;
-        awpu::FastArgs a{};
-        a.frames = d_frames;
-        a.lut = lut->d;
-        a.index = h->d_index;
-        a.row_off = compact ? h->d_row_off_compact : (layout == kRing ? h->d_row_off_ring : h->d_row_off);
-        a.power = d_power;
-        a.n_streams = h->cfg.n_streams;
-        a.hist = hist_eff;
-        a.usable = h->usable();
-        a.usable_pad = plan.usable_pad;
-        a.pixel_count = h->cfg.pixel_count;
-        a.wstart = wstart_eff;
-        a.wr = plan.wr;
-        a.chunk = plan.chunk;
-        a.batch = batch;
-        {   // frames per persistent workgroup: keep >= ~3 workgroups per CU in the grid
-            static const int env_fpw = std::getenv("AWPU_FAST_FPW") ? std::atoi(std::getenv("AWPU_FAST_FPW")) : 0;
-            const long tiles = ((long) h->cfg.pixel_count + 16 * ppw - 1) / (16 * ppw);
-            (void) tiles;
-            int fpw = 1;  // measured: persistence over frames buys nothing
-            if (env_fpw > 0) fpw = env_fpw;
-            a.frames_per_wg = std::min(fpw, batch);
-        }
-        static const int debug = std::getenv("AWPU_FAST_DEBUG") ? std::atoi(std::getenv("AWPU_FAST_DEBUG")) : 0;
-        a.debug = debug;
-        a.debug_out = nullptr;
-        if (debug & 16) {  // diagnostics: dump per-wave cycle sums of the last launch to stderr
-            static unsigned long long *d_dbg = nullptr;
-            const int wg_waves = nw == 24 ? 12 : 16;
-            const size_t n_waves = (size_t) wg_waves * ((batch + a.frames_per_wg - 1) / a.frames_per_wg) * ((h->cfg.pixel_count + wg_waves * ppw - 1) / (wg_waves * ppw));
-            if (!d_dbg) AWPU_HIP_TRY(hipMalloc(&d_dbg, (size_t) 16 * batch * ((h->cfg.pixel_count + 63) / 64) * 12 * sizeof(unsigned long long)));
-            a.debug_out = d_dbg;
-            AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, s));
-            AWPU_HIP_TRY(hipStreamSynchronize(s));
-            std::vector<unsigned long long> hbuf(n_waves * 12);
-            AWPU_HIP_TRY(hipMemcpy(hbuf.data(), d_dbg, hbuf.size() * 8, hipMemcpyDeviceToHost));
-            double w = 0, al = 0, tot = 0, nb = 0;
-            double ph[5] = {0, 0, 0, 0, 0};
-            for (size_t i = 0; i < n_waves; i++) {
-                w += hbuf[12*i]; al += hbuf[12*i+1]; tot += hbuf[12*i+2]; nb += hbuf[12*i+3];
-                for (int k = 0; k < 5; k++) ph[k] += hbuf[12*i+4+k];
-            }
-            {   // by wave slot inside the workgroup: who waits at the barrier, who is waited for
-                const int nw_wg = nw == 24 ? 12 : 16;
-                std::vector<double> sw(nw_wg, 0), ba(nw_wg, 0);
-                for (size_t i = 0; i < n_waves; i++) {
-                    sw[i % nw_wg] += hbuf[12 * i + 5];
-                    ba[i % nw_wg] += hbuf[12 * i + 8];
-                }
-                std::fprintf(stderr, "[awpu diag] wave slot: sweep / barrier kcycles:");
-                for (int k = 0; k < nw_wg; k++) std::fprintf(stderr, " %d:%.0f/%.0f", k, sw[k] * nw_wg / n_waves / 1e3, ba[k] * nw_wg / n_waves / 1e3);
-                std::fprintf(stderr, "\n");
-            }
-            std::fprintf(stderr, "[awpu diag] per wave cycles: load-issue %.0f  sweep %.0f  tail %.0f  store %.0f  barrier %.0f\n",
-                         ph[0] / n_waves, ph[1] / n_waves, ph[2] / n_waves, ph[3] / n_waves, ph[4] / n_waves);
-            std::fprintf(stderr, "[awpu diag] waves %zu: per wave cycles total %.0f, in sweep blocks %.0f (%.1f%%), first table wait %.0f (%.1f%%); per block %.0f cycles, wait %.0f\n",
-                         n_waves, tot / n_waves, al / n_waves, 100 * al / tot, w / n_waves, 100 * w / tot, al / nb, w / nb);
-            return AWPU_OK;
-        }
-        if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-        AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, s));
-    }
+// a launch is over: close the timing bracket and count it (also on the diagnostic paths)
+int finish_launch(awpu_hip *h, int batch, hipStream_t s) {
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_end, s));
     h->stats.launches += 1;
     h->stats.frames += (uint64_t) batch;
     return AWPU_OK;
 }
 
+// AWPU_FAST_DEBUG=16: per-wave cycle stamps of the launch just enqueued (12 words per wave) to stderr
+int dump_diag(awpu_hip *h, size_t n_waves, int wg_waves, const char *tag, hipStream_t s) {
+    AWPU_HIP_TRY(hipStreamSynchronize(s));
+    std::vector<unsigned long long> hb(n_waves * 12);
+    AWPU_HIP_TRY(hipMemcpy(hb.data(), h->d_diag, hb.size() * 8, hipMemcpyDeviceToHost));
+    double v[9] = {0};
+    std::vector<double> sw(wg_waves, 0), ba(wg_waves, 0);
+    for (size_t i = 0; i < n_waves; i++) {
+        for (int k = 0; k < 9; k++) v[k] += (double) hb[12 * i + k];
+        sw[i % wg_waves] += (double) hb[12 * i + 5];
+        ba[i % wg_waves] += (double) hb[12 * i + 8];
+    }
+    std::fprintf(stderr, "[awpu diag %s] waves %zu, per wave cycles: total %.0f | dma-issue %.0f sweep %.0f (in blocks %.0f = %.1f%%, "
+                 "first table wait %.0f) tail %.0f dma-wait %.0f barrier %.0f | per block %.0f\n", tag, n_waves, v[2] / n_waves,
+                 v[4] / n_waves, v[5] / n_waves, v[1] / n_waves, 100 * v[1] / v[2], v[0] / n_waves, v[6] / n_waves,
+                 v[7] / n_waves, v[8] / n_waves, v[1] / v[3]);
+    std::fprintf(stderr, "[awpu diag %s] wave slot sweep/barrier kcycles:", tag);
+    for (int k = 0; k < wg_waves; k++)
+        std::fprintf(stderr, " %d:%.0f/%.0f", k, sw[k] * wg_waves / n_waves / 1e3, ba[k] * wg_waves / n_waves / 1e3);
+    std::fprintf(stderr, "\n");
+    return AWPU_OK;
+}
+
+int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
+    awpu::SweepArgs a{};
+    a.frames = d_frames;
+    a.lut = h->d_lut;
+    a.index = h->d_index;
+    a.power = d_power;
+    a.gain = h->d_gain;
+    a.n_streams = h->cfg.n_streams;
+    a.hist = hist_eff;
+    a.usable = h->usable();
+    a.pixel_count = h->cfg.pixel_count;
+    a.wstart = wstart_eff;
+    a.window = h->window;
+    a.batch = batch;
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    if (h->cfg.interp == AWPU_INTERP_FIR8) {
+        AWPU_HIP_TRY(awpu::launch_das_fir8(a, h->d_fir, s));
+    } else {
+        AWPU_HIP_TRY(awpu::launch_das_exact(a, s));
+    }
+    return finish_launch(h, batch, s);
+}
+
+// frame-pair shape: two frames per item, for batches on grids that fill the chip
+int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_frames, int batch, float *d_power,
+                 hipStream_t s, int hist_eff, int wstart_eff) {
+    const awpu::FastPlan &pp = plut->plan;
+    const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * h->usable() * pp.wr * 2;
+    if (h->pack_cap < need) {
+        dev_free(h->d_pack);
+        h->pack_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
+        h->pack_cap = need;
+    }
+    awpu::PairArgs pa{};
+    pa.packed = h->d_pack;
+    pa.lut = plut->d;
+    pa.power = d_power;
+    pa.usable = h->usable();
+    pa.usable_pad = pp.usable_pad;
+    pa.pixel_count = h->cfg.pixel_count;
+    pa.wp = pp.wr;
+    pa.chunk = pp.chunk;
+    pa.batch = batch;
+    pa.cols = h->pair_cols;
+    pa.debug = env().debug;
+    pa.debug_out = nullptr;
+    size_t n_waves = 0;
+    if (pa.debug & 16) {
+        n_waves = (size_t) 16 * ((batch + 1) / 2) * awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols);
+        const int rc = ensure_diag(h, n_waves * 12);
+        if (rc != AWPU_OK) return rc;
+        pa.debug_out = h->d_diag;
+    }
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.wr,
+                                         batch, h->d_pack, s));
+    AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
+    const int rc = finish_launch(h, batch, s);
+    if (rc != AWPU_OK || !(pa.debug & 16)) return rc;
+    return dump_diag(h, n_waves, 16, "pairs", s);
+}
+
+int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int layout = kFull) {
+    const bool compact = layout == kCompact;
+    const int hist_eff = compact ? h->compact_hist : (layout == kRing ? 2048 : h->cfg.hist);
+    const int wstart_eff = compact ? 0 : h->wstart;
+    if (h->cfg.math == AWPU_MATH_F32_EXACT || h->cfg.interp == AWPU_INTERP_FIR8)
+        return launch_exact(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+
+    // ---- frame-pair shape: batches on grids that fill the chip (AWPU_FAST_PAIRS=0/1 overrides)
+    const int env_pairs = env().pairs;
+    const long pair_wgs = (long) awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols) * ((batch + 1) / 2);
+    if (layout != kRing && batch >= 2 && env_pairs != 0 && (pair_wgs >= 256 || env_pairs == 1)) {
+        const awpu_hip::FastLut *plut = nullptr;
+        const int rc = build_fast_lut(h, 2, -1, &plut);
+        if (rc == AWPU_OK) return launch_pairs(h, plut, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+        // a window too wide for the pair image is served by the single-frame shapes below; anything
+        // else (an allocation or copy that failed) is the caller's to know about
+        if (rc != AWPU_ERR_INVALID) return rc;
+    }
+    int fpi = 1, ppw = 8, nw = 8;
+    choose_fast_variant(h, batch, &fpi, &ppw, &nw);
+    const awpu_hip::FastLut *lut = nullptr;
+    int rc = build_fast_lut(h, fpi, awpu::fast_image_bytes(nw), &lut);
+    if (rc != AWPU_OK && rc != AWPU_ERR_INVALID) return rc;
+    // the double-buffered shapes read whole 16-byte pieces of every staged row
+    if (nw != 8 && (rc != AWPU_OK || !awpu::fast_db_fits(lut->plan) || wstart_eff + 1 + lut->plan.wr > hist_eff)) {
+        nw = 8;
+        if (ppw > 4 && fpi == 2) ppw = 4;
+        rc = build_fast_lut(h, fpi, awpu::fast_image_bytes(nw), &lut);
+    }
+    if (rc != AWPU_OK) return rc;
+    const awpu::FastPlan &plan = lut->plan;
+    awpu::FastArgs a{};
+    a.frames = d_frames;
+    a.lut = lut->d;
+    a.index = h->d_index;
+    a.row_off = compact ? h->d_row_off_compact : (layout == kRing ? h->d_row_off_ring : h->d_row_off);
+    a.power = d_power;
+    a.n_streams = h->cfg.n_streams;
+    a.hist = hist_eff;
+    a.usable = h->usable();
+    a.usable_pad = plan.usable_pad;
+    a.pixel_count = h->cfg.pixel_count;
+    a.wstart = wstart_eff;
+    a.wr = plan.wr;
+    a.chunk = plan.chunk;
+    a.batch = batch;
+    // frames per persistent workgroup: measured, persistence over frames buys nothing
+    a.frames_per_wg = std::min(env().fpw > 0 ? env().fpw : 1, batch);
+    a.debug = env().debug;
+    a.debug_out = nullptr;
+    size_t n_waves = 0;
+    const int wg_waves = nw == 24 ? 12 : 16;
+    if ((a.debug & 16) && nw != 8) {  // the double-buffered shapes have a stamped build
+        n_waves = (size_t) wg_waves * ((batch + a.frames_per_wg - 1) / a.frames_per_wg) *
+                  ((h->cfg.pixel_count + wg_waves * ppw - 1) / (wg_waves * ppw));
+        rc = ensure_diag(h, n_waves * 12);
+        if (rc != AWPU_OK) return rc;
+        a.debug_out = h->d_diag;
+    }
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, s));
+    rc = finish_launch(h, batch, s);
+    if (rc != AWPU_OK || !a.debug_out) return rc;
+    return dump_diag(h, n_waves, wg_waves, "single", s);
+}
+
 int check_ready(awpu_hip *h, int batch) {
     if (!h) return invalid("null handle");
     if (batch < 1 || batch > h->cfg.max_batch) return invalid("batch outside [1, max_batch]");
     if (!h->have_table || !h->have_mics) {
-        g_last_error = "delay table and active mics must be set before processing";
-        return AWPU_ERR_STATE;
+        return fail(AWPU_ERR_STATE, "delay table and active mics must be set before processing");
     }
     if (h->cfg.interp == AWPU_INTERP_FIR8 && !h->have_fir) {
-        g_last_error = "AWPU_INTERP_FIR8 needs awpu_hip_set_fir_table";
-        return AWPU_ERR_STATE;
+        return fail(AWPU_ERR_STATE, "AWPU_INTERP_FIR8 needs awpu_hip_set_fir_table");
     }
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     if (!h->prepared) {
@@ -578,14 +618,12 @@ int awpu_hip_create(awpu_hip_t **out, const awpu_hip_cfg *cfg) {
 
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || c.device < 0 || c.device >= n_dev) {
-        g_last_error = "no usable HIP device (this library has no CPU path)";
-        return AWPU_ERR_NO_DEVICE;
+        return fail(AWPU_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c.device) != hipSuccess ||
         std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        g_last_error = "device is not gfx950 (MI355X); kernels are built for gfx950 only";
-        return AWPU_ERR_NO_DEVICE;
+        return fail(AWPU_ERR_NO_DEVICE, "device is not gfx950 (MI355X); kernels are built for gfx950 only");
     }
     AWPU_HIP_TRY(hipSetDevice(c.device));
 
@@ -616,6 +654,7 @@ int awpu_hip_destroy(awpu_hip_t *h) {
 }
 
 int awpu_hip_set_delay_table(awpu_hip_t *h, const int32_t *off, const float *frac) {
+    AWPU_CTX(h);
     if (!h || !off || !frac) return invalid("null argument");
     const size_t n = (size_t) h->cfg.pixel_count * h->cfg.lut_stride;
     for (size_t i = 0; i < n; i++) {
@@ -629,6 +668,7 @@ int awpu_hip_set_delay_table(awpu_hip_t *h, const int32_t *off, const float *fra
 }
 
 int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable) {
+    AWPU_CTX(h);
     if (!h) return invalid("null handle");
     const int limit = std::min(h->cfg.n_streams, h->cfg.lut_stride);
     if (usable < 1 || usable > limit) return invalid("usable outside [1, min(n_streams, lut_stride)]");
@@ -644,6 +684,7 @@ int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable
 }
 
 int awpu_hip_set_mic_gains(awpu_hip_t *h, const float *gains) {
+    AWPU_CTX(h);
     if (!h) return invalid("null handle");
     if (!gains) {
         h->gain.clear();
@@ -694,6 +735,7 @@ int calibrate_rows(awpu_hip *h, const float *d_rows, int pitch, int hist, float 
 
 int awpu_hip_calibrate_device(awpu_hip_t *h, const float *d_frame, int32_t array, float reference_power_level,
                               int32_t *index, float *correction, float *median, int32_t *usable, void *stream) {
+    AWPU_CTX(h);
     if (!h || !d_frame || !index || !correction || !usable) return invalid("null argument");
     if (array < 0 || (array + 1) * AWPU_ELEMENTS > h->cfg.n_streams) return invalid("array outside the streams");
     if (h->cfg.hist > 16384) return invalid("history too long for the calibration kernel");
@@ -703,13 +745,34 @@ int awpu_hip_calibrate_device(awpu_hip_t *h, const float *d_frame, int32_t array
                           reference_power_level, index, correction, median, usable, s);
 }
 
+int awpu_hip_calibrate_host(awpu_hip_t *h, const float *frame, int32_t array, float reference_power_level,
+                             int32_t *index, float *correction, float *median, int32_t *usable) {
+    AWPU_CTX(h);
+    if (!h || !frame || !index || !correction || !usable) return invalid("null argument");
+    if (array < 0 || (array + 1) * AWPU_ELEMENTS > h->cfg.n_streams) return invalid("array outside the streams");
+    if (h->cfg.hist > 16384) return invalid("history too long for the calibration kernel");
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    // only the array's 64 streams travel; they share the frame staging buffer of awpu_hip_process
+    const size_t need = (size_t) AWPU_ELEMENTS * h->cfg.hist;
+    if (h->frames_cap < need) {
+        dev_free(h->d_frames);
+        h->frames_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_frames, need * sizeof(float)));
+        h->frames_cap = need;
+    }
+    AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, frame + (size_t) array * AWPU_ELEMENTS * h->cfg.hist, need * sizeof(float),
+                                hipMemcpyHostToDevice, h->stream));
+    return calibrate_rows(h, h->d_frames, h->cfg.hist, h->cfg.hist, reference_power_level, index, correction, median,
+                          usable, h->stream);
+}
+
 int awpu_hip_calibrate_ring(awpu_hip_t *h, int32_t array, float reference_power_level, int32_t *index,
                             float *correction, float *median, int32_t *usable) {
+    AWPU_CTX(h);
     if (!h || !index || !correction || !usable) return invalid("null argument");
     if (array < 0 || (array + 1) * AWPU_ELEMENTS > h->cfg.n_streams) return invalid("array outside the streams");
     if (!h->d_ring) {
-        g_last_error = "no block ingested yet";
-        return AWPU_ERR_STATE;
+        return fail(AWPU_ERR_STATE, "no block ingested yet");
     }
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     return calibrate_rows(h, h->d_ring + (size_t) array * AWPU_ELEMENTS * 2048 + h->ring_pos, 2048, AWPU_HIST,
@@ -718,18 +781,17 @@ int awpu_hip_calibrate_ring(awpu_hip_t *h, int32_t array, float reference_power_
 
 int awpu_hip_beams(awpu_hip_t *h, const float *d_frame, const int32_t *off, const float *frac, int32_t n_dir,
                    float *power, float *beams) {
+    AWPU_CTX(h);
     if (!h || !off || !frac || (!power && !beams)) return invalid("null argument");
     if (n_dir < 1 || n_dir > 65535) return invalid("n_dir outside [1, 65535]");
     if (!h->have_mics) {
-        g_last_error = "active mics not set";
-        return AWPU_ERR_STATE;
+        return fail(AWPU_ERR_STATE, "active mics not set");
     }
     int pitch = h->cfg.hist;
     const float *frame = d_frame;
     if (!frame) {  // the current snapshot of the ingest ring
         if (!h->d_ring) {
-            g_last_error = "no block ingested yet";
-            return AWPU_ERR_STATE;
+            return fail(AWPU_ERR_STATE, "no block ingested yet");
         }
         frame = h->d_ring + h->ring_pos;
         pitch = 2048;
@@ -742,8 +804,7 @@ int awpu_hip_beams(awpu_hip_t *h, const float *d_frame, const int32_t *off, cons
             const int o = off[(size_t) d * stride + id];
             const float f = frac[(size_t) d * stride + id];
             if (o < 0 || o + awpu::kSamples > h->cfg.hist - 1) {  // delay() reads X[off .. off+256]
-                g_last_error = "delay table entry reads outside the frame history";
-                return AWPU_ERR_RANGE;
+                return fail(AWPU_ERR_RANGE, "delay table entry reads outside the frame history");
             }
             if (!(f >= 0.0f && f <= 1.0f)) return invalid("fraction outside [0, 1]");
             entries[(size_t) d * U + s] = awpu::LutEntry{id * pitch + o, f};
@@ -776,6 +837,7 @@ int awpu_hip_beams(awpu_hip_t *h, const float *d_frame, const int32_t *off, cons
 }
 
 int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {
+    AWPU_CTX(h);
     if (!h || !coeffs) return invalid("null argument");
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     if (!h->d_fir) AWPU_HIP_TRY(hipMalloc(&h->d_fir, 101 * 8 * sizeof(float)));
@@ -785,6 +847,7 @@ int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {
 }
 
 int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *power) {
+    AWPU_CTX(h);
     if (!frames || !power) return invalid("null argument");
     int rc = check_ready(h, batch);
     if (rc != AWPU_OK) return rc;
@@ -829,6 +892,7 @@ int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *p
 
 int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch, float *d_power,
                             void *stream) {
+    AWPU_CTX(h);
     if (!d_frames || !d_power) return invalid("null argument");
     const int rc = check_ready(h, batch);
     if (rc != AWPU_OK) return rc;
@@ -878,6 +942,7 @@ int ensure_power(awpu_hip *h, size_t need_power) {
 }  // namespace
 
 int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes) {
+    AWPU_CTX(h);
     const int rc = enqueue_ingest(h, datagrams, stride_bytes);
     if (rc != AWPU_OK) return rc;
     // the staging buffer is reused by the next call: finish the copy before returning
@@ -888,6 +953,7 @@ int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_b
 int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes, float *power, int32_t rows,
                         int32_t cols, uint8_t *image, int32_t out_rows, int32_t out_cols, const uint8_t *d_colormap,
                         uint8_t *big_image) {
+    AWPU_CTX(h);
     int rc = check_ready(h, 1);
     if (rc != AWPU_OK) return rc;
     const int n = h->cfg.n_pixels;
@@ -926,12 +992,12 @@ int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_byt
 }
 
 int awpu_hip_process_ring(awpu_hip_t *h, float *power) {
+    AWPU_CTX(h);
     if (!power) return invalid("null argument");
     int rc = check_ready(h, 1);
     if (rc != AWPU_OK) return rc;
     if (!h->d_ring) {
-        g_last_error = "no block ingested yet";
-        return AWPU_ERR_STATE;
+        return fail(AWPU_ERR_STATE, "no block ingested yet");
     }
     const size_t need_power = (size_t) h->cfg.pixel_count;
     rc = ensure_power(h, need_power);
@@ -944,10 +1010,10 @@ int awpu_hip_process_ring(awpu_hip_t *h, float *power) {
 }
 
 int awpu_hip_ring_snapshot(awpu_hip_t *h, float *frames) {
+    AWPU_CTX(h);
     if (!h || !frames) return invalid("null argument");
     if (!h->d_ring) {
-        g_last_error = "no block ingested yet";
-        return AWPU_ERR_STATE;
+        return fail(AWPU_ERR_STATE, "no block ingested yet");
     }
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     AWPU_HIP_TRY(hipMemcpy2DAsync(frames, AWPU_HIST * sizeof(float), h->d_ring + h->ring_pos, 2048 * sizeof(float),
@@ -958,6 +1024,7 @@ int awpu_hip_ring_snapshot(awpu_hip_t *h, float *frames) {
 
 int awpu_hip_heatmap_u8_device(awpu_hip_t *h, const float *d_power, int32_t n, int32_t batch, float *d_peak,
                                int32_t peak_given, uint8_t *d_pix, void *stream) {
+    AWPU_CTX(h);
     if (!h || !d_power || !d_peak || !d_pix || n < 1 || batch < 1 || batch > 65535) return invalid("bad argument");
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
@@ -968,6 +1035,7 @@ int awpu_hip_heatmap_u8_device(awpu_hip_t *h, const float *d_power, int32_t n, i
 int awpu_hip_upscale_u8_device(awpu_hip_t *h, const uint8_t *d_pix, int32_t rows, int32_t cols, int32_t batch,
                                const uint8_t *d_colormap, uint8_t *d_out, int32_t out_rows, int32_t out_cols,
                                void *stream) {
+    AWPU_CTX(h);
     if (!h || !d_pix || !d_out || rows < 1 || cols < 1 || batch < 1 || batch > 65535) return invalid("bad argument");
     if (out_rows < rows || out_cols < cols || out_rows > 65535) return invalid("upscale only: out >= in, out_rows <= 65535");
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
@@ -1018,6 +1086,7 @@ int awpu_hip_resize_linear_u8(const uint8_t *pix, int32_t rows, int32_t cols, ui
 }
 
 int awpu_hip_synchronize(awpu_hip_t *h) {
+    AWPU_CTX(h);
     if (!h) return invalid("null handle");
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1025,6 +1094,7 @@ int awpu_hip_synchronize(awpu_hip_t *h) {
 }
 
 int awpu_hip_get_stats(awpu_hip_t *h, awpu_hip_stats *stats) {
+    AWPU_CTX(h);
     if (!h || !stats) return invalid("null argument");
     *stats = h->stats;
     return AWPU_OK;
@@ -1044,6 +1114,8 @@ const char *awpu_hip_strerror(int status) {
 }
 
 const char *awpu_hip_last_error(void) { return g_last_error.c_str(); }
+
+const char *awpu_hip_last_error_of(awpu_hip_t *h) { return h ? h->last_error.c_str() : ""; }
 
 int awpu_hip_abi_version(void) { return AWPU_HIP_ABI_VERSION; }
 

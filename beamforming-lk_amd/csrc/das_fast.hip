@@ -36,6 +36,8 @@
 //         C += f*y   -> out[128+2l], out[129+2l]    R += g*y   -> out[127+2l], out[128+2l]
 #include "das_kernels.h"
 
+#include <atomic>
+
 namespace awpu {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -821,21 +823,24 @@ bool fast_plan(int window, int usable, int fpi, int image_bytes, FastPlan *plan)
 
 // Kernels that ask for more than 64 KiB of dynamic LDS need the limit raised once per function AND
 // per device (a process may hold handles on several GPUs); `done` is the caller's per-function flags.
-static hipError_t allow_lds(const void *kernel, int bytes, bool (&done)[64]) {
+// The flags are atomics: every worker thread launches through its own handle, and two first launches may
+// meet here (setting the attribute twice is harmless; a torn flag would not be).
+typedef std::atomic<bool> LdsFlags[64];
+static hipError_t allow_lds(const void *kernel, int bytes, LdsFlags &done) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !done[dev]) {
+    if (dev < 0 || dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
         e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) done[dev] = true;
+        if (dev >= 0 && dev < 64) done[dev].store(true, std::memory_order_release);
     }
     return hipSuccess;
 }
 
 template <int NW, int PPW, int FPI, int WPS>
 static hipError_t launch_variant(const FastArgs &a, hipStream_t stream) {
-    static bool attr_set[64] = {};
+    static LdsFlags attr_set = {};
     if (hipError_t e = allow_lds((const void *) das_fast_kernel<NW, PPW, FPI, WPS>, kFastLdsBytes, attr_set); e != hipSuccess)
         return e;
     const int pix_per_block = NW * PPW;
@@ -847,7 +852,7 @@ static hipError_t launch_variant(const FastArgs &a, hipStream_t stream) {
 
 template <int NW, int PPW, int BUF, int WPS, bool DIAG>
 static hipError_t launch_db(const FastArgs &a, hipStream_t stream) {
-    static bool attr_set[64] = {};
+    static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * BUF + kFastSideBytes;
     if (hipError_t e = allow_lds((const void *) das_fast_db_kernel<NW, PPW, BUF, WPS, DIAG>, lds_bytes, attr_set); e != hipSuccess)
         return e;
@@ -886,7 +891,7 @@ hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int
 
 template <int PPW, bool DIAG, bool SHARE>
 static hipError_t launch_pair_variant(const PairArgs &a, hipStream_t stream) {
-    static bool attr_set[64] = {};
+    static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_pair_kernel<PPW, DIAG, SHARE>, lds_bytes, attr_set); e != hipSuccess) return e;
     static_assert(16 * PPW == 64, "pair_tiles() counts 64-pixel tiles");

@@ -212,7 +212,8 @@ __global__ void heatmap_scale_kernel(const float *power, int n, const float *pea
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         // mimo.cpp:85-91: float division, then double scaling and clipping, then the uchar cast
         double level = (double) (p[i] / max_v) * 255.0;
-        level = level < 0.0 ? 0.0 : (level > 255.0 ? 255.0 : level);
+        // all-zero frame: 0/0 = NaN, defined as level 0 (awpu_hip_heatmap_u8 on the host does the same)
+        level = !(level >= 0.0) ? 0.0 : (level > 255.0 ? 255.0 : level);
         o[i] = (uint8_t) level;
     }
 }

@@ -157,7 +157,9 @@ int awpu_hip_heatmap_u8(const float *power, int32_t n, uint8_t *pix) {
     for (int i = 0; i < n; i++) max_v = power[i] > max_v ? power[i] : max_v;
     for (int i = 0; i < n; i++) {  // mimo.cpp:85-91 with USE_DB 0
         double level = static_cast<double>(power[i] / max_v) * 255.0;
-        level = level < 0.0 ? 0.0 : (level > 255.0 ? 255.0 : level);
+        // An all-zero frame gives 0/0 = NaN here; the reference then casts NaN to uchar (undefined, 0 on
+        // x86).  Defined here: a level that is not a number is level 0.
+        level = !(level >= 0.0) ? 0.0 : (level > 255.0 ? 255.0 : level);
         pix[i] = static_cast<uint8_t>(level);
     }
     return AWPU_OK;

@@ -3,6 +3,7 @@
 #include "aw_processing_unit_hip.h"
 
 #include <cstdio>
+#include <mutex>
 
 namespace awpu_host {
 
@@ -32,21 +33,53 @@ void AWProcessingUnitHip::setupAntennas() {  // .cpp:58-65: one identical 8x8 ar
 }
 
 void AWProcessingUnitHip::calibrate(const float reference_power_level) {  // .cpp:102-212
-    for (int i = 0; i < AWPU_HIST / AWPU_N_SAMPLES; i++) pipeline->barrier();  // wait for full buffers
-    std::vector<float> signals((size_t) AWPU_ELEMENTS * AWPU_HIST);
+    // The per-mic mean squares are computed on the device (awpu_hip_calibrate_ring / _host) by a
+    // short-lived engine of this unit's own: a pipeline that feeds device rings fills that engine's ring
+    // while we wait for full buffers; any other source hands over the snapshot read_stream assembles.
+    const int n_sensors = pipeline->get_n_sensors();
+    awpu_hip_cfg cfg;
+    awpu_hip_default_cfg(&cfg);
+    cfg.device = device;
+    cfg.n_streams = n_sensors;
+    cfg.n_pixels = 1;  // calibration sweeps nothing
+    awpu_hip_t *engine = nullptr;
+    calibrate_status = awpu_hip_create(&engine, &cfg);
+    if (calibrate_status != AWPU_OK) {
+        std::fprintf(stderr, "AWProcessingUnitHip::calibrate: %s (%s)\n", awpu_hip_strerror(calibrate_status),
+                     awpu_hip_last_error());
+        return;  // no device, no calibration: every antenna stays at usable = 0 and start() refuses
+    }
+    std::mutex guard;
+    const bool from_ring = pipeline->feeds_device_ring();
+    if (from_ring) pipeline->attach(engine, &guard);
+    for (int i = 0; i < AWPU_HIST / AWPU_N_SAMPLES; i++) pipeline->barrier();  // wait for full buffers (.cpp:106-109)
+    std::vector<float> signals;
+    if (!from_ring) {
+        signals.resize((size_t) n_sensors * AWPU_HIST);
+        for (int s = 0; s < n_sensors; s++) pipeline->read_stream((unsigned) s, &signals[(size_t) s * AWPU_HIST]);
+    }
     for (size_t a = 0; a < antennas.size(); a++) {
-        for (int s = 0; s < AWPU_ELEMENTS; s++)
-            pipeline->read_stream((unsigned) (s + a * AWPU_ELEMENTS), &signals[(size_t) s * AWPU_HIST]);
         AntennaState &ant = antennas[a];
         ant.index.assign(AWPU_ELEMENTS, 0);
         ant.power_correction_mask.assign(AWPU_ELEMENTS, 0.f);
-        ant.usable = calibrate_array(signals.data(), AWPU_HIST, reference_power_level, ant.index.data(),
-                                     ant.power_correction_mask.data(), &ant.median);
+        int32_t usable = 0;
+        {
+            std::lock_guard<std::mutex> hold(guard);  // the producer ingests into this engine from its own thread
+            calibrate_status = from_ring
+                ? awpu_hip_calibrate_ring(engine, (int32_t) a, reference_power_level, ant.index.data(),
+                                          ant.power_correction_mask.data(), &ant.median, &usable)
+                : awpu_hip_calibrate_host(engine, signals.data(), (int32_t) a, reference_power_level, ant.index.data(),
+                                          ant.power_correction_mask.data(), &ant.median, &usable);
+        }
+        if (calibrate_status != AWPU_OK) usable = 0;
+        ant.usable = usable;
         ant.index.resize(ant.usable);
         ant.power_correction_mask.resize(ant.usable);
         if (verbose)
             std::printf("Calibrated antenna %zu Usable: %d Median: %g\n", a, ant.usable, (double) ant.median);
     }
+    if (from_ring) pipeline->detach(engine);
+    awpu_hip_destroy(engine);
 }
 
 bool AWProcessingUnitHip::start(const worker_t worker) {  // .cpp:67-95

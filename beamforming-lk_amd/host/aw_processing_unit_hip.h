@@ -56,6 +56,7 @@ public:
     int usable(int a = 0) const { return antennas[a].usable; }
     const std::vector<int> &index(int a = 0) const { return antennas[a].index; }
     int status() const;
+    int calibration_status() const { return calibrate_status; }
 
 protected:
     struct AntennaState {  // src/geometry/antenna.h:80-103
@@ -72,6 +73,7 @@ protected:
     std::vector<std::unique_ptr<MIMOWorkerHip>> workers;
     FrameSource *pipeline;
     bool running = false;
+    int calibrate_status = AWPU_OK;  // last C-ABI status of calibrate()
     std::vector<AntennaState> antennas;
 };
 

@@ -2,10 +2,7 @@
 // there is no CPU implementation of the sweep here.
 #include "mimo_worker_hip.h"
 
-#include <algorithm>
-#include <cmath>
 #include <cstdio>
-#include <cstring>
 
 namespace awpu_host {
 
@@ -41,9 +38,14 @@ MIMOWorkerHip::MIMOWorkerHip(FrameSource *pipeline, const AntennaView &antenna, 
 }
 
 MIMOWorkerHip::~MIMOWorkerHip() {
+    // Order matters: the source's producer thread ingests into `engine` under `lock`.  Cut that link first
+    // (detach waits for an ingest in flight), then stop our own loop, and only then free the engine.
+    if (from_ring && engine) pipeline->detach(engine);
     looping = false;
     if (thread_loop.joinable()) thread_loop.join();
+    std::lock_guard<std::mutex> guard(lock);
     awpu_hip_destroy(engine);
+    engine = nullptr;
 }
 
 // mimo.cpp:20-59: the tables are built on the host exactly as the reference does (one-off), kept in
@@ -88,35 +90,6 @@ void MIMOWorkerHip::loop() {  // worker.h:212-224
         update();
         lock.unlock();
     }
-}
-
-// aw_processing_unit.cpp:128-200, one array
-int calibrate_array(const float *X, int hist, float reference_power_level, int *index, float *correction,
-                    float *median_out) {
-    float power[AWPU_ELEMENTS];
-    for (int s = 0; s < AWPU_ELEMENTS; s++) {
-        float power_value = 0.0f;
-        for (int i = 0; i < hist; i++) power_value += X[(size_t) s * hist + i] * X[(size_t) s * hist + i];
-        power[s] = power_value / (float) hist;
-    }
-    float medians[AWPU_ELEMENTS];
-    std::memcpy(medians, power, sizeof(medians));
-    std::sort(std::begin(medians), std::end(medians));
-    // the reference averages elements 32 and 33 (aw_processing_unit.cpp:150)
-    const float median = (float) ((medians[AWPU_ELEMENTS / 2] + medians[AWPU_ELEMENTS / 2 + 1]) / 2.0);
-    int count = 0;
-    for (int s = 0; s < AWPU_ELEMENTS; s++) {
-        const float diff = std::fabs(power[s] - median);
-        if (diff > 1e-4) {                      // too far from the median
-        } else if (power[s] < median * 1e-3) {  // dead
-        } else {
-            index[count] = s;
-            correction[count] = reference_power_level / power[s];
-            count++;
-        }
-    }
-    if (median_out) *median_out = median;
-    return count;
 }
 
 }  // namespace awpu_host

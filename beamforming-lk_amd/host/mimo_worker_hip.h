@@ -39,6 +39,9 @@ public:
         (void) engine;
         (void) guard;
     }
+    // The engine is about to be destroyed: after detach() returns the source touches neither the engine
+    // nor its guard again (an ingest in flight finishes first).
+    virtual void detach(awpu_hip_t *engine) { (void) engine; }
 };
 
 // src/geometry/antenna.h:80-103 without Eigen: points is xyz[3][n] row-major by coordinate.
@@ -95,10 +98,5 @@ private:
     std::vector<float> signals;           // the snapshot update() takes: [n_sensors][1024] (mimo.cpp:100-103)
     awpu_hip_t *engine = nullptr;
 };
-
-// AWProcessingUnit::calibrate for one array (src/aw_processing_unit/aw_processing_unit.cpp:128-200):
-// X = the 64 streams [64][hist]; fills index/correction (<= 64 each), returns usable.
-int calibrate_array(const float *X, int hist, float reference_power_level, int *index, float *correction,
-                    float *median_out = nullptr);
 
 }  // namespace awpu_host

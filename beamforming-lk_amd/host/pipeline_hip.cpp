@@ -123,6 +123,14 @@ void PipelineHip::attach(awpu_hip_t *engine, std::mutex *guard) {
     engines.push_back(Attached{engine, guard});
 }
 
+void PipelineHip::detach(awpu_hip_t *engine) {
+    // receive_exposure() holds ring_mutex for its whole ingest loop, so once we have it no ingest into
+    // `engine` is running and none will start
+    std::unique_lock<std::mutex> lock(ring_mutex);
+    for (auto it = engines.begin(); it != engines.end();)
+        it = it->engine == engine ? engines.erase(it) : it + 1;
+}
+
 void PipelineHip::producer() {
     while (isRunning()) {
         receive_exposure();

@@ -50,6 +50,7 @@ public:
     // every exposure from now on also goes, raw, into this engine's device ring; `guard` (may be null) is
     // held around the call -- the engine handle is not thread-safe and its worker sweeps from another thread
     void attach(awpu_hip_t *engine, std::mutex *guard) override;
+    void detach(awpu_hip_t *engine) override;
     bool feeds_device_ring() override { return true; }
     int last_status() const { return status; }
 

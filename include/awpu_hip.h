@@ -144,6 +144,11 @@ int awpu_hip_calibrate_device(awpu_hip_t *h, const float *d_frame, int32_t array
                               int32_t *index, float *correction, float *median, int32_t *usable, void *stream);
 int awpu_hip_calibrate_ring(awpu_hip_t *h, int32_t array, float reference_power_level, int32_t *index,
                             float *correction, float *median, int32_t *usable);
+/* _host: frame [n_streams][hist] in host memory, the snapshot AWProcessingUnit::calibrate assembles with
+ * Streams::read_stream (aw_processing_unit.cpp:116-122); the array's 64 streams are uploaded, the rest is as
+ * above.  What the C++ mirror's AWProcessingUnit::calibrate calls when its pipeline keeps host rings. */
+int awpu_hip_calibrate_host(awpu_hip_t *h, const float *frame, int32_t array, float reference_power_level,
+                            int32_t *index, float *correction, float *median, int32_t *usable);
 
 /* ---- few-beam delay-and-sum for the trackers --------------------------------- */
 
@@ -184,7 +189,8 @@ int awpu_hip_synchronize(awpu_hip_t *h);
 
 /* replaces: MIMOWorker::populateHeatmap (USE_DB 0), src/dsp/mimo.cpp:61-95, with the
  * cv::Mat replaced by a plain rows*columns uint8 image: pix = clip(power/max*255).
- * power/pix are host buffers of `n` elements (n = whole grid). */
+ * power/pix are host buffers of `n` elements (n = whole grid).  An all-zero frame (max 0, so 0/0: the
+ * reference casts a NaN to uchar there, which is undefined) gives an all-zero image, here and on the device. */
 int awpu_hip_heatmap_u8(const float *power, int32_t n, uint8_t *pix);
 
 /* the same display step on buffers resident in device memory: d_power [batch][n]
@@ -262,8 +268,12 @@ int awpu_hip_build_delay_table(const float *xyz, int32_t n, int32_t rows, int32_
 
 int awpu_hip_get_stats(awpu_hip_t *h, awpu_hip_stats *stats);
 const char *awpu_hip_strerror(int status);
-/* text of the last HIP error seen by this thread ("" if none) */
+/* text of the last error seen by this thread ("" if none) */
 const char *awpu_hip_last_error(void);
+/* text of the last error any thread ran into while working on this handle ("" if none): a worker thread
+ * owns the handle, the thread that asks (the reference's GUI thread) usually is another one.  The
+ * pointer stays valid until the handle's next failing call. */
+const char *awpu_hip_last_error_of(awpu_hip_t *h);
 int awpu_hip_abi_version(void);
 
 #ifdef __cplusplus

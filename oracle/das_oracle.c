@@ -282,6 +282,9 @@ void oracle_heatmap_u8(const float *power, int P, uint8_t *pix) {
         db *= 255.0;
         if (db < 0.0) db = 0.0;
         if (db > 255.0) db = 255.0;
+        /* An all-zero frame makes db NaN (0/0); the reference then casts NaN to uchar, which C and C++
+         * leave undefined (0 on x86-64).  The product defines that case as level 0; so does the checker. */
+        if (db != db) db = 0.0;
         pix[i] = (uint8_t) db;
     }
 }

@@ -7,6 +7,7 @@ cpu_baseline leg.  Nothing under beamforming-lk_amd/ may import this.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 from typing import Optional
@@ -27,6 +28,8 @@ _u8p = C.POINTER(C.c_uint8)
 
 def build(ref: bool = True) -> None:
     """make the restatement, and (when the reference tree is present) oracle/_ref."""
+    if os.environ.get("AWPU_NO_BUILD") == "1":  # set by the profiling scripts: no child processes under rocprofv3
+        raise RuntimeError("AWPU_NO_BUILD=1: the oracle library is missing or stale and may not be built from this process")
     subprocess.run(["make", "-s", "-C", str(HERE), "oracle"], check=True)
     if ref and (REFERENCE_TREE / "src/dsp/delay.cpp").exists():
         subprocess.run(["make", "-s", "-C", str(HERE), "ref"], check=True)

@@ -160,7 +160,17 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 1024; i++) snap[(size_t) 40 * 1024 + i] *= 3.0f;  // loud mic 40
         int index[64], index_o[64];
         float corr[64], corr_o[64], med = 0, med_o = 0;
-        const int usable = calibrate_array(snap.data(), 1024, 1e-5f, index, corr, &med);
+        int32_t usable = 0;
+        {   // the C ABI's calibration (device mean squares) on the host snapshot, through an engine of its own
+            awpu_hip_cfg cfg;
+            awpu_hip_default_cfg(&cfg);
+            cfg.n_pixels = 1;
+            awpu_hip_t *cal = nullptr;
+            CHECK(awpu_hip_create(&cal, &cfg) == AWPU_OK, "create: %s", awpu_hip_last_error());
+            CHECK(awpu_hip_calibrate_host(cal, snap.data(), 0, 1e-5f, index, corr, &med, &usable) == AWPU_OK,
+                  "calibrate_host: %s", awpu_hip_last_error_of(cal));
+            awpu_hip_destroy(cal);
+        }
         const int usable_o = oracle_calibrate(snap.data(), 1024, 1e-5f, index_o, corr_o, &med_o);
         CHECK(usable == usable_o && usable == 62 && std::equal(index, index + usable, index_o) && med == med_o,
               "calibrate: usable %d vs %d", usable, usable_o);
@@ -257,7 +267,8 @@ int main(int argc, char **argv) {
         CHECK(pipeline.connect() == 0, "connect");
         CHECK(pipeline.get_n_sensors() == 64, "n_sensors %d", pipeline.get_n_sensors());
         {
-            AWProcessingUnitHip awpu(&pipeline, 180.f, rows, /*verbose=*/0);  // calibrates on the host copy of the ring
+            AWProcessingUnitHip awpu(&pipeline, 180.f, rows, /*verbose=*/0);  // calibrates on a device ring of its own
+            CHECK(awpu.calibration_status() == AWPU_OK, "calibrate: %d", awpu.calibration_status());
             CHECK(awpu.usable() == 64, "calibrate kept %d mics", awpu.usable());
             CHECK(awpu.start(MIMO), "start(MIMO): %s", awpu_hip_last_error());
             awpu.resume();
@@ -274,7 +285,19 @@ int main(int argc, char **argv) {
             CHECK(img[k] == 255 && k / cols == 8 && k % cols == 10, "live heatmap peak at (%d,%d), expected (8,10)", k / cols, k % cols);
             std::printf("5. UDP -> device ring -> sweep: heatmap peak at (%d,%d) after %d blocks\n", k / cols, k % cols,
                         pipeline.mostRecent());
-        }
+            // stop the worker while blocks are still arriving: the pipeline must let go of the engine before it
+            // is destroyed (the producer ingests into it from its own thread), and keep running afterwards
+            const int before = pipeline.mostRecent();
+            CHECK(awpu.stop(MIMO) && !awpu.stop(MIMO), "stop(MIMO) once, while the sender is running");
+            for (int spin = 0; spin < 400 && pipeline.mostRecent() < before + 4; spin++)
+                std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            CHECK(pipeline.mostRecent() >= before + 4 && pipeline.last_status() == AWPU_OK,
+                  "the pipeline stalled after the worker was stopped (status %d)", pipeline.last_status());
+            // and a second worker can be started on the same pipeline
+            CHECK(awpu.start(MIMO), "restart(MIMO): %s", awpu_hip_last_error());
+            std::this_thread::sleep_for(std::chrono::milliseconds(60));
+            CHECK(awpu.status() == AWPU_OK, "restarted worker status %d", awpu.status());
+        }  // ~AWProcessingUnitHip with the sender still running: same hand-over in the destructor
         sending = false;
         sender.join();
         CHECK(pipeline.disconnect() == 0, "disconnect");

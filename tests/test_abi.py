@@ -109,6 +109,14 @@ def test_heatmap_equals_oracle(pkg, oracle):
     rng = np.random.default_rng(0)
     p = rng.uniform(0, 3e-5, 4096).astype(np.float32)
     assert np.array_equal(pkg.heatmap_u8(p), oracle.heatmap_u8(p))
+    # an all-zero frame (0/0 in mimo.cpp:85; the reference's cast of the NaN is undefined): a black image
+    zero = np.zeros(64, np.float32)
+    assert not pkg.heatmap_u8(zero).any() and not oracle.heatmap_u8(zero).any()
+    assert lib_last_error_of_null(pkg) == b""
+
+
+def lib_last_error_of_null(pkg):
+    return pkg.binding.load().awpu_hip_last_error_of(None)
 
 
 def test_null_arguments_are_refused_not_dereferenced(pkg):
@@ -143,6 +151,7 @@ def test_null_arguments_are_refused_not_dereferenced(pkg):
     call("awpu_hip_resize_linear_u8", None, 4, 4, up, 8, 8)
     call("awpu_hip_calibrate_device", None, None, 0, 1e-5, ip, fp, None, None, None)
     call("awpu_hip_calibrate_ring", None, 0, 1e-5, ip, fp, None, None)
+    call("awpu_hip_calibrate_host", None, fp, 0, 1e-5, ip, fp, None, None)
     call("awpu_hip_beams", None, None, ip, fp, 1, fp, fp)
     call("awpu_hip_steer_table", None, 4, None, None, 1, ip, fp)
     call("awpu_hip_create_antenna", 8, 8, 0.02, None)
@@ -152,5 +161,6 @@ def test_null_arguments_are_refused_not_dereferenced(pkg):
     call("awpu_hip_get_stats", None, None)
     call("awpu_hip_create", None, None)
     untested = set(B.EXPORTED_SYMBOLS) - set(seen) - {"awpu_hip_destroy", "awpu_hip_default_cfg", "awpu_hip_strerror",
-                                                      "awpu_hip_last_error", "awpu_hip_abi_version"}
+                                                      "awpu_hip_last_error", "awpu_hip_last_error_of",
+                                                      "awpu_hip_abi_version"}
     assert not untested, untested

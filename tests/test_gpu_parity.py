@@ -316,7 +316,7 @@ def test_device_heatmap_equals_populate_heatmap(pkg, oracle):
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz)
     frames = S.make_frames(xyz, 3, seed=9)
-    frames[2] *= 0.0  # an all-zero frame: max 0 -> 0/0 -> NaN -> clipped like the reference does
+    frames[2] *= 0.0  # an all-zero frame: max 0 -> 0/0 -> NaN, defined as level 0 (host, device and checker alike)
     dev = torch.device("cuda:0")
     with pkg.Engine(n_pixels=spec.n_pixels, max_batch=3) as eng:
         eng.set_delay_table(off, frac)
@@ -332,6 +332,8 @@ def test_device_heatmap_equals_populate_heatmap(pkg, oracle):
         for b in range(2):
             assert np.array_equal(pix[b], oracle.heatmap_u8(power[b]))
             assert pix[b].max() == 255
+        assert not power[2].any() and not pix[2].any()  # the all-zero frame: a black image, not garbage
+        assert np.array_equal(pkg.binding.heatmap_u8(power[2]), pix[2])
         # externally supplied peak (what a rank does with the all-reduced maximum of all tiles)
         d_peak.fill_(float(2.0 * power[0].max()))
         eng.heatmap_device(d_power.data_ptr(), spec.n_pixels, 1, d_peak.data_ptr(), d_pix.data_ptr(), peak_given=True)

@@ -2,13 +2,19 @@
 # pmc_hbm.sh -- HBM-side traffic of the sweep launch: FETCH_SIZE and WRITE_SIZE in SEPARATE passes
 # (TCC has 4 slots; FETCH_SIZE takes 3, WRITE_SIZE 2), counters only, no trace domains.
 # usage: tools/pmc_hbm.sh <outdir-under-gpurun_out> [bench args...]
-set -e
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run under gpurun)}"
 out=gpurun_out/$1; shift
-mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$out"
+# Build BEFORE the profiler is in the picture: under rocprofv3 every child inherits the preloaded tool
+# library, and a compiler or make started from a process whose GPU it has initialised is an exec the pool
+# forbids.  AWPU_NO_BUILD=1 then makes the binding and the oracle loader refuse to build (they raise).
+python3 -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1
+export AWPU_NO_BUILD=1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_REQ_sum TCC_READ_sum"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --output-format csv -d $out/$tag -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 "$@" > $out/$tag.log 2>&1 || true
+  rocprofv3 --pmc $grp --output-format csv -d $out/$tag -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 "$@" > $out/$tag.log 2>&1 || { echo "rocprofv3 pass $tag failed, see $out/$tag.log" >&2; exit 1; }
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
