@@ -241,6 +241,32 @@ def reference_fir_table():
     return table
 
 
+def ref_fir_table_probe():
+    """The weights the reference's compiled 8-tap delay() (oracle/_ref/libref_das_fir.so) applies, recovered
+    by running it on a unit impulse for every fraction k/100: [101, 8].  Works wherever oracle/_ref is
+    (also on the GPU box, where the reference tree is not); None when the library is absent."""
+    if not ref_available("fir"):
+        return None
+    lib = ref("fir")
+    impulse = np.zeros(263, np.float32)
+    impulse[7] = 1.0
+    table = np.empty((101, 8), np.float32)
+    for k in range(101):
+        out = np.zeros(256, np.float32)
+        lib.ref_delay(_p32(out), _p32(impulse), float(np.float32(k / 100.0)))
+        table[k] = out[7::-1]
+    return table
+
+
+def delay_fir8(out, signal, fraction, coeffs):
+    """The restated 8-tap delay() (delay.cpp:31-40): accumulates into `out` [256] in place."""
+    coeffs = np.ascontiguousarray(coeffs, np.float32)
+    signal = np.ascontiguousarray(signal, np.float32)
+    assert out.dtype == np.float32 and out.shape == (256,) and signal.size >= 263 and coeffs.shape == (101, 8)
+    oracle().oracle_delay_fir8(_p32(out), _p32(signal), float(fraction), _p32(coeffs))
+    return out
+
+
 def ref_bench(X, off, frac, index=None, min_seconds=1.0):
     """frames/s of the reference-kernel loop nest on one thread over the P pixels of `off`."""
     X, off, frac, index = _sweep_args(X, off, frac, index)

@@ -49,6 +49,58 @@ def delay_kat():
     print("delay_kat.npz", outs.shape)
 
 
+def delay_kat_fir8():
+    """Known answers of the reference's OTHER delay(), the 8-tap table variant its build selects without
+    -mavx2 (src/dsp/delay.cpp:31-40), from oracle/_ref/libref_das_fir.so:
+      * impulse responses: signal = a unit impulse at sample 7, fraction k/100 for k = 0..100; out[7 - t] is
+        then exactly the weight the compiled reference puts on tap t (one product by 1.0, the rest by 0.0);
+      * a noise signal through a few fractions, on a non-zero accumulator.
+    Only outputs of the compiled function are stored."""
+    ref = O.ref("fir")
+    assert ref.ref_variant() == 2
+    impulse = np.zeros(263, np.float32)
+    impulse[7] = 1.0
+    fractions = (np.arange(101) / 100.0).astype(np.float32)
+    rows = (fractions * np.float32(100.0) + np.float32(0.5)).astype(np.int32)  # delay.cpp:32-33
+    assert np.array_equal(rows, np.arange(101))
+    response = np.empty((101, 8), np.float32)
+    for k, f in enumerate(fractions):
+        out = np.zeros(256, np.float32)
+        ref.ref_delay(out.ctypes.data_as(_f32p), impulse.ctypes.data_as(_f32p), float(f))
+        response[k] = out[7::-1]
+        assert not out[8:].any()
+    sig = util.hash_frames(1, 320, seed=21, scale=1.0)[0, 0]
+    acc0 = util.hash_frames(1, 256, seed=22, scale=4.0)[0, 0]
+    kat_f = np.array([0.0, 0.004, 0.005, 0.5, 0.25, 0.994, 0.995, 0.999999, 0.3333333, 0.6180339], np.float32)
+    starts = np.array([0, 1, 7, 43, 0, 13, 2, 30, 5, 57], np.int32)
+    outs = np.empty((kat_f.size, 256), np.float32)
+    for j, (f, s0) in enumerate(zip(kat_f, starts)):
+        out = acc0.copy()
+        window = np.ascontiguousarray(sig[s0:s0 + 263])
+        ref.ref_delay(out.ctypes.data_as(_f32p), window.ctypes.data_as(_f32p), float(f))
+        outs[j] = out
+    np.savez_compressed(HERE / "delay_kat_fir8.npz", impulse_at=7, impulse_fractions=fractions, impulse_response=response,
+                        sig_seed=21, acc_seed=22, fractions=kat_f, starts=starts, expected=outs)
+    print("delay_kat_fir8.npz", response.shape, outs.shape)
+    return response
+
+
+def sweep_case_fir8(name, arrays_x, arrays_y, res, pixels, seed, index=None, hist=1024, fov=180.0):
+    """The sweep of mimo.cpp:121-151 around the reference's 8-tap delay() (libref_das_fir.so, which carries
+    the reference's coefficient table inside): inputs and the powers it produced."""
+    xyz = O.create_tiled_antenna(arrays_x, arrays_y)
+    off, frac = O.compute_delay_lut(xyz, res, res, fov)
+    off, frac = off[pixels], frac[pixels]
+    n = xyz.shape[1]
+    X = util.hash_frames(n, hist, seed=seed)[0]
+    power = O.das_fir8_f32(X, off, frac, np.zeros((101, 8), np.float32), index, impl="ref")
+    np.savez_compressed(
+        HERE / f"{name}.npz", arrays=np.array([arrays_x, arrays_y]), res=res, fov=fov, pixels=pixels,
+        seed=seed, hist=hist, off=off, frac=frac,
+        index=np.arange(n, dtype=np.int32) if index is None else index.astype(np.int32), power=power)
+    print(f"{name}.npz", off.shape, "power range", power.min(), power.max())
+
+
 def sweep_case(name, arrays_x, arrays_y, res, pixels, seed, index=None, hist=1024, fov=180.0):
     xyz = O.create_tiled_antenna(arrays_x, arrays_y)
     off, frac = O.compute_delay_lut(xyz, res, res, fov)
@@ -113,6 +165,15 @@ def main():
     # 512 mics (4x2 arrays), 128x128 grid, shortest legal history
     pix = np.unique(np.concatenate([[0, 16383], rng.choice(16384, 22, replace=False)]))
     sweep_case("sweep_c3", 4, 2, 128, pix, seed=105, hist=520)
+    # ---- the 8-tap variant of delay() (the reference built without -mavx2)
+    delay_kat_fir8()
+    sweep_case_fir8("sweep_c1_fir8", 1, 1, 32, np.arange(1, 1024, 9), seed=111)
+    keep = np.sort(rng.choice(64, size=47, replace=False)).astype(np.int32)
+    sweep_case_fir8("sweep_c1_ragged_fir8", 1, 1, 32, np.arange(5, 1024, 23), seed=112, index=keep)
+    pix = np.unique(np.concatenate([[0, 127, 16256, 16383], rng.choice(16384, 36, replace=False)]))
+    sweep_case_fir8("sweep_headline_fir8", 4, 1, 128, pix, seed=113, hist=640)
+    pix = np.unique(np.concatenate([[0, 16383], rng.choice(16384, 18, replace=False)]))
+    sweep_case_fir8("sweep_c3_fir8", 4, 2, 128, pix, seed=114, hist=528)
 
 
 if __name__ == "__main__":

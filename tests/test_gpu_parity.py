@@ -279,13 +279,37 @@ def test_device_pointer_entry_with_torch(pkg, oracle):
         assert util.power_rel_err(got[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
 
 
+FIR8_SWEEPS = ["sweep_c1_fir8", "sweep_c1_ragged_fir8", "sweep_headline_fir8", "sweep_c3_fir8"]
+
+
+def measured_fir_table():
+    """The weights the reference's compiled 8-tap delay() applies (its impulse responses, measured from
+    oracle/_ref/libref_das_fir.so by tests/golden/make_golden.py): the table a caller would pass."""
+    return np.load(GOLDEN / "delay_kat_fir8.npz")["impulse_response"]
+
+
+@pytest.mark.parametrize("name", FIR8_SWEEPS)
+def test_fir8_golden_vectors(pkg, name):
+    """AWPU_INTERP_FIR8 on the GPU vs the powers the reference's own non-AVX2 build produced (delay.cpp:31-40
+    inside mimo.cpp:121-151): 64, 256 and 512 mics, a ragged mic list, clipped corner pixels."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    ax, ay = g["arrays"]
+    n = 64 * int(ax) * int(ay)
+    X = util.hash_frames(n, int(g["hist"]), seed=int(g["seed"]))[0]
+    eng = pkg.Engine(n_pixels=g["off"].shape[0], n_streams=n, hist=int(g["hist"]), interp=pkg.binding.INTERP_FIR8)
+    with eng:
+        eng.set_delay_table(g["off"], g["frac"])
+        eng.set_active_mics(g["index"])
+        eng.set_fir_table(measured_fir_table())
+        power = eng.process(X)
+    assert util.power_rel_err(power, g["power"]) < util.POWER_RTOL
+
+
 @pytest.mark.parametrize("table_kind", ["synthetic", "reference"])
 def test_fir8_mode_vs_oracle(pkg, oracle, table_kind):
     """AWPU_INTERP_FIR8 (delay.cpp:31-40): GPU vs the restated FIR sweep, 64 and 256 mics, with a
-    synthetic table and -- where the reference tree is present -- the reference's own."""
-    table = util.synthetic_fir_table() if table_kind == "synthetic" else oracle.reference_fir_table()
-    if table is None:
-        pytest.skip("reference tree absent on this box")
+    synthetic table and the reference's own (as measured from its compiled delay(), tests/golden)."""
+    table = util.synthetic_fir_table() if table_kind == "synthetic" else measured_fir_table()
     for arrays, res, usable in [((1, 1), 16, 64), ((4, 1), 8, 200)]:
         xyz = oracle.create_tiled_antenna(*arrays)
         off, frac = oracle.compute_delay_lut(xyz, res, res)

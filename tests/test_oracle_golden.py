@@ -215,3 +215,55 @@ def test_fir8_at_zero_fraction_is_a_three_sample_delay(oracle):
     p_fir = oracle.das_fir8_f32(X, off, frac, table)
     p_lin = oracle.das_f32(X, off + 2, frac)
     assert np.allclose(p_fir, p_lin, rtol=1e-6, atol=0)
+
+
+FIR8_SWEEPS = ["sweep_c1_fir8", "sweep_c1_ragged_fir8", "sweep_headline_fir8", "sweep_c3_fir8"]
+
+
+def fir8_table_from_fixture():
+    """The weights the reference's compiled 8-tap delay() applies, as measured from it (impulse responses,
+    tests/golden/delay_kat_fir8.npz): what the GPU box, which has no reference tree, feeds set_fir_table."""
+    g = np.load(GOLDEN / "delay_kat_fir8.npz")
+    table = g["impulse_response"]
+    assert table.shape == (101, 8) and abs(float(table[0, 3]) - 1.0) < 1e-4
+    return g, table
+
+
+def test_fir8_known_answers(oracle):
+    """delay(), 8-tap variant (src/dsp/delay.cpp:31-40): the restatement fed the measured weights reproduces
+    what the reference's non-AVX2 build returned for a noise signal (the reference is -Ofast: its 8-term
+    sums are in the compiler's order, so a few ulp of the accumulator, not bits)."""
+    g, table = fir8_table_from_fixture()
+    sig = util.hash_frames(1, 320, seed=int(g["sig_seed"]), scale=1.0)[0, 0]
+    acc0 = util.hash_frames(1, 256, seed=int(g["acc_seed"]), scale=4.0)[0, 0]
+    for f, s0, want in zip(g["fractions"], g["starts"], g["expected"]):
+        out = oracle.delay_fir8(acc0.copy(), sig[s0:s0 + 263], float(f), table)
+        assert np.abs(out - want).max() <= 4 * np.spacing(np.float32(np.abs(want).max()))
+    # the rounding of the row index (delay.cpp:32-33): 0.004 -> row 0, 0.005 -> row 1, 0.994 -> 99, 0.995 -> 100
+    rows = (g["fractions"] * np.float32(100.0) + np.float32(0.5)).astype(np.int32)
+    assert rows[:3].tolist() == [0, 0, 1] and rows[5:8].tolist() == [99, 100, 100]
+
+
+def test_fir8_fixture_table_is_what_the_build_applies(oracle):
+    """Where oracle/_ref is present the impulse responses are re-measured live and must equal the fixture; where
+    the reference tree is present too, they must equal its filter.h, read where it lies."""
+    _, table = fir8_table_from_fixture()
+    live = oracle.ref_fir_table_probe()
+    if live is None:
+        pytest.skip("oracle/_ref FIR build not available")
+    assert np.array_equal(live, table)
+    header = oracle.reference_fir_table()
+    if header is not None:
+        assert np.array_equal(header, table)
+
+
+@pytest.mark.parametrize("name", FIR8_SWEEPS)
+def test_fir8_sweep_goldens(oracle, name):
+    """The restated FIR8 sweep against powers produced by the reference's own non-AVX2 delay() in the loop
+    nest of mimo.cpp:121-151 (tests/golden/make_golden.py, libref_das_fir.so)."""
+    _, table = fir8_table_from_fixture()
+    g = np.load(GOLDEN / f"{name}.npz")
+    ax, ay = g["arrays"]
+    X = util.hash_frames(64 * int(ax) * int(ay), int(g["hist"]), seed=int(g["seed"]))[0]
+    power = oracle.das_fir8_f32(X, g["off"], g["frac"], table, g["index"])
+    assert util.power_rel_err(power, g["power"]) < 5e-6
