@@ -10,6 +10,7 @@ The directory name has a hyphen; import it with
 """
 from . import _build, binding, synthetic  # noqa: F401
 from .binding import (  # noqa: F401
+    MATH_BF16_ACC,
     MATH_F32_EXACT,
     MATH_F32_FAST,
     AwpuError,
@@ -24,7 +25,7 @@ from .binding import (  # noqa: F401
 )
 
 __all__ = [
-    "Engine", "AwpuError", "MATH_F32_EXACT", "MATH_F32_FAST", "build_delay_table",
+    "Engine", "AwpuError", "MATH_F32_EXACT", "MATH_F32_FAST", "MATH_BF16_ACC", "build_delay_table",
     "create_antenna", "create_tiled_antenna", "steering_delays", "heatmap_u8", "resize_linear_u8", "steer_table", "binding",
     "synthetic", "_build",
 ]

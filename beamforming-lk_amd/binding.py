@@ -20,7 +20,7 @@ ELEMENTS = 64
 DATAGRAM_BYTES = 1032  # sizeof(message), src/fpga/receiver.h:24-30
 
 INTERP_LERP, INTERP_FIR8 = 0, 1
-MATH_F32_EXACT, MATH_F32_FAST = 0, 1
+MATH_F32_EXACT, MATH_F32_FAST, MATH_BF16_ACC = 0, 1, 2
 
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_RANGE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 

@@ -228,7 +228,7 @@ int prepare(awpu_hip *h) {
         }
     }
 
-    if (c.math == AWPU_MATH_F32_EXACT || c.interp == AWPU_INTERP_FIR8) {
+    if (c.math != AWPU_MATH_F32_FAST || c.interp == AWPU_INTERP_FIR8) {
         int chunk = 0;
         if (awpu::das_exact_lds_bytes(h->window, U, &chunk) == 0)
             return invalid("delay window does not fit the LDS budget");
@@ -449,7 +449,7 @@ int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     if (h->cfg.interp == AWPU_INTERP_FIR8) {
         AWPU_HIP_TRY(awpu::launch_das_fir8(a, h->d_fir, s));
     } else {
-        AWPU_HIP_TRY(awpu::launch_das_exact(a, s));
+        AWPU_HIP_TRY(awpu::launch_das_exact(a, h->cfg.math == AWPU_MATH_BF16_ACC, s));
     }
     return finish_launch(h, batch, s);
 }
@@ -498,7 +498,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     const bool compact = layout == kCompact;
     const int hist_eff = compact ? h->compact_hist : (layout == kRing ? 2048 : h->cfg.hist);
     const int wstart_eff = compact ? 0 : h->wstart;
-    if (h->cfg.math == AWPU_MATH_F32_EXACT || h->cfg.interp == AWPU_INTERP_FIR8)
+    if (h->cfg.math != AWPU_MATH_F32_FAST || h->cfg.interp == AWPU_INTERP_FIR8)
         return launch_exact(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
 
     // ---- frame-pair shape: batches on grids that fill the chip (AWPU_FAST_PAIRS=0/1 overrides)
@@ -606,8 +606,10 @@ int awpu_hip_create(awpu_hip_t **out, const awpu_hip_cfg *cfg) {
     if (cfg->hist < AWPU_N_SAMPLES + 1) return invalid("hist must hold at least 257 samples");
     if (cfg->max_batch > 65535) return invalid("max_batch above 65535");
     if (cfg->interp != AWPU_INTERP_LERP && cfg->interp != AWPU_INTERP_FIR8) return invalid("cfg.interp");
-    if (cfg->math != AWPU_MATH_F32_EXACT && cfg->math != AWPU_MATH_F32_FAST)
+    if (cfg->math != AWPU_MATH_F32_EXACT && cfg->math != AWPU_MATH_F32_FAST && cfg->math != AWPU_MATH_BF16_ACC)
         return invalid("cfg.math");
+    if (cfg->math == AWPU_MATH_BF16_ACC && cfg->interp != AWPU_INTERP_LERP)
+        return invalid("the bf16 accumulator is built for the linear interpolation only");
     awpu_hip_cfg c = *cfg;
     if (c.pixel_count == 0) {
         c.pixel_begin = 0;

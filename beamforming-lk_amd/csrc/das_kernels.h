@@ -96,8 +96,9 @@ int fast_image_bytes(int nw);
 hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream);
 bool fast_db_fits(const FastPlan &plan);
 
-// exact-order kernel (AWPU_MATH_F32_EXACT): sub, fma, add per sample, mics in order.
-hipError_t launch_das_exact(const SweepArgs &a, hipStream_t stream);
+// exact-order kernel (AWPU_MATH_F32_EXACT): sub, fma, add per sample, mics in order; with
+// bf16_accumulator (AWPU_MATH_BF16_ACC) the running sums are rounded to bf16 after every mic.
+hipError_t launch_das_exact(const SweepArgs &a, bool bf16_accumulator, hipStream_t stream);
 
 // FIR8 variant: LutEntry.frac holds the coefficient-row index k as an int bit pattern; window
 // must cover off + 263.  d_coeffs = [101][8] floats on the device.

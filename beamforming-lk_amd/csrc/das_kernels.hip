@@ -52,7 +52,14 @@ constexpr int kExactThreads = 256;
 constexpr int kExactPPW = 4;
 constexpr size_t kExactLdsBudget = 64 * 1024;
 
-template <int PPW>
+// AWPU_MATH_BF16_ACC: the running sum of a sample is KEPT in bf16 -- rounded to nearest even after every
+// mic's term -- while the term itself is computed in fp32 as above.  gfx950 has no packed bf16 add: a bf16
+// accumulate is an fp32 add plus v_cvt_pk_bf16_f32 (and the unpack shift), i.e. strictly more VALU work than
+// the fp32 accumulator it replaces.  Built so that BASELINE configs[4]'s "bf16 vs fp32 accumulator" is a
+// measurement (error and rate, bench.py "bf16"), not an argument.
+__device__ __forceinline__ float round_to_bf16(float x) { return (float) (__bf16) x; }
+
+template <int PPW, bool BF16ACC>
 __global__ __launch_bounds__(kExactThreads) void das_exact_kernel(SweepArgs a, int chunk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(kExactThreads) void das_exact_kernel(SweepArgs a, i
                         const float nxt = x[64 * k + 1];
                         const float d = cur - nxt;
                         const float t = __builtin_fmaf(f, d, nxt);
-                        acc[pp][k] = acc[pp][k] + t;
+                        acc[pp][k] = BF16ACC ? round_to_bf16(acc[pp][k] + t) : acc[pp][k] + t;
                     }
                 }
             }
@@ -417,14 +424,17 @@ size_t das_exact_lds_bytes(int window, int usable, int *chunk_out) {
     return (size_t) chunk * row;
 }
 
-hipError_t launch_das_exact(const SweepArgs &a, hipStream_t stream) {
+hipError_t launch_das_exact(const SweepArgs &a, bool bf16_accumulator, hipStream_t stream) {
     int chunk = 0;
     const size_t lds = das_exact_lds_bytes(a.window, a.usable, &chunk);
     if (lds == 0) return hipErrorInvalidValue;
     const int pix_per_block = (kExactThreads / 64) * kExactPPW;
     dim3 grid((a.pixel_count + pix_per_block - 1) / pix_per_block, a.batch);
-    hipLaunchKernelGGL(das_exact_kernel<kExactPPW>, grid, dim3(kExactThreads), lds, stream, a,
-                       chunk);
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    if (bf16_accumulator)
+        hipLaunchKernelGGL((das_exact_kernel<kExactPPW, true>), grid, dim3(kExactThreads), lds, stream, a, chunk);
+    else
+        hipLaunchKernelGGL((das_exact_kernel<kExactPPW, false>), grid, dim3(kExactThreads), lds, stream, a, chunk);
     return hipGetLastError();
 }
 

@@ -62,7 +62,13 @@ typedef enum {
     AWPU_MATH_F32_EXACT = 0,
     /* fp32, two FMAs per sample (f*cur + (1-f)*next), LDS-tiled fast kernel; differs from
      * EXACT by fp32 rounding only */
-    AWPU_MATH_F32_FAST = 1
+    AWPU_MATH_F32_FAST = 1,
+    /* EXACT's structure with the running sum of every sample KEPT in bf16 (rounded to nearest even after
+     * every mic; the interpolation term and the epilogue stay fp32).  Not in the reference and not for
+     * production: it exists so that BASELINE configs[4] ("bf16 vs fp32 accumulator") is measured on the
+     * device -- per-pixel power moves by about 1e-2 relative, and gfx950 has no packed bf16 add, so it is
+     * also slower than the fp32 accumulator */
+    AWPU_MATH_BF16_ACC = 2
 } awpu_math;
 
 typedef struct awpu_hip awpu_hip_t;

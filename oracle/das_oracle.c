@@ -246,6 +246,35 @@ void oracle_das_fir8_f32(const float *X, int hist, const int32_t *off, const flo
     }
 }
 
+/* NOT a restatement of reference code: the checker of the build's own AWPU_MATH_BF16_ACC mode (BASELINE
+ * configs[4], "bf16 vs fp32 accumulator").  The sweep of oracle_das_f32 with the running sum of every sample
+ * kept in bfloat16: after each mic  acc = bf16(acc + term), round to nearest even; term and epilogue in fp32. */
+static float oracle_round_bf16(float x) {
+    uint32_t u;
+    memcpy(&u, &x, sizeof(u));
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u; /* finite inputs only */
+    memcpy(&x, &u, sizeof(u));
+    return x;
+}
+
+void oracle_das_bf16acc(const float *X, int hist, const int32_t *off, const float *frac, int P,
+                        int lut_stride, const int32_t *index, int usable, float *power) {
+    for (int m = 0; m < P; m++) {
+        float out[ORACLE_N_SAMPLES];
+        for (int i = 0; i < ORACLE_N_SAMPLES; i++) out[i] = 0.0f;
+        for (int s = 0; s < usable; s++) {
+            const int id = index[s];
+            const float f = frac[(size_t) m * lut_stride + id];
+            const float *sig = X + (size_t) id * hist + off[(size_t) m * lut_stride + id];
+            for (int i = 0; i < ORACLE_N_SAMPLES; i++) {
+                const float t = fmaf(f, sig[i] - sig[i + 1], sig[i + 1]);
+                out[i] = oracle_round_bf16(out[i] + t);
+            }
+        }
+        power[m] = epilogue_f32(out, usable);
+    }
+}
+
 void oracle_das_f64(const float *X, int hist, const int32_t *off, const float *frac, int P,
                     int lut_stride, const int32_t *index, int usable, double *power) {
     for (int m = 0; m < P; m++) {

@@ -76,6 +76,10 @@ void oracle_delay_fir8(float *out, const float *signal, float fraction, const fl
 void oracle_das_f32(const float *X, int hist, const int32_t *off, const float *frac, int P,
                     int lut_stride, const int32_t *index, int usable, float *power,
                     float *out_dbg);
+/* the build's own bf16-accumulator mode (AWPU_MATH_BF16_ACC; not reference code): every running sum
+ * rounded to bfloat16 after each mic, term and epilogue in fp32. */
+void oracle_das_bf16acc(const float *X, int hist, const int32_t *off, const float *frac, int P,
+                        int lut_stride, const int32_t *index, int usable, float *power);
 /* same with every sum in fp64 (inputs still the fp32 tables). */
 void oracle_das_f64(const float *X, int hist, const int32_t *off, const float *frac, int P,
                     int lut_stride, const int32_t *index, int usable, double *power);

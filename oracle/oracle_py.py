@@ -55,6 +55,8 @@ def oracle() -> C.CDLL:
         lib.oracle_delay_lerp.argtypes = [_f32p, _f32p, C.c_float]
         lib.oracle_delay_fir8.argtypes = [_f32p, _f32p, C.c_float, _f32p]
         lib.oracle_das_f32.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
+        lib.oracle_das_bf16acc.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p]
+        lib.oracle_das_bf16acc.restype = None
         lib.oracle_das_f64.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f64p]
         lib.oracle_das_fir8_f32.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
         lib.oracle_particle_beams.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
@@ -192,6 +194,16 @@ def particle_beams(X, off, frac, index=None, impl="oracle"):
     fn = oracle().oracle_particle_beams if impl == "oracle" else ref("avx2").ref_particle_beams
     fn(_p32(X), X.shape[1], _pi(off), _p32(frac), n, off.shape[1], _pi(index), index.size, _p32(power), _p32(beams))
     return power, beams
+
+
+def das_bf16acc(X, off, frac, index=None) -> np.ndarray:
+    """The build's bf16-accumulator mode (AWPU_MATH_BF16_ACC), restated: power[P] for one frame."""
+    X, off, frac, index = _sweep_args(X, off, frac, index)
+    P = off.shape[0]
+    power = np.empty(P, np.float32)
+    oracle().oracle_das_bf16acc(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index), index.size,
+                                _p32(power))
+    return power
 
 
 def das_f64(X, off, frac, index=None) -> np.ndarray:

@@ -612,6 +612,74 @@ def test_c4_rank_slab_of_eight(pkg, oracle):
     assert seam.max() < 0.25
 
 
+def test_bf16_accumulator_mode(pkg, oracle):
+    """AWPU_MATH_BF16_ACC (BASELINE configs[4], "bf16 vs fp32 accumulator"): the device keeps the running sums in
+    bf16 exactly as the restatement does (same operations in the same order: the pre-epilogue sums are the same
+    bits, the power agrees to the epilogue's summation order), and the distance to the fp32 result is the
+    percent-level error the mode is known for -- reported, not gated to 1e-5."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 2, seed=12)
+    eng = pkg.Engine(n_pixels=spec.n_pixels, math=pkg.MATH_BF16_ACC, max_batch=2)
+    with eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        power = eng.process(frames)
+    for b in range(2):
+        assert util.power_rel_err(power[b], oracle.das_bf16acc(frames[b], off, frac)) < 2e-6
+        err = util.power_rel_err(power[b], oracle.das_f32(frames[b], off, frac))
+        assert 1e-4 < err < 1e-1, err
+    with pytest.raises(pkg.AwpuError):  # the mode exists for the linear interpolation only
+        pkg.Engine(n_pixels=16, math=pkg.MATH_BF16_ACC, interp=pkg.binding.INTERP_FIR8)
+
+
+def test_c5_1024_frames_512_mics_rank_slab(pkg, oracle):
+    """BASELINE configs[4] at its real size on one rank: 1024 frames in flight x 512 mics x the slab of a
+    256x256 grid that one of 8 GPUs owns (32 rows, 8192 pixels) -- one call, 512 frame pairs.  The oracle checks
+    sampled pixels of the first, a middle and the last frame; frames that repeat give the same bits wherever
+    they sit in the batch; the bf16-accumulator mode is run on the same call and its error recorded."""
+    sharding = importlib.import_module("beamforming-lk_amd.sharding")
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c4"]
+    xyz = S.geometry(spec)
+    shard = sharding.shard_rows(spec.res, spec.res, 8, 3)
+    off, frac = S.delay_table(spec, xyz, shard.row_begin, shard.row_count)
+    B = 1024
+    distinct = np.concatenate([util.hash_frames(spec.n_mics, 1024, seed=70 + k, batch=16) for k in range(4)])  # 64 frames
+    frames = np.empty((B, spec.n_mics, 1024), np.float32)  # 2.1 GB
+    for k in range(B // 64):
+        frames[64 * k:64 * (k + 1)] = distinct
+    del distinct
+    eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, lut_stride=spec.n_mics, max_batch=B,
+                     pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count, grid_columns=spec.res)
+    with eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        power = eng.process(frames)
+        st = eng.stats()
+    assert power.shape == (B, 8192) and st.usable == 512 and st.frames == B
+    pick = np.random.default_rng(5).choice(shard.pixel_count, 48, replace=False)
+    for b in (0, 511, 1023):
+        want = oracle.das_f32(frames[b], off[pick], frac[pick])
+        floor = util.NULL_FLOOR * float(power[b].max())
+        assert float((np.abs(power[b][pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+    assert np.array_equal(power[64:128], power[:64]) and np.array_equal(power[960:], power[:64])
+    # the same call with the bf16 accumulator (a slower kernel: 64 frames of the batch are enough)
+    eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, lut_stride=spec.n_mics, max_batch=64,
+                     math=pkg.MATH_BF16_ACC, pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count)
+    with eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        p16 = eng.process(frames[:64])
+    err = util.power_rel_err(p16, power[:64])
+    print(f"c5 bf16-accumulator max rel err vs the fp32 sweep: {err:.3e}")
+    assert 1e-4 < err < 1e-1
+    want16 = oracle.das_bf16acc(frames[63], off[pick], frac[pick])
+    assert float((np.abs(p16[63][pick] - want16) / np.maximum(want16, util.NULL_FLOOR * float(p16[63].max()))).max()) < 2e-6
+
+
 def test_1024_frames_in_flight(pkg, oracle):
     """BASELINE configs[4] batches 1024 frames per step: one call, 512 frame pairs (c1 geometry so that the
     oracle can check whole frames): first, last and two middle frames against the oracle, and repeated frames

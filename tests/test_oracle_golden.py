@@ -267,3 +267,19 @@ def test_fir8_sweep_goldens(oracle, name):
     X = util.hash_frames(64 * int(ax) * int(ay), int(g["hist"]), seed=int(g["seed"]))[0]
     power = oracle.das_fir8_f32(X, g["off"], g["frac"], table, g["index"])
     assert util.power_rel_err(power, g["power"]) < 5e-6
+
+
+def test_bf16_accumulator_restatement(oracle):
+    """The checker of the AWPU_MATH_BF16_ACC mode (BASELINE configs[4]: bf16 vs fp32 accumulator): keeping the
+    running sums in bfloat16 moves the per-pixel power by about a percent -- three orders of magnitude outside
+    the 1e-5 the fp32 path is held to -- and never by nothing."""
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 16, 16)
+    X = util.hash_frames(64, 1024, seed=61)[0]
+    p32 = oracle.das_f32(X, off, frac)
+    p16 = oracle.das_bf16acc(X, off, frac)
+    err = util.power_rel_err(p16, p32)
+    assert 1e-4 < err < 1e-1
+    # one mic: the sum is one term, rounded once -- within bf16's half ulp (2^-9) of the fp32 sum, per sample
+    one = np.array([11], np.int32)
+    assert util.power_rel_err(oracle.das_bf16acc(X, off, frac, one), oracle.das_f32(X, off, frac, one)) < 2.0 ** -7
