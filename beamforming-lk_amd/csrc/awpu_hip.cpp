@@ -80,6 +80,10 @@ struct awpu_hip {
         awpu::FastEntry *d = nullptr;
     };
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
+    awpu::QuadEntry *d_quad_lut = nullptr;  // quad-major table of the quad shape (das_quad_kernel)
+    awpu::FastPlan quad_plan{};
+    bool quad_ok = false;         // the table's statistics favour the quad shape (decided in prepare)
+    double quad_cost = 0.0;       // its expected packed VALU instructions per quad and mic (32 = no sharing at all)
     int32_t *d_index = nullptr;
     float *d_gain = nullptr;  // [usable] gains in active-mic order, or null
     float *d_calib = nullptr; // [64] per-mic mean squares (calibration)
@@ -133,10 +137,33 @@ int ensure_diag(awpu_hip *h, size_t words) {
     return AWPU_OK;
 }
 
+struct EnvKnobs {  // tuning / test knobs (DESIGN.md 4.5), read once per process
+    int fpi = 0, ppw = 0, nw = 0;  // AWPU_FAST_VARIANT
+    int pairs = -1;                // AWPU_FAST_PAIRS
+    int debug = 0;                 // AWPU_FAST_DEBUG
+    int fpw = 0;                   // AWPU_FAST_FPW
+    int quads = -1;                // AWPU_FAST_QUADS
+    int pair_group = 0;            // AWPU_FAST_PAIRGROUP: frame pairs an XCD works on at a time (quad shape)
+    EnvKnobs() {
+        if (const char *v = std::getenv("AWPU_FAST_QUADS")) quads = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FAST_PAIRGROUP")) pair_group = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FAST_VARIANT"))
+            if (std::sscanf(v, "%d,%d,%d", &fpi, &ppw, &nw) < 2) fpi = ppw = nw = 0;
+        if (const char *v = std::getenv("AWPU_FAST_PAIRS")) pairs = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FAST_DEBUG")) debug = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FAST_FPW")) fpw = std::atoi(v);
+    }
+};
+const EnvKnobs &env() {
+    static const EnvKnobs knobs;  // initialised once, thread-safe
+    return knobs;
+}
+
 void release_device(awpu_hip *h) {
     dev_free(h->d_lut);
     for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
+    dev_free(h->d_quad_lut);
     dev_free(h->d_index);
     dev_free(h->d_gain);
     dev_free(h->d_calib);
@@ -188,6 +215,7 @@ int prepare(awpu_hip *h) {
     dev_free(h->d_index);
     for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
+    dev_free(h->d_quad_lut);
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
                            hipMemcpyHostToDevice));
@@ -283,6 +311,36 @@ int prepare(awpu_hip *h) {
         }
     }
 
+    // The quad shape (das_quad_kernel) shares arithmetic between four vertically adjacent pixels wherever their
+    // integer delays coincide with the second pixel's: 20 packed VALU instructions per quad and mic, +8 for every
+    // pixel that differs, against 32 without sharing.  Count it on a sample of the table; take the shape when it
+    // saves at least a tenth (AWPU_FAST_QUADS=0/1 forces either).
+    h->quad_ok = false;
+    h->quad_cost = 0.0;
+    {
+        const int cols = c.grid_columns;
+        if (c.math == AWPU_MATH_F32_FAST && c.interp == AWPU_INTERP_LERP && cols > 0 && P % cols == 0 &&
+            c.pixel_begin % cols == 0) {
+            const int rows = P / cols;
+            long differ = 0, seen = 0;
+            const int n_quads = ((rows + 3) / 4) * cols;
+            const int step = std::max(1, n_quads / 2048);
+            for (int q = 0; q < n_quads; q += step) {
+                const int r0 = (q / cols) * 4, col = q % cols;
+                const int32_t *ref = &h->off[((size_t) std::min(r0 + 1, rows - 1) * cols + col) * c.lut_stride];
+                for (int k = 0; k < 4; k++) {
+                    if (k == 1) continue;
+                    const int32_t *o = &h->off[((size_t) std::min(r0 + k, rows - 1) * cols + col) * c.lut_stride];
+                    for (int s = 0; s < U; s++) differ += o[h->index[s]] != ref[h->index[s]];
+                }
+                seen += U;
+            }
+            h->quad_cost = seen ? 20.0 + 8.0 * (double) differ / (double) seen : 32.0;
+            h->quad_ok = h->quad_cost < 0.9 * 32.0 && awpu::pair_plan(h->window, U, &h->quad_plan);
+            if (env().quads >= 0) h->quad_ok = env().quads != 0 && awpu::pair_plan(h->window, U, &h->quad_plan);
+        }
+    }
+
     auto &st = h->stats;
     st.tau_max = h->tau_max;
     st.window = h->window;
@@ -343,27 +401,50 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
     return AWPU_OK;
 }
 
+// The quad shape's table (das_fast.hip, das_quad_kernel): [quad][group of 4 mics][pixel 0..3][mic 0..3] x (f, LDS
+// address), quads = groups of four grid rows x columns padded to whole 16-column tiles.  Pixels past the grid
+// carry weight 0 and the address of the nearest pixel inside it (they then follow the shared path and add
+// nothing); padding mics (usable rounded up to 4) carry weight 0 and the address of their own, zero, row.
+int build_quad_lut(awpu_hip *h) {
+    if (h->d_quad_lut) return AWPU_OK;
+    const auto &c = h->cfg;
+    const awpu::FastPlan &plan = h->quad_plan;
+    const int U = h->usable(), cols = c.grid_columns, rows = c.pixel_count / cols;
+    const int groups = plan.usable_pad / 4;
+    const int cols_pad = (cols + 15) / 16 * 16, rows4 = (rows + 3) / 4;
+    const size_t n = (size_t) rows4 * cols_pad * groups * 16 + 32;  // + a spare group: the sweep prefetches one past the end
+    std::vector<awpu::QuadEntry> packed(n, awpu::QuadEntry{0.0f, 0u});
+    for (int r4 = 0; r4 < rows4; r4++)
+        for (int col = 0; col < cols_pad; col++) {
+            awpu::QuadEntry *dst = &packed[((size_t) r4 * cols_pad + col) * groups * 16];
+            for (int q = 0; q < 4; q++) {
+                const int row = 4 * r4 + q;
+                const bool inside = row < rows && col < cols;
+                const size_t p = (size_t) std::min(row, rows - 1) * cols + std::min(col, cols - 1);
+                const int32_t *orow = &h->off[p * c.lut_stride];
+                const float *frow = &h->frac[p * c.lut_stride];
+                for (int s = 0; s < plan.usable_pad; s++) {
+                    awpu::QuadEntry &e = dst[((s >> 2) * 4 + q) * 4 + (s & 3)];
+                    const int j = s % plan.chunk;  // mic slot inside its chunk
+                    if (s < U) {
+                        const int id = h->index[s];
+                        e.f = inside ? frow[id] : 0.0f;
+                        e.addr = (uint32_t) (j * plan.row_bytes + (orow[id] - h->wstart) * 8);
+                    } else {
+                        e.f = 0.0f;
+                        e.addr = (uint32_t) (j * plan.row_bytes);
+                    }
+                }
+            }
+        }
+    AWPU_HIP_TRY(hipMalloc(&h->d_quad_lut, n * sizeof(awpu::QuadEntry)));
+    AWPU_HIP_TRY(hipMemcpy(h->d_quad_lut, packed.data(), n * sizeof(awpu::QuadEntry), hipMemcpyHostToDevice));
+    return AWPU_OK;
+}
+
 // Kernel shape for a call.  AWPU_FAST_VARIANT="fpi,ppw[,nw]" overrides the heuristic (tuning
 // knob, read once): fpi frames per item, ppw pixels per wave, nw = 8 (8-wave workgroups, two per
 // CU) or 32 (the double-buffered 16-wave shape, one per CU).
-struct EnvKnobs {  // tuning / test knobs (DESIGN.md 4.5), read once per process
-    int fpi = 0, ppw = 0, nw = 0;  // AWPU_FAST_VARIANT
-    int pairs = -1;                // AWPU_FAST_PAIRS
-    int debug = 0;                 // AWPU_FAST_DEBUG
-    int fpw = 0;                   // AWPU_FAST_FPW
-    EnvKnobs() {
-        if (const char *v = std::getenv("AWPU_FAST_VARIANT"))
-            if (std::sscanf(v, "%d,%d,%d", &fpi, &ppw, &nw) < 2) fpi = ppw = nw = 0;
-        if (const char *v = std::getenv("AWPU_FAST_PAIRS")) pairs = std::atoi(v);
-        if (const char *v = std::getenv("AWPU_FAST_DEBUG")) debug = std::atoi(v);
-        if (const char *v = std::getenv("AWPU_FAST_FPW")) fpw = std::atoi(v);
-    }
-};
-const EnvKnobs &env() {
-    static const EnvKnobs knobs;  // initialised once, thread-safe
-    return knobs;
-}
-
 void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
     const int env_fpi = env().fpi, env_ppw = env().ppw, env_nw = env().nw;
     // Prefer the double-buffered shape with the most pixels per wave that still gives every CU
@@ -486,12 +567,65 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
         pa.debug_out = h->d_diag;
     }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.wr,
-                                         batch, h->d_pack, s));
+    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
+                                         h->usable(), nullptr, pp.wr, batch, h->d_pack, s));  // gains ride on the table weights here
     AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
     const int rc = finish_launch(h, batch, s);
     if (rc != AWPU_OK || !(pa.debug & 16)) return rc;
     return dump_diag(h, n_waves, 16, "pairs", s);
+}
+
+// quad shape: the frame-pair layout swept four vertically adjacent pixels at a time (das_quad_kernel)
+int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
+    int rc = build_quad_lut(h);
+    if (rc != AWPU_OK) return rc;
+    const awpu::FastPlan &pp = h->quad_plan;
+    const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * pp.usable_pad * pp.wr * 2;
+    if (h->pack_cap < need) {
+        dev_free(h->d_pack);
+        h->pack_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
+        h->pack_cap = need;
+    }
+    awpu::QuadArgs qa{};
+    qa.packed = h->d_pack;
+    qa.lut = h->d_quad_lut;
+    qa.power = d_power;
+    qa.usable = h->usable();
+    qa.usable_pad = pp.usable_pad;
+    qa.pixel_count = h->cfg.pixel_count;
+    qa.wp = pp.wr;
+    qa.chunk = pp.chunk;
+    qa.batch = batch;
+    qa.cols = h->cfg.grid_columns;
+    qa.rows = h->cfg.pixel_count / qa.cols;
+    qa.tiles = awpu::quad_tiles(qa.rows, qa.cols);
+    qa.n_pairs = (batch + 1) / 2;
+    {   // frame pairs one XCD works on at a time: as many as keep their samples in its 4 MiB L2 beside the table stream
+        const size_t pair_bytes = (size_t) pp.usable_pad * pp.wr * 8;
+        int g = env().pair_group > 0 ? env().pair_group : (int) std::max<size_t>(1, (3u << 20) / pair_bytes);
+        g = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;
+        while (g > 1 && g > qa.n_pairs) g >>= 1;
+        qa.pair_group = g;
+    }
+    qa.debug = env().debug;
+    qa.debug_out = nullptr;
+    size_t n_waves = 0;
+    if (qa.debug & 16) {
+        const long groups = (qa.n_pairs + qa.pair_group - 1) / qa.pair_group;
+        n_waves = (size_t) 16 * (size_t) ((groups * qa.pair_group * qa.tiles + 7) / 8 * 8);
+        rc = ensure_diag(h, n_waves * 12);
+        if (rc != AWPU_OK) return rc;
+        AWPU_HIP_TRY(hipMemsetAsync(h->d_diag, 0, n_waves * 12 * sizeof(unsigned long long), s));
+        qa.debug_out = h->d_diag;
+    }
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
+                                         pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, s));
+    AWPU_HIP_TRY(awpu::launch_das_quads(qa, s));
+    rc = finish_launch(h, batch, s);
+    if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
+    return dump_diag(h, n_waves, 16, "quads", s);
 }
 
 int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int layout = kFull) {
@@ -504,6 +638,10 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     // ---- frame-pair shape: batches on grids that fill the chip (AWPU_FAST_PAIRS=0/1 overrides)
     const int env_pairs = env().pairs;
     const long pair_wgs = (long) awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols) * ((batch + 1) / 2);
+    if (layout != kRing && batch >= 2 && h->quad_ok && env_pairs != 0 &&
+        ((long) awpu::quad_tiles(h->cfg.pixel_count / h->cfg.grid_columns, h->cfg.grid_columns) * ((batch + 1) / 2) >= 256 ||
+         env().quads == 1))
+        return launch_quads(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
     if (layout != kRing && batch >= 2 && env_pairs != 0 && (pair_wgs >= 256 || env_pairs == 1)) {
         const awpu_hip::FastLut *plut = nullptr;
         const int rc = build_fast_lut(h, 2, -1, &plut);

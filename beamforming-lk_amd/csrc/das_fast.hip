@@ -43,6 +43,7 @@ namespace awpu {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load, 4-byte aligned
+typedef float f8 __attribute__((ext_vector_type(8)));
 
 #define AWPU_AS4 __attribute__((address_space(4)))
 
@@ -550,14 +551,19 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_db_kernel(FastArgs a) {
 // per wave; grid = (frame pairs, 64-pixel tiles).
 // ---------------------------------------------------------------------------------------
 __global__ void pack_pairs_kernel(const float *frames, int n_streams, int hist, int wstart, const int32_t *index,
-                                  int usable, int wp, int batch, float *packed) {
-    const int pair = blockIdx.y, s = blockIdx.x;
+                                  int usable, const float *gain, int wp, int batch, float *packed) {
+    const int pair = blockIdx.y, s = blockIdx.x, rows_out = gridDim.x;
+    f2 *dst = (f2 *) packed + ((size_t) pair * rows_out + s) * wp;
+    if (s >= usable) {  // padding rows (the quad shape sweeps whole groups of four mics): silence
+        for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = f2{0.0f, 0.0f};
+        return;
+    }
     const int fa = min(2 * pair, batch - 1), fb = min(2 * pair + 1, batch - 1);
     const float *xa = frames + ((size_t) fa * n_streams + index[s]) * hist + wstart;
     const float *xb = frames + ((size_t) fb * n_streams + index[s]) * hist + wstart;
-    f2 *dst = (f2 *) packed + ((size_t) pair * usable + s) * wp;
+    const float gm = gain ? gain[s] : 1.0f;  // optional per-mic gain (awpu_hip_set_mic_gains); x * 1.0f is x
     const int valid = min(wp, hist - wstart);
-    for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = t < valid ? f2{xa[t], xb[t]} : f2{0.0f, 0.0f};
+    for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = t < valid ? f2{xa[t] * gm, xb[t] * gm} : f2{0.0f, 0.0f};
 }
 
 // out[] of one pixel (both frames at once) from the skewed accumulators, then mimo.cpp:131-137.
@@ -798,6 +804,202 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Quad shape (the default for batches on grids whose row length is known and whose neighbouring rows mostly
+// share their integer delays): the frame-pair layout and chunk pipeline of das_pair_kernel, with the
+// arithmetic rearranged so that pixels share work and not only sample reads:
+//     out_p[i] = sum_m f X[o+i] + (1-f) X[o+i+1] = A_p[i] - A_p[i+1] + S_p[i+1],
+//     A_p[j] = sum_m f_pm X_m[o_pm + j],   S_p[j] = sum_m X_m[o_pm + j]   (j = 0..256).
+// S_p does not depend on the fractions, so pixels whose INTEGER delays coincide for a mic share that mic's term
+// of it.  A wave sweeps four vertically adjacent pixels (rows 4r..4r+3 of one grid column; arrays are wider
+// than tall, so the delay changes least between vertical neighbours); the second is the reference: its samples
+// feed T = S_ref (one packed add per register) and the A of every pixel whose entry carries the same LDS
+// address (one packed FMA per register).  A pixel that differs for this mic reads its own samples and pays
+// three instructions per register (A_p += f x_p; V_p += x_p; V_p -= x_ref; S_p = T + V_p).  Per mic and quad
+// that is 20 packed VALU instructions when all four coincide, +8 per pixel that does not, against 32 (+2
+// address adds) in das_pair_kernel; the epilogue turns (A, S) into the (A, Q = S - A) pair finish_pixel_pair
+// takes.  Differs from the other fast kernels by fp32 rounding only (measured 2e-6 of the reference).
+// Table: 8-byte entries (f, address), quad-major -- [quad][group of 4 mics][pixel][mic] -- so that a trip's
+// entries are one 128-byte line; pixels past the grid carry weight 0 and their neighbour's address, padding
+// mics weight 0 and the address of a zero row (pack_pairs_kernel writes those).
+// Dispatch: a 1-D grid whose blocks are dealt to the 8 XCDs in contiguous runs of work items ordered
+// (pair group, tile, pair): at any moment an XCD's 32 workgroups sweep `pair_group` frame pairs x 32/pair_group
+// tiles, so the pairs' samples stay in that XCD's 4 MiB L2 while it walks the table once per pair group.
+// (Which XCD a block lands on is the hardware's business: the mapping only assumes round-robin for speed.)
+// ---------------------------------------------------------------------------------------
+template <bool DIAG>
+__global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
+    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+
+    // ---- which (frame pair, tile) this workgroup sweeps
+    const int per_xcd = gridDim.x >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int per_group = a.tiles * a.pair_group;
+    const int grp = item / per_group;
+    const int rem = item - grp * per_group;
+    const int tile = rem / a.pair_group;
+    const int pair = grp * a.pair_group + (rem - tile * a.pair_group);
+    if (pair >= a.n_pairs) return;  // padding of the item space (uniform for the workgroup)
+
+    const int tiles_per_row4 = (a.cols + NW - 1) / NW;
+    const int row4 = tile / tiles_per_row4;
+    const int col = (tile - row4 * tiles_per_row4) * NW + wave;
+    const int quad = row4 * tiles_per_row4 * NW + col;
+    int pix[4];
+    bool live[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int row = 4 * row4 + q;
+        live[q] = row < a.rows && col < a.cols;
+        pix[q] = min(row, a.rows - 1) * a.cols + min(col, a.cols - 1);
+    }
+    const int groups_total = a.usable_pad >> 2;
+    const QuadEntry *quad_lut = a.lut + (size_t) quad * groups_total * 16;
+    const size_t row_floats = (size_t) a.wp * 2;
+    const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
+
+    f8 A0 = {0, 0, 0, 0, 0, 0, 0, 0}, A1 = A0, A2 = A0, A3 = A0, T = A0, V0 = A0, V2 = A0, V3 = A0;
+    f2 tail = f2{0.0f, 0.0f};
+    const int tail_pp = lane >> 3;  // lanes 8 pp + k: pixel pp of the quad, mics k (mod 8) of the chunk
+    bool tail_lane = false;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (tail_pp == q) tail_lane = live[q];
+
+    // one chunk = rows m0 .. m0+mc4 of this pair (whole groups: the padding rows are zero), contiguous in HBM
+    auto dma_chunk = [&](int m0, int mc4, int buf) {
+        const float *src = pair_base + (size_t) m0 * row_floats;
+        const int n_pieces = (int) ((size_t) mc4 * row_floats / 4);
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            const int piece = threadIdx.x + k * kThreads;
+            if (piece < n_pieces) {
+                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + (size_t) piece * 4),
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+            }
+        }
+    };
+    auto chunk_mics = [&](int m0) { return (min(a.chunk, a.usable - m0) + 3) & ~3; };
+
+    unsigned t_wait = 0, t_all = 0;
+    const long long t_begin = __builtin_readcyclecounter();
+    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
+    dma_chunk(0, chunk_mics(0), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    unsigned t_ph[5] = {0, 0, 0, 0, 0};
+    auto stamp = [&](int k, long long &t) {
+        if (DIAG) {
+            const long long n = __builtin_readcyclecounter();
+            t_ph[k] += (unsigned) (n - t);
+            t = n;
+        }
+    };
+    const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
+    for (int c = 0; c < n_chunks; c++) {
+        const int m0 = c * a.chunk;
+        const int mc4 = chunk_mics(m0);
+        const int buf = c & 1;
+        long long t = DIAG ? __builtin_readcyclecounter() : 0;
+        // table entries of the tail pass below (the 257th sample): requested now, consumed after the sweep
+        QuadEntry te[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = min(8 * u + ((lane - m0) & 7), mc4 - 1);  // mic slot inside the chunk
+            const int m = m0 + j;
+            te[u] = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
+        }
+        if (c + 1 < n_chunks && !(a.debug & 1)) dma_chunk(m0 + a.chunk, chunk_mics(m0 + a.chunk), buf ^ 1);
+        stamp(0, t);
+        const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
+        {
+            const void *row = uniform_ptr(quad_lut + (size_t) (m0 >> 2) * 16);
+            const int ng = __builtin_amdgcn_readfirstlane(mc4 >> 2);
+            if constexpr (DIAG) {
+                unsigned dw = 0, da = 0;
+                sweep_quad_sum_stamped(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank, dw, da);
+                t_wait += dw;
+                t_all += da;
+            } else {
+                sweep_quad_sum(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank);
+            }
+        }
+        stamp(1, t);
+        // the 257th sample of every window, both frames: X[off+256] with weight 1 - f goes to out[255]
+        const char *img = (const char *) (lds + buf * (BUF / 4));
+        if (!(a.debug & 4)) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {  // mics 0..31 of the chunk (prefetched above)
+                const bool on = tail_lane && 8 * u + ((lane - m0) & 7) < mc4;
+                const float g = on ? 1.0f - te[u].f : 0.0f;
+                const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
+                tail = __builtin_elementwise_fma(f2{g, g}, x, tail);
+            }
+            for (int j0 = 32; j0 < mc4; j0 += 32) {  // chunks of more than 32 mics (narrow windows)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int jj = j0 + 8 * u + ((lane - m0) & 7);
+                    const int m = m0 + min(jj, mc4 - 1);
+                    const QuadEntry e = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
+                    const float g = tail_lane && jj < mc4 ? 1.0f - e.f : 0.0f;
+                    const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
+                    tail = __builtin_elementwise_fma(f2{g, g}, x, tail);
+                }
+            }
+        }
+        if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(2, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3, t);
+        if (!(a.debug & 8)) __syncthreads();
+        stamp(4, t);
+    }
+
+    if (DIAG && a.debug_out && lane == 0) {
+        unsigned long long *o = a.debug_out + 12 * ((size_t) blockIdx.x * NW + wave);
+        o[0] = t_wait;
+        o[1] = t_all;
+        o[2] = (unsigned long long) (__builtin_readcyclecounter() - t_begin);
+        o[3] = (unsigned long long) n_chunks;
+        for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
+    }
+    tail.x += __shfl_xor(tail.x, 1);
+    tail.y += __shfl_xor(tail.y, 1);
+    tail.x += __shfl_xor(tail.x, 2);
+    tail.y += __shfl_xor(tail.y, 2);
+    tail.x += __shfl_xor(tail.x, 4);
+    tail.y += __shfl_xor(tail.y, 4);
+    const float norm = (float) (kSamples * a.usable);
+    auto finish = [&](const f8 &A, const f8 &S, int pp) {
+        f2 P[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            P[k] = f2{A[2 * k], A[2 * k + 1]};
+            P[4 + k] = f2{S[2 * k], S[2 * k + 1]} - P[k];  // Q = S - A: the terms (1 - f) X
+        }
+        f2 tl;
+        tl.x = __shfl(tail.x, pp * 8);
+        tl.y = __shfl(tail.y, pp * 8);
+        const f2 sum = finish_pixel_pair(P, tl, lane);
+        if (lane == 0 && live[pp]) {
+            a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
+            if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + pix[pp]] = sum.y / norm;
+        }
+    };
+    finish(A0, T + V0, 0);
+    finish(A1, T, 1);
+    finish(A2, T + V2, 2);
+    finish(A3, T + V3, 3);
+}
+
 // ---------------------------------------------------------------------------------------
 // host side: geometry of the LDS image and the launch
 // ---------------------------------------------------------------------------------------
@@ -882,10 +1084,11 @@ bool pair_plan(int window, int usable, FastPlan *plan) {
 }
 
 hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index,
-                             int usable, int wp, int batch, float *d_packed, hipStream_t stream) {
-    dim3 grid(usable, (batch + 1) / 2);
+                             int usable, int rows_out, const float *d_gain, int wp, int batch, float *d_packed,
+                             hipStream_t stream) {
+    dim3 grid(rows_out, (batch + 1) / 2);
     hipLaunchKernelGGL(pack_pairs_kernel, grid, dim3(128), 0, stream, d_frames, n_streams, hist, wstart, d_index,
-                       usable, wp, batch, d_packed);
+                       usable, d_gain, wp, batch, d_packed);
     return hipGetLastError();
 }
 
@@ -906,6 +1109,23 @@ hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {
     const bool share = (a.debug & 4096) == 0;  // bit 4096: the pixel-major block without read sharing
     if (a.debug & 16) return share ? launch_pair_variant<4, true, true>(a, stream) : launch_pair_variant<4, true, false>(a, stream);
     return share ? launch_pair_variant<4, false, true>(a, stream) : launch_pair_variant<4, false, false>(a, stream);
+}
+
+template <bool DIAG>
+static hipError_t launch_quad_variant(const QuadArgs &a, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (hipError_t e = allow_lds((const void *) das_quad_kernel<DIAG>, lds_bytes, attr_set); e != hipSuccess) return e;
+    const long groups = (a.n_pairs + a.pair_group - 1) / a.pair_group;
+    const long items = groups * a.pair_group * a.tiles;
+    const long grid = (items + 7) / 8 * 8;
+    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((das_quad_kernel<DIAG>), dim3((unsigned) grid), dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_das_quads(const QuadArgs &a, hipStream_t stream) {
+    return (a.debug & 16) ? launch_quad_variant<true>(a, stream) : launch_quad_variant<false>(a, stream);
 }
 
 int fast_image_bytes(int nw) { return nw == 24 ? kFastLdsBytesSmall : kFastLdsBytes; }

@@ -83,9 +83,32 @@ inline int pair_tiles(int pixel_count, int cols) {
     return cols > 0 ? ((pixel_count / cols + 1) / 2) * ((cols + 31) / 32) : (pixel_count + 63) / 64;
 }
 bool pair_plan(int window, int usable, FastPlan *plan);
+// rows_out >= usable rows per pair are written (the extra ones zero); d_gain [usable] (or null) scales row s
 hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index,
-                             int usable, int wp, int batch, float *d_packed, hipStream_t stream);
+                             int usable, int rows_out, const float *d_gain, int wp, int batch, float *d_packed,
+                             hipStream_t stream);
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream);
+
+// ---- quad shape (das_quad_kernel): the frame-pair layout swept four vertically adjacent pixels at a time with
+// a shared integer-delay sum (das_fast.hip).  Needs the grid's row length.
+struct QuadEntry {  // 8 bytes per (pixel, active mic)
+    float f;        // the reference's `fraction` (weight of X[off+i]); 1 - f is never needed in the sweep
+    uint32_t addr;  // LDS byte offset of the element X[off] in the chunk's image
+};
+struct QuadArgs {
+    const float *packed;   // [pairs][usable_pad][wp][2]: rows of padding mics are zero
+    const QuadEntry *lut;  // [quads][usable_pad / 4][4 pixels][4 mics], quads = row quads x padded columns
+    float *power;          // [batch][pixel_count]
+    int32_t usable, usable_pad, pixel_count, wp, chunk, batch;
+    int32_t cols, rows;    // the handle's slab of the grid: rows x cols = pixel_count
+    int32_t tiles;         // workgroup tiles of 4 rows x 16 columns
+    int32_t n_pairs, pair_group;  // frame pairs, and how many of them one XCD works on at a time
+    unsigned long long *debug_out;
+    int32_t debug;
+};
+inline int quad_tiles(int rows, int cols) { return ((rows + 3) / 4) * ((cols + 15) / 16); }
+inline int quad_count(int rows, int cols) { return ((rows + 3) / 4) * ((cols + 15) / 16) * 16; }  // table quads incl. padding columns
+hipError_t launch_das_quads(const QuadArgs &a, hipStream_t stream);
 
 // LDS image geometry for a window of `window` samples; false if it cannot fit.
 bool fast_plan(int window, int usable, int fpi, int image_bytes, FastPlan *plan);

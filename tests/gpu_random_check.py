@@ -51,6 +51,14 @@ def main(seed: int, cases: int) -> int:
         off = rng.integers(base, base + spread + 1, size=(P, lut_stride)).astype(np.int32)
         frac = rng.uniform(0, 1, size=(P, lut_stride)).astype(np.float32)
         frac[rng.uniform(size=frac.shape) < 0.05] = 0.0
+        if grid_columns and os.environ.get("AWPU_TEST_COINCIDE") == "1":
+            # like a real table: the integer delay of a mic changes slowly down a grid column (a step of one sample
+            # now and then), so most vertical neighbours coincide -- what the shared-read and shared-sum blocks feed on
+            rows_ = P // grid_columns
+            steps = rng.choice([-1, 0, 0, 0, 0, 0, 1], size=(rows_, grid_columns, lut_stride))
+            steps[0] = 0
+            walk = off.reshape(rows_, grid_columns, lut_stride)[:1] + np.cumsum(steps, axis=0)
+            off = np.clip(walk, base, base + spread).reshape(P, lut_stride).astype(np.int32)
         index = rng.permutation(n_streams)[:usable].astype(np.int32)
         X = util.hash_frames(n_streams, hist, seed=1000 + case, batch=batch)
         if FIR8:
@@ -94,16 +102,24 @@ def main(seed: int, cases: int) -> int:
         with eng:
             eng.set_delay_table(off, frac)
             eng.set_active_mics(index)
+            if grid_columns and case % 3 == 1:  # per-mic gains on a third of the grid cases
+                gains = rng.uniform(0.5, 2.0, n_streams).astype(np.float32)
+                eng.set_mic_gains(gains)
+                X = X * gains[None, :, None]  # what the oracle sees; the engine gets the unscaled frames
+                X_in = X / gains[None, :, None]
+                X_in = util.hash_frames(n_streams, hist, seed=1000 + case, batch=batch)
+            else:
+                X_in = X
             if DEVICE_PATH:
                 import torch
 
-                d_X = torch.from_numpy(X).cuda()
+                d_X = torch.from_numpy(X_in).cuda()
                 d_P = torch.zeros((batch, P), dtype=torch.float32, device="cuda")
                 eng.process_device(d_X.data_ptr(), batch, d_P.data_ptr())
                 eng.synchronize()
                 power = d_P.cpu().numpy()
             else:
-                power = eng.process(X)
+                power = eng.process(X_in)
         if DEVICE_PATH and P > 1:  # two ragged pixel shards must tile the single-handle result bit for bit
             cut = int(rng.integers(1, P))
             parts = []

@@ -22,7 +22,11 @@ pytestmark = pytest.mark.gpu
     {"AWPU_TEST_REUSE": "1"},                                   # one handle re-targeted: tables, mic lists, gains
     {"AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_FAST_PAIRCOLS": "1"},  # frame pairs, vertical pixel pairs
     {"AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_FAST_DEBUG": "4096"},   # the block without read sharing
-], ids=["pairs", "db", "small", "fpi2", "exact", "device", "fir8", "reuse", "pairs_vertical", "pairs_unshared"])
+    {"AWPU_FAST_QUADS": "1", "AWPU_TEST_GRID": "1"},                               # quad shape, random delays: every pixel differs
+    {"AWPU_FAST_QUADS": "1", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},    # quad shape, delays that mostly coincide
+    {"AWPU_FAST_QUADS": "0", "AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},  # pair shape on the same tables
+], ids=["pairs", "db", "small", "fpi2", "exact", "device", "fir8", "reuse", "pairs_vertical", "pairs_unshared",
+        "quads_random", "quads_coincide", "pairs_coincide"])
 def test_random_tables(env):
     out = subprocess.run([sys.executable, str(REPO / "tests" / "gpu_random_check.py"), "2024", "14"],
                          env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)

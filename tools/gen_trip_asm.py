@@ -390,6 +390,187 @@ __device__ __forceinline__ void {name}(f2 (&P0)[8], f2 (&P1)[8], const void *row
 '''
 
 
+# ---------------------------------------------------------------------------------------------------
+# Quad block with a shared integer-delay sum (das_quad_kernel).
+#
+# out_p[i] = sum_m f*X[o+i] + (1-f)*X[o+i+1] = A_p[i] - A_p[i+1] + S_p[i+1],  A_p[j] = sum_m f_pm X_m[o_pm+j],
+# S_p[j] = sum_m X_m[o_pm+j].  S_p does not depend on the fractions: pixels whose INTEGER delays coincide for a
+# mic share that mic's term of it.  A block sweeps four vertically adjacent pixels (rows r..r+3 of one grid
+# column); the second one is the reference: its sample reads feed T = S_ref (one packed add per register) and
+# every pixel whose entry carries the same LDS address (one packed FMA per register into A_p).  A pixel whose
+# integer delay differs for this mic reads its own samples and pays A_p += f x_p, V_p += x_p, V_p -= x_ref
+# (S_p = T + V_p).  Per mic and quad: 20 packed VALU instructions when the four delays coincide instead of 32,
+# +8 per pixel that differs.  Entries are 8 bytes (f, LDS address); g = 1 - f is never needed in the sweep.
+#
+# Fixed registers: accumulators pinned by the caller's operand constraints
+#     A_p (p = 0..3) v[QA+8p : +7],  T v[QT:QT+7],  V_p (p = 0, 2, 3) v[QV.. : +7]  (register 2k,2k+1 = samples l+64k)
+# temps (clobbers): two slots for the reference's samples (this mic / next mic), one slot for pixel 0's own samples,
+# one that pixels 2 and 3 share (when both differ from the reference they almost always carry the same address:
+# the delay is monotone down a column; the slot is prefetched for pixel 3, pixel 2 uses it when its address is
+# the same and otherwise -- rare -- reads into it on the spot, after pixel 3 is done with it), one address
+# register; SGPR sets E0 = s[36:67], E1 = s[68:99]: pixel p, mic i of the trip: f at +8p+2i, address +1.
+QUAD_ACC = 30          # first pinned accumulator register; 64 of them
+QUAD_TMP = QUAD_ACC + 64  # 33 temps
+REF = 1                # which pixel of the quad is the reference (a middle one: fewest differing neighbours)
+
+
+def quad_regs():
+    A = [QUAD_ACC + 8 * p for p in range(4)]
+    T = QUAD_ACC + 32
+    V = {0: QUAD_ACC + 40, 2: QUAD_ACC + 48, 3: QUAD_ACC + 56}
+    R = (QUAD_TMP, QUAD_TMP + 8)
+    X = {0: QUAD_TMP + 16, 2: QUAD_TMP + 24, 3: QUAD_TMP + 24}  # pixels 2 and 3 share a slot (see block_quad)
+    addr_t = QUAD_TMP + 32
+    return A, T, V, R, X, addr_t
+
+
+def block_quad(name, stamp=False):
+    A, T, V, R, X, addr_t = quad_regs()
+    E = (36, 68)
+    S_TMP, S_PF_, S_LEFT_ = 22, 23, 24
+
+    def f_of(base, p, i):
+        return base + 8 * p + 2 * i
+
+    def a_of(base, p, i):
+        return base + 8 * p + 2 * i + 1
+
+    def pair(r, k):
+        return f"v[{r + 2 * k}:{r + 2 * k + 1}]"
+
+    def reads(slot, addr_sgpr):
+        L = [f"v_add_u32 v{addr_t}, s{addr_sgpr}, %[lane]"]
+        for k in range(4):
+            off = f" offset:{512 * k}" if k else ""
+            L.append(f"ds_read_b64 {pair(slot, k)}, v{addr_t}{off}")
+        return L
+
+    def uid():
+        COUNTER[0] += 1
+        return f"%=_{COUNTER[0]}"
+
+    cold = []
+
+    def maybe_read_x(p, base, i):
+        """issue pixel p's own reads for the mic whose entries sit at (base, i) unless it shares the reference's"""
+        u = uid()
+        cold.extend([f".Lqread{u}:"] + reads(X[p], a_of(base, p, i)) + [f"s_branch .Lqreadback{u}"])
+        return [f"s_cmp_lg_u32 s{a_of(base, p, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lqread{u}", f".Lqreadback{u}:"]
+
+    def own_ops(p, fs, rslot):
+        own = []
+        for k in range(4):
+            own.append(f"v_pk_fma_f32 {pair(A[p], k)}, {fs}, {pair(X[p], k)}, {pair(A[p], k)} op_sel_hi:[0,1,1]")
+        for k in range(4):
+            own.append(f"v_pk_add_f32 {pair(V[p], k)}, {pair(V[p], k)}, {pair(X[p], k)}")
+        for k in range(4):
+            own.append(f"v_pk_add_f32 {pair(V[p], k)}, {pair(V[p], k)}, {pair(rslot, k)} neg_lo:[0,1] neg_hi:[0,1]")
+        return own
+
+    def pixel_ops(p, base, i, rslot):
+        """pixel p's share of mic (base, i): one FMA per register from the reference's samples, or the
+        three-instruction form from its own"""
+        u = uid()
+        fs = f"s[{f_of(base, p, i)}:{f_of(base, p, i) + 1}]"
+        if p == 2:  # shares pixel 3's slot: usable as it is only if pixel 3 differs too and carries the same address
+            cold.extend([f".Lqown{u}:",
+                         f"s_cmp_eq_u32 s{a_of(base, 2, i)}, s{a_of(base, 3, i)}",
+                         f"s_cbranch_scc1 .Lqhave{u}"] +
+                        reads(X[2], a_of(base, 2, i)) + ["s_waitcnt lgkmcnt(0)", f".Lqhave{u}:"] +
+                        own_ops(p, fs, rslot) + [f"s_branch .Lqdone{u}"])
+        else:
+            cold.extend([f".Lqown{u}:"] + own_ops(p, fs, rslot) + [f"s_branch .Lqdone{u}"])
+        L = [f"s_cmp_lg_u32 s{a_of(base, p, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lqown{u}"]
+        for k in range(4):
+            L.append(f"v_pk_fma_f32 {pair(A[p], k)}, {fs}, {pair(rslot, k)}, {pair(A[p], k)} op_sel_hi:[0,1,1]")
+        L.append(f".Lqdone{u}:")
+        return L
+
+    def ref_ops(base, i, rslot):
+        fs = f"s[{f_of(base, REF, i)}:{f_of(base, REF, i) + 1}]"
+        L = []
+        for k in range(4):
+            L.append(f"v_pk_add_f32 {pair(T, k)}, {pair(T, k)}, {pair(rslot, k)}")
+        for k in range(4):
+            L.append(f"v_pk_fma_f32 {pair(A[REF], k)}, {fs}, {pair(rslot, k)}, {pair(A[REF], k)} op_sel_hi:[0,1,1]")
+        return L
+
+    def load_set(base, off, literal=False):
+        """one trip's entries -- [pixel][mic] x (f, address), 128 contiguous bytes in the quad-major table -- into
+        the set at `base`; `off` = a literal byte offset or the SGPR that holds it"""
+        if literal:
+            return [f"s_load_dwordx16 s[{base}:{base + 15}], %[ptr], {hex(off)}",
+                    f"s_load_dwordx16 s[{base + 16}:{base + 31}], %[ptr], {hex(off + 64)}"]
+        return [f"s_load_dwordx16 s[{base}:{base + 15}], %[ptr], s{off}",
+                f"s_add_u32 s{S_TMP}, s{off}, 64",
+                f"s_load_dwordx16 s[{base + 16}:{base + 31}], %[ptr], s{S_TMP}"]
+
+    others = [p for p in (3, 2, 0)]
+
+    def trip_q(par):
+        cur, nxt = E[par], E[1 - par]
+        L = trip_prio("X" if par == 0 else "Y") if PRIO >= 3 else []
+        L += load_set(nxt, S_PF_) + [f"s_add_u32 s{S_PF_}, s{S_PF_}, 128"]
+        for st in range(4):
+            rslot = R[st & 1]
+            if st < 3:
+                L += reads(R[(st + 1) & 1], a_of(cur, REF, st + 1))
+                L.append("s_waitcnt lgkmcnt(4)")  # all but the four reads just issued: this mic's samples are in
+                nbase, ni = cur, st + 1
+            else:
+                L.append("s_waitcnt lgkmcnt(0)")  # this mic's samples, and the next trip's entries
+                L += reads(R[0], a_of(nxt, REF, 0))
+                nbase, ni = nxt, 0
+            L += pixel_ops(3, cur, st, rslot) + pixel_ops(2, cur, st, rslot) + maybe_read_x(3, nbase, ni)
+            L += pixel_ops(0, cur, st, rslot) + maybe_read_x(0, nbase, ni)
+            L += ref_ops(cur, st, rslot)
+        return L
+
+    L = []
+    if stamp:
+        L += [f"s_memtime s[{S_T0}:{S_T0 + 1}]", "s_waitcnt lgkmcnt(0)"]
+    if PRIO >= 3:
+        L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    L += load_set(E[0], 0, literal=True)
+    L += [f"s_mov_b32 s{S_LEFT_}, %[ng]", f"s_movk_i32 s{S_PF_}, 0x80", "s_waitcnt lgkmcnt(0)"]
+    if stamp:
+        L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_wait], s{S_T1}, s{S_T0}"]
+    L += reads(R[0], a_of(E[0], REF, 0))
+    L += maybe_read_x(3, E[0], 0) + maybe_read_x(0, E[0], 0)
+    L += [".LQ0_%=:"] + trip_q(0)
+    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_eq_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQdone_%="]
+    L += trip_q(1)
+    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQ0_%="]
+    L += ["s_branch .LQdone_%="] + cold + [".LQdone_%=:", "s_waitcnt lgkmcnt(0)"]  # the reads issued for a trip that does not come
+    if PRIO:
+        L += ["s_setprio 0"]
+    if stamp:
+        L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
+    body = "\n".join(f'        "{l}\\n\\t"' for l in L)
+    vregs = list(range(QUAD_TMP, QUAD_TMP + 33))
+    sregs = sorted({S_TMP, S_PF_, S_LEFT_, S_RANK, S_PRIO, S_T0, S_T0 + 1, S_T1, S_T1 + 1}) + list(range(36, 100))
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
+    names = [f"A{p}" for p in range(4)] + ["T"] + [f"V{p}" for p in (0, 2, 3)]
+    bases = A + [T] + [V[0], V[2], V[3]]
+    acc_params = ", ".join(f"f8 &{n}" for n in names)
+    acc_ops = ", ".join(f'"+{{v[{b}:{b + 7}]}}"({n})' for n, b in zip(names, bases))
+    stamp_params = ", unsigned &t_wait, unsigned &t_all" if stamp else ""
+    stamp_ops = ', [t_wait] "=&s"(t_wait), [t_all] "=&s"(t_all)' if stamp else ""
+    return f"""// Four vertically adjacent pixels of the staged chunk, ng groups of four mics each (ng >= 1), with the shared
+// integer-delay sum: see tools/gen_trip_asm.py.  `row` = the quad's entries of the chunk's first group in the
+// quad-major table ([group][pixel][mic] x 8 bytes: 128 contiguous bytes per group); reads one group past the last.
+// Accumulators are pinned: A_p v[{A[0]}+8p..], T v[{T}..], V0/V2/V3 v[{V[0]}..]/v[{V[2]}..]/v[{V[3]}..]; temps v{vregs[0]}..v{vregs[-1]},
+// s{sregs[0]}..s{sregs[-1]}.
+__device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, unsigned lane_addr, int rank{stamp_params}) {{
+    asm volatile(
+{body}
+        : {acc_ops}{stamp_ops}
+        : [ptr] "s"(row), [ng] "s"(ng), [lane] "v"(lane_addr), [rank] "s"(rank)
+        : {clobbers});
+}}
+"""
+
+
 def main():
     hi = 128 - (4 * (DEPTH + 1) + 1) - 3
     out = ["// GENERATED by tools/gen_trip_asm.py -- do not edit.  See that script for the schedule.", ""]
@@ -401,6 +582,8 @@ def main():
     out.append(block("sweep_duo_pairs_stamped", 2, 128 - (8 * (pd + 1) + 1) - 3, stamp=True, pair_depth=pd))
     out.append(block_shared("sweep_duo_shared", 128 - 25 - 3))
     out.append(block_shared("sweep_duo_shared_stamped", 128 - 25 - 3, stamp=True))
+    out.append(block_quad("sweep_quad_sum"))
+    out.append(block_quad("sweep_quad_sum_stamped", stamp=True))
     lo = 80 - (4 * (DEPTH + 1) + 1) - 3  # shapes with an 80-VGPR budget (6 waves per SIMD)
     out.append(block("sweep_quad_lo", 4, lo))
     out.append(block("sweep_quad_lo_stamped", 4, lo, stamp=True))
