@@ -561,11 +561,11 @@ def test_full_size_properties(pkg, oracle, wl, batch):
     off, frac = S.delay_table(spec, xyz)
     frames = S.make_frames(xyz, batch, seed=3)
     frames[1] = 4.0 * frames[0]
-    power, st = run_engine(pkg, frames, off, frac, grid_columns=spec.res)  # vertical pixel pairs in the batched sweep
-    assert st.usable == spec.n_mics
+    power, st = run_engine(pkg, frames, off, frac, grid_columns=spec.res)  # row length known: the quad shape where the
+    assert st.usable == spec.n_mics                                        # table favours it, else vertical pixel pairs
     assert np.array_equal(power[1], 16.0 * power[0])
-    plain, _ = run_engine(pkg, frames, off, frac)  # without the hint: consecutive pixels paired, same bits
-    assert np.array_equal(plain, power)
+    plain, _ = run_engine(pkg, frames, off, frac)  # without the hint: consecutive pixels paired (another summation order)
+    assert util.power_rel_err(plain, power) < 5e-6
     r, c = divmod(int(power[0].argmax()), spec.res)
     er, ec = S.source_pixel(spec)
     assert abs(r - er) <= 1 and abs(c - ec) <= 1
