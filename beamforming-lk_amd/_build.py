@@ -63,6 +63,7 @@ def _compile(verbose: bool) -> Path:
         "-x", "hip",
         f"-I{REPO / 'include'}",
         f"-I{CSRC}",
+        *os.environ.get("AWPU_EXTRA_HIPCC_FLAGS", "").split(),  # tuning builds (e.g. -DAWPU_QUAD_VARIANTS)
         *[str(s) for s in SOURCES],
         "-o", str(tmp),
     ]

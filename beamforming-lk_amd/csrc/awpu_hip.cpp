@@ -144,9 +144,11 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
     int fpw = 0;                   // AWPU_FAST_FPW
     int quads = -1;                // AWPU_FAST_QUADS
     int pair_group = 0;            // AWPU_FAST_PAIRGROUP: frame pairs an XCD works on at a time (quad shape)
+    int quad_variant = 0;          // AWPU_QUAD_VARIANT (tuning builds)
     EnvKnobs() {
         if (const char *v = std::getenv("AWPU_FAST_QUADS")) quads = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_PAIRGROUP")) pair_group = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_QUAD_VARIANT")) quad_variant = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_VARIANT"))
             if (std::sscanf(v, "%d,%d,%d", &fpi, &ppw, &nw) < 2) fpi = ppw = nw = 0;
         if (const char *v = std::getenv("AWPU_FAST_PAIRS")) pairs = std::atoi(v);
@@ -609,6 +611,7 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
         qa.pair_group = g;
     }
     qa.debug = env().debug;
+    qa.variant = env().quad_variant;
     qa.debug_out = nullptr;
     size_t n_waves = 0;
     if (qa.debug & 16) {

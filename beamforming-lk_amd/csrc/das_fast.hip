@@ -828,7 +828,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
 // tiles, so the pairs' samples stay in that XCD's 4 MiB L2 while it walks the table once per pair group.
 // (Which XCD a block lands on is the hardware's business: the mapping only assumes round-robin for speed.)
 // ---------------------------------------------------------------------------------------
-template <bool DIAG>
+template <bool DIAG, int VAR>
 __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
@@ -929,6 +929,12 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                 t_wait += dw;
                 t_all += da;
             } else {
+#ifdef AWPU_QUAD_VARIANTS  // tuning builds: the wave-priority schemes of tools/gen_trip_asm.py side by side
+                if constexpr (VAR == 1) sweep_quad_sum_v0(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank);
+                else if constexpr (VAR == 2) sweep_quad_sum_v3(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank);
+                else if constexpr (VAR == 3) sweep_quad_sum_v4(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank);
+                else
+#endif
                 sweep_quad_sum(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank);
             }
         }
@@ -1111,21 +1117,27 @@ hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {
     return share ? launch_pair_variant<4, false, true>(a, stream) : launch_pair_variant<4, false, false>(a, stream);
 }
 
-template <bool DIAG>
+template <bool DIAG, int VAR>
 static hipError_t launch_quad_variant(const QuadArgs &a, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
-    if (hipError_t e = allow_lds((const void *) das_quad_kernel<DIAG>, lds_bytes, attr_set); e != hipSuccess) return e;
+    if (hipError_t e = allow_lds((const void *) das_quad_kernel<DIAG, VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
     const long groups = (a.n_pairs + a.pair_group - 1) / a.pair_group;
     const long items = groups * a.pair_group * a.tiles;
     const long grid = (items + 7) / 8 * 8;
     if (grid > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((das_quad_kernel<DIAG>), dim3((unsigned) grid), dim3(1024), lds_bytes, stream, a);
+    hipLaunchKernelGGL((das_quad_kernel<DIAG, VAR>), dim3((unsigned) grid), dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_das_quads(const QuadArgs &a, hipStream_t stream) {
-    return (a.debug & 16) ? launch_quad_variant<true>(a, stream) : launch_quad_variant<false>(a, stream);
+    if (a.debug & 16) return launch_quad_variant<true, 0>(a, stream);
+#ifdef AWPU_QUAD_VARIANTS
+    if (a.variant == 1) return launch_quad_variant<false, 1>(a, stream);
+    if (a.variant == 2) return launch_quad_variant<false, 2>(a, stream);
+    if (a.variant == 3) return launch_quad_variant<false, 3>(a, stream);
+#endif
+    return launch_quad_variant<false, 0>(a, stream);
 }
 
 int fast_image_bytes(int nw) { return nw == 24 ? kFastLdsBytesSmall : kFastLdsBytes; }

@@ -103,6 +103,7 @@ struct QuadArgs {
     int32_t cols, rows;    // the handle's slab of the grid: rows x cols = pixel_count
     int32_t tiles;         // workgroup tiles of 4 rows x 16 columns
     int32_t n_pairs, pair_group;  // frame pairs, and how many of them one XCD works on at a time
+    int32_t variant;              // tuning builds only (AWPU_QUAD_VARIANT)
     unsigned long long *debug_out;
     int32_t debug;
 };

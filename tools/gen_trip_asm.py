@@ -424,7 +424,8 @@ def quad_regs():
     return A, T, V, R, X, addr_t
 
 
-def block_quad(name, stamp=False):
+def block_quad(name, stamp=False, prio=None):
+    prio = PRIO if prio is None else prio
     A, T, V, R, X, addr_t = quad_regs()
     E = (36, 68)
     S_TMP, S_PF_, S_LEFT_ = 22, 23, 24
@@ -509,7 +510,11 @@ def block_quad(name, stamp=False):
 
     def trip_q(par):
         cur, nxt = E[par], E[1 - par]
-        L = trip_prio("X" if par == 0 else "Y") if PRIO >= 3 else []
+        L = []
+        if prio == 3 or (prio == 5 and par == 0):
+            L += select_prio(S_PRIO, 1)   # the top priority moves on to the next wave of the SIMD
+        elif prio == 5:
+            L += select_prio(S_RANK, 0)   # youngest first
         L += load_set(nxt, S_PF_) + [f"s_add_u32 s{S_PF_}, s{S_PF_}, 128"]
         for st in range(4):
             rslot = R[st & 1]
@@ -529,8 +534,9 @@ def block_quad(name, stamp=False):
     L = []
     if stamp:
         L += [f"s_memtime s[{S_T0}:{S_T0 + 1}]", "s_waitcnt lgkmcnt(0)"]
-    if PRIO >= 3:
-        L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    if prio == 4:
+        L += select_prio(S_RANK, 0)  # static: youngest first for the whole block
     L += load_set(E[0], 0, literal=True)
     L += [f"s_mov_b32 s{S_LEFT_}, %[ng]", f"s_movk_i32 s{S_PF_}, 0x80", "s_waitcnt lgkmcnt(0)"]
     if stamp:
@@ -542,7 +548,7 @@ def block_quad(name, stamp=False):
     L += trip_q(1)
     L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQ0_%="]
     L += ["s_branch .LQdone_%="] + cold + [".LQdone_%=:", "s_waitcnt lgkmcnt(0)"]  # the reads issued for a trip that does not come
-    if PRIO:
+    if prio:
         L += ["s_setprio 0"]
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
@@ -584,6 +590,9 @@ def main():
     out.append(block_shared("sweep_duo_shared_stamped", 128 - 25 - 3, stamp=True))
     out.append(block_quad("sweep_quad_sum"))
     out.append(block_quad("sweep_quad_sum_stamped", stamp=True))
+    if os.environ.get("QUAD_VARIANTS"):  # tuning builds: the priority schemes side by side (AWPU_QUAD_VARIANT picks)
+        for v in (0, 3, 4):
+            out.append(block_quad(f"sweep_quad_sum_v{v}", prio=v))
     lo = 80 - (4 * (DEPTH + 1) + 1) - 3  # shapes with an 80-VGPR budget (6 waves per SIMD)
     out.append(block("sweep_quad_lo", 4, lo))
     out.append(block("sweep_quad_lo_stamped", 4, lo, stamp=True))

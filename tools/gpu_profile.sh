@@ -1,0 +1,17 @@
+#!/bin/bash
+# rocprofv3 evidence for one bench.py command line: kernel stats, SQ counters, HBM-side counters (separate passes)
+# usage: tools/gpu_profile.sh <tag> [bench args...]
+set -euo pipefail
+: "${GRAFT_REPO_ROOT:?run under gpurun}"
+tag=$1; shift
+out=gpurun_out/$tag
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p $out
+python3 -c "import __graft_entry__ as g; g.build()" > $out/build.log 2>&1
+export AWPU_NO_BUILD=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --cpu-seconds 0 --no-extras "$@" > $out/bench_under_rocprof.json 2> $out/stats.log
+find $out/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
+head -6 $out/kernel_stats.csv
+bash tools/pmc.sh $tag/pmc --no-extras "$@" > $out/pmc_sq_summary.txt
+bash tools/pmc_hbm.sh $tag/hbm --no-extras "$@" > $out/pmc_hbm_summary.txt
+cat $out/pmc_sq_summary.txt $out/pmc_hbm_summary.txt

@@ -9,7 +9,9 @@ mkdir -p "$out"
 # Build BEFORE the profiler is in the picture: under rocprofv3 every child inherits the preloaded tool
 # library, and a compiler or make started from a process whose GPU it has initialised is an exec the pool
 # forbids.  AWPU_NO_BUILD=1 then makes the binding and the oracle loader refuse to build (they raise).
-python3 -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1
+if [ "${AWPU_NO_BUILD:-}" != "1" ]; then  # (a caller that has built already says so)
+  python3 -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1
+fi
 export AWPU_NO_BUILD=1
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT" \

@@ -10,7 +10,9 @@ mkdir -p "$out"
 # Build BEFORE the profiler is in the picture: under rocprofv3 every child inherits the preloaded tool
 # library, and a compiler or make started from a process whose GPU it has initialised is an exec the pool
 # forbids.  AWPU_NO_BUILD=1 then makes the binding and the oracle loader refuse to build (they raise).
-python3 -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1
+if [ "${AWPU_NO_BUILD:-}" != "1" ]; then  # (a caller that has built already says so)
+  python3 -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1
+fi
 export AWPU_NO_BUILD=1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_REQ_sum TCC_READ_sum"; do
   tag=$(echo $grp | cut -d' ' -f1)
