@@ -81,7 +81,9 @@ struct awpu_hip {
     };
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     awpu::QuadEntry *d_quad_lut = nullptr;  // quad-major table of the quad shape (das_quad_kernel)
-    awpu::FastPlan quad_plan{};
+    awpu::QuadEntry *d_quad1_lut = nullptr; // the same with the single-frame layout's LDS addresses (das_quad1_kernel)
+    awpu::FastPlan quad_plan{}, quad1_plan{};
+    bool quad1_fits = false;
     bool quad_ok = false;         // the table's statistics favour the quad shape (decided in prepare)
     double quad_cost = 0.0;       // its expected packed VALU instructions per quad and mic (32 = no sharing at all)
     int32_t *d_index = nullptr;
@@ -166,6 +168,7 @@ void release_device(awpu_hip *h) {
     for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
     dev_free(h->d_quad_lut);
+    dev_free(h->d_quad1_lut);
     dev_free(h->d_index);
     dev_free(h->d_gain);
     dev_free(h->d_calib);
@@ -218,6 +221,7 @@ int prepare(awpu_hip *h) {
     for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
     dev_free(h->d_quad_lut);
+    dev_free(h->d_quad1_lut);
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
                            hipMemcpyHostToDevice));
@@ -340,6 +344,9 @@ int prepare(awpu_hip *h) {
             h->quad_cost = seen ? 20.0 + 8.0 * (double) differ / (double) seen : 32.0;
             h->quad_ok = h->quad_cost < 0.9 * 32.0 && awpu::pair_plan(h->window, U, &h->quad_plan);
             if (env().quads >= 0) h->quad_ok = env().quads != 0 && awpu::pair_plan(h->window, U, &h->quad_plan);
+            h->quad1_fits = h->quad_ok && h->gain.empty() &&  // (gains ride on the weights of the other single-frame tables)
+                            awpu::fast_plan(h->window, U, 1, awpu::kFastLdsBytes - awpu::kQuad1ZeroBytes, &h->quad1_plan) &&
+                            awpu::fast_db_fits(h->quad1_plan);
         }
     }
 
@@ -407,10 +414,11 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
 // address), quads = groups of four grid rows x columns padded to whole 16-column tiles.  Pixels past the grid
 // carry weight 0 and the address of the nearest pixel inside it (they then follow the shared path and add
 // nothing); padding mics (usable rounded up to 4) carry weight 0 and the address of their own, zero, row.
-int build_quad_lut(awpu_hip *h) {
-    if (h->d_quad_lut) return AWPU_OK;
+int build_quad_lut(awpu_hip *h, bool single) {
+    awpu::QuadEntry *&d_lut = single ? h->d_quad1_lut : h->d_quad_lut;
+    if (d_lut) return AWPU_OK;
     const auto &c = h->cfg;
-    const awpu::FastPlan &plan = h->quad_plan;
+    const awpu::FastPlan &plan = single ? h->quad1_plan : h->quad_plan;
     const int U = h->usable(), cols = c.grid_columns, rows = c.pixel_count / cols;
     const int groups = plan.usable_pad / 4;
     const int cols_pad = (cols + 15) / 16 * 16, rows4 = (rows + 3) / 4;
@@ -430,17 +438,23 @@ int build_quad_lut(awpu_hip *h) {
                     const int j = s % plan.chunk;  // mic slot inside its chunk
                     if (s < U) {
                         const int id = h->index[s];
-                        e.f = inside ? frow[id] : 0.0f;
-                        e.addr = (uint32_t) (j * plan.row_bytes + (orow[id] - h->wstart) * 8);
-                    } else {
+                        const int off_rel = orow[id] - h->wstart;
+                        e.f = inside ? frow[id] - 0.5f : 0.0f;  // centred weight (das_fast.hip, das_quad_kernel)
+                        if (single) {  // copy (off & 1) of the window starts 8-byte aligned
+                            const int par = off_rel & 1;
+                            e.addr = (uint32_t) ((j * 2 + par) * plan.row_bytes + (off_rel - par) * 4);
+                        } else {
+                            e.addr = (uint32_t) (j * plan.row_bytes + off_rel * 8);
+                        }
+                    } else {  // padding mic: silence (the pair layout packs zero rows; the single-frame images end in one)
                         e.f = 0.0f;
-                        e.addr = (uint32_t) (j * plan.row_bytes);
+                        e.addr = single ? (uint32_t) (awpu::kFastLdsBytes - awpu::kQuad1ZeroBytes) : (uint32_t) (j * plan.row_bytes);
                     }
                 }
             }
         }
-    AWPU_HIP_TRY(hipMalloc(&h->d_quad_lut, n * sizeof(awpu::QuadEntry)));
-    AWPU_HIP_TRY(hipMemcpy(h->d_quad_lut, packed.data(), n * sizeof(awpu::QuadEntry), hipMemcpyHostToDevice));
+    AWPU_HIP_TRY(hipMalloc(&d_lut, n * sizeof(awpu::QuadEntry)));
+    AWPU_HIP_TRY(hipMemcpy(d_lut, packed.data(), n * sizeof(awpu::QuadEntry), hipMemcpyHostToDevice));
     return AWPU_OK;
 }
 
@@ -579,7 +593,7 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
 
 // quad shape: the frame-pair layout swept four vertically adjacent pixels at a time (das_quad_kernel)
 int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
-    int rc = build_quad_lut(h);
+    int rc = build_quad_lut(h, false);
     if (rc != AWPU_OK) return rc;
     const awpu::FastPlan &pp = h->quad_plan;
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * pp.usable_pad * pp.wr * 2;
@@ -631,6 +645,43 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     return dump_diag(h, n_waves, 16, "quads", s);
 }
 
+// quad shape for single frames (das_quad1_kernel): frames read in place, qpw quads per wave
+int launch_quads1(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff,
+                  const int32_t *d_row_off, int qpw) {
+    int rc = build_quad_lut(h, true);
+    if (rc != AWPU_OK) return rc;
+    const awpu::FastPlan &pp = h->quad1_plan;
+    awpu::Quad1Args qa{};
+    qa.frames = d_frames;
+    qa.lut = h->d_quad1_lut;
+    qa.row_off = d_row_off;
+    qa.power = d_power;
+    qa.n_streams = h->cfg.n_streams;
+    qa.hist = hist_eff;
+    qa.usable = h->usable();
+    qa.usable_pad = pp.usable_pad;
+    qa.pixel_count = h->cfg.pixel_count;
+    qa.wr = pp.wr;
+    qa.chunk = pp.chunk;
+    qa.batch = batch;
+    qa.cols = h->cfg.grid_columns;
+    qa.rows = h->cfg.pixel_count / qa.cols;
+    qa.debug = env().debug;
+    qa.debug_out = nullptr;
+    size_t n_waves = 0;
+    if (qa.debug & 16) {
+        n_waves = (size_t) 16 * batch * awpu::quad1_tiles(qa.rows, qa.cols, qpw);
+        rc = ensure_diag(h, n_waves * 12);
+        if (rc != AWPU_OK) return rc;
+        qa.debug_out = h->d_diag;
+    }
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_das_quads1(qa, qpw, s));
+    rc = finish_launch(h, batch, s);
+    if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
+    return dump_diag(h, n_waves, 16, "quads1", s);
+}
+
 int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int layout = kFull) {
     const bool compact = layout == kCompact;
     const int hist_eff = compact ? h->compact_hist : (layout == kRing ? 2048 : h->cfg.hist);
@@ -652,6 +703,14 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         // a window too wide for the pair image is served by the single-frame shapes below; anything
         // else (an allocation or copy that failed) is the caller's to know about
         if (rc != AWPU_ERR_INVALID) return rc;
+    }
+    // ---- single frames on a grid whose table favours the quad shape (AWPU_FAST_VARIANT set: the older shapes)
+    if (h->quad1_fits && env().fpi == 0 && wstart_eff + 1 + h->quad1_plan.wr <= hist_eff) {
+        const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
+        const int qpw = (long) awpu::quad1_tiles(rows, cols, 2) * batch >= 256 ? 2 : 1;
+        if ((long) awpu::quad1_tiles(rows, cols, qpw) * batch >= 192 || env().quads == 1)
+            return launch_quads1(h, d_frames, batch, d_power, s, hist_eff,
+                                 compact ? h->d_row_off_compact : (layout == kRing ? h->d_row_off_ring : h->d_row_off), qpw);
     }
     int fpi = 1, ppw = 8, nw = 8;
     choose_fast_variant(h, batch, &fpi, &ppw, &nw);

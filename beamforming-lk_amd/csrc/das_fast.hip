@@ -809,8 +809,10 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
 // Quad shape (the default for batches on grids whose row length is known and whose neighbouring rows mostly
 // share their integer delays): the frame-pair layout and chunk pipeline of das_pair_kernel, with the
 // arithmetic rearranged so that pixels share work and not only sample reads:
-//     out_p[i] = sum_m f X[o+i] + (1-f) X[o+i+1] = A_p[i] - A_p[i+1] + S_p[i+1],
-//     A_p[j] = sum_m f_pm X_m[o_pm + j],   S_p[j] = sum_m X_m[o_pm + j]   (j = 0..256).
+//     out_p[i] = sum_m f X[o+i] + (1-f) X[o+i+1] = A_p[i] - A_p[i+1] + (S_p[i] + S_p[i+1]) / 2,
+//     A_p[j] = sum_m (f_pm - 1/2) X_m[o_pm + j],   S_p[j] = sum_m X_m[o_pm + j]   (j = 0..256)
+// (the weights centred on zero keep A_p an incoherent sum even where the beam adds up coherently, so its rounding
+// errors stay small beside S_p, which is a plain sum).
 // S_p does not depend on the fractions, so pixels whose INTEGER delays coincide for a mic share that mic's term
 // of it.  A wave sweeps four vertically adjacent pixels (rows 4r..4r+3 of one grid column; arrays are wider
 // than tall, so the delay changes least between vertical neighbours); the second is the reference: its samples
@@ -818,7 +820,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
 // address (one packed FMA per register).  A pixel that differs for this mic reads its own samples and pays
 // three instructions per register (A_p += f x_p; V_p += x_p; V_p -= x_ref; S_p = T + V_p).  Per mic and quad
 // that is 20 packed VALU instructions when all four coincide, +8 per pixel that does not, against 32 (+2
-// address adds) in das_pair_kernel; the epilogue turns (A, S) into the (A, Q = S - A) pair finish_pixel_pair
+// address adds) in das_pair_kernel; the epilogue turns (A, S) into the (S/2 + A, S/2 - A) pair finish_pixel_pair
 // takes.  Differs from the other fast kernels by fp32 rounding only (measured 2e-6 of the reference).
 // Table: 8-byte entries (f, address), quad-major -- [quad][group of 4 mics][pixel][mic] -- so that a trip's
 // entries are one 128-byte line; pixels past the grid carry weight 0 and their neighbour's address, padding
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {  // mics 0..31 of the chunk (prefetched above)
                 const bool on = tail_lane && 8 * u + ((lane - m0) & 7) < mc4;
-                const float g = on ? 1.0f - te[u].f : 0.0f;
+                const float g = on ? 0.5f - te[u].f : 0.0f;  // 1 - f
                 const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
                 tail = __builtin_elementwise_fma(f2{g, g}, x, tail);
             }
@@ -955,7 +957,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                     const int jj = j0 + 8 * u + ((lane - m0) & 7);
                     const int m = m0 + min(jj, mc4 - 1);
                     const QuadEntry e = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
-                    const float g = tail_lane && jj < mc4 ? 1.0f - e.f : 0.0f;
+                    const float g = tail_lane && jj < mc4 ? 0.5f - e.f : 0.0f;
                     const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
                     tail = __builtin_elementwise_fma(f2{g, g}, x, tail);
                 }
@@ -988,8 +990,9 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         f2 P[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            P[k] = f2{A[2 * k], A[2 * k + 1]};
-            P[4 + k] = f2{S[2 * k], S[2 * k + 1]} - P[k];  // Q = S - A: the terms (1 - f) X
+            const f2 Ak = f2{A[2 * k], A[2 * k + 1]}, Hk = 0.5f * f2{S[2 * k], S[2 * k + 1]};
+            P[k] = Hk + Ak;      // sum f X      (A was accumulated with f - 1/2: see QuadEntry)
+            P[4 + k] = Hk - Ak;  // sum (1 - f) X
         }
         f2 tl;
         tl.x = __shfl(tail.x, pp * 8);
@@ -1006,6 +1009,188 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
     finish(A3, T + V3, 3);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Quad shape for single frames (calls of one frame, frames read in place from the ingest ring): the staging of
+// das_fast_db_kernel -- one 16-wave workgroup per CU, two LDS images of [mic][copy q][wr] floats filled by LDS-DMA,
+// copy q = the window shifted by q samples so that any integer delay starts 8-byte aligned -- under the quad
+// arithmetic of das_quad_kernel: a wave sweeps QPW quads of four vertically adjacent pixels; lane l owns samples
+// {2l, 2l+1} and {128+2l, 129+2l}, so a quad's accumulators are 32 registers (A_p, T, V_p: two register pairs
+// each).  Per mic and quad 10 packed VALU instructions and 2 LDS reads where the four integer delays coincide
+// (+4 and +2 per pixel that differs), against 16 and 8 in das_fast_db_kernel.  Same 8-byte quad-major table
+// layout as das_quad_kernel, with this layout's LDS addresses; grid = (frames, tiles of 4 rows x 16 QPW columns).
+// ---------------------------------------------------------------------------------------
+template <int QPW, bool DIAG>
+__global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
+    static_assert(QPW == 1 || QPW == 2, "one or two quads per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
+    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int frame = blockIdx.x;
+    const int tile = blockIdx.y;
+    const int wr = a.wr, wr4 = wr >> 2;
+
+    const int tile_cols = NW * QPW;
+    const int tiles_per_row4 = (a.cols + tile_cols - 1) / tile_cols;
+    const int cols_pad = (a.cols + 15) / 16 * 16;  // the table's quads: columns padded to 16 (quad_count)
+    const int row4 = tile / tiles_per_row4;
+    const int col0 = (tile - row4 * tiles_per_row4) * tile_cols + wave * QPW;
+    const int groups_total = a.usable_pad >> 2;
+
+    int *row_off_lds = (int *) (lds + 2 * (BUF / 4));
+    for (int i = threadIdx.x; i < 2 * a.usable_pad; i += kThreads) row_off_lds[i] = a.row_off[i];
+    int piece_rc[kPieces];  // row << 16 | column of this thread's 16-byte pieces of the flat image
+#pragma unroll
+    for (int k = 0; k < kPieces; k++) {
+        const int piece = threadIdx.x + k * kThreads;
+        const int row = piece / wr4;
+        piece_rc[k] = (row << 16) | ((piece - row * wr4) * 4);
+    }
+    __syncthreads();
+
+    f4 A0a = {0, 0, 0, 0}, A1a = A0a, A2a = A0a, A3a = A0a, Ta = A0a, V0a = A0a, V2a = A0a, V3a = A0a;
+    f4 A0b = A0a, A1b = A0a, A2b = A0a, A3b = A0a, Tb = A0a, V0b = A0a, V2b = A0a, V3b = A0a;
+    float tail = 0.0f;
+    // tail pass: lane 8 pp + k takes pixel slot pp (quad pp / 4, pixel pp % 4) and the mics k (mod 8)
+    const int tail_pp = lane >> 3;
+    const int tail_col = min(col0 + (tail_pp >> 2), cols_pad - 1);
+    const bool tail_lane = tail_pp < 4 * QPW && col0 + (tail_pp >> 2) < a.cols && 4 * row4 + (tail_pp & 3) < a.rows;
+    const QuadEntry *tail_lut = a.lut + ((size_t) row4 * cols_pad + tail_col) * groups_total * 16;
+
+    const float *frame_base = a.frames + (size_t) frame * a.n_streams * a.hist;
+    auto dma_chunk = [&](int m0, int mc, int buf) {
+        const int rows = 2 * mc;
+        int src_off[kPieces];  // all row offsets first (one LDS round trip), then the transfers back to back
+#pragma unroll
+        for (int k = 0; k < kPieces; k++)
+            src_off[k] = row_off_lds[2 * m0 + min(piece_rc[k] >> 16, rows - 1)] + (piece_rc[k] & 0xffff);
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            if ((piece_rc[k] >> 16) < rows) {
+                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (frame_base + src_off[k]),
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+            }
+        }
+    };
+    // Padding mics (usable rounded up to 4) carry weight 0 and the address of the zero row that closes either
+    // image (kQuad1ZeroBytes, never touched by the DMA): they add nothing to T either.
+    for (int i = threadIdx.x; i < 2 * (kQuad1ZeroBytes / 4); i += kThreads)
+        lds[(i / (kQuad1ZeroBytes / 4)) * (BUF / 4) + (BUF - kQuad1ZeroBytes) / 4 + i % (kQuad1ZeroBytes / 4)] = 0.0f;
+
+    unsigned t_wait = 0, t_all = 0;
+    const long long t_begin = __builtin_readcyclecounter();
+    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
+    dma_chunk(0, min(a.chunk, a.usable), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    unsigned t_ph[5] = {0, 0, 0, 0, 0};
+    auto stamp = [&](int k, long long &t) {
+        if (DIAG) {
+            const long long n = __builtin_readcyclecounter();
+            t_ph[k] += (unsigned) (n - t);
+            t = n;
+        }
+    };
+    const int rank = wave >> 2;
+    for (int c = 0; c < n_chunks; c++) {
+        const int m0 = c * a.chunk;
+        const int mc = min(a.chunk, a.usable - m0);
+        const int mc4 = (mc + 3) & ~3;
+        const int buf = c & 1;
+        long long t = DIAG ? __builtin_readcyclecounter() : 0;
+        // table entries of the tail pass below (the 257th sample): requested now, consumed after the sweep
+        QuadEntry te[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int m = m0 + min(8 * u + ((lane - m0) & 7), mc4 - 1);
+            te[u] = tail_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
+        }
+        if (c + 1 < n_chunks && !(a.debug & 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
+        stamp(0, t);
+        const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
+        const int ng = __builtin_amdgcn_readfirstlane(mc4 >> 2);
+        {
+            const void *row = uniform_ptr(a.lut + (((size_t) row4 * cols_pad + min(col0, cols_pad - 1)) * groups_total + (m0 >> 2)) * 16);
+            if constexpr (DIAG) {
+                unsigned dw = 0, da = 0;
+                sweep_quad1_sum_a_stamped(A0a, A1a, A2a, A3a, Ta, V0a, V2a, V3a, row, ng, lane_addr, rank, dw, da);
+                t_wait += dw;
+                t_all += da;
+            } else {
+                sweep_quad1_sum_a(A0a, A1a, A2a, A3a, Ta, V0a, V2a, V3a, row, ng, lane_addr, rank);
+            }
+        }
+        if constexpr (QPW == 2) {
+            const void *row = uniform_ptr(a.lut + (((size_t) row4 * cols_pad + min(col0 + 1, cols_pad - 1)) * groups_total + (m0 >> 2)) * 16);
+            sweep_quad1_sum_b(A0b, A1b, A2b, A3b, Tb, V0b, V2b, V3b, row, ng, lane_addr, rank);
+        }
+        stamp(1, t);
+        // the 257th sample of every window (X[off+256], weight 1 - f, goes to out[255])
+        const float *buf_f = lds + buf * (BUF / 4);
+        if (!(a.debug & 4))
+#pragma unroll
+            for (int u = 0; u < 4; u++) {  // mics 0..31 of the chunk (prefetched above)
+                const bool on = tail_lane && 8 * u + ((lane - m0) & 7) < mc;
+                tail = __builtin_fmaf(on ? 0.5f - te[u].f : 0.0f, buf_f[(te[u].addr + 1024u) >> 2], tail);  // 1 - f
+            }
+        for (int j0 = 32; j0 < ((a.debug & 4) ? 0 : mc4); j0 += 32) {  // chunks of more than 32 mics (narrow windows)
+            QuadEntry e[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 8 * u + ((lane - m0) & 7);
+                const int m = m0 + min(j, mc4 - 1);
+                e[u] = tail_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
+                on[u] = tail_lane && j < mc;  // padding mics (j >= mc) add nothing
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                tail = __builtin_fmaf(on[u] ? 0.5f - e[u].f : 0.0f, buf_f[(e[u].addr + 1024u) >> 2], tail);  // 1 - f
+        }
+        if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(2, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3, t);
+        if (!(a.debug & 8)) __syncthreads();
+        stamp(4, t);
+    }
+
+    if (DIAG && a.debug_out && lane == 0) {
+        unsigned long long *o = a.debug_out + 12 * ((size_t) (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+        o[0] = t_wait;
+        o[1] = t_all;
+        o[2] = (unsigned long long) (__builtin_readcyclecounter() - t_begin);
+        o[3] = (unsigned long long) n_chunks;
+        for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
+    }
+    tail += __shfl_xor(tail, 1);
+    tail += __shfl_xor(tail, 2);
+    tail += __shfl_xor(tail, 4);
+    const float norm = (float) (kSamples * a.usable);
+    auto finish = [&](const f4 &A, const f4 &S, int slot) {
+        const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
+        const f2 Ax = f2{A[0], A[1]}, Ay = f2{A[2], A[3]};  // accumulated with f - 1/2 (see QuadEntry)
+        const f2 Hx = 0.5f * f2{S[0], S[1]}, Hy = 0.5f * f2{S[2], S[3]};
+        const float tl = __shfl(tail, slot * 8);
+        const float sum = finish_pixel(Hx + Ax, Hx - Ax, Hy + Ay, Hy - Ay, tl, lane);  // sum f X, sum (1 - f) X
+        if (lane == 0 && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = sum / norm;
+    };
+    finish(A0a, Ta + V0a, 0);
+    finish(A1a, Ta, 1);
+    finish(A2a, Ta + V2a, 2);
+    finish(A3a, Ta + V3a, 3);
+    if constexpr (QPW == 2) {
+        finish(A0b, Tb + V0b, 4);
+        finish(A1b, Tb, 5);
+        finish(A2b, Tb + V2b, 6);
+        finish(A3b, Tb + V3b, 7);
+    }
+}
 // ---------------------------------------------------------------------------------------
 // host side: geometry of the LDS image and the launch
 // ---------------------------------------------------------------------------------------
@@ -1138,6 +1323,22 @@ hipError_t launch_das_quads(const QuadArgs &a, hipStream_t stream) {
     if (a.variant == 3) return launch_quad_variant<false, 3>(a, stream);
 #endif
     return launch_quad_variant<false, 0>(a, stream);
+}
+
+template <int QPW, bool DIAG>
+static hipError_t launch_quad1_variant(const Quad1Args &a, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes + kFastSideBytes;
+    if (hipError_t e = allow_lds((const void *) das_quad1_kernel<QPW, DIAG>, lds_bytes, attr_set); e != hipSuccess) return e;
+    dim3 grid(a.batch, quad1_tiles(a.rows, a.cols, QPW));
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((das_quad1_kernel<QPW, DIAG>), grid, dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_das_quads1(const Quad1Args &a, int qpw, hipStream_t stream) {
+    if (a.debug & 16) return qpw == 2 ? launch_quad1_variant<2, true>(a, stream) : launch_quad1_variant<1, true>(a, stream);
+    return qpw == 2 ? launch_quad1_variant<2, false>(a, stream) : launch_quad1_variant<1, false>(a, stream);
 }
 
 int fast_image_bytes(int nw) { return nw == 24 ? kFastLdsBytesSmall : kFastLdsBytes; }

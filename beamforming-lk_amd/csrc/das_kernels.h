@@ -92,7 +92,7 @@ hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream);
 // ---- quad shape (das_quad_kernel): the frame-pair layout swept four vertically adjacent pixels at a time with
 // a shared integer-delay sum (das_fast.hip).  Needs the grid's row length.
 struct QuadEntry {  // 8 bytes per (pixel, active mic)
-    float f;        // the reference's `fraction` (weight of X[off+i]); 1 - f is never needed in the sweep
+    float f;        // the reference's `fraction` (weight of X[off+i]) MINUS 1/2; 1 - f is never needed in the sweep
     uint32_t addr;  // LDS byte offset of the element X[off] in the chunk's image
 };
 struct QuadArgs {
@@ -110,6 +110,22 @@ struct QuadArgs {
 inline int quad_tiles(int rows, int cols) { return ((rows + 3) / 4) * ((cols + 15) / 16); }
 inline int quad_count(int rows, int cols) { return ((rows + 3) / 4) * ((cols + 15) / 16) * 16; }  // table quads incl. padding columns
 hipError_t launch_das_quads(const QuadArgs &a, hipStream_t stream);
+
+// the same arithmetic for single frames (das_quad1_kernel): the staging of the single-frame shapes (parity copies,
+// rows fetched in place from the frame), each image closed by a zero row that padding mics point at
+constexpr int kQuad1ZeroBytes = 1152;  // >= 64 lanes x 8 B + 512 + 8 (the widest read of a row), whole 128-byte lines
+struct Quad1Args {
+    const float *frames;      // [batch][n_streams][hist]
+    const QuadEntry *lut;     // [quads][usable_pad / 4][4 pixels][4 mics], this layout's LDS addresses
+    const int32_t *row_off;   // [2 * usable_pad + spare] float offset of staged row 2 s + q in a frame
+    float *power;             // [batch][pixel_count]
+    int32_t n_streams, hist, usable, usable_pad, pixel_count, wr, chunk, batch;
+    int32_t cols, rows;
+    unsigned long long *debug_out;
+    int32_t debug;
+};
+inline int quad1_tiles(int rows, int cols, int qpw) { return ((rows + 3) / 4) * ((cols + 16 * qpw - 1) / (16 * qpw)); }
+hipError_t launch_das_quads1(const Quad1Args &a, int qpw, hipStream_t stream);
 
 // LDS image geometry for a window of `window` samples; false if it cannot fit.
 bool fast_plan(int window, int usable, int fpi, int image_bytes, FastPlan *plan);

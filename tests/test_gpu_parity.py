@@ -548,6 +548,34 @@ def test_wire_ingest_and_ring_sweep(pkg, oracle):
     tx.close()
 
 
+def test_single_frames_on_the_headline_grid(pkg, oracle):
+    """One frame per call on the full headline grid with the row length known -- the call MIMOWorker::update makes,
+    and (from the ingest ring) the live path: the single-frame quad shape.  Host buffer, device ring and the
+    batched call must agree with the oracle on sampled pixels, and with each other to rounding."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["headline"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    rng = np.random.default_rng(3)
+    ring = np.zeros((spec.n_mics, 1024), np.float32)
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=2, grid_columns=spec.res) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        for b in range(4):  # four blocks of 24-bit noise fill the ring
+            stream = rng.integers(-(1 << 21), 1 << 21, size=(256, 256), dtype=np.int32)
+            eng.ingest_block(make_datagrams(stream, counter0=256 * b, n_arrays=4))
+            ring = np.concatenate([ring[:, 256:], oracle.unpack_exposure(stream, spec.n_mics)], axis=1)
+        from_ring = eng.process_ring()
+        from_host = eng.process(ring)
+        batched = eng.process(np.stack([ring, 2.0 * ring]))
+    assert np.array_equal(from_ring, from_host)  # same kernel, same bits, whichever way the frame came in
+    assert util.power_rel_err(batched[0], from_host) < 5e-6 and np.array_equal(batched[1], 4.0 * batched[0])
+    pick = np.random.default_rng(4).choice(spec.n_pixels, 160, replace=False)
+    want = oracle.das_f32(ring, off[pick], frac[pick])
+    floor = util.NULL_FLOOR * float(from_host.max())
+    assert float((np.abs(from_host[pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+
+
 @pytest.mark.parametrize("wl,batch", [("headline", 4), ("c3", 2)])
 def test_full_size_properties(pkg, oracle, wl, batch):
     """BASELINE's full sizes (256 mics x 128x128, 512 mics x 128x128), where the oracle would take

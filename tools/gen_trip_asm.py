@@ -414,19 +414,27 @@ QUAD_TMP = QUAD_ACC + 64  # 33 temps
 REF = 1                # which pixel of the quad is the reference (a middle one: fewest differing neighbours)
 
 
-def quad_regs():
-    A = [QUAD_ACC + 8 * p for p in range(4)]
-    T = QUAD_ACC + 32
-    V = {0: QUAD_ACC + 40, 2: QUAD_ACC + 48, 3: QUAD_ACC + 56}
-    R = (QUAD_TMP, QUAD_TMP + 8)
-    X = {0: QUAD_TMP + 16, 2: QUAD_TMP + 24, 3: QUAD_TMP + 24}  # pixels 2 and 3 share a slot (see block_quad)
-    addr_t = QUAD_TMP + 32
+def quad_regs(nk=4, acc=QUAD_ACC, tmp=QUAD_TMP):
+    """nk = register pairs per accumulator: 4 in the frame-pair layout (lane l owns samples l+64k, the two packed
+    lanes are two frames), 2 in the single-frame layout (lane l owns samples {2l,2l+1} and {128+2l,129+2l})"""
+    w = 2 * nk
+    A = [acc + w * p for p in range(4)]
+    T = acc + 4 * w
+    V = {0: acc + 5 * w, 2: acc + 6 * w, 3: acc + 7 * w}
+    R = (tmp, tmp + w)
+    X = {0: tmp + 2 * w, 2: tmp + 3 * w, 3: tmp + 3 * w}  # pixels 2 and 3 share a slot (see block_quad)
+    addr_t = tmp + 4 * w
     return A, T, V, R, X, addr_t
 
 
-def block_quad(name, stamp=False, prio=None):
+# single-frame layout: two quads per wave, each with its own pinned accumulators (32 registers), shared temps
+QUAD1_ACC = (16, 48)
+QUAD1_TMP = 80
+
+
+def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP):
     prio = PRIO if prio is None else prio
-    A, T, V, R, X, addr_t = quad_regs()
+    A, T, V, R, X, addr_t = quad_regs(nk, acc, tmp)
     E = (36, 68)
     S_TMP, S_PF_, S_LEFT_ = 22, 23, 24
 
@@ -441,7 +449,7 @@ def block_quad(name, stamp=False, prio=None):
 
     def reads(slot, addr_sgpr):
         L = [f"v_add_u32 v{addr_t}, s{addr_sgpr}, %[lane]"]
-        for k in range(4):
+        for k in range(nk):
             off = f" offset:{512 * k}" if k else ""
             L.append(f"ds_read_b64 {pair(slot, k)}, v{addr_t}{off}")
         return L
@@ -460,11 +468,11 @@ def block_quad(name, stamp=False, prio=None):
 
     def own_ops(p, fs, rslot):
         own = []
-        for k in range(4):
+        for k in range(nk):
             own.append(f"v_pk_fma_f32 {pair(A[p], k)}, {fs}, {pair(X[p], k)}, {pair(A[p], k)} op_sel_hi:[0,1,1]")
-        for k in range(4):
+        for k in range(nk):
             own.append(f"v_pk_add_f32 {pair(V[p], k)}, {pair(V[p], k)}, {pair(X[p], k)}")
-        for k in range(4):
+        for k in range(nk):
             own.append(f"v_pk_add_f32 {pair(V[p], k)}, {pair(V[p], k)}, {pair(rslot, k)} neg_lo:[0,1] neg_hi:[0,1]")
         return own
 
@@ -482,7 +490,7 @@ def block_quad(name, stamp=False, prio=None):
         else:
             cold.extend([f".Lqown{u}:"] + own_ops(p, fs, rslot) + [f"s_branch .Lqdone{u}"])
         L = [f"s_cmp_lg_u32 s{a_of(base, p, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lqown{u}"]
-        for k in range(4):
+        for k in range(nk):
             L.append(f"v_pk_fma_f32 {pair(A[p], k)}, {fs}, {pair(rslot, k)}, {pair(A[p], k)} op_sel_hi:[0,1,1]")
         L.append(f".Lqdone{u}:")
         return L
@@ -490,9 +498,9 @@ def block_quad(name, stamp=False, prio=None):
     def ref_ops(base, i, rslot):
         fs = f"s[{f_of(base, REF, i)}:{f_of(base, REF, i) + 1}]"
         L = []
-        for k in range(4):
+        for k in range(nk):
             L.append(f"v_pk_add_f32 {pair(T, k)}, {pair(T, k)}, {pair(rslot, k)}")
-        for k in range(4):
+        for k in range(nk):
             L.append(f"v_pk_fma_f32 {pair(A[REF], k)}, {fs}, {pair(rslot, k)}, {pair(A[REF], k)} op_sel_hi:[0,1,1]")
         return L
 
@@ -520,7 +528,7 @@ def block_quad(name, stamp=False, prio=None):
             rslot = R[st & 1]
             if st < 3:
                 L += reads(R[(st + 1) & 1], a_of(cur, REF, st + 1))
-                L.append("s_waitcnt lgkmcnt(4)")  # all but the four reads just issued: this mic's samples are in
+                L.append(f"s_waitcnt lgkmcnt({nk})")  # all but the reads just issued: this mic's samples are in
                 nbase, ni = cur, st + 1
             else:
                 L.append("s_waitcnt lgkmcnt(0)")  # this mic's samples, and the next trip's entries
@@ -553,13 +561,13 @@ def block_quad(name, stamp=False, prio=None):
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
-    vregs = list(range(QUAD_TMP, QUAD_TMP + 33))
+    vregs = list(range(tmp, tmp + 8 * nk + 1))
     sregs = sorted({S_TMP, S_PF_, S_LEFT_, S_RANK, S_PRIO, S_T0, S_T0 + 1, S_T1, S_T1 + 1}) + list(range(36, 100))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
     names = [f"A{p}" for p in range(4)] + ["T"] + [f"V{p}" for p in (0, 2, 3)]
     bases = A + [T] + [V[0], V[2], V[3]]
-    acc_params = ", ".join(f"f8 &{n}" for n in names)
-    acc_ops = ", ".join(f'"+{{v[{b}:{b + 7}]}}"({n})' for n, b in zip(names, bases))
+    acc_params = ", ".join(f"{'f8' if nk == 4 else 'f4'} &{n}" for n in names)
+    acc_ops = ", ".join(f'"+{{v[{b}:{b + 2 * nk - 1}]}}"({n})' for n, b in zip(names, bases))
     stamp_params = ", unsigned &t_wait, unsigned &t_all" if stamp else ""
     stamp_ops = ', [t_wait] "=&s"(t_wait), [t_all] "=&s"(t_all)' if stamp else ""
     return f"""// Four vertically adjacent pixels of the staged chunk, ng groups of four mics each (ng >= 1), with the shared
@@ -567,6 +575,154 @@ def block_quad(name, stamp=False, prio=None):
 // quad-major table ([group][pixel][mic] x 8 bytes: 128 contiguous bytes per group); reads one group past the last.
 // Accumulators are pinned: A_p v[{A[0]}+8p..], T v[{T}..], V0/V2/V3 v[{V[0]}..]/v[{V[2]}..]/v[{V[3]}..]; temps v{vregs[0]}..v{vregs[-1]},
 // s{sregs[0]}..s{sregs[-1]}.
+__device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, unsigned lane_addr, int rank{stamp_params}) {{
+    asm volatile(
+{body}
+        : {acc_ops}{stamp_ops}
+        : [ptr] "s"(row), [ng] "s"(ng), [lane] "v"(lane_addr), [rank] "s"(rank)
+        : {clobbers});
+}}
+"""
+
+
+def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP):
+    """The quad block for the single-frame layout, "always read" schedule.  With two register pairs per
+    accumulator a mic's share of the work is only ~13 VALU instructions, too short a stage to hide an LDS read
+    that is issued -- conditionally, late in the previous stage -- only when a pixel's integer delay differs from
+    the reference's.  Here pixel 0 and pixel 3 ALWAYS read their own samples, one full stage ahead and together
+    with the reference's (three read groups per mic into alternating slot sets, one static wait count), their
+    FMAs always take their own samples, and only the correction of the shared sum (V_p += x_p - x_ref) stays
+    conditional.  Pixel 2 takes the reference's samples, or pixel 3's when it carries pixel 3's address, or --
+    rare -- reads on the spot.  LDS reads per mic and quad: 3 groups instead of 1.7 on average (the LDS has the
+    room: the quad arithmetic needs a third of the reads of the older shapes); VALU instructions: the same."""
+    prio = PRIO if prio is None else prio
+    w = 2 * nk
+    A = [acc + w * p for p in range(4)]
+    T = acc + 4 * w
+    V = {0: acc + 5 * w, 2: acc + 6 * w, 3: acc + 7 * w}
+    Z = [dict(R=tmp + 3 * w * z, X0=tmp + 3 * w * z + w, X23=tmp + 3 * w * z + 2 * w) for z in range(2)]
+    spot = tmp + 6 * w
+    addr_t = tmp + 7 * w
+    n_tmp = 7 * w + 1
+    E = (36, 68)
+    S_TMP, S_PF_, S_LEFT_ = 22, 23, 24
+
+    def f_of(base, p, i):
+        return base + 8 * p + 2 * i
+
+    def a_of(base, p, i):
+        return base + 8 * p + 2 * i + 1
+
+    def pair(r, k):
+        return f"v[{r + 2 * k}:{r + 2 * k + 1}]"
+
+    def reads(slot, addr_sgpr):
+        L = [f"v_add_u32 v{addr_t}, s{addr_sgpr}, %[lane]"]
+        for k in range(nk):
+            off = f" offset:{512 * k}" if k else ""
+            L.append(f"ds_read_b64 {pair(slot, k)}, v{addr_t}{off}")
+        return L
+
+    def uid():
+        COUNTER[0] += 1
+        return f"%=_{COUNTER[0]}"
+
+    cold = []
+
+    def fmas(p, fs, src):
+        return [f"v_pk_fma_f32 {pair(A[p], k)}, {fs}, {pair(src, k)}, {pair(A[p], k)} op_sel_hi:[0,1,1]" for k in range(nk)]
+
+    def correct(p, own, ref):
+        return ([f"v_pk_add_f32 {pair(V[p], k)}, {pair(V[p], k)}, {pair(own, k)}" for k in range(nk)] +
+                [f"v_pk_add_f32 {pair(V[p], k)}, {pair(V[p], k)}, {pair(ref, k)} neg_lo:[0,1] neg_hi:[0,1]" for k in range(nk)])
+
+    def issue(z, base, i):
+        return reads(Z[z]["R"], a_of(base, REF, i)) + reads(Z[z]["X0"], a_of(base, 0, i)) + reads(Z[z]["X23"], a_of(base, 3, i))
+
+    def stage(base, i, z):
+        R, X0, X23 = Z[z]["R"], Z[z]["X0"], Z[z]["X23"]
+        fs = lambda p: f"s[{f_of(base, p, i)}:{f_of(base, p, i) + 1}]"
+        L = []
+        # pixel 3: own samples always; the shared sum's correction only where its delay differs
+        u = uid()
+        cold.extend([f".Lac{u}:"] + correct(3, X23, R) + [f"s_branch .Lad{u}"])
+        L += fmas(3, fs(3), X23) + [f"s_cmp_lg_u32 s{a_of(base, 3, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lac{u}", f".Lad{u}:"]
+        # pixel 2: the reference's samples, or pixel 3's, or (rare) its own read on the spot
+        u = uid()
+        cold.extend([f".Lac{u}:",
+                     f"s_cmp_eq_u32 s{a_of(base, 2, i)}, s{a_of(base, 3, i)}",
+                     f"s_cbranch_scc0 .Lae{u}"] + fmas(2, fs(2), X23) + correct(2, X23, R) + [f"s_branch .Lad{u}",
+                     f".Lae{u}:"] + reads(spot, a_of(base, 2, i)) + ["s_waitcnt lgkmcnt(0)"] + fmas(2, fs(2), spot) + correct(2, spot, R) +
+                    [f"s_branch .Lad{u}"])
+        L += [f"s_cmp_lg_u32 s{a_of(base, 2, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lac{u}"] + fmas(2, fs(2), R) + [f".Lad{u}:"]
+        # pixel 0
+        u = uid()
+        cold.extend([f".Lac{u}:"] + correct(0, X0, R) + [f"s_branch .Lad{u}"])
+        L += fmas(0, fs(0), X0) + [f"s_cmp_lg_u32 s{a_of(base, 0, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lac{u}", f".Lad{u}:"]
+        # the reference: the shared sum and its own A
+        L += [f"v_pk_add_f32 {pair(T, k)}, {pair(T, k)}, {pair(R, k)}" for k in range(nk)] + fmas(REF, fs(REF), R)
+        return L
+
+    def load_set(base, off, literal=False):
+        if literal:
+            return [f"s_load_dwordx16 s[{base}:{base + 15}], %[ptr], {hex(off)}",
+                    f"s_load_dwordx16 s[{base + 16}:{base + 31}], %[ptr], {hex(off + 64)}"]
+        return [f"s_load_dwordx16 s[{base}:{base + 15}], %[ptr], s{off}",
+                f"s_add_u32 s{S_TMP}, s{off}, 64",
+                f"s_load_dwordx16 s[{base + 16}:{base + 31}], %[ptr], s{S_TMP}"]
+
+    def trip_q(par):
+        cur, nxt = E[par], E[1 - par]
+        L = []
+        if prio == 3 or (prio == 5 and par == 0):
+            L += select_prio(S_PRIO, 1)
+        elif prio == 5:
+            L += select_prio(S_RANK, 0)
+        L += load_set(nxt, S_PF_) + [f"s_add_u32 s{S_PF_}, s{S_PF_}, 128"]
+        for st in range(4):
+            if st < 3:
+                L += issue((st + 1) & 1, cur, st + 1)
+                L.append(f"s_waitcnt lgkmcnt({3 * nk})")  # all but the three read groups just issued
+            else:
+                L.append("s_waitcnt lgkmcnt(0)")  # this mic's samples, and the next trip's entries
+                L += issue(0, nxt, 0)
+            L += stage(cur, st, st & 1)
+        return L
+
+    L = []
+    if stamp:
+        L += [f"s_memtime s[{S_T0}:{S_T0 + 1}]", "s_waitcnt lgkmcnt(0)"]
+    L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    if prio == 4:
+        L += select_prio(S_RANK, 0)
+    L += load_set(E[0], 0, literal=True)
+    L += [f"s_mov_b32 s{S_LEFT_}, %[ng]", f"s_movk_i32 s{S_PF_}, 0x80", "s_waitcnt lgkmcnt(0)"]
+    if stamp:
+        L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_wait], s{S_T1}, s{S_T0}"]
+    L += issue(0, E[0], 0)
+    L += [".LQ0_%=:"] + trip_q(0)
+    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_eq_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQdone_%="]
+    L += trip_q(1)
+    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQ0_%="]
+    L += ["s_branch .LQdone_%="] + cold + [".LQdone_%=:", "s_waitcnt lgkmcnt(0)"]
+    if prio:
+        L += ["s_setprio 0"]
+    if stamp:
+        L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
+    body = "\n".join(f'        "{l}\\n\\t"' for l in L)
+    vregs = list(range(tmp, tmp + n_tmp))
+    sregs = sorted({S_TMP, S_PF_, S_LEFT_, S_RANK, S_PRIO, S_T0, S_T0 + 1, S_T1, S_T1 + 1}) + list(range(36, 100))
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
+    names = [f"A{p}" for p in range(4)] + ["T"] + [f"V{p}" for p in (0, 2, 3)]
+    bases = A + [T] + [V[0], V[2], V[3]]
+    vt = "f8" if nk == 4 else "f4"
+    acc_params = ", ".join(f"{vt} &{n}" for n in names)
+    acc_ops = ", ".join(f'"+{{v[{b}:{b + w - 1}]}}"({n})' for n, b in zip(names, bases))
+    stamp_params = ", unsigned &t_wait, unsigned &t_all" if stamp else ""
+    stamp_ops = ', [t_wait] "=&s"(t_wait), [t_all] "=&s"(t_all)' if stamp else ""
+    return f"""// Four vertically adjacent pixels of the staged chunk, single-frame layout, shared integer-delay sum, reads always
+// one stage ahead: see block_quad_ar in tools/gen_trip_asm.py.  `row` = the quad's entries of the chunk's first
+// group in the quad-major table; reads one group past the last.  Accumulators pinned from v{acc}, temps v{vregs[0]}..v{vregs[-1]}.
 __device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, unsigned lane_addr, int rank{stamp_params}) {{
     asm volatile(
 {body}
@@ -590,6 +746,9 @@ def main():
     out.append(block_shared("sweep_duo_shared_stamped", 128 - 25 - 3, stamp=True))
     out.append(block_quad("sweep_quad_sum"))
     out.append(block_quad("sweep_quad_sum_stamped", stamp=True))
+    for q, base in enumerate(QUAD1_ACC):  # single-frame layout, first / second quad of a wave
+        out.append(block_quad_ar(f"sweep_quad1_sum_{'ab'[q]}", nk=2, acc=base, tmp=QUAD1_TMP))
+    out.append(block_quad_ar("sweep_quad1_sum_a_stamped", stamp=True, nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP))
     if os.environ.get("QUAD_VARIANTS"):  # tuning builds: the priority schemes side by side (AWPU_QUAD_VARIANT picks)
         for v in (0, 3, 4):
             out.append(block_quad(f"sweep_quad_sum_v{v}", prio=v))

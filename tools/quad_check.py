@@ -14,7 +14,8 @@ from oracle import oracle_py as O  # noqa: E402
 
 pkg = importlib.import_module("beamforming-lk_amd")
 S = pkg.synthetic
-for wl, rows, batch in [("c1", (0, 32), 2), ("c1", (3, 6), 3), ("c2", (16, 8), 4), ("headline", (40, 8), 4), ("c3", (100, 12), 2)]:
+for wl, rows, batch in [("c1", (0, 32), 2), ("c1", (3, 6), 3), ("c2", (16, 8), 4), ("headline", (40, 8), 4), ("c3", (100, 12), 2),
+                        ("c1", (0, 32), 1), ("c1", (3, 6), 1), ("c2", (0, 64), 1), ("headline", (40, 30), 1), ("c3", (100, 12), 1)]:
     spec = S.WORKLOADS[wl]
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz, *rows)
