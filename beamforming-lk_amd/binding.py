@@ -39,7 +39,9 @@ class Cfg(C.Structure):
         ("pixel_begin", C.c_int32),
         ("pixel_count", C.c_int32),
         ("grid_columns", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("n_devices", C.c_int32),
+        ("devices", C.c_int32 * 8),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -246,11 +248,16 @@ class Engine:
     def __init__(self, n_pixels: int, n_streams: int = ELEMENTS, lut_stride: Optional[int] = None,
                  hist: int = HIST, math: int = MATH_F32_FAST, interp: int = INTERP_LERP,
                  max_batch: int = 1, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0,
-                 grid_columns: int = 0):
+                 grid_columns: int = 0, devices=None):
         lib = load()
         cfg = Cfg()
         lib.awpu_hip_default_cfg(C.byref(cfg))
         cfg.device = device
+        if devices is not None:  # a device group: the pixels are spread over these GPUs (include/awpu_hip.h)
+            cfg.n_devices = len(devices)
+            for i, d in enumerate(devices[:8]):  # (more than AWPU_MAX_DEVICES: the library refuses the count)
+                cfg.devices[i] = d
+            cfg.device = devices[0]
         cfg.grid_columns = grid_columns
         cfg.n_streams = n_streams
         cfg.hist = hist

@@ -113,6 +113,17 @@ struct awpu_hip {
     int wstart = 0, window = 0, tau_max = 0;
     int pair_cols = 0;  // frame-pair sweep: > 0 = waves take vertically adjacent pixels (grid row length), 0 = consecutive
 
+    // device group (cfg.n_devices > 1): this handle owns no sweep state of its own, only one part per device
+    std::vector<awpu_hip *> parts;
+    hipEvent_t ev_fan = nullptr;            // group: recorded on the caller's stream, awaited by every part
+    // a part's share of the fan-out (awpu_hip_process_device on a group): two window buffers, so that the copy of
+    // call k+1 (on copy_stream) runs beside the sweep of call k (on stream)
+    hipStream_t copy_stream = nullptr;
+    float *d_fan[2] = {nullptr, nullptr};
+    size_t fan_cap = 0;                     // floats per buffer
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_swept[2] = {nullptr, nullptr}, ev_done = nullptr;
+    unsigned fan_turn = 0;
+
     awpu_hip_stats stats{};
     std::string last_error;                  // awpu_hip_last_error_of
     unsigned long long *d_diag = nullptr;    // AWPU_FAST_DEBUG=16 cycle stamps of the last launch
@@ -147,10 +158,12 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
     int quads = -1;                // AWPU_FAST_QUADS
     int pair_group = 0;            // AWPU_FAST_PAIRGROUP: frame pairs an XCD works on at a time (quad shape)
     int quad_variant = 0;          // AWPU_QUAD_VARIANT (tuning builds)
+    int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0] (tests)
     EnvKnobs() {
         if (const char *v = std::getenv("AWPU_FAST_QUADS")) quads = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_PAIRGROUP")) pair_group = std::atoi(v);
         if (const char *v = std::getenv("AWPU_QUAD_VARIANT")) quad_variant = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_GROUP_FORCE_COPY")) group_copy = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_VARIANT"))
             if (std::sscanf(v, "%d,%d,%d", &fpi, &ppw, &nw) < 2) fpi = ppw = nw = 0;
         if (const char *v = std::getenv("AWPU_FAST_PAIRS")) pairs = std::atoi(v);
@@ -188,6 +201,9 @@ void release_device(awpu_hip *h) {
     dev_free(h->d_power);
     dev_free(h->d_diag);
     h->diag_cap = 0;
+    dev_free(h->d_fan[0]);
+    dev_free(h->d_fan[1]);
+    h->fan_cap = 0;
     h->beam_cap = h->beam_lut_cap = h->pack_cap = h->frames_cap = h->power_cap = 0;
 }
 
@@ -777,6 +793,235 @@ int check_ready(awpu_hip *h, int batch) {
     return AWPU_OK;
 }
 
+int ensure_power(awpu_hip *h, size_t need_power) {
+    if (h->power_cap < need_power) {
+        dev_free(h->d_power);
+        h->power_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
+        h->power_cap = need_power;
+    }
+    return AWPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device group (cfg.n_devices > 1): one handle, one part (an ordinary single-device engine) per GPU,
+// each owning a contiguous slab of the handle's pixels.  Everything below runs in the caller's thread; the parts'
+// streams run concurrently.  No collective library: host frames are uploaded by every device itself, device
+// frames fan out from devices[0] by one peer copy per destination (a different xGMI link each).
+// ------------------------------------------------------------------------------------------------
+int create_group(awpu_hip_t **out, const awpu_hip_cfg &c) {
+    if (c.n_devices > AWPU_MAX_DEVICES) return invalid("n_devices above AWPU_MAX_DEVICES");
+    const int G = c.n_devices;
+    // slabs: whole grid rows when the row length is known and the handle's range is whole rows, else pixels
+    const bool by_rows = c.grid_columns > 0 && c.pixel_count % c.grid_columns == 0 && c.pixel_begin % c.grid_columns == 0;
+    const int unit = by_rows ? c.grid_columns : 1, units = c.pixel_count / unit;
+    if (units < G) return invalid("fewer grid rows (or pixels) than devices");
+    awpu_hip *g = new (std::nothrow) awpu_hip();
+    if (!g) return AWPU_ERR_NOMEM;
+    g->cfg = c;
+    g->cfg.device = c.devices[0];
+    int begin = 0;
+    for (int k = 0; k < G; k++) {
+        awpu_hip_cfg pc = c;
+        pc.n_devices = 1;
+        pc.device = c.devices[k];
+        const int n = units / G + (k < units % G ? 1 : 0);  // the first units % G devices take one more
+        pc.pixel_begin = c.pixel_begin + begin * unit;
+        pc.pixel_count = n * unit;
+        begin += n;
+        awpu_hip *part = nullptr;
+        int rc = awpu_hip_create(&part, &pc);
+        if (rc == AWPU_OK) {  // what the fan-out needs on top of an ordinary engine
+            hipError_t e = hipStreamCreateWithFlags(&part->copy_stream, hipStreamNonBlocking);
+            for (int b = 0; b < 2 && e == hipSuccess; b++) {
+                e = hipEventCreateWithFlags(&part->ev_copied[b], hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_swept[b], hipEventDisableTiming);
+            }
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_done, hipEventDisableTiming);
+            if (e != hipSuccess) rc = hip_fail(e, "group stream/event creation");
+            g->parts.push_back(part);
+        }
+        if (rc != AWPU_OK) {
+            const std::string why = g_last_error;
+            awpu_hip_destroy(g);
+            note_error(why);
+            return rc;
+        }
+    }
+    // direct copies between devices[0] and the others (an error here only means "already enabled" or "no peer
+    // path": the copies then go through the host, slower but correct)
+    for (int k = 1; k < G; k++) {
+        if (c.devices[k] == c.devices[0]) continue;
+        if (hipSetDevice(c.devices[0]) == hipSuccess) (void) hipDeviceEnablePeerAccess(c.devices[k], 0);
+        if (hipSetDevice(c.devices[k]) == hipSuccess) (void) hipDeviceEnablePeerAccess(c.devices[0], 0);
+    }
+    (void) hipGetLastError();
+    AWPU_HIP_TRY(hipSetDevice(c.devices[0]));
+    hipError_t e = hipEventCreateWithFlags(&g->ev_fan, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        awpu_hip_destroy(g);
+        return hip_fail(e, "group event creation");
+    }
+    *out = g;
+    return AWPU_OK;
+}
+
+// a part ran into an error: the group reports it as its own
+int part_failed(awpu_hip *g, awpu_hip *part, int rc) {
+    g->last_error = part->last_error.empty() ? g_last_error : part->last_error;
+    g_last_error = g->last_error;
+    return rc;
+}
+
+template <class F>
+int for_each_part(awpu_hip *g, F f) {
+    for (awpu_hip *part : g->parts) {
+        const int rc = f(part);
+        if (rc != AWPU_OK) return part_failed(g, part, rc);
+    }
+    return AWPU_OK;
+}
+
+int slab_offset(const awpu_hip *g, const awpu_hip *part) { return part->cfg.pixel_begin - g->cfg.pixel_begin; }
+
+// upload of host frames + the sweep into h->d_power, all on h->stream, nothing waited for
+int enqueue_host_process(awpu_hip *h, const float *frames, int batch) {
+    int rc = check_ready(h, batch);
+    if (rc != AWPU_OK) return rc;
+    const bool compact = h->compact_hist > 0;
+    const int dev_hist = compact ? h->compact_hist : h->cfg.hist;
+    const size_t need_frames = (size_t) h->cfg.n_streams * dev_hist * batch;
+    if (h->frames_cap < need_frames) {
+        dev_free(h->d_frames);
+        h->frames_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_frames, need_frames * sizeof(float)));
+        h->frames_cap = need_frames;
+    }
+    rc = ensure_power(h, (size_t) h->cfg.pixel_count * batch);
+    if (rc != AWPU_OK) return rc;
+    if (compact) {  // rows of compact_hist floats cut out of rows of hist floats: a third of the PCIe bytes
+        AWPU_HIP_TRY(hipMemcpy2DAsync(h->d_frames, (size_t) dev_hist * sizeof(float), frames + h->wstart,
+                                      (size_t) h->cfg.hist * sizeof(float), (size_t) dev_hist * sizeof(float),
+                                      (size_t) batch * h->cfg.n_streams, hipMemcpyHostToDevice, h->stream));
+    } else {
+        AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, frames, need_frames * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    return launch(h, h->d_frames, batch, h->d_power, h->stream, compact ? kCompact : kFull);
+}
+
+// h->d_power [batch][pixel_count] -> host rows `pitch` floats apart (a slab of a wider image), on h->stream
+int enqueue_power_to_host(awpu_hip *h, int batch, float *power, size_t pitch) {
+    const size_t row = (size_t) h->cfg.pixel_count * sizeof(float);
+    if (pitch == (size_t) h->cfg.pixel_count) {
+        AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_power, row * batch, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        AWPU_HIP_TRY(hipMemcpy2DAsync(power, pitch * sizeof(float), h->d_power, row, row, (size_t) batch, hipMemcpyDeviceToHost, h->stream));
+    }
+    return AWPU_OK;
+}
+
+int wait_and_time(awpu_hip *h) {
+    AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->timing) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, h->ev_begin, h->ev_end) == hipSuccess) {
+            h->stats.last_kernel_ms = ms;
+            h->stats.total_kernel_ms += ms;
+        }
+    }
+    return AWPU_OK;
+}
+
+int group_process(awpu_hip *g, const float *frames, int batch, float *power) {
+    const size_t pitch = (size_t) g->cfg.pixel_count;
+    int rc = for_each_part(g, [&](awpu_hip *part) {
+        AWPU_CTX(part);
+        const int r = enqueue_host_process(part, frames, batch);
+        return r != AWPU_OK ? r : enqueue_power_to_host(part, batch, power + slab_offset(g, part), pitch);
+    });
+    if (rc != AWPU_OK) return rc;
+    return for_each_part(g, [&](awpu_hip *part) { return wait_and_time(part); });
+}
+
+// Frames and power in the memory of devices[0], on the caller's stream there.  The window of every stream that the
+// tables touch travels to each other device by one (2-D) peer copy on that device's copy stream; the slabs are
+// swept concurrently; the tiles return by peer copies on the caller's stream, which thereby waits for all of it.
+int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d_power, hipStream_t stream) {
+    const int dev0 = g->cfg.devices[0];
+    AWPU_HIP_TRY(hipSetDevice(dev0));
+    hipStream_t s = stream ? stream : g->parts[0]->stream;
+    AWPU_HIP_TRY(hipEventRecord(g->ev_fan, s));  // the frames are in place once the caller's stream gets here
+    int rc = for_each_part(g, [&](awpu_hip *part) {
+        AWPU_CTX(part);
+        int r = check_ready(part, batch);  // (selects the part's device)
+        if (r != AWPU_OK) return r;
+        r = ensure_power(part, (size_t) part->cfg.pixel_count * batch);
+        if (r != AWPU_OK) return r;
+        const bool keep = part->timing;
+        part->timing = false;  // asynchronous path: the caller times its own stream
+        if (part->cfg.device == dev0 && !env().group_copy) {  // same GPU: sweep the caller's buffer in place
+            AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, g->ev_fan, 0));
+            r = launch(part, d_frames, batch, part->d_power, part->stream, kFull);
+        } else {
+            const bool compact = part->compact_hist > 0;
+            const int dev_hist = compact ? part->compact_hist : part->cfg.hist;
+            const size_t need = (size_t) part->cfg.n_streams * dev_hist * part->cfg.max_batch;
+            if (part->fan_cap < need) {
+                AWPU_HIP_TRY(hipStreamSynchronize(part->stream));
+                AWPU_HIP_TRY(hipStreamSynchronize(part->copy_stream));
+                dev_free(part->d_fan[0]);
+                dev_free(part->d_fan[1]);
+                part->fan_cap = 0;
+                AWPU_HIP_TRY(hipMalloc(&part->d_fan[0], need * sizeof(float)));
+                AWPU_HIP_TRY(hipMalloc(&part->d_fan[1], need * sizeof(float)));
+                part->fan_cap = need;
+                part->fan_turn = 0;
+            }
+            const int b = part->fan_turn++ & 1;
+            AWPU_HIP_TRY(hipStreamWaitEvent(part->copy_stream, g->ev_fan, 0));
+            if (part->fan_turn > 2) AWPU_HIP_TRY(hipStreamWaitEvent(part->copy_stream, part->ev_swept[b], 0));  // buffer b is free again
+            const size_t row = (size_t) dev_hist * sizeof(float);
+            AWPU_HIP_TRY(hipMemcpy2DAsync(part->d_fan[b], row, d_frames + (compact ? part->wstart : 0),
+                                          (size_t) part->cfg.hist * sizeof(float), row, (size_t) batch * part->cfg.n_streams,
+                                          hipMemcpyDeviceToDevice, part->copy_stream));
+            AWPU_HIP_TRY(hipEventRecord(part->ev_copied[b], part->copy_stream));
+            AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, part->ev_copied[b], 0));
+            r = launch(part, part->d_fan[b], batch, part->d_power, part->stream, compact ? kCompact : kFull);
+            if (r == AWPU_OK) AWPU_HIP_TRY(hipEventRecord(part->ev_swept[b], part->stream));
+        }
+        part->timing = keep;
+        if (r == AWPU_OK) AWPU_HIP_TRY(hipEventRecord(part->ev_done, part->stream));
+        return r;
+    });
+    if (rc != AWPU_OK) return rc;
+    AWPU_HIP_TRY(hipSetDevice(dev0));
+    const size_t pitch = (size_t) g->cfg.pixel_count * sizeof(float);
+    for (awpu_hip *part : g->parts) {  // tiles back into the caller's [batch][pixel_count] image
+        AWPU_HIP_TRY(hipStreamWaitEvent(s, part->ev_done, 0));
+        const size_t row = (size_t) part->cfg.pixel_count * sizeof(float);
+        AWPU_HIP_TRY(hipMemcpy2DAsync(d_power + slab_offset(g, part), pitch, part->d_power, row, row, (size_t) batch,
+                                      hipMemcpyDeviceToDevice, s));
+    }
+    return AWPU_OK;
+}
+
+int group_stats(awpu_hip *g, awpu_hip_stats *out) {
+    awpu_hip_stats st = g->parts[0]->stats;
+    for (size_t k = 1; k < g->parts.size(); k++) {
+        const awpu_hip_stats &p = g->parts[k]->stats;
+        st.launches += p.launches;
+        st.last_kernel_ms = std::max(st.last_kernel_ms, p.last_kernel_ms);   // the slabs run side by side
+        st.total_kernel_ms = std::max(st.total_kernel_ms, p.total_kernel_ms);
+        st.alg_bytes_frame += p.alg_bytes_frame;
+        st.alg_flops_frame += p.alg_flops_frame;
+        st.tau_max = std::max(st.tau_max, p.tau_max);
+        st.window = std::max(st.window, p.window);
+    }
+    *out = st;
+    return AWPU_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -818,6 +1063,8 @@ int awpu_hip_create(awpu_hip_t **out, const awpu_hip_cfg *cfg) {
     if (c.pixel_begin < 0 || c.pixel_count < 1 || c.pixel_begin + c.pixel_count > c.n_pixels)
         return invalid("pixel shard outside the grid");
 
+    if (c.n_devices > 1) return create_group(out, c);
+    c.n_devices = 1;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || c.device < 0 || c.device >= n_dev) {
         return fail(AWPU_ERR_NO_DEVICE, "no usable HIP device (this library has no CPU path)");
@@ -835,6 +1082,7 @@ int awpu_hip_create(awpu_hip_t **out, const awpu_hip_cfg *cfg) {
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_begin);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_end);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fan, hipEventDisableTiming);
     if (e != hipSuccess) {
         awpu_hip_destroy(h);
         return hip_fail(e, "stream/event creation");
@@ -845,12 +1093,16 @@ int awpu_hip_create(awpu_hip_t **out, const awpu_hip_cfg *cfg) {
 
 int awpu_hip_destroy(awpu_hip_t *h) {
     if (!h) return AWPU_OK;
+    for (awpu_hip *part : h->parts) awpu_hip_destroy(part);
+    h->parts.clear();
     (void) hipSetDevice(h->cfg.device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
+    if (h->copy_stream) (void) hipStreamSynchronize(h->copy_stream);
     release_device(h);
-    if (h->ev_begin) (void) hipEventDestroy(h->ev_begin);
-    if (h->ev_end) (void) hipEventDestroy(h->ev_end);
+    for (hipEvent_t ev : {h->ev_begin, h->ev_end, h->ev_fan, h->ev_copied[0], h->ev_copied[1], h->ev_swept[0], h->ev_swept[1], h->ev_done})
+        if (ev) (void) hipEventDestroy(ev);
     if (h->stream) (void) hipStreamDestroy(h->stream);
+    if (h->copy_stream) (void) hipStreamDestroy(h->copy_stream);
     delete h;
     return AWPU_OK;
 }
@@ -858,6 +1110,11 @@ int awpu_hip_destroy(awpu_hip_t *h) {
 int awpu_hip_set_delay_table(awpu_hip_t *h, const int32_t *off, const float *frac) {
     AWPU_CTX(h);
     if (!h || !off || !frac) return invalid("null argument");
+    if (!h->parts.empty())  // every device gets the rows of its slab
+        return for_each_part(h, [&](awpu_hip *part) {
+            const size_t first = (size_t) slab_offset(h, part) * h->cfg.lut_stride;
+            return awpu_hip_set_delay_table(part, off + first, frac + first);
+        });
     const size_t n = (size_t) h->cfg.pixel_count * h->cfg.lut_stride;
     for (size_t i = 0; i < n; i++) {
         if (!(frac[i] >= 0.0f && frac[i] <= 1.0f)) return invalid("fraction outside [0, 1]");
@@ -872,6 +1129,7 @@ int awpu_hip_set_delay_table(awpu_hip_t *h, const int32_t *off, const float *fra
 int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable) {
     AWPU_CTX(h);
     if (!h) return invalid("null handle");
+    if (!h->parts.empty()) return for_each_part(h, [&](awpu_hip *part) { return awpu_hip_set_active_mics(part, index, usable); });
     const int limit = std::min(h->cfg.n_streams, h->cfg.lut_stride);
     if (usable < 1 || usable > limit) return invalid("usable outside [1, min(n_streams, lut_stride)]");
     std::vector<int32_t> idx(usable);
@@ -888,6 +1146,7 @@ int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable
 int awpu_hip_set_mic_gains(awpu_hip_t *h, const float *gains) {
     AWPU_CTX(h);
     if (!h) return invalid("null handle");
+    if (!h->parts.empty()) return for_each_part(h, [&](awpu_hip *part) { return awpu_hip_set_mic_gains(part, gains); });
     if (!gains) {
         h->gain.clear();
     } else {
@@ -937,6 +1196,7 @@ int calibrate_rows(awpu_hip *h, const float *d_rows, int pitch, int hist, float 
 
 int awpu_hip_calibrate_device(awpu_hip_t *h, const float *d_frame, int32_t array, float reference_power_level,
                               int32_t *index, float *correction, float *median, int32_t *usable, void *stream) {
+    if (h && !h->parts.empty()) h = h->parts[0];  // not pixel-sharded: a device group answers with its first device
     AWPU_CTX(h);
     if (!h || !d_frame || !index || !correction || !usable) return invalid("null argument");
     if (array < 0 || (array + 1) * AWPU_ELEMENTS > h->cfg.n_streams) return invalid("array outside the streams");
@@ -949,6 +1209,7 @@ int awpu_hip_calibrate_device(awpu_hip_t *h, const float *d_frame, int32_t array
 
 int awpu_hip_calibrate_host(awpu_hip_t *h, const float *frame, int32_t array, float reference_power_level,
                              int32_t *index, float *correction, float *median, int32_t *usable) {
+    if (h && !h->parts.empty()) h = h->parts[0];  // not pixel-sharded: a device group answers with its first device
     AWPU_CTX(h);
     if (!h || !frame || !index || !correction || !usable) return invalid("null argument");
     if (array < 0 || (array + 1) * AWPU_ELEMENTS > h->cfg.n_streams) return invalid("array outside the streams");
@@ -970,6 +1231,7 @@ int awpu_hip_calibrate_host(awpu_hip_t *h, const float *frame, int32_t array, fl
 
 int awpu_hip_calibrate_ring(awpu_hip_t *h, int32_t array, float reference_power_level, int32_t *index,
                             float *correction, float *median, int32_t *usable) {
+    if (h && !h->parts.empty()) h = h->parts[0];  // not pixel-sharded: a device group answers with its first device
     AWPU_CTX(h);
     if (!h || !index || !correction || !usable) return invalid("null argument");
     if (array < 0 || (array + 1) * AWPU_ELEMENTS > h->cfg.n_streams) return invalid("array outside the streams");
@@ -983,6 +1245,7 @@ int awpu_hip_calibrate_ring(awpu_hip_t *h, int32_t array, float reference_power_
 
 int awpu_hip_beams(awpu_hip_t *h, const float *d_frame, const int32_t *off, const float *frac, int32_t n_dir,
                    float *power, float *beams) {
+    if (h && !h->parts.empty()) h = h->parts[0];  // not pixel-sharded: a device group answers with its first device
     AWPU_CTX(h);
     if (!h || !off || !frac || (!power && !beams)) return invalid("null argument");
     if (n_dir < 1 || n_dir > 65535) return invalid("n_dir outside [1, 65535]");
@@ -1041,6 +1304,7 @@ int awpu_hip_beams(awpu_hip_t *h, const float *d_frame, const int32_t *off, cons
 int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {
     AWPU_CTX(h);
     if (!h || !coeffs) return invalid("null argument");
+    if (!h->parts.empty()) return for_each_part(h, [&](awpu_hip *part) { return awpu_hip_set_fir_table(part, coeffs); });
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     if (!h->d_fir) AWPU_HIP_TRY(hipMalloc(&h->d_fir, 101 * 8 * sizeof(float)));
     AWPU_HIP_TRY(hipMemcpy(h->d_fir, coeffs, 101 * 8 * sizeof(float), hipMemcpyHostToDevice));
@@ -1050,52 +1314,22 @@ int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {
 
 int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *power) {
     AWPU_CTX(h);
+    if (!h) return invalid("null handle");
     if (!frames || !power) return invalid("null argument");
-    int rc = check_ready(h, batch);
+    if (!h->parts.empty()) return group_process(h, frames, batch, power);
+    int rc = enqueue_host_process(h, frames, batch);
     if (rc != AWPU_OK) return rc;
-    const bool compact = h->compact_hist > 0;
-    const int dev_hist = compact ? h->compact_hist : h->cfg.hist;
-    const size_t frame_floats = (size_t) h->cfg.n_streams * dev_hist;
-    const size_t need_frames = frame_floats * batch, need_power = (size_t) h->cfg.pixel_count * batch;
-    if (h->frames_cap < need_frames) {
-        dev_free(h->d_frames);
-        h->frames_cap = 0;
-        AWPU_HIP_TRY(hipMalloc(&h->d_frames, need_frames * sizeof(float)));
-        h->frames_cap = need_frames;
-    }
-    if (h->power_cap < need_power) {
-        dev_free(h->d_power);
-        h->power_cap = 0;
-        AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
-        h->power_cap = need_power;
-    }
-    if (compact) {  // rows of compact_hist floats cut out of rows of hist floats
-        AWPU_HIP_TRY(hipMemcpy2DAsync(h->d_frames, (size_t) dev_hist * sizeof(float), frames + h->wstart,
-                                      (size_t) h->cfg.hist * sizeof(float), (size_t) dev_hist * sizeof(float),
-                                      (size_t) batch * h->cfg.n_streams, hipMemcpyHostToDevice, h->stream));
-    } else {
-        AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, frames, need_frames * sizeof(float),
-                                    hipMemcpyHostToDevice, h->stream));
-    }
-    rc = launch(h, h->d_frames, batch, h->d_power, h->stream, compact ? kCompact : kFull);
+    rc = enqueue_power_to_host(h, batch, power, (size_t) h->cfg.pixel_count);
     if (rc != AWPU_OK) return rc;
-    AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_power, need_power * sizeof(float),
-                                hipMemcpyDeviceToHost, h->stream));
-    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->timing) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, h->ev_begin, h->ev_end) == hipSuccess) {
-            h->stats.last_kernel_ms = ms;
-            h->stats.total_kernel_ms += ms;
-        }
-    }
-    return AWPU_OK;
+    return wait_and_time(h);
 }
 
 int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch, float *d_power,
                             void *stream) {
     AWPU_CTX(h);
+    if (!h) return invalid("null handle");
     if (!d_frames || !d_power) return invalid("null argument");
+    if (!h->parts.empty()) return group_process_device(h, d_frames, batch, d_power, static_cast<hipStream_t>(stream));
     const int rc = check_ready(h, batch);
     if (rc != AWPU_OK) return rc;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
@@ -1131,20 +1365,22 @@ int enqueue_ingest(awpu_hip *h, const void *datagrams, int32_t stride_bytes) {
     return AWPU_OK;
 }
 
-int ensure_power(awpu_hip *h, size_t need_power) {
-    if (h->power_cap < need_power) {
-        dev_free(h->d_power);
-        h->power_cap = 0;
-        AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
-        h->power_cap = need_power;
-    }
-    return AWPU_OK;
-}
-
 }  // namespace
 
 int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes) {
     AWPU_CTX(h);
+    if (h && !h->parts.empty()) {  // every device keeps the whole ring (264 KB per block each, over its own PCIe link)
+        int rc = for_each_part(h, [&](awpu_hip *part) {
+            AWPU_CTX(part);
+            return enqueue_ingest(part, datagrams, stride_bytes);
+        });
+        if (rc != AWPU_OK) return rc;
+        return for_each_part(h, [&](awpu_hip *part) {
+            AWPU_HIP_TRY(hipSetDevice(part->cfg.device));
+            AWPU_HIP_TRY(hipStreamSynchronize(part->stream));
+            return (int) AWPU_OK;
+        });
+    }
     const int rc = enqueue_ingest(h, datagrams, stride_bytes);
     if (rc != AWPU_OK) return rc;
     // the staging buffer is reused by the next call: finish the copy before returning
@@ -1156,6 +1392,7 @@ int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_byt
                         int32_t cols, uint8_t *image, int32_t out_rows, int32_t out_cols, const uint8_t *d_colormap,
                         uint8_t *big_image) {
     AWPU_CTX(h);
+    if (h && !h->parts.empty()) return invalid("the display step needs the whole grid on one device");
     int rc = check_ready(h, 1);
     if (rc != AWPU_OK) return rc;
     const int n = h->cfg.n_pixels;
@@ -1195,7 +1432,21 @@ int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_byt
 
 int awpu_hip_process_ring(awpu_hip_t *h, float *power) {
     AWPU_CTX(h);
+    if (!h) return invalid("null handle");
     if (!power) return invalid("null argument");
+    if (!h->parts.empty()) {  // every device sweeps its slab of its own ring's snapshot
+        int grc = for_each_part(h, [&](awpu_hip *part) {
+            AWPU_CTX(part);
+            int r = check_ready(part, 1);
+            if (r != AWPU_OK) return r;
+            if (!part->d_ring) return fail(AWPU_ERR_STATE, "no block ingested yet");
+            r = ensure_power(part, (size_t) part->cfg.pixel_count);
+            if (r == AWPU_OK) r = launch(part, part->d_ring + part->ring_pos, 1, part->d_power, part->stream, kRing);
+            return r != AWPU_OK ? r : enqueue_power_to_host(part, 1, power + slab_offset(h, part), (size_t) h->cfg.pixel_count);
+        });
+        if (grc != AWPU_OK) return grc;
+        return for_each_part(h, [&](awpu_hip *part) { return wait_and_time(part); });
+    }
     int rc = check_ready(h, 1);
     if (rc != AWPU_OK) return rc;
     if (!h->d_ring) {
@@ -1212,6 +1463,7 @@ int awpu_hip_process_ring(awpu_hip_t *h, float *power) {
 }
 
 int awpu_hip_ring_snapshot(awpu_hip_t *h, float *frames) {
+    if (h && !h->parts.empty()) h = h->parts[0];  // not pixel-sharded: a device group answers with its first device
     AWPU_CTX(h);
     if (!h || !frames) return invalid("null argument");
     if (!h->d_ring) {
@@ -1226,6 +1478,7 @@ int awpu_hip_ring_snapshot(awpu_hip_t *h, float *frames) {
 
 int awpu_hip_heatmap_u8_device(awpu_hip_t *h, const float *d_power, int32_t n, int32_t batch, float *d_peak,
                                int32_t peak_given, uint8_t *d_pix, void *stream) {
+    if (h && !h->parts.empty()) h = h->parts[0];  // not pixel-sharded: a device group answers with its first device
     AWPU_CTX(h);
     if (!h || !d_power || !d_peak || !d_pix || n < 1 || batch < 1 || batch > 65535) return invalid("bad argument");
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
@@ -1237,6 +1490,7 @@ int awpu_hip_heatmap_u8_device(awpu_hip_t *h, const float *d_power, int32_t n, i
 int awpu_hip_upscale_u8_device(awpu_hip_t *h, const uint8_t *d_pix, int32_t rows, int32_t cols, int32_t batch,
                                const uint8_t *d_colormap, uint8_t *d_out, int32_t out_rows, int32_t out_cols,
                                void *stream) {
+    if (h && !h->parts.empty()) h = h->parts[0];  // not pixel-sharded: a device group answers with its first device
     AWPU_CTX(h);
     if (!h || !d_pix || !d_out || rows < 1 || cols < 1 || batch < 1 || batch > 65535) return invalid("bad argument");
     if (out_rows < rows || out_cols < cols || out_rows > 65535) return invalid("upscale only: out >= in, out_rows <= 65535");
@@ -1290,6 +1544,13 @@ int awpu_hip_resize_linear_u8(const uint8_t *pix, int32_t rows, int32_t cols, ui
 int awpu_hip_synchronize(awpu_hip_t *h) {
     AWPU_CTX(h);
     if (!h) return invalid("null handle");
+    if (!h->parts.empty())
+        return for_each_part(h, [&](awpu_hip *part) {
+            AWPU_HIP_TRY(hipSetDevice(part->cfg.device));
+            AWPU_HIP_TRY(hipStreamSynchronize(part->copy_stream));
+            AWPU_HIP_TRY(hipStreamSynchronize(part->stream));
+            return (int) AWPU_OK;
+        });
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
     return AWPU_OK;
@@ -1298,6 +1559,7 @@ int awpu_hip_synchronize(awpu_hip_t *h) {
 int awpu_hip_get_stats(awpu_hip_t *h, awpu_hip_stats *stats) {
     AWPU_CTX(h);
     if (!h || !stats) return invalid("null argument");
+    if (!h->parts.empty()) return group_stats(h, stats);
     *stats = h->stats;
     return AWPU_OK;
 }

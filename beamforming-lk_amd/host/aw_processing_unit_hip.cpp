@@ -8,8 +8,8 @@
 namespace awpu_host {
 
 AWProcessingUnitHip::AWProcessingUnitHip(FrameSource *pipeline, float fov, int small_res, int verbose,
-                                         bool use_audio, int device)
-    : fov(fov), small_res(small_res), verbose(verbose), device(device), pipeline(pipeline) {
+                                         bool use_audio, int device, std::vector<int> devices)
+    : fov(fov), small_res(small_res), verbose(verbose), device(device), devices(std::move(devices)), pipeline(pipeline) {
     (void) use_audio;
     setupAntennas();  // .cpp:28
     calibrate();      // .cpp:34
@@ -86,7 +86,8 @@ bool AWProcessingUnitHip::start(const worker_t worker) {  // .cpp:67-95
     if (worker != MIMO || antennas.empty() || antennas[0].usable == 0) return false;
     // the reference beamforms antennas[0] only (.cpp:74)
     AntennaView view{antennas[0].points.data(), AWPU_ELEMENTS, antennas[0].usable, antennas[0].index.data()};
-    auto job = std::make_unique<MIMOWorkerHip>(pipeline, view, &running, small_res, small_res, fov, device);
+    auto job = std::make_unique<MIMOWorkerHip>(pipeline, view, &running, small_res, small_res, fov, device,
+                                               /*autostart=*/true, AWPU_MATH_F32_FAST, devices);
     if (job->status() != AWPU_OK) return false;
     workers.push_back(std::move(job));
     return true;

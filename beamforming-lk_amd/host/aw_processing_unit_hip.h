@@ -33,8 +33,9 @@ class AWProcessingUnitHip {
 public:
     // aw_processing_unit.h:45: AWProcessingUnit(Pipeline *pipeline, int verbose = 1, bool use_audio = false)
     // (+ the grid parameters of the address/port constructor, :37: fov = FOV, small_res = MIMO_SIZE)
+    // `devices` (optional, not in the reference): the GPUs the MIMO worker spreads its grid over
     AWProcessingUnitHip(FrameSource *pipeline, float fov = 180.0f, int small_res = 256, int verbose = 1,
-                        bool use_audio = false, int device = 0);
+                        bool use_audio = false, int device = 0, std::vector<int> devices = {});
     ~AWProcessingUnitHip();
 
     void setupAntennas();                 // .cpp:58-65
@@ -70,6 +71,7 @@ protected:
     int small_res;
     int verbose;
     int device;
+    std::vector<int> devices;
     std::vector<std::unique_ptr<MIMOWorkerHip>> workers;
     FrameSource *pipeline;
     bool running = false;

@@ -7,7 +7,7 @@
 namespace awpu_host {
 
 MIMOWorkerHip::MIMOWorkerHip(FrameSource *pipeline, const AntennaView &antenna, bool *running, int rows,
-                             int columns, float fov, int device, bool autostart, int math)
+                             int columns, float fov, int device, bool autostart, int math, const std::vector<int> &devices)
     : pipeline(pipeline), antenna(antenna), running(running), rows(rows), columns(columns), fov(fov) {
     maxIndex = rows * columns;                       // mimo.cpp:8
     powerdB = std::vector<float>(maxIndex, 0.0f);    // mimo.cpp:10
@@ -22,6 +22,10 @@ MIMOWorkerHip::MIMOWorkerHip(FrameSource *pipeline, const AntennaView &antenna, 
     cfg.lut_stride = antenna.n;
     cfg.grid_columns = columns;  // lets the batched sweep pair vertically adjacent pixels (results unchanged)
     cfg.math = math;
+    if (devices.size() > 1 && devices.size() <= AWPU_MAX_DEVICES) {  // a device group: rows of the grid per GPU
+        cfg.n_devices = (int32_t) devices.size();
+        for (size_t k = 0; k < devices.size(); k++) cfg.devices[k] = devices[k];
+    }
     last_status = awpu_hip_create(&engine, &cfg);
     if (last_status != AWPU_OK) {
         // the reference reports on std::cerr and carries on (pipeline.cpp:33-36); same here

@@ -32,12 +32,13 @@
 extern "C" {
 #endif
 
-#define AWPU_HIP_ABI_VERSION 1
+#define AWPU_HIP_ABI_VERSION 2
 
 /* compile-time constants of the reference */
 #define AWPU_N_SAMPLES 256 /* src/fpga/streams.hpp:28  N_SAMPLES */
 #define AWPU_HIST 1024     /* src/fpga/streams.hpp:32  N_ITEMS_BUFFER = PAGE_SIZE/4 */
 #define AWPU_ELEMENTS 64   /* src/geometry/antenna.h:20 ELEMENTS */
+#define AWPU_MAX_DEVICES 8 /* GPUs one handle can spread its pixels over (one node) */
 
 typedef enum {
     AWPU_OK = 0,
@@ -94,7 +95,16 @@ typedef struct {
      * whose integer delays coincide for most mics (one sample read then serves both).  Ignored unless
      * pixel_begin and pixel_count are whole rows. */
     int32_t grid_columns;
-    int32_t reserved[4];
+    /* Device group: with n_devices > 1 the handle spreads its pixels over devices[0 .. n_devices-1]
+     * (HIP ordinals; `device` is then ignored) in contiguous slabs -- whole grid rows when grid_columns is set --
+     * one internal engine, stream and table slab per device; all in this one process, no collective library.
+     * Entry points keep their meaning: host frames are uploaded by every device over its own PCIe link; device
+     * frames (awpu_hip_process_device, pointers on devices[0]) fan out by direct peer copies over xGMI, one per
+     * destination on that destination's stream; the slabs are swept concurrently; power tiles come back to the
+     * caller's buffer.  awpu_hip_ingest_block feeds every device's ring.  0 or 1 = one device, as before. */
+    int32_t n_devices;
+    int32_t devices[AWPU_MAX_DEVICES];
+    int32_t reserved[3];
 } awpu_hip_cfg;
 
 typedef struct {

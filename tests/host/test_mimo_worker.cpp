@@ -302,6 +302,19 @@ int main(int argc, char **argv) {
         sender.join();
         CHECK(pipeline.disconnect() == 0, "disconnect");
     }
+    // ---- 6. a device group behind the same worker: the grid's rows over two engines (both on this box's one GPU)
+    {
+        SyntheticSource src(xyz.data(), 64, theta, phi);
+        AntennaView ant{xyz.data(), 64, 64, all.data()};
+        for (int b = 0; b < 5; b++) src.publish_block();
+        MIMOWorkerHip one(&src, ant, &run, rows, cols, 180.f, 0, false);
+        MIMOWorkerHip two(&src, ant, &run, rows, cols, 180.f, 0, false, AWPU_MATH_F32_FAST, {0, 0});
+        CHECK(two.status() == AWPU_OK, "group create: %s", awpu_hip_last_error());
+        one.update();
+        two.update();
+        CHECK(two.status() == AWPU_OK && one.power() == two.power(), "device group differs from the single device");
+        std::printf("6. device group {0, 0}: identical heatmap\n");
+    }
     std::printf(failures ? "FAILED\n" : "OK\n");
     return failures ? 1 : 0;
 }

@@ -24,13 +24,13 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/awpu_hip.h but not exported"
     assert sorted(pkg.binding.EXPORTED_SYMBOLS) == names
-    assert lib.awpu_hip_abi_version() == 1
+    assert lib.awpu_hip_abi_version() == 2
 
 
 def test_cfg_struct_matches_header(pkg):
     cfg = pkg.binding.Cfg()
     pkg.binding.load().awpu_hip_default_cfg(C.byref(cfg))
-    assert cfg.struct_size == C.sizeof(pkg.binding.Cfg) == 64
+    assert cfg.struct_size == C.sizeof(pkg.binding.Cfg) == 96
     assert (cfg.n_streams, cfg.hist, cfg.lut_stride, cfg.max_batch) == (64, 1024, 64, 1)
     assert cfg.math == pkg.MATH_F32_FAST and cfg.interp == 0
 

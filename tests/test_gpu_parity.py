@@ -640,6 +640,73 @@ def test_c4_rank_slab_of_eight(pkg, oracle):
     assert seam.max() < 0.25
 
 
+GROUP_CHILD = r"""
+import importlib, sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import util
+pkg = importlib.import_module("beamforming-lk_amd")
+S = pkg.synthetic
+spec = S.WORKLOADS["c2"]
+xyz = S.geometry(spec)
+off, frac = S.delay_table(spec, xyz)
+frames = S.make_frames(xyz, 6, seed=21)
+def run(devices, batch, **kw):
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=8, grid_columns=spec.res, devices=devices, **kw) as eng:
+        eng.set_delay_table(off, frac); eng.set_active_mics(None)
+        host = eng.process(frames[:batch])
+        d_X = torch.from_numpy(frames[:batch]).cuda(); d_P = torch.zeros((batch, spec.n_pixels), dtype=torch.float32, device="cuda")
+        st = torch.cuda.Stream()
+        for _ in range(3):  # three calls back to back: both fan-out buffers of every part get reused
+            eng.process_device(d_X.data_ptr(), batch, d_P.data_ptr(), st.cuda_stream)
+        st.synchronize(); eng.synchronize()
+        dev = d_P.cpu().numpy()
+        wire = util_wire()
+        for b in range(4): eng.ingest_block(wire[b])
+        ring = eng.process_ring(); snap = eng.ring_snapshot(); stats = eng.stats()
+    return host, dev, ring, snap, stats
+def util_wire():
+    rng = np.random.default_rng(9); out = []
+    for b in range(4):
+        msg = np.zeros(256, dtype=np.dtype([("frequency", "<u2"), ("n_arrays", "u1"), ("version", "u1"), ("counter", "<u4"), ("stream", "<i4", (256,))]))
+        msg["n_arrays"] = 4; msg["stream"] = rng.integers(-(1 << 21), 1 << 21, size=(256, 256), dtype=np.int32); out.append(msg.tobytes())
+    return out
+for batch in (1, 6):
+    one = run(None, batch)
+    for devices in ([0, 0], [0, 0, 0]):
+        grp = run(devices, batch)
+        for name, a, b in zip(("host", "device", "ring", "snapshot"), one[:4], grp[:4]):
+            assert np.array_equal(a, b), (name, devices, batch)
+        assert grp[4].frames == one[4].frames and grp[4].usable == one[4].usable and grp[4].alg_flops_frame == one[4].alg_flops_frame
+# uneven slabs (64 rows over 3 devices = 22 + 21 + 21) and a group that owns only part of the grid
+with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, grid_columns=spec.res, devices=[0, 0], pixel_begin=10 * spec.res, pixel_count=7 * spec.res) as eng:
+    eng.set_delay_table(off[10 * spec.res:17 * spec.res], frac[10 * spec.res:17 * spec.res]); eng.set_active_mics(None)
+    assert np.array_equal(eng.process(frames[0]), run(None, 1)[0][0][10 * spec.res:17 * spec.res])
+try:
+    pkg.Engine(n_pixels=4, devices=list(range(9)))
+except pkg.AwpuError as e:
+    assert e.status == pkg.binding.ERR_INVALID
+else:
+    raise SystemExit("9 devices accepted")
+print("GROUP OK")
+"""
+
+
+@pytest.mark.parametrize("force_copy", ["0", "1"])
+def test_device_group_equals_one_device(force_copy):
+    """awpu_hip_cfg.n_devices > 1 (the multi-GPU split under the C ABI): a handle that spreads the grid's rows over
+    two / three engines -- here all on the one GPU of the box, the same code path with devices[k] equal -- gives
+    the bits of the single-device handle through the host entry, the device-pointer entry (three calls back to
+    back) and the ingest ring, for one frame and for a batch.  force_copy=1 makes every part take the copy path of
+    the fan-out (2-D window copies, two buffers per part, events between the copy and the sweep streams) that a
+    part on another GPU takes."""
+    import os, subprocess, sys
+    out = subprocess.run([sys.executable, "-c", GROUP_CHILD, str(Path(__file__).resolve().parent.parent)],
+                         env=dict(os.environ, AWPU_GROUP_FORCE_COPY=force_copy), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "GROUP OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_bf16_accumulator_mode(pkg, oracle):
     """AWPU_MATH_BF16_ACC (BASELINE configs[4], "bf16 vs fp32 accumulator"): the device keeps the running sums in
     bf16 exactly as the restatement does (same operations in the same order: the pre-epilogue sums are the same
