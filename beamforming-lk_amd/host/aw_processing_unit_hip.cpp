@@ -116,10 +116,15 @@ void AWProcessingUnitHip::draw_heatmap(uint8_t *heatmap) const {
 int AWProcessingUnitHip::status() const { return workers.empty() ? AWPU_ERR_STATE : workers[0]->status(); }
 
 void AWProcessingUnitHip::draw(uint8_t *compact, uint8_t *normal, int normal_res) const {
+    draw(compact, normal, normal_res, normal_res);
+}
+
+void AWProcessingUnitHip::draw(uint8_t *compact, uint8_t *normal, int normal_rows, int normal_cols) const {
     for (auto &w : workers)
         if (w->get_type() == MIMO) w->draw(compact);
     // cv::resize(*compact, *normal, normal->size(), 0, 0, cv::INTER_LINEAR), .cpp:252
-    if (normal && normal_res >= small_res) awpu_hip_resize_linear_u8(compact, small_res, small_res, normal, normal_res, normal_res);
+    if (normal && normal_rows >= small_res && normal_cols >= small_res)
+        awpu_hip_resize_linear_u8(compact, small_res, small_res, normal, normal_rows, normal_cols);
 }
 
 }  // namespace awpu_host

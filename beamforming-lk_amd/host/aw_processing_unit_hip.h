@@ -52,6 +52,8 @@ public:
     // .cpp:245-259: compact = the MIMO heatmap; normal = compact resized (cv::resize INTER_LINEAR
     // arithmetic) to normal_res^2, normal_res >= small_res
     void draw(uint8_t *compact, uint8_t *normal, int normal_res) const;
+    void draw(uint8_t *compact, uint8_t *normal, int normal_rows, int normal_cols) const;  // a non-square big image
+    void set_devices(std::vector<int> list) { devices = std::move(list); }  // GPUs of the next start(MIMO)
 
     int n_antennas() const { return (int) antennas.size(); }
     int usable(int a = 0) const { return antennas[a].usable; }

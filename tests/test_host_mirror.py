@@ -9,14 +9,36 @@ REPO = Path(__file__).resolve().parent.parent
 EXE = REPO / "tests" / "host" / "test_mimo_worker"
 
 
-def build(pkg, oracle):
+EXACT = REPO / "tests" / "host" / "test_exact_signatures"
+
+
+def build(pkg, oracle, exact=False):
     pkg.binding.load()  # builds libawpu_hip.so
     pkgdir = REPO / "beamforming-lk_amd"
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", f"-I{REPO / 'include'}", f"-I{pkgdir / 'host'}",
-           f"-I{REPO / 'oracle'}", str(REPO / "tests/host/test_mimo_worker.cpp"), str(pkgdir / "host/mimo_worker_hip.cpp"), str(pkgdir / "host/aw_processing_unit_hip.cpp"), str(pkgdir / "host/pipeline_hip.cpp"),
+    host = [str(pkgdir / "host" / f) for f in ("mimo_worker_hip.cpp", "aw_processing_unit_hip.cpp", "pipeline_hip.cpp",
+                                                "aw_processing_unit.cpp")]
+    # the exact-signature class needs cv::Mat: OpenCV is absent from this image, the tests bring a few-line stand-in
+    extra = ["-DAWPU_WITH_OPENCV", f"-I{REPO / 'tests/host/mock_opencv'}"] if exact else []
+    main, exe = ("test_exact_signatures.cpp", EXACT) if exact else ("test_mimo_worker.cpp", EXE)
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", *extra, f"-I{REPO / 'include'}", f"-I{pkgdir / 'host'}",
+           f"-I{REPO / 'oracle'}", str(REPO / "tests/host" / main), *host,
            f"-L{pkgdir}", "-lawpu_hip", f"-L{REPO / 'oracle'}", "-loracle_das", "-lm",
-           f"-Wl,-rpath,{pkgdir}", f"-Wl,-rpath,{REPO / 'oracle'}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(EXE)]
+           f"-Wl,-rpath,{pkgdir}", f"-Wl,-rpath,{REPO / 'oracle'}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
+
+
+def test_exact_signature_unit_compiles(pkg, oracle):
+    """class AWProcessingUnit with the reference's own constructor and draw(cv::Mat*, cv::Mat*) signatures
+    (aw_processing_unit.h:37-45,125) builds against the C ABI (AWPU_WITH_OPENCV)."""
+    build(pkg, oracle, exact=True)
+    assert EXACT.exists()
+
+
+@pytest.mark.gpu
+def test_exact_signature_unit_runs_like_the_control_unit_drives_it(pkg, oracle):
+    build(pkg, oracle, exact=True)
+    out = subprocess.run([str(EXACT)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
 
 
 def test_host_mirror_builds_and_fails_loudly_without_gpu(pkg, oracle):
