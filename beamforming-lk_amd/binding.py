@@ -80,6 +80,8 @@ _SIGNATURES = {
     "awpu_hip_set_active_mics": (C.c_int, [C.c_void_p, _i32p, C.c_int32]),
     "awpu_hip_set_fir_table": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_process": (C.c_int, [C.c_void_p, _f32p, C.c_int32, _f32p]),
+    "awpu_hip_process_async": (C.c_int, [C.c_void_p, _f32p, C.c_int32, _f32p]),
+    "awpu_hip_wait": (C.c_int, [C.c_void_p]),
     "awpu_hip_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "awpu_hip_synchronize": (C.c_int, [C.c_void_p]),
     "awpu_hip_ingest_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
@@ -344,6 +346,21 @@ class Engine:
         _check(self._lib.awpu_hip_process(self._h, _f32(frames), frames.shape[0], _f32(power)),
                "awpu_hip_process")
         return power[0] if single else power
+
+    def process_async(self, frames: np.ndarray):
+        """awpu_hip_process_async: enqueue upload + sweep + read-back and return; wait() hands out the power.
+        The arrays are kept alive (and must not be touched) until wait() returns."""
+        frames = np.ascontiguousarray(frames, np.float32)
+        if frames.ndim != 3 or frames.shape[1:] != (self.cfg.n_streams, self.cfg.hist):
+            raise ValueError(f"frames must be [batch, {self.cfg.n_streams}, {self.cfg.hist}]")
+        power = np.empty((frames.shape[0], self.pixel_count), np.float32)
+        _check(self._lib.awpu_hip_process_async(self._h, _f32(frames), frames.shape[0], _f32(power)), "awpu_hip_process_async")
+        self._pending = (frames, power)
+
+    def wait(self) -> Optional[np.ndarray]:
+        _check(self._lib.awpu_hip_wait(self._h), "awpu_hip_wait")
+        pending, self._pending = getattr(self, "_pending", None), None
+        return pending[1] if pending else None
 
     def process_device(self, d_frames_ptr: int, batch: int, d_power_ptr: int, stream: int = 0) -> None:
         """Asynchronous sweep on device pointers (e.g. torch tensors' data_ptr()) on `stream`."""

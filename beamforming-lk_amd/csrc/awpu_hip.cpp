@@ -123,6 +123,7 @@ struct awpu_hip {
     size_t fan_cap = 0;                     // floats per buffer
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_swept[2] = {nullptr, nullptr}, ev_done = nullptr;
     unsigned fan_turn = 0;
+    bool in_flight = false;                 // awpu_hip_process_async without its awpu_hip_wait yet
 
     awpu_hip_stats stats{};
     std::string last_error;                  // awpu_hip_last_error_of
@@ -158,12 +159,14 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
     int quads = -1;                // AWPU_FAST_QUADS
     int pair_group = 0;            // AWPU_FAST_PAIRGROUP: frame pairs an XCD works on at a time (quad shape)
     int quad_variant = 0;          // AWPU_QUAD_VARIANT (tuning builds)
+    int wgs = 0;                   // AWPU_FAST_WGS: persistent workgroups of the quad shape (0 = one per CU)
     int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0] (tests)
     EnvKnobs() {
         if (const char *v = std::getenv("AWPU_FAST_QUADS")) quads = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_PAIRGROUP")) pair_group = std::atoi(v);
         if (const char *v = std::getenv("AWPU_QUAD_VARIANT")) quad_variant = std::atoi(v);
         if (const char *v = std::getenv("AWPU_GROUP_FORCE_COPY")) group_copy = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FAST_WGS")) wgs = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_VARIANT"))
             if (std::sscanf(v, "%d,%d,%d", &fpi, &ppw, &nw) < 2) fpi = ppw = nw = 0;
         if (const char *v = std::getenv("AWPU_FAST_PAIRS")) pairs = std::atoi(v);
@@ -642,11 +645,14 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     }
     qa.debug = env().debug;
     qa.variant = env().quad_variant;
+    qa.wgs = env().wgs;
     qa.debug_out = nullptr;
     size_t n_waves = 0;
     if (qa.debug & 16) {
-        const long groups = (qa.n_pairs + qa.pair_group - 1) / qa.pair_group;
-        n_waves = (size_t) 16 * (size_t) ((groups * qa.pair_group * qa.tiles + 7) / 8 * 8);
+        int n_cu = 256;
+        (void) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+        const long per_xcd = ((long) qa.n_pairs * qa.tiles + 7) / 8;
+        n_waves = (size_t) 16 * 8 * (size_t) std::min<long>(per_xcd, std::max(1, (qa.wgs > 0 ? qa.wgs : n_cu) / 8));
         rc = ensure_diag(h, n_waves * 12);
         if (rc != AWPU_OK) return rc;
         AWPU_HIP_TRY(hipMemsetAsync(h->d_diag, 0, n_waves * 12 * sizeof(unsigned long long), s));
@@ -1321,6 +1327,36 @@ int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *p
     if (rc != AWPU_OK) return rc;
     rc = enqueue_power_to_host(h, batch, power, (size_t) h->cfg.pixel_count);
     if (rc != AWPU_OK) return rc;
+    return wait_and_time(h);
+}
+
+int awpu_hip_process_async(awpu_hip_t *h, const float *frames, int32_t batch, float *power) {
+    AWPU_CTX(h);
+    if (!h) return invalid("null handle");
+    if (!frames || !power) return invalid("null argument");
+    if (h->in_flight) return fail(AWPU_ERR_STATE, "a call is in flight already: awpu_hip_wait first");
+    int rc;
+    if (!h->parts.empty()) {
+        const size_t pitch = (size_t) h->cfg.pixel_count;
+        rc = for_each_part(h, [&](awpu_hip *part) {
+            AWPU_CTX(part);
+            const int r = enqueue_host_process(part, frames, batch);
+            return r != AWPU_OK ? r : enqueue_power_to_host(part, batch, power + slab_offset(h, part), pitch);
+        });
+    } else {
+        rc = enqueue_host_process(h, frames, batch);
+        if (rc == AWPU_OK) rc = enqueue_power_to_host(h, batch, power, (size_t) h->cfg.pixel_count);
+    }
+    h->in_flight = rc == AWPU_OK;
+    return rc;
+}
+
+int awpu_hip_wait(awpu_hip_t *h) {
+    AWPU_CTX(h);
+    if (!h) return invalid("null handle");
+    if (!h->in_flight) return AWPU_OK;  // nothing to wait for
+    h->in_flight = false;
+    if (!h->parts.empty()) return for_each_part(h, [&](awpu_hip *part) { return wait_and_time(part); });
     return wait_and_time(h);
 }
 

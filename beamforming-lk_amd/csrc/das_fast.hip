@@ -36,6 +36,7 @@
 //         C += f*y   -> out[128+2l], out[129+2l]    R += g*y   -> out[127+2l], out[128+2l]
 #include "das_kernels.h"
 
+#include <algorithm>
 #include <atomic>
 
 namespace awpu {
@@ -839,64 +840,51 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
 
-    // ---- which (frame pair, tile) this workgroup sweeps
-    const int per_xcd = gridDim.x >> 3;
-    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int per_group = a.tiles * a.pair_group;
-    const int grp = item / per_group;
-    const int rem = item - grp * per_group;
-    const int tile = rem / a.pair_group;
-    const int pair = grp * a.pair_group + (rem - tile * a.pair_group);
-    if (pair >= a.n_pairs) return;  // padding of the item space (uniform for the workgroup)
+    // ---- which work items (frame pair, tile) this workgroup sweeps: the item space, ordered (pair group, tile,
+    // pair), is cut into 8 contiguous runs, one per XCD (blockIdx & 7: round-robin placement, assumed for speed
+    // only); the workgroups of an XCD walk their run side by side, so that at any moment they work on consecutive
+    // items.  A workgroup is persistent: the chunk pipeline runs on across its items (the first chunk of the next
+    // item lands while the last chunk of this one is swept), so only its very first chunk is waited for.
+    const int total = a.n_pairs * a.tiles;
+    const int per_xcd = (total + 7) >> 3;
+    const int wgs_per_xcd = gridDim.x >> 3;
+    const int run_begin = (blockIdx.x & 7) * per_xcd, run_end = min(total, run_begin + per_xcd);
+    const int full_items = (a.n_pairs / a.pair_group) * a.pair_group * a.tiles;  // items of whole pair groups
+    auto decode = [&](int item, int &pair, int &tile) {
+        const int ga = item < full_items ? a.pair_group : a.n_pairs % a.pair_group;  // the last group may be smaller
+        const int rem = item < full_items ? item : item - full_items;
+        const int grp = rem / (a.tiles * ga), in = rem - grp * a.tiles * ga;
+        tile = in / ga;
+        pair = (item < full_items ? grp * a.pair_group : a.n_pairs - ga) + (in - tile * ga);
+    };
+    int item = run_begin + (blockIdx.x >> 3);
+    if (item >= run_end) return;  // (uniform for the workgroup)
 
     const int tiles_per_row4 = (a.cols + NW - 1) / NW;
-    const int row4 = tile / tiles_per_row4;
-    const int col = (tile - row4 * tiles_per_row4) * NW + wave;
-    const int quad = row4 * tiles_per_row4 * NW + col;
-    int pix[4];
-    bool live[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int row = 4 * row4 + q;
-        live[q] = row < a.rows && col < a.cols;
-        pix[q] = min(row, a.rows - 1) * a.cols + min(col, a.cols - 1);
-    }
     const int groups_total = a.usable_pad >> 2;
-    const QuadEntry *quad_lut = a.lut + (size_t) quad * groups_total * 16;
     const size_t row_floats = (size_t) a.wp * 2;
-    const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
-
-    f8 A0 = {0, 0, 0, 0, 0, 0, 0, 0}, A1 = A0, A2 = A0, A3 = A0, T = A0, V0 = A0, V2 = A0, V3 = A0;
-    f2 tail = f2{0.0f, 0.0f};
-    const int tail_pp = lane >> 3;  // lanes 8 pp + k: pixel pp of the quad, mics k (mod 8) of the chunk
-    bool tail_lane = false;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        if (tail_pp == q) tail_lane = live[q];
-
-    // one chunk = rows m0 .. m0+mc4 of this pair (whole groups: the padding rows are zero), contiguous in HBM
-    auto dma_chunk = [&](int m0, int mc4, int buf) {
-        const float *src = pair_base + (size_t) m0 * row_floats;
-        const int n_pieces = (int) ((size_t) mc4 * row_floats / 4);
+    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
+    const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
+    const float norm = (float) (kSamples * a.usable);
+    auto chunk_mics = [&](int m0) { return (min(a.chunk, a.usable - m0) + 3) & ~3; };
+    // one chunk = mc4 rows of a pair (whole groups: the padding rows are zero), contiguous in HBM from `src` (a
+    // wave-uniform pointer: the transfers take it as a scalar base plus one per-lane byte offset)
+    const unsigned lane_bytes = threadIdx.x * 16;
+    auto dma_chunk = [&](const float *src, int mc4, int buf) {
+        const unsigned n_bytes = (unsigned) ((size_t) mc4 * row_floats * 4);
 #pragma unroll
         for (int k = 0; k < kPieces; k++) {
-            const int piece = threadIdx.x + k * kThreads;
-            if (piece < n_pieces) {
+            if (lane_bytes + k * kThreads * 16 < n_bytes) {
+                const char *base = (const char *) uniform_ptr((const char *) src + k * kThreads * 16);
                 float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + (size_t) piece * 4),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (base + lane_bytes),
                                                  (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
             }
         }
     };
-    auto chunk_mics = [&](int m0) { return (min(a.chunk, a.usable - m0) + 3) & ~3; };
 
-    unsigned t_wait = 0, t_all = 0;
+    unsigned t_wait = 0, t_all = 0, n_blocks = 0;
     const long long t_begin = __builtin_readcyclecounter();
-    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
-    dma_chunk(0, chunk_mics(0), 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     unsigned t_ph[5] = {0, 0, 0, 0, 0};
     auto stamp = [&](int k, long long &t) {
         if (DIAG) {
@@ -905,70 +893,161 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
             t = n;
         }
     };
-    const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
-    for (int c = 0; c < n_chunks; c++) {
-        const int m0 = c * a.chunk;
-        const int mc4 = chunk_mics(m0);
-        const int buf = c & 1;
-        long long t = DIAG ? __builtin_readcyclecounter() : 0;
-        // table entries of the tail pass below (the 257th sample): requested now, consumed after the sweep
-        QuadEntry te[4];
+
+    int pair, tile;
+    decode(item, pair, tile);
+    dma_chunk(a.packed + (size_t) pair * a.usable_pad * row_floats, chunk_mics(0), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned step = 0;  // chunks swept so far: chunk `step` lives in image step & 1
+
+    for (;;) {
+        // ---- this item's pixels
+        const int row4 = tile / tiles_per_row4;
+        const int col = (tile - row4 * tiles_per_row4) * NW + wave;
+        const int quad = row4 * tiles_per_row4 * NW + col;
+        int pix[4];
+        bool live[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = min(8 * u + ((lane - m0) & 7), mc4 - 1);  // mic slot inside the chunk
-            const int m = m0 + j;
-            te[u] = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
+        for (int q = 0; q < 4; q++) {
+            const int row = 4 * row4 + q;
+            live[q] = row < a.rows && col < a.cols;
+            pix[q] = min(row, a.rows - 1) * a.cols + min(col, a.cols - 1);
         }
-        if (c + 1 < n_chunks && !(a.debug & 1)) dma_chunk(m0 + a.chunk, chunk_mics(m0 + a.chunk), buf ^ 1);
-        stamp(0, t);
-        const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
-        {
-            const void *row = uniform_ptr(quad_lut + (size_t) (m0 >> 2) * 16);
+        const QuadEntry *quad_lut = a.lut + (size_t) quad * groups_total * 16;
+        const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
+        const int tail_pp = lane >> 3;  // lanes 8 pp + k: pixel pp of the quad, mics k (mod 8) of the chunk
+        bool tail_lane = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (tail_pp == q) tail_lane = live[q];
+        // ---- the item after it
+        const int item_next = item + wgs_per_xcd;
+        int pair_next = 0, tile_next = 0;
+        if (item_next < run_end) decode(item_next, pair_next, tile_next);
+
+        f8 A0 = {0, 0, 0, 0, 0, 0, 0, 0}, A1 = A0, A2 = A0, A3 = A0, T = A0, V0 = A0, V2 = A0, V3 = A0;
+        f2 tail = f2{0.0f, 0.0f};
+        for (int c = 0; c < n_chunks; c++, step++) {
+            const int m0 = c * a.chunk;
+            const int mc4 = chunk_mics(m0);
+            const int buf = step & 1;
+            long long t = DIAG ? __builtin_readcyclecounter() : 0;
+            // table entries of the tail pass below (the 257th sample): requested now, consumed after the sweep
+            QuadEntry te[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int m = m0 + min(8 * u + ((lane - m0) & 7), mc4 - 1);
+                te[u] = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
+            }
+            // The refill of the other image (this item's next chunk, or the next item's first) goes out at the head of
+            // the chunk, from every wave for its own pieces.  (Measured and rejected: the waves of a SIMD taking
+            // turns -- rank r sweeping r quarters of the chunk first -- so that not all 16 issue at once: 1.8 % slower,
+            // the later refills land later and the barrier waits for them.  a.debug & 512 brings that order back.)
             const int ng = __builtin_amdgcn_readfirstlane(mc4 >> 2);
-            if constexpr (DIAG) {
-                unsigned dw = 0, da = 0;
-                sweep_quad_sum_stamped(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank, dw, da);
-                t_wait += dw;
-                t_all += da;
-            } else {
+            const int g_head = (a.debug & 512) ? __builtin_amdgcn_readfirstlane((ng * rank) >> 2) : 0;
+            const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
+            auto sweep = [&](int g0, int n) {
+                const void *row = uniform_ptr(quad_lut + (size_t) ((m0 >> 2) + g0) * 16);
+                if constexpr (DIAG) {
+                    unsigned dw = 0, da = 0;
+                    sweep_quad_sum_stamped(A0, A1, A2, A3, T, V0, V2, V3, row, n, lane_addr, rank, dw, da);
+                    t_wait += dw;
+                    t_all += da;
+                    n_blocks++;
+                } else {
 #ifdef AWPU_QUAD_VARIANTS  // tuning builds: the wave-priority schemes of tools/gen_trip_asm.py side by side
-                if constexpr (VAR == 1) sweep_quad_sum_v0(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank);
-                else if constexpr (VAR == 2) sweep_quad_sum_v3(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank);
-                else if constexpr (VAR == 3) sweep_quad_sum_v4(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank);
-                else
+                    if constexpr (VAR == 1) sweep_quad_sum_v0(A0, A1, A2, A3, T, V0, V2, V3, row, n, lane_addr, rank);
+                    else if constexpr (VAR == 2) sweep_quad_sum_v3(A0, A1, A2, A3, T, V0, V2, V3, row, n, lane_addr, rank);
+                    else if constexpr (VAR == 3) sweep_quad_sum_v4(A0, A1, A2, A3, T, V0, V2, V3, row, n, lane_addr, rank);
+                    else
 #endif
-                sweep_quad_sum(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank);
+                    sweep_quad_sum(A0, A1, A2, A3, T, V0, V2, V3, row, n, lane_addr, rank);
+                }
+            };
+            if (g_head > 0) sweep(0, g_head);
+            long long t_dma = DIAG ? __builtin_readcyclecounter() : 0;
+            {
+                const float *next_src = nullptr;
+                int next_mc4 = 0;
+                if (c + 1 < n_chunks) {
+                    next_src = pair_base + (size_t) (m0 + a.chunk) * row_floats;
+                    next_mc4 = chunk_mics(m0 + a.chunk);
+                } else if (item_next < run_end) {
+                    next_src = a.packed + (size_t) pair_next * a.usable_pad * row_floats;
+                    next_mc4 = chunk_mics(0);
+                }
+                if (next_mc4 && !(a.debug & 1)) dma_chunk(next_src, next_mc4, buf ^ 1);
             }
-        }
-        stamp(1, t);
-        // the 257th sample of every window, both frames: X[off+256] with weight 1 - f goes to out[255]
-        const char *img = (const char *) (lds + buf * (BUF / 4));
-        if (!(a.debug & 4)) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {  // mics 0..31 of the chunk (prefetched above)
-                const bool on = tail_lane && 8 * u + ((lane - m0) & 7) < mc4;
-                const float g = on ? 0.5f - te[u].f : 0.0f;  // 1 - f
-                const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
-                tail = __builtin_elementwise_fma(f2{g, g}, x, tail);
+            if (DIAG) {
+                const long long n = __builtin_readcyclecounter();
+                t_ph[0] += (unsigned) (n - t_dma);
+                t += n - t_dma;  // (the sweep's share below excludes it)
             }
-            for (int j0 = 32; j0 < mc4; j0 += 32) {  // chunks of more than 32 mics (narrow windows)
+            if (ng - g_head > 0) sweep(g_head, ng - g_head);
+            stamp(1, t);
+            // the 257th sample of every window, both frames: X[off+256] with weight 1 - f goes to out[255]
+            const char *img = (const char *) (lds + buf * (BUF / 4));
+            if (!(a.debug & 4)) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int jj = j0 + 8 * u + ((lane - m0) & 7);
-                    const int m = m0 + min(jj, mc4 - 1);
-                    const QuadEntry e = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
-                    const float g = tail_lane && jj < mc4 ? 0.5f - e.f : 0.0f;
-                    const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
+                for (int u = 0; u < 4; u++) {  // mics 0..31 of the chunk (prefetched above)
+                    const bool on = tail_lane && 8 * u + ((lane - m0) & 7) < mc4;
+                    const float g = on ? 0.5f - te[u].f : 0.0f;  // 1 - f
+                    const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
                     tail = __builtin_elementwise_fma(f2{g, g}, x, tail);
                 }
+                for (int j0 = 32; j0 < mc4; j0 += 32) {  // chunks of more than 32 mics (narrow windows)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int jj = j0 + 8 * u + ((lane - m0) & 7);
+                        const int m = m0 + min(jj, mc4 - 1);
+                        const QuadEntry e = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
+                        const float g = tail_lane && jj < mc4 ? 0.5f - e.f : 0.0f;
+                        const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
+                        tail = __builtin_elementwise_fma(f2{g, g}, x, tail);
+                    }
+                }
             }
+            if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp(2, t);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(3, t);
+            if (!(a.debug & 8)) __syncthreads();
+            stamp(4, t);
         }
-        if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stamp(2, t);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(3, t);
-        if (!(a.debug & 8)) __syncthreads();
-        stamp(4, t);
+
+        // ---- this item's powers (the next item's first chunk is in its image already)
+        tail.x += __shfl_xor(tail.x, 1);
+        tail.y += __shfl_xor(tail.y, 1);
+        tail.x += __shfl_xor(tail.x, 2);
+        tail.y += __shfl_xor(tail.y, 2);
+        tail.x += __shfl_xor(tail.x, 4);
+        tail.y += __shfl_xor(tail.y, 4);
+        auto finish = [&](const f8 &A, const f8 &S, int pp) {
+            f2 P[8];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const f2 Ak = f2{A[2 * k], A[2 * k + 1]}, Hk = 0.5f * f2{S[2 * k], S[2 * k + 1]};
+                P[k] = Hk + Ak;      // sum f X      (A was accumulated with f - 1/2: see QuadEntry)
+                P[4 + k] = Hk - Ak;  // sum (1 - f) X
+            }
+            f2 tl;
+            tl.x = __shfl(tail.x, pp * 8);
+            tl.y = __shfl(tail.y, pp * 8);
+            const f2 sum = finish_pixel_pair(P, tl, lane);
+            if (lane == 0 && live[pp]) {
+                a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
+                if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + pix[pp]] = sum.y / norm;
+            }
+        };
+        finish(A0, T + V0, 0);
+        finish(A1, T, 1);
+        finish(A2, T + V2, 2);
+        finish(A3, T + V3, 3);
+        if (item_next >= run_end) break;
+        item = item_next;
+        pair = pair_next;
+        tile = tile_next;
     }
 
     if (DIAG && a.debug_out && lane == 0) {
@@ -976,39 +1055,10 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         o[0] = t_wait;
         o[1] = t_all;
         o[2] = (unsigned long long) (__builtin_readcyclecounter() - t_begin);
-        o[3] = (unsigned long long) n_chunks;
+        o[3] = n_blocks;
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
     }
-    tail.x += __shfl_xor(tail.x, 1);
-    tail.y += __shfl_xor(tail.y, 1);
-    tail.x += __shfl_xor(tail.x, 2);
-    tail.y += __shfl_xor(tail.y, 2);
-    tail.x += __shfl_xor(tail.x, 4);
-    tail.y += __shfl_xor(tail.y, 4);
-    const float norm = (float) (kSamples * a.usable);
-    auto finish = [&](const f8 &A, const f8 &S, int pp) {
-        f2 P[8];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const f2 Ak = f2{A[2 * k], A[2 * k + 1]}, Hk = 0.5f * f2{S[2 * k], S[2 * k + 1]};
-            P[k] = Hk + Ak;      // sum f X      (A was accumulated with f - 1/2: see QuadEntry)
-            P[4 + k] = Hk - Ak;  // sum (1 - f) X
-        }
-        f2 tl;
-        tl.x = __shfl(tail.x, pp * 8);
-        tl.y = __shfl(tail.y, pp * 8);
-        const f2 sum = finish_pixel_pair(P, tl, lane);
-        if (lane == 0 && live[pp]) {
-            a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
-            if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + pix[pp]] = sum.y / norm;
-        }
-    };
-    finish(A0, T + V0, 0);
-    finish(A1, T, 1);
-    finish(A2, T + V2, 2);
-    finish(A3, T + V3, 3);
 }
-
 
 // ---------------------------------------------------------------------------------------
 // Quad shape for single frames (calls of one frame, frames read in place from the ingest ring): the staging of
@@ -1307,11 +1357,14 @@ static hipError_t launch_quad_variant(const QuadArgs &a, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_quad_kernel<DIAG, VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
-    const long groups = (a.n_pairs + a.pair_group - 1) / a.pair_group;
-    const long items = groups * a.pair_group * a.tiles;
-    const long grid = (items + 7) / 8 * 8;
-    if (grid > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((das_quad_kernel<DIAG, VAR>), dim3((unsigned) grid), dim3(1024), lds_bytes, stream, a);
+    // persistent workgroups: one per CU (the two LDS images fill it), fewer when there are fewer items
+    int dev = 0, n_cu = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (hipError_t e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
+    const long items = (long) a.n_pairs * a.tiles;
+    const long per_xcd = (items + 7) / 8;
+    const long wgs_per_xcd = std::min<long>(per_xcd, std::max(1, (a.wgs > 0 ? a.wgs : n_cu) / 8));
+    hipLaunchKernelGGL((das_quad_kernel<DIAG, VAR>), dim3((unsigned) (8 * wgs_per_xcd)), dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }
 

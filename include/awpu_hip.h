@@ -194,6 +194,15 @@ int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs);
  * Synchronous: returns when power is written. */
 int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *power);
 
+/* The same call split in two, so that the caller's thread can do something else while the frames travel and the
+ * sweep runs: _async enqueues the upload, the sweep and the read-back on the handle's stream and
+ * returns; awpu_hip_wait blocks until `power` is written (and updates the kernel time in the stats).  `frames`
+ * and `power` must stay valid and untouched until awpu_hip_wait returns; one call in flight per handle (a second
+ * _async before the wait is AWPU_ERR_STATE).  Page-locked host buffers make the copies truly asynchronous;
+ * pageable ones work, the runtime then stages them. */
+int awpu_hip_process_async(awpu_hip_t *h, const float *frames, int32_t batch, float *power);
+int awpu_hip_wait(awpu_hip_t *h);
+
 /* same sweep on buffers already resident in device memory, enqueued on `stream`
  * (a hipStream_t, NULL = the handle's own stream); asynchronous.  d_frames
  * [batch][n_streams][hist], d_power [batch][pixel_count]. */

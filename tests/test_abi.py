@@ -140,6 +140,8 @@ def test_null_arguments_are_refused_not_dereferenced(pkg):
     call("awpu_hip_set_mic_gains", None, fp)
     call("awpu_hip_process", None, fp, 1, fp)
     call("awpu_hip_process_device", None, None, 1, None, None)
+    call("awpu_hip_process_async", None, fp, 1, fp)
+    call("awpu_hip_wait", None)
     call("awpu_hip_synchronize", None)
     call("awpu_hip_ingest_block", None, None, 1032)
     call("awpu_hip_process_ring", None, fp)

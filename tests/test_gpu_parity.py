@@ -252,6 +252,33 @@ def test_error_paths(pkg, oracle):
         assert util.power_rel_err(ok[0], oracle.das_f32(X[0], off, frac)) < util.POWER_RTOL
 
 
+def test_host_buffer_entry_split_in_two(pkg, oracle):
+    """awpu_hip_process_async / awpu_hip_wait: the same bits as the synchronous call, one call in flight per handle,
+    the caller's thread free in between (two handles overlap their work)."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 4, seed=31)
+    engines = [pkg.Engine(n_pixels=spec.n_pixels, max_batch=4) for _ in range(2)]
+    for eng in engines:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+    want = engines[0].process(frames)
+    engines[0].process_async(frames)
+    engines[1].process_async(frames[::-1])  # both in flight
+    with pytest.raises(pkg.AwpuError) as ei:
+        engines[0].process_async(frames)
+    assert ei.value.status == pkg.binding.ERR_STATE
+    got1 = engines[1].wait()
+    got0 = engines[0].wait()
+    assert np.array_equal(got0, want) and np.array_equal(got1, want[::-1])
+    assert engines[0].wait() is None  # nothing in flight: a no-op
+    assert engines[0].stats().last_kernel_ms > 0
+    for eng in engines:
+        eng.close()
+
+
 def test_device_pointer_entry_with_torch(pkg, oracle):
     """awpu_hip_process_device on torch-owned HBM buffers and a torch stream (the bench.py path)."""
     import torch
