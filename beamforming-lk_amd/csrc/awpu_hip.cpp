@@ -339,7 +339,8 @@ int prepare(awpu_hip *h) {
     // The quad shape (das_quad_kernel) shares arithmetic between four vertically adjacent pixels wherever their
     // integer delays coincide with the second pixel's: 20 packed VALU instructions per quad and mic, +8 for every
     // pixel that differs, against 32 without sharing.  Count it on a sample of the table; take the shape when it
-    // saves at least a tenth (AWPU_FAST_QUADS=0/1 forces either).
+    // saves VALU work at all once its own address adds are counted (measured: a count of 30.2 -- BASELINE c2 -- is
+    // 4 % faster than the pair shape, 29.4 -- c3 -- 8 %, 25.3 -- the headline -- 20 %; AWPU_FAST_QUADS=0/1 forces either).
     h->quad_ok = false;
     h->quad_cost = 0.0;
     {
@@ -361,7 +362,7 @@ int prepare(awpu_hip *h) {
                 seen += U;
             }
             h->quad_cost = seen ? 20.0 + 8.0 * (double) differ / (double) seen : 32.0;
-            h->quad_ok = h->quad_cost < 0.9 * 32.0 && awpu::pair_plan(h->window, U, &h->quad_plan);
+            h->quad_ok = h->quad_cost < 31.0 && awpu::pair_plan(h->window, U, &h->quad_plan);
             if (env().quads >= 0) h->quad_ok = env().quads != 0 && awpu::pair_plan(h->window, U, &h->quad_plan);
             h->quad1_fits = h->quad_ok && h->gain.empty() &&  // (gains ride on the weights of the other single-frame tables)
                             awpu::fast_plan(h->window, U, 1, awpu::kFastLdsBytes - awpu::kQuad1ZeroBytes, &h->quad1_plan) &&
