@@ -940,10 +940,10 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                 const int m = m0 + min(8 * u + ((lane - m0) & 7), mc4 - 1);
                 te[u] = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
             }
-            // The refill of the other image (this item's next chunk, or the next item's first) goes out at the head of
-            // the chunk, from every wave for its own pieces.  (Measured and rejected: the waves of a SIMD taking
-            // turns -- rank r sweeping r quarters of the chunk first -- so that not all 16 issue at once: 1.8 % slower,
-            // the later refills land later and the barrier waits for them.  a.debug & 512 brings that order back.)
+            // The stamped and the tuning builds issue the refill themselves (the production build lets the sweep block
+            // do it piece by piece, below): all pieces at the head of the chunk, from every wave at once (the order
+            // of round 1); or, with a.debug & 512, the waves of a SIMD taking turns, rank r sweeping r quarters of
+            // the chunk first (measured: 1.8 % slower: the later refills land later and the barrier waits for them).
             const int ng = __builtin_amdgcn_readfirstlane(mc4 >> 2);
             const int g_head = (a.debug & 512) ? __builtin_amdgcn_readfirstlane((ng * rank) >> 2) : 0;
             const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
@@ -965,26 +965,34 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                     sweep_quad_sum(A0, A1, A2, A3, T, V0, V2, V3, row, n, lane_addr, rank);
                 }
             };
-            if (g_head > 0) sweep(0, g_head);
-            long long t_dma = DIAG ? __builtin_readcyclecounter() : 0;
-            {
-                const float *next_src = nullptr;
-                int next_mc4 = 0;
-                if (c + 1 < n_chunks) {
-                    next_src = pair_base + (size_t) (m0 + a.chunk) * row_floats;
-                    next_mc4 = chunk_mics(m0 + a.chunk);
-                } else if (item_next < run_end) {
-                    next_src = a.packed + (size_t) pair_next * a.usable_pad * row_floats;
-                    next_mc4 = chunk_mics(0);
+            // the refill of the other image: this item's next chunk, or the next item's first
+            const float *next_src = nullptr;
+            int next_mc4 = 0;
+            if (c + 1 < n_chunks) {
+                next_src = pair_base + (size_t) (m0 + a.chunk) * row_floats;
+                next_mc4 = chunk_mics(m0 + a.chunk);
+            } else if (item_next < run_end) {
+                next_src = a.packed + (size_t) pair_next * a.usable_pad * row_floats;
+                next_mc4 = chunk_mics(0);
+            }
+            if (a.debug & 1) next_mc4 = 0;
+            if constexpr (!DIAG && VAR == 0) {
+                // ... issued by the sweep block itself, one 16 KiB piece per trip (tools/gen_trip_asm.py, dma=True)
+                const void *row = uniform_ptr(quad_lut + (size_t) (m0 >> 2) * 16);
+                const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (buf ^ 1) * BUF + wave * 1024);
+                const unsigned n_bytes = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) next_mc4 * row_floats * 4));
+                sweep_quad_sum_dma(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank, uniform_ptr(next_src), dst0, n_bytes, lane_bytes);
+            } else {
+                if (g_head > 0) sweep(0, g_head);
+                long long t_dma = DIAG ? __builtin_readcyclecounter() : 0;
+                if (next_mc4) dma_chunk(next_src, next_mc4, buf ^ 1);
+                if (DIAG) {
+                    const long long n = __builtin_readcyclecounter();
+                    t_ph[0] += (unsigned) (n - t_dma);
+                    t += n - t_dma;  // (the sweep's share below excludes it)
                 }
-                if (next_mc4 && !(a.debug & 1)) dma_chunk(next_src, next_mc4, buf ^ 1);
+                if (ng - g_head > 0) sweep(g_head, ng - g_head);
             }
-            if (DIAG) {
-                const long long n = __builtin_readcyclecounter();
-                t_ph[0] += (unsigned) (n - t_dma);
-                t += n - t_dma;  // (the sweep's share below excludes it)
-            }
-            if (ng - g_head > 0) sweep(g_head, ng - g_head);
             stamp(1, t);
             // the 257th sample of every window, both frames: X[off+256] with weight 1 - f goes to out[255]
             const char *img = (const char *) (lds + buf * (BUF / 4));

@@ -432,8 +432,16 @@ QUAD1_ACC = (16, 48)
 QUAD1_TMP = 80
 
 
-def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP):
+def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, dma=False):
+    """dma=True: the block also issues the refill of the other LDS image (the next chunk: `dbytes` bytes from `dsrc`,
+    16 KiB pieces of 64 lanes x 16 bytes per wave, this wave's first piece landing at LDS address `ddst`), one
+    piece at the head of each trip instead of all of them before the sweep: the 16 waves of the workgroup then do not
+    queue at the CU's one address unit right after the barrier, and every wave's pieces go out beside the other
+    waves' FMAs.  Pieces a short chunk has no trip for follow the last trip.  The caller's s_waitcnt vmcnt(0)
+    before the barrier covers them (hipcc does not count loads issued inside an asm)."""
     prio = PRIO if prio is None else prio
+    assert not (dma and stamp), "the stamped builds keep the refill outside the block (s28..s31 hold the stamps)"
+    S_SB, S_DST, S_REM, S_K, S_NP, S_M0 = 20, 25, 28, 29, 30, 31  # s[20:21] running source address, ...
     A, T, V, R, X, addr_t = quad_regs(nk, acc, tmp)
     E = (36, 68)
     S_TMP, S_PF_, S_LEFT_ = 22, 23, 24
@@ -516,9 +524,22 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP):
 
     others = [p for p in (3, 2, 0)]
 
+    def dma_piece():
+        """one 16 KiB piece of the refill, if any is left"""
+        u = uid()
+        return [f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Ldskip{u}",
+                f"v_cmp_gt_u32 vcc, s{S_REM}, %[lbytes]",  # lanes whose 16 bytes lie inside the chunk
+                "s_mov_b64 exec, vcc",                      # (the block runs with all 64 lanes on: restored to -1 below)
+                f"s_mov_b32 m0, s{S_DST}", "s_nop 0",
+                f"global_load_lds_dwordx4 %[lbytes], s[{S_SB}:{S_SB + 1}]",
+                "s_mov_b64 exec, -1",
+                f"s_add_u32 s{S_SB}, s{S_SB}, 0x4000", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+                f"s_add_u32 s{S_DST}, s{S_DST}, 0x4000", f"s_sub_u32 s{S_REM}, s{S_REM}, 0x4000",
+                f"s_add_u32 s{S_K}, s{S_K}, 1", f".Ldskip{u}:"]
+
     def trip_q(par):
         cur, nxt = E[par], E[1 - par]
-        L = []
+        L = dma_piece() if dma else []
         if prio == 3 or (prio == 5 and par == 0):
             L += select_prio(S_PRIO, 1)   # the top priority moves on to the next wave of the SIMD
         elif prio == 5:
@@ -545,6 +566,10 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP):
     L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
     if prio == 4:
         L += select_prio(S_RANK, 0)  # static: youngest first for the whole block
+    if dma:
+        L += [f"s_mov_b32 s{S_M0}, m0",
+              f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[dsrc]", f"s_mov_b32 s{S_DST}, %[ddst]", f"s_mov_b32 s{S_REM}, %[dbytes]",
+              f"s_mov_b32 s{S_K}, 0", f"s_add_u32 s{S_NP}, %[dbytes], 0x3fff", f"s_lshr_b32 s{S_NP}, s{S_NP}, 14"]
     L += load_set(E[0], 0, literal=True)
     L += [f"s_mov_b32 s{S_LEFT_}, %[ng]", f"s_movk_i32 s{S_PF_}, 0x80", "s_waitcnt lgkmcnt(0)"]
     if stamp:
@@ -556,18 +581,24 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP):
     L += trip_q(1)
     L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQ0_%="]
     L += ["s_branch .LQdone_%="] + cold + [".LQdone_%=:", "s_waitcnt lgkmcnt(0)"]  # the reads issued for a trip that does not come
+    if dma:  # pieces a short chunk had no trip for
+        L += [".LQmore_%=:", f"s_cmp_ge_u32 s{S_K}, s{S_NP}", "s_cbranch_scc1 .LQnomore_%="] + dma_piece() + ["s_branch .LQmore_%=", ".LQnomore_%=:",
+              f"s_mov_b32 m0, s{S_M0}"]
     if prio:
         L += ["s_setprio 0"]
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
     vregs = list(range(tmp, tmp + 8 * nk + 1))
-    sregs = sorted({S_TMP, S_PF_, S_LEFT_, S_RANK, S_PRIO, S_T0, S_T0 + 1, S_T1, S_T1 + 1}) + list(range(36, 100))
-    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
+    sregs = sorted({S_TMP, S_PF_, S_LEFT_, S_RANK, S_PRIO, S_T0, S_T0 + 1, S_T1, S_T1 + 1} |
+                   ({S_SB, S_SB + 1, S_DST, S_REM, S_K, S_NP, S_M0} if dma else set())) + list(range(36, 100))
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'] + (['"vcc"'] if dma else []))
     names = [f"A{p}" for p in range(4)] + ["T"] + [f"V{p}" for p in (0, 2, 3)]
     bases = A + [T] + [V[0], V[2], V[3]]
     acc_params = ", ".join(f"{'f8' if nk == 4 else 'f4'} &{n}" for n in names)
     acc_ops = ", ".join(f'"+{{v[{b}:{b + 2 * nk - 1}]}}"({n})' for n, b in zip(names, bases))
+    dma_params = ", const void *dsrc, unsigned ddst, unsigned dbytes, unsigned lbytes" if dma else ""
+    dma_ops = ', [dsrc] "s"(dsrc), [ddst] "s"(ddst), [dbytes] "s"(dbytes), [lbytes] "v"(lbytes)' if dma else ""
     stamp_params = ", unsigned &t_wait, unsigned &t_all" if stamp else ""
     stamp_ops = ', [t_wait] "=&s"(t_wait), [t_all] "=&s"(t_all)' if stamp else ""
     return f"""// Four vertically adjacent pixels of the staged chunk, ng groups of four mics each (ng >= 1), with the shared
@@ -575,11 +606,11 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP):
 // quad-major table ([group][pixel][mic] x 8 bytes: 128 contiguous bytes per group); reads one group past the last.
 // Accumulators are pinned: A_p v[{A[0]}+8p..], T v[{T}..], V0/V2/V3 v[{V[0]}..]/v[{V[2]}..]/v[{V[3]}..]; temps v{vregs[0]}..v{vregs[-1]},
 // s{sregs[0]}..s{sregs[-1]}.
-__device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, unsigned lane_addr, int rank{stamp_params}) {{
+__device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, unsigned lane_addr, int rank{dma_params}{stamp_params}) {{
     asm volatile(
 {body}
         : {acc_ops}{stamp_ops}
-        : [ptr] "s"(row), [ng] "s"(ng), [lane] "v"(lane_addr), [rank] "s"(rank)
+        : [ptr] "s"(row), [ng] "s"(ng), [lane] "v"(lane_addr), [rank] "s"(rank){dma_ops}
         : {clobbers});
 }}
 """
@@ -745,6 +776,7 @@ def main():
     out.append(block_shared("sweep_duo_shared", 128 - 25 - 3))
     out.append(block_shared("sweep_duo_shared_stamped", 128 - 25 - 3, stamp=True))
     out.append(block_quad("sweep_quad_sum"))
+    out.append(block_quad("sweep_quad_sum_dma", dma=True))
     out.append(block_quad("sweep_quad_sum_stamped", stamp=True))
     for q, base in enumerate(QUAD1_ACC):  # single-frame layout, first / second quad of a wave
         out.append(block_quad_ar(f"sweep_quad1_sum_{'ab'[q]}", nk=2, acc=base, tmp=QUAD1_TMP))
