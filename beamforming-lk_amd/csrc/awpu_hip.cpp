@@ -821,7 +821,11 @@ int create_group(awpu_hip_t **out, const awpu_hip_cfg &c) {
     const int G = c.n_devices;
     // slabs: whole grid rows when the row length is known and the handle's range is whole rows, else pixels
     const bool by_rows = c.grid_columns > 0 && c.pixel_count % c.grid_columns == 0 && c.pixel_begin % c.grid_columns == 0;
-    const int unit = by_rows ? c.grid_columns : 1, units = c.pixel_count / unit;
+    int unit = by_rows ? c.grid_columns : 1;
+    // groups of four rows where that divides (the quad shapes sweep four rows at a time: slabs that start on a
+    // multiple of four rows sweep the same quads as one device would, and give the same bits)
+    if (by_rows && c.pixel_count % (4 * unit) == 0 && c.pixel_count / (4 * unit) >= G) unit *= 4;
+    const int units = c.pixel_count / unit;
     if (units < G) return invalid("fewer grid rows (or pixels) than devices");
     awpu_hip *g = new (std::nothrow) awpu_hip();
     if (!g) return AWPU_ERR_NOMEM;

@@ -679,6 +679,8 @@ spec = S.WORKLOADS["c2"]
 xyz = S.geometry(spec)
 off, frac = S.delay_table(spec, xyz)
 frames = S.make_frames(xyz, 6, seed=21)
+import os
+EXACT = os.environ.get("AWPU_FAST_QUADS") == "0"
 def run(devices, batch, **kw):
     with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=8, grid_columns=spec.res, devices=devices, **kw) as eng:
         eng.set_delay_table(off, frac); eng.set_active_mics(None)
@@ -704,12 +706,18 @@ for batch in (1, 6):
     for devices in ([0, 0], [0, 0, 0]):
         grp = run(devices, batch)
         for name, a, b in zip(("host", "device", "ring", "snapshot"), one[:4], grp[:4]):
-            assert np.array_equal(a, b), (name, devices, batch)
+            # the same bits where the slabs run the kernel shapes the whole grid runs (the shapes of round 1 do not
+            # depend on the slab: AWPU_FAST_QUADS=0); a small slab may pick another shape than the whole grid, and
+            # the quad shapes differ from the others by rounding
+            if EXACT or name == "snapshot":
+                assert np.array_equal(a, b), (name, devices, batch)
+            else:
+                assert util.power_rel_err(b, a) < 5e-6, (name, devices, batch)
         assert grp[4].frames == one[4].frames and grp[4].usable == one[4].usable and grp[4].alg_flops_frame == one[4].alg_flops_frame
 # uneven slabs (64 rows over 3 devices = 22 + 21 + 21) and a group that owns only part of the grid
 with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, grid_columns=spec.res, devices=[0, 0], pixel_begin=10 * spec.res, pixel_count=7 * spec.res) as eng:
     eng.set_delay_table(off[10 * spec.res:17 * spec.res], frac[10 * spec.res:17 * spec.res]); eng.set_active_mics(None)
-    assert np.array_equal(eng.process(frames[0]), run(None, 1)[0][0][10 * spec.res:17 * spec.res])
+    assert util.power_rel_err(eng.process(frames[0]), run(None, 1)[0][0][10 * spec.res:17 * spec.res]) < (1e-12 if EXACT else 5e-6)
 try:
     pkg.Engine(n_pixels=4, devices=list(range(9)))
 except pkg.AwpuError as e:
@@ -720,17 +728,21 @@ print("GROUP OK")
 """
 
 
-@pytest.mark.parametrize("force_copy", ["0", "1"])
-def test_device_group_equals_one_device(force_copy):
+@pytest.mark.parametrize("force_copy,quads", [("0", "0"), ("1", "0"), ("0", ""), ("1", "")])
+def test_device_group_equals_one_device(force_copy, quads):
     """awpu_hip_cfg.n_devices > 1 (the multi-GPU split under the C ABI): a handle that spreads the grid's rows over
     two / three engines -- here all on the one GPU of the box, the same code path with devices[k] equal -- gives
     the bits of the single-device handle through the host entry, the device-pointer entry (three calls back to
-    back) and the ingest ring, for one frame and for a batch.  force_copy=1 makes every part take the copy path of
-    the fan-out (2-D window copies, two buffers per part, events between the copy and the sweep streams) that a
-    part on another GPU takes."""
+    back) and the ingest ring, for one frame and for a batch (quads="0": with the kernel shapes that do not depend
+    on the slab; otherwise to rounding, a small slab may run another shape than the whole grid).  force_copy=1 makes
+    every part take the copy path of the fan-out (2-D window copies, two buffers per part, events between the copy
+    and the sweep streams) that a part on another GPU takes."""
     import os, subprocess, sys
+    env = dict(os.environ, AWPU_GROUP_FORCE_COPY=force_copy)
+    if quads:
+        env["AWPU_FAST_QUADS"] = quads
     out = subprocess.run([sys.executable, "-c", GROUP_CHILD, str(Path(__file__).resolve().parent.parent)],
-                         env=dict(os.environ, AWPU_GROUP_FORCE_COPY=force_copy), capture_output=True, text=True, timeout=600)
+                         env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "GROUP OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
