@@ -159,6 +159,7 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
     int quads = -1;                // AWPU_FAST_QUADS
     int pair_group = 0;            // AWPU_FAST_PAIRGROUP: frame pairs an XCD works on at a time (quad shape)
     int quad_variant = 0;          // AWPU_QUAD_VARIANT (tuning builds)
+    int stationary = -1;           // AWPU_FAST_STATIONARY=0/1: never / always (where it fits) the stationary pair shape
     int wgs = 0;                   // AWPU_FAST_WGS: persistent workgroups of the quad shape (0 = one per CU)
     int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0] (tests)
     EnvKnobs() {
@@ -167,6 +168,7 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
         if (const char *v = std::getenv("AWPU_QUAD_VARIANT")) quad_variant = std::atoi(v);
         if (const char *v = std::getenv("AWPU_GROUP_FORCE_COPY")) group_copy = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_WGS")) wgs = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FAST_STATIONARY")) stationary = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_VARIANT"))
             if (std::sscanf(v, "%d,%d,%d", &fpi, &ppw, &nw) < 2) fpi = ppw = nw = 0;
         if (const char *v = std::getenv("AWPU_FAST_PAIRS")) pairs = std::atoi(v);
@@ -394,8 +396,10 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
     const int U = h->usable(), P = c.pixel_count;
     awpu_hip::FastLut lut;
     const bool pairs = image_bytes < 0;  // frame-pair layout: one image row per mic, 8-byte elements
-    if (!(pairs ? awpu::pair_plan(h->window, U, &lut.plan) : awpu::fast_plan(h->window, U, fpi, image_bytes, &lut.plan)))
-        return invalid("delay window does not fit the LDS budget");
+    const bool planned = image_bytes == -2 ? awpu::pair_plan_stationary(h->window, U, &lut.plan)  // every mic resident
+                         : pairs         ? awpu::pair_plan(h->window, U, &lut.plan)
+                                         : awpu::fast_plan(h->window, U, fpi, image_bytes, &lut.plan);
+    if (!planned) return invalid("delay window does not fit the LDS budget");
     const awpu::FastPlan &plan = lut.plan;
     // rows for whole pixel tiles (the kernels sweep every pixel slot of a workgroup; slots past the
     // grid get null rows) + spare groups: the kernels prefetch entries past the row they sweep
@@ -573,7 +577,7 @@ int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
 
 // frame-pair shape: two frames per item, for batches on grids that fill the chip
 int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_frames, int batch, float *d_power,
-                 hipStream_t s, int hist_eff, int wstart_eff) {
+                 hipStream_t s, int hist_eff, int wstart_eff, int stationary_tiles = 0) {
     const awpu::FastPlan &pp = plut->plan;
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * h->usable() * pp.wr * 2;
     if (h->pack_cap < need) {
@@ -596,6 +600,7 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
     pa.debug = env().debug;
     pa.debug_out = nullptr;
     size_t n_waves = 0;
+    if (stationary_tiles > 0) pa.debug &= ~16;  // (no stamped build of the stationary shape)
     if (pa.debug & 16) {
         n_waves = (size_t) 16 * ((batch + 1) / 2) * awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols);
         const int rc = ensure_diag(h, n_waves * 12);
@@ -605,7 +610,11 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
                                          h->usable(), nullptr, pp.wr, batch, h->d_pack, s));  // gains ride on the table weights here
-    AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
+    if (stationary_tiles > 0) {
+        AWPU_HIP_TRY(awpu::launch_das_pairs_stationary(pa, stationary_tiles, s));
+    } else {
+        AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
+    }
     const int rc = finish_launch(h, batch, s);
     if (rc != AWPU_OK || !(pa.debug & 16)) return rc;
     return dump_diag(h, n_waves, 16, "pairs", s);
@@ -719,6 +728,21 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         ((long) awpu::quad_tiles(h->cfg.pixel_count / h->cfg.grid_columns, h->cfg.grid_columns) * ((batch + 1) / 2) >= 256 ||
          env().quads == 1))
         return launch_quads(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+    // ---- stationary shape: the whole window of every active mic of a frame pair fits the LDS (one 8x8 array does)
+    if (layout != kRing && batch >= 2 && env_pairs != 0 && env().stationary != 0) {
+        awpu::FastPlan sp;
+        const long tiles = awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols), pairs = (batch + 1) / 2;
+        if (awpu::pair_plan_stationary(h->window, h->usable(), &sp) && (pairs * tiles >= 128 || env().stationary == 1)) {
+            const awpu_hip::FastLut *slut = nullptr;
+            const int rc = build_fast_lut(h, 2, -2, &slut);
+            if (rc == AWPU_OK) {
+                // tiles per workgroup: enough to amortise the staging, few enough to leave every CU a workgroup
+                const int tpw = (int) std::max<long>(1, std::min<long>(tiles, pairs * tiles / 256));
+                return launch_pairs(h, slut, d_frames, batch, d_power, s, hist_eff, wstart_eff, tpw);
+            }
+            if (rc != AWPU_ERR_INVALID) return rc;
+        }
+    }
     if (layout != kRing && batch >= 2 && env_pairs != 0 && (pair_wgs >= 256 || env_pairs == 1)) {
         const awpu_hip::FastLut *plut = nullptr;
         const int rc = build_fast_lut(h, 2, -1, &plut);

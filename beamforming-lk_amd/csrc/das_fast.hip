@@ -807,6 +807,142 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
 
 
 // ---------------------------------------------------------------------------------------
+// Stationary shape: when the touched window of EVERY active mic of a frame pair fits the CU's LDS at once -- the
+// reference's own configuration does: one 8x8 array, 64 mics x 285 samples x 8 bytes = 146 KB of the 156 KB the two
+// images span -- a workgroup stages the pair once and then sweeps `tiles_per_wg` tiles of the grid from it, every
+// wave on its own: no refill, no chunk loop, no barrier after the first, and the staging is amortised over
+// several tiles (das_pair_kernel re-stages the pair for every tile and meets a barrier per chunk: on such small
+// problems that machinery, not the arithmetic, was where the time went).  Same blocks, same per-pixel order of the
+// items as das_pair_kernel: the sums are the same bits.  grid = (frame pairs, groups of tiles).
+// ---------------------------------------------------------------------------------------
+template <bool SHARE>
+__global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a, int n_tiles, int tiles_per_wg) {
+    constexpr int PPW = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, kThreads = NW * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int pair = blockIdx.x;
+    const size_t row_floats = (size_t) a.wp * 2;
+    const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
+
+    // ---- stage all rows of the pair: one linear LDS-DMA stream (16 bytes per lane, 16 KiB per workgroup pass)
+    const unsigned lane_bytes = threadIdx.x * 16;
+    const unsigned n_bytes = (unsigned) ((size_t) a.usable * row_floats * 4);
+    for (unsigned base = 0; base < n_bytes; base += kThreads * 16) {
+        if (base + lane_bytes < n_bytes) {
+            const char *src = (const char *) uniform_ptr((const char *) pair_base + base);
+            float *dst = lds + (base >> 2) + wave * 256;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + lane_bytes),
+                                             (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int rank = wave >> 2;
+    const int ng = __builtin_amdgcn_readfirstlane(a.usable_pad >> 2);
+    const unsigned lane_addr = lds_base + lane * 8;
+    const float norm = (float) (kSamples * a.usable);
+    const int tile_end = min(n_tiles, (int) (blockIdx.y + 1) * tiles_per_wg);
+    for (int tile = blockIdx.y * tiles_per_wg; tile < tile_end; tile++) {
+        int pix[PPW];
+        bool live[PPW];
+        int pair_rows;
+        if (a.cols > 0) {  // 2 rows x 32 columns per workgroup, a wave two vertical pixel pairs (see das_pair_kernel)
+            const int tiles_per_rowpair = (a.cols + 2 * NW - 1) / (2 * NW);
+            const int row2 = tile / tiles_per_rowpair, col0 = (tile - row2 * tiles_per_rowpair) * 2 * NW + 2 * wave;
+            const int rows = a.pixel_count / a.cols;
+#pragma unroll
+            for (int q = 0; q < PPW; q++) {
+                const int row = 2 * row2 + (q & 1), col = col0 + (q >> 1);
+                live[q] = row < rows && col < a.cols;
+                pix[q] = min(2 * row2 * a.cols + col, a.pixel_count - 1) + (q & 1) * a.cols;
+            }
+            pair_rows = a.cols;
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPW; q++) {
+                pix[q] = (tile * NW + wave) * PPW + q;
+                live[q] = pix[q] < a.pixel_count;
+            }
+            pair_rows = 1;
+        }
+        const int tail_pp = lane >> 3;
+        int tail_pix = pix[0];
+        bool tail_lane = false;
+#pragma unroll
+        for (int q = 0; q < PPW; q++)
+            if (tail_pp == q) {
+                tail_pix = pix[q];
+                tail_lane = live[q];
+            }
+        if (!tail_lane) tail_pix = pix[0];
+        const FastEntry *tail_row = a.lut + (size_t) tail_pix * a.usable_pad;
+        struct AddrG {
+            unsigned addr;
+            float g;
+        };
+        AddrG te[4];  // the tail pass's entries of mics 0..31: requested now, consumed after the sweep
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = 8 * u + (lane & 7);
+            te[u] = *(const AddrG *) ((const char *) (tail_row + min(j, a.usable_pad - 1)) + 4);  // fields addr, g
+            if (!tail_lane || j >= a.usable_pad) te[u].g = 0.0f;
+        }
+
+        f2 acc[PPW][8];
+#pragma unroll
+        for (int pp = 0; pp < PPW; pp++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[pp][k] = f2{0.0f, 0.0f};
+        const int stride = pair_rows * a.usable_pad * (int) sizeof(FastEntry);
+#pragma unroll
+        for (int q = 0; q < PPW; q += 2) {
+            const void *row = uniform_ptr(a.lut + (size_t) pix[q] * a.usable_pad);
+            if constexpr (SHARE) sweep_duo_shared(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
+            else sweep_duo_pairs(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
+        }
+        // the 257th sample of every window, both frames: lane 8*pp + k takes the mics s = k (mod 8)
+        f2 tail = f2{0.0f, 0.0f};
+        const char *img = (const char *) lds;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
+            tail = __builtin_elementwise_fma(f2{te[u].g, te[u].g}, x, tail);
+        }
+        for (int j0 = 32; j0 < a.usable_pad; j0 += 32) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 8 * u + (lane & 7);
+                AddrG e = *(const AddrG *) ((const char *) (tail_row + min(j, a.usable_pad - 1)) + 4);
+                if (!tail_lane || j >= a.usable_pad) e.g = 0.0f;
+                const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
+                tail = __builtin_elementwise_fma(f2{e.g, e.g}, x, tail);
+            }
+        }
+        tail.x += __shfl_xor(tail.x, 1);
+        tail.y += __shfl_xor(tail.y, 1);
+        tail.x += __shfl_xor(tail.x, 2);
+        tail.y += __shfl_xor(tail.y, 2);
+        tail.x += __shfl_xor(tail.x, 4);
+        tail.y += __shfl_xor(tail.y, 4);
+#pragma unroll
+        for (int pp = 0; pp < PPW; pp++) {
+            f2 tl;
+            tl.x = __shfl(tail.x, pp * 8);
+            tl.y = __shfl(tail.y, pp * 8);
+            const f2 sum = finish_pixel_pair(acc[pp], tl, lane);
+            if (lane == 0 && live[pp]) {
+                a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
+                if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + pix[pp]] = sum.y / norm;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Quad shape (the default for batches on grids whose row length is known and whose neighbouring rows mostly
 // share their integer delays): the frame-pair layout and chunk pipeline of das_pair_kernel, with the
 // arithmetic rearranged so that pixels share work and not only sample reads:
@@ -1351,6 +1487,34 @@ static hipError_t launch_pair_variant(const PairArgs &a, hipStream_t stream) {
     if (a.debug & 256) grid = dim3(grid.y, grid.x);
     if (grid.y > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL((das_pair_kernel<PPW, DIAG, SHARE>), grid, dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+bool pair_plan_stationary(int window, int usable, FastPlan *plan) {
+    const int wp = (window + 1) & ~1;
+    const size_t row_bytes = (size_t) wp * 8;
+    const int usable_pad = (usable + 3) & ~3;
+    if ((size_t) usable * row_bytes > (size_t) 2 * kFastLdsBytes) return false;  // (null entries of padding mics point at row 0)
+    plan->fpi = 2;
+    plan->wr = wp;
+    plan->chunk = usable_pad;  // every mic has its own slot: addresses are not folded into chunks
+    plan->usable_pad = usable_pad;
+    plan->row_bytes = (int) row_bytes;
+    plan->image_bytes = -2;  // marks the stationary layout
+    return true;
+}
+
+hipError_t launch_das_pairs_stationary(const PairArgs &a, int tiles_per_wg, hipStream_t stream) {
+    static LdsFlags attr_set[2] = {};
+    const bool share = (a.debug & 4096) == 0;
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    const void *fn = share ? (const void *) das_pair_stationary_kernel<true> : (const void *) das_pair_stationary_kernel<false>;
+    if (hipError_t e = allow_lds(fn, lds_bytes, attr_set[share]); e != hipSuccess) return e;
+    const int n_tiles = pair_tiles(a.pixel_count, a.cols);
+    dim3 grid((a.batch + 1) / 2, (n_tiles + tiles_per_wg - 1) / tiles_per_wg);
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    if (share) hipLaunchKernelGGL(das_pair_stationary_kernel<true>, grid, dim3(1024), lds_bytes, stream, a, n_tiles, tiles_per_wg);
+    else hipLaunchKernelGGL(das_pair_stationary_kernel<false>, grid, dim3(1024), lds_bytes, stream, a, n_tiles, tiles_per_wg);
     return hipGetLastError();
 }
 

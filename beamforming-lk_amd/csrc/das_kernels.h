@@ -88,6 +88,10 @@ hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int
                              int usable, int rows_out, const float *d_gain, int wp, int batch, float *d_packed,
                              hipStream_t stream);
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream);
+// stationary shape: every active mic's window of a frame pair in LDS at once (plan->chunk = usable_pad); a
+// workgroup stages the pair once and sweeps tiles_per_wg tiles from it
+bool pair_plan_stationary(int window, int usable, FastPlan *plan);
+hipError_t launch_das_pairs_stationary(const PairArgs &a, int tiles_per_wg, hipStream_t stream);
 
 // ---- quad shape (das_quad_kernel): the frame-pair layout swept four vertically adjacent pixels at a time with
 // a shared integer-delay sum (das_fast.hip).  Needs the grid's row length.
