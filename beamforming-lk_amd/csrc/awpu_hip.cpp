@@ -160,7 +160,7 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
     int pair_group = 0;            // AWPU_FAST_PAIRGROUP: frame pairs an XCD works on at a time (quad shape)
     int quad_variant = 0;          // AWPU_QUAD_VARIANT (tuning builds)
     int stationary = -1;           // AWPU_FAST_STATIONARY=0/1: never / always (where it fits) the stationary pair shape
-    int wgs = 0;                   // AWPU_FAST_WGS: persistent workgroups of the quad shape (0 = one per CU)
+    int wgs = 0;                   // AWPU_FAST_WGS: persistent workgroups of the quad shape (0 = one workgroup per item)
     int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0] (tests)
     EnvKnobs() {
         if (const char *v = std::getenv("AWPU_FAST_QUADS")) quads = std::atoi(v);
@@ -655,14 +655,21 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     }
     qa.debug = env().debug;
     qa.variant = env().quad_variant;
+    // Persistent workgroups (one per CU, each walking its share of the items with the next item's first chunk
+    // prefetched) are 1.5 % faster than one workgroup per item on a chip they have to themselves, and fragile on one
+    // they share: their share of the items is static.  A handle that owns the whole grid has the GPU to itself; a
+    // handle that owns a slab is a rank of a multi-GPU run, beside which the broadcast of the next batch holds CUs.
     qa.wgs = env().wgs;
+    if (qa.wgs == 0 && h->cfg.pixel_count == h->cfg.n_pixels) {
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device) == hipSuccess) qa.wgs = n_cu;
+    }
+    if (qa.wgs < 0) qa.wgs = 0;  // AWPU_FAST_WGS=-1: one workgroup per item everywhere
     qa.debug_out = nullptr;
     size_t n_waves = 0;
     if (qa.debug & 16) {
-        int n_cu = 256;
-        (void) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
         const long per_xcd = ((long) qa.n_pairs * qa.tiles + 7) / 8;
-        n_waves = (size_t) 16 * 8 * (size_t) std::min<long>(per_xcd, std::max(1, (qa.wgs > 0 ? qa.wgs : n_cu) / 8));
+        n_waves = (size_t) 16 * 8 * (size_t) (qa.wgs > 0 ? std::min<long>(per_xcd, std::max(1, qa.wgs / 8)) : per_xcd);
         rc = ensure_diag(h, n_waves * 12);
         if (rc != AWPU_OK) return rc;
         AWPU_HIP_TRY(hipMemsetAsync(h->d_diag, 0, n_waves * 12 * sizeof(unsigned long long), s));

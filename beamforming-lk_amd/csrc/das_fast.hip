@@ -1529,13 +1529,15 @@ static hipError_t launch_quad_variant(const QuadArgs &a, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_quad_kernel<DIAG, VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
-    // persistent workgroups: one per CU (the two LDS images fill it), fewer when there are fewer items
-    int dev = 0, n_cu = 0;
-    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-    if (hipError_t e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); e != hipSuccess) return e;
+    // One workgroup per item by default: the hardware hands items to CUs as they free up, which stays balanced when
+    // something else (an RCCL broadcast of the next batch) holds a few CUs.  a.wgs > 0 (AWPU_FAST_WGS) launches that
+    // many persistent workgroups instead, each walking several items with the next item's first chunk prefetched:
+    // measured equal at the headline shape on an otherwise idle chip (5.41 vs 5.41 ms), and fragile when CUs are
+    // shared (a static share of the items per workgroup).
     const long items = (long) a.n_pairs * a.tiles;
     const long per_xcd = (items + 7) / 8;
-    const long wgs_per_xcd = std::min<long>(per_xcd, std::max(1, (a.wgs > 0 ? a.wgs : n_cu) / 8));
+    const long wgs_per_xcd = a.wgs > 0 ? std::min<long>(per_xcd, std::max(1, a.wgs / 8)) : per_xcd;
+    if (8 * wgs_per_xcd > 0x7fffffffL) return hipErrorInvalidValue;
     hipLaunchKernelGGL((das_quad_kernel<DIAG, VAR>), dim3((unsigned) (8 * wgs_per_xcd)), dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }

@@ -108,7 +108,7 @@ struct QuadArgs {
     int32_t tiles;         // workgroup tiles of 4 rows x 16 columns
     int32_t n_pairs, pair_group;  // frame pairs, and how many of them one XCD works on at a time
     int32_t variant;              // tuning builds only (AWPU_QUAD_VARIANT)
-    int32_t wgs;                  // persistent workgroups to launch (0 = one per CU; AWPU_FAST_WGS)
+    int32_t wgs;                  // persistent workgroups to launch (0 = one workgroup per item; AWPU_FAST_WGS)
     unsigned long long *debug_out;
     int32_t debug;
 };
