@@ -432,7 +432,7 @@ QUAD1_ACC = (16, 48)
 QUAD1_TMP = 80
 
 
-def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, dma=False):
+def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, dma=False, early_x=False):
     """dma=True: the block also issues the refill of the other LDS image (the next chunk: `dbytes` bytes from `dsrc`,
     16 KiB pieces of 64 lanes x 16 bytes per wave, this wave's first piece landing at LDS address `ddst`), one
     piece at the head of each trip instead of all of them before the sweep: the 16 waves of the workgroup then do not
@@ -440,9 +440,21 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
     waves' FMAs.  Pieces a short chunk has no trip for follow the last trip.  The caller's s_waitcnt vmcnt(0)
     before the barrier covers them (hipcc does not count loads issued inside an asm)."""
     prio = PRIO if prio is None else prio
+    # early_x (the single-frame layout, where a stage is too short to hide a read issued at its end): the own-sample
+    # slots are double-buffered like the reference's, and the conditional reads of the NEXT mic go out at the head of
+    # the stage, right behind the wait that proves this mic's samples -- a whole stage of flight, no more LDS reads
+    # than are needed.  MEASURED SLOWER than the always-read schedule of block_quad_ar (headline, one frame per call:
+    # 79-80 us against 70-73 us in the same kernel): five compare-and-branch pairs per stage instead of three weigh
+    # more than the LDS reads saved.  Kept as a generator option (QUAD1_EARLY_X=1), not built by default.
     assert not (dma and stamp), "the stamped builds keep the refill outside the block (s28..s31 hold the stamps)"
     S_SB, S_DST, S_REM, S_K, S_NP, S_M0 = 20, 25, 28, 29, 30, 31  # s[20:21] running source address, ...
     A, T, V, R, X, addr_t = quad_regs(nk, acc, tmp)
+    XS = [X, X]
+    if early_x:
+        w_ = 2 * nk
+        XS = [{0: tmp + 2 * w_, 2: tmp + 3 * w_, 3: tmp + 3 * w_}, {0: tmp + 4 * w_, 2: tmp + 5 * w_, 3: tmp + 5 * w_}]
+        addr_t = tmp + 6 * w_
+    xz = [0]  # which own-sample slot set the code being generated uses
     E = (36, 68)
     S_TMP, S_PF_, S_LEFT_ = 22, 23, 24
 
@@ -471,10 +483,11 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
     def maybe_read_x(p, base, i):
         """issue pixel p's own reads for the mic whose entries sit at (base, i) unless it shares the reference's"""
         u = uid()
-        cold.extend([f".Lqread{u}:"] + reads(X[p], a_of(base, p, i)) + [f"s_branch .Lqreadback{u}"])
+        cold.extend([f".Lqread{u}:"] + reads(XS[xz[0]][p], a_of(base, p, i)) + [f"s_branch .Lqreadback{u}"])
         return [f"s_cmp_lg_u32 s{a_of(base, p, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lqread{u}", f".Lqreadback{u}:"]
 
     def own_ops(p, fs, rslot):
+        X = XS[xz[0]]
         own = []
         for k in range(nk):
             own.append(f"v_pk_fma_f32 {pair(A[p], k)}, {fs}, {pair(X[p], k)}, {pair(A[p], k)} op_sel_hi:[0,1,1]")
@@ -493,7 +506,7 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
             cold.extend([f".Lqown{u}:",
                          f"s_cmp_eq_u32 s{a_of(base, 2, i)}, s{a_of(base, 3, i)}",
                          f"s_cbranch_scc1 .Lqhave{u}"] +
-                        reads(X[2], a_of(base, 2, i)) + ["s_waitcnt lgkmcnt(0)", f".Lqhave{u}:"] +
+                        reads(XS[xz[0]][2], a_of(base, 2, i)) + ["s_waitcnt lgkmcnt(0)", f".Lqhave{u}:"] +
                         own_ops(p, fs, rslot) + [f"s_branch .Lqdone{u}"])
         else:
             cold.extend([f".Lqown{u}:"] + own_ops(p, fs, rslot) + [f"s_branch .Lqdone{u}"])
@@ -555,8 +568,14 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
                 L.append("s_waitcnt lgkmcnt(0)")  # this mic's samples, and the next trip's entries
                 L += reads(R[0], a_of(nxt, REF, 0))
                 nbase, ni = nxt, 0
-            L += pixel_ops(3, cur, st, rslot) + pixel_ops(2, cur, st, rslot) + maybe_read_x(3, nbase, ni)
-            L += pixel_ops(0, cur, st, rslot) + maybe_read_x(0, nbase, ni)
+            if early_x:
+                xz[0] = (st + 1) & 1  # the next mic's own samples, into the other slot set, a whole stage ahead
+                L += maybe_read_x(3, nbase, ni) + maybe_read_x(0, nbase, ni)
+                xz[0] = st & 1
+                L += pixel_ops(3, cur, st, rslot) + pixel_ops(2, cur, st, rslot) + pixel_ops(0, cur, st, rslot)
+            else:
+                L += pixel_ops(3, cur, st, rslot) + pixel_ops(2, cur, st, rslot) + maybe_read_x(3, nbase, ni)
+                L += pixel_ops(0, cur, st, rslot) + maybe_read_x(0, nbase, ni)
             L += ref_ops(cur, st, rslot)
         return L
 
@@ -575,6 +594,7 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_wait], s{S_T1}, s{S_T0}"]
     L += reads(R[0], a_of(E[0], REF, 0))
+    xz[0] = 0
     L += maybe_read_x(3, E[0], 0) + maybe_read_x(0, E[0], 0)
     L += [".LQ0_%=:"] + trip_q(0)
     L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_eq_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQdone_%="]
@@ -589,7 +609,7 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
-    vregs = list(range(tmp, tmp + 8 * nk + 1))
+    vregs = list(range(tmp, tmp + (12 if early_x else 8) * nk + 1))
     sregs = sorted({S_TMP, S_PF_, S_LEFT_, S_RANK, S_PRIO, S_T0, S_T0 + 1, S_T1, S_T1 + 1} |
                    ({S_SB, S_SB + 1, S_DST, S_REM, S_K, S_NP, S_M0} if dma else set())) + list(range(36, 100))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'] + (['"vcc"'] if dma else []))
@@ -781,6 +801,9 @@ def main():
     for q, base in enumerate(QUAD1_ACC):  # single-frame layout, first / second quad of a wave
         out.append(block_quad_ar(f"sweep_quad1_sum_{'ab'[q]}", nk=2, acc=base, tmp=QUAD1_TMP))
     out.append(block_quad_ar("sweep_quad1_sum_a_stamped", stamp=True, nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP))
+    if os.environ.get("QUAD1_EARLY_X"):  # tuning builds: conditional reads at the head of the stage (measured: 79 vs 71 us)
+        for q, base in enumerate(QUAD1_ACC):
+            out.append(block_quad(f"sweep_quad1_early_{'ab'[q]}", nk=2, acc=base, tmp=QUAD1_TMP, early_x=True))
     if os.environ.get("QUAD_VARIANTS"):  # tuning builds: the priority schemes side by side (AWPU_QUAD_VARIANT picks)
         for v in (0, 3, 4):
             out.append(block_quad(f"sweep_quad_sum_v{v}", prio=v))
