@@ -82,6 +82,8 @@ struct awpu_hip {
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     awpu::QuadEntry *d_quad_lut = nullptr;  // quad-major table of the quad shape (das_quad_kernel)
     awpu::QuadEntry *d_quad1_lut = nullptr; // the same with the single-frame layout's LDS addresses (das_quad1_kernel)
+    awpu::LutEntry *d_fir_pair_lut = nullptr;  // FIR8 on the frame-pair layout: {LDS address, coefficient row} per (pixel, mic)
+    awpu::FastPlan fir_plan{};
     awpu::FastPlan quad_plan{}, quad1_plan{};
     bool quad1_fits = false;
     bool quad_ok = false;         // the table's statistics favour the quad shape (decided in prepare)
@@ -187,6 +189,7 @@ void release_device(awpu_hip *h) {
     h->fast_luts.clear();
     dev_free(h->d_quad_lut);
     dev_free(h->d_quad1_lut);
+    dev_free(h->d_fir_pair_lut);
     dev_free(h->d_index);
     dev_free(h->d_gain);
     dev_free(h->d_calib);
@@ -243,6 +246,7 @@ int prepare(awpu_hip *h) {
     h->fast_luts.clear();
     dev_free(h->d_quad_lut);
     dev_free(h->d_quad1_lut);
+    dev_free(h->d_fir_pair_lut);
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
                            hipMemcpyHostToDevice));
@@ -575,6 +579,50 @@ int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     return finish_launch(h, batch, s);
 }
 
+// FIR8 on the frame-pair layout (das_fir8_pair_kernel): batches of the 8-tap variant with AWPU_MATH_F32_FAST
+int launch_fir8_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
+    const awpu::FastPlan &pp = h->fir_plan;
+    const int U = h->usable(), P = h->cfg.pixel_count;
+    if (!h->d_fir_pair_lut) {
+        std::vector<awpu::LutEntry> packed((size_t) P * pp.usable_pad, awpu::LutEntry{0, 0});
+        for (int p = 0; p < P; p++) {
+            const int32_t *orow = &h->off[(size_t) p * h->cfg.lut_stride];
+            const float *frow = &h->frac[(size_t) p * h->cfg.lut_stride];
+            for (int m = 0; m < U; m++) {
+                const int id = h->index[m];
+                const float get_filter = frow[id] * 100.0f + 0.5f;  // delay.cpp:32-33: the coefficient row
+                packed[(size_t) p * pp.usable_pad + m] =
+                    awpu::LutEntry{(int32_t) ((m % pp.chunk) * pp.row_bytes + (orow[id] - h->wstart) * 8), (float) 0};
+                const int32_t k = (int32_t) get_filter;
+                std::memcpy(&packed[(size_t) p * pp.usable_pad + m].frac, &k, sizeof(k));
+            }
+        }
+        AWPU_HIP_TRY(hipMalloc(&h->d_fir_pair_lut, packed.size() * sizeof(awpu::LutEntry)));
+        AWPU_HIP_TRY(hipMemcpy(h->d_fir_pair_lut, packed.data(), packed.size() * sizeof(awpu::LutEntry), hipMemcpyHostToDevice));
+    }
+    const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * U * pp.wr * 2;
+    if (h->pack_cap < need) {
+        dev_free(h->d_pack);
+        h->pack_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
+        h->pack_cap = need;
+    }
+    awpu::PairArgs pa{};
+    pa.packed = h->d_pack;
+    pa.power = d_power;
+    pa.usable = U;
+    pa.usable_pad = pp.usable_pad;
+    pa.pixel_count = P;
+    pa.wp = pp.wr;
+    pa.chunk = pp.chunk;
+    pa.batch = batch;
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, U, U, h->d_gain,
+                                         pp.wr, batch, h->d_pack, s));
+    AWPU_HIP_TRY(awpu::launch_das_fir8_pairs(pa, h->d_fir_pair_lut, h->d_fir, s));
+    return finish_launch(h, batch, s);
+}
+
 // frame-pair shape: two frames per item, for batches on grids that fill the chip
 int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_frames, int batch, float *d_power,
                  hipStream_t s, int hist_eff, int wstart_eff, int stationary_tiles = 0) {
@@ -725,6 +773,10 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     const bool compact = layout == kCompact;
     const int hist_eff = compact ? h->compact_hist : (layout == kRing ? 2048 : h->cfg.hist);
     const int wstart_eff = compact ? 0 : h->wstart;
+    if (h->cfg.interp == AWPU_INTERP_FIR8 && h->cfg.math == AWPU_MATH_F32_FAST && layout != kRing && batch >= 2 &&
+        env().pairs != 0 && (long) ((h->cfg.pixel_count + 63) / 64) * ((batch + 1) / 2) >= 256 &&
+        awpu::pair_plan(h->window, h->usable(), &h->fir_plan))
+        return launch_fir8_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
     if (h->cfg.math != AWPU_MATH_F32_FAST || h->cfg.interp == AWPU_INTERP_FIR8)
         return launch_exact(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
 

@@ -943,6 +943,127 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
 }
 
 // ---------------------------------------------------------------------------------------
+// FIR8 on the frame-pair layout (AWPU_INTERP_FIR8 with AWPU_MATH_F32_FAST, batches): the 8-tap table variant of
+// delay(), src/dsp/delay.cpp:31-40,
+//     k = (int)(frac * 100 + 0.5);  out[n] += sum_{t<8} C[k][t] * X[off + n + t],
+// swept like das_pair_kernel sweeps the linear one: the window (here off .. off + 262) of a chunk of mics in LDS as
+// (frame a, frame b) sample pairs, two images filled by LDS-DMA, lane l owns samples l + 64 j, the two packed lanes
+// are the two frames.  An item is 32 ds_read_b64 (4 sample groups x 8 taps, the taps 8 bytes apart: immediate
+// offsets off one address) and 32 v_pk_fma_f32 with the 8 coefficients of its table row as scalar operands -- no
+// skewed accumulators, no 257th-sample pass: out[n] is complete in its lane.  Taps accumulate in the reference's
+// order t = 0..7, mics in order.  Compiler-scheduled (the FMA-to-read ratio is 1:1 and every read is independent).
+// ---------------------------------------------------------------------------------------
+struct FirEntry {
+    uint32_t addr;  // LDS byte offset of the element X[off] in the chunk's image
+    int32_t k;      // coefficient row (delay.cpp:32-33)
+};
+
+template <int PPW>
+__global__ __launch_bounds__(1024, 4) void das_fir8_pair_kernel(PairArgs a, const FirEntry *lut, const float *coeffs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
+    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.x, tile = blockIdx.y;
+    const int pix0 = (tile * NW + wave) * PPW;
+    const size_t row_floats = (size_t) a.wp * 2;
+    const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
+    const unsigned lane_bytes = threadIdx.x * 16;
+    auto dma_chunk = [&](int m0, int mc, int buf) {
+        const unsigned n_bytes = (unsigned) ((size_t) mc * row_floats * 4);
+        const char *src = (const char *) (pair_base + (size_t) m0 * row_floats);
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            if (lane_bytes + k * kThreads * 16 < n_bytes) {
+                const char *base = (const char *) uniform_ptr(src + k * kThreads * 16);
+                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (base + lane_bytes),
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+            }
+        }
+    };
+    f2 acc[PPW][4];
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[pp][j] = f2{0.0f, 0.0f};
+
+    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
+    dma_chunk(0, min(a.chunk, a.usable), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const int m0 = c * a.chunk;
+        const int mc = min(a.chunk, a.usable - m0);
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
+        const char *img = (const char *) (lds + buf * (BUF / 4)) + lane * 8;
+#pragma unroll
+        for (int pp = 0; pp < PPW; pp++) {
+            const int p = min(pix0 + pp, a.pixel_count - 1);  // pixels past the grid repeat the last one (not stored)
+            const AWPU_AS4 FirEntry *row = (const AWPU_AS4 FirEntry *) (unsigned long long) (lut + (size_t) p * a.usable_pad + m0);
+            // An item's address and its eight coefficients are wave-uniform: scalar loads.  They are requested for
+            // the NEXT mic after this mic's last FMA and waited for at the head of the next iteration, so that no
+            // scalar load is in flight while LDS reads are (hipcc waits lgkmcnt(0) for an LDS result whenever a
+            // scalar load is pending: the two share the counter and scalar loads return out of order).
+            unsigned addr_n = row[0].addr;
+            const AWPU_AS4 float *cf_n = (const AWPU_AS4 float *) (unsigned long long) (coeffs + 8 * row[0].k);
+            float ct_n[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) ct_n[t] = cf_n[t];
+            for (int m = 0; m < mc; m++) {
+                const char *x = img + addr_n;
+                float ct[8];
+#pragma unroll
+                for (int t = 0; t < 8; t++) ct[t] = ct_n[t];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {  // two sample groups' reads in flight (16), then their FMAs
+                    f2 v[2][8];
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int t = 0; t < 8; t++) {
+                            v[u][t] = *(const f2 *) (x + 512 * (j + u) + 8 * t);
+                            no_fuse();
+                        }
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int t = 0; t < 8; t++)
+                            acc[pp][j + u] = __builtin_elementwise_fma(f2{ct[t], ct[t]}, v[u][t], acc[pp][j + u]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int mn = min(m + 1, mc - 1);
+                addr_n = row[mn].addr;
+                const AWPU_AS4 float *cf = (const AWPU_AS4 float *) (unsigned long long) (coeffs + 8 * row[mn].k);
+#pragma unroll
+                for (int t = 0; t < 8; t++) ct_n[t] = cf[t];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const float norm = (float) (kSamples * a.usable);
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) {
+        f2 P[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            P[j] = acc[pp][j];
+            P[4 + j] = f2{0.0f, 0.0f};  // no skewed terms: out[n] is complete in its lane
+        }
+        const f2 sum = finish_pixel_pair(P, f2{0.0f, 0.0f}, lane);
+        const int p = pix0 + pp;
+        if (lane == 0 && p < a.pixel_count) {
+            a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
+            if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Quad shape (the default for batches on grids whose row length is known and whose neighbouring rows mostly
 // share their integer delays): the frame-pair layout and chunk pipeline of das_pair_kernel, with the
 // arithmetic rearranged so that pixels share work and not only sample reads:
@@ -1515,6 +1636,16 @@ hipError_t launch_das_pairs_stationary(const PairArgs &a, int tiles_per_wg, hipS
     if (grid.y > 65535) return hipErrorInvalidValue;
     if (share) hipLaunchKernelGGL(das_pair_stationary_kernel<true>, grid, dim3(1024), lds_bytes, stream, a, n_tiles, tiles_per_wg);
     else hipLaunchKernelGGL(das_pair_stationary_kernel<false>, grid, dim3(1024), lds_bytes, stream, a, n_tiles, tiles_per_wg);
+    return hipGetLastError();
+}
+
+hipError_t launch_das_fir8_pairs(const PairArgs &a, const void *d_entries, const float *d_coeffs, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (hipError_t e = allow_lds((const void *) das_fir8_pair_kernel<4>, lds_bytes, attr_set); e != hipSuccess) return e;
+    dim3 grid((a.batch + 1) / 2, (a.pixel_count + 63) / 64);
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(das_fir8_pair_kernel<4>, grid, dim3(1024), lds_bytes, stream, a, (const FirEntry *) d_entries, d_coeffs);
     return hipGetLastError();
 }
 

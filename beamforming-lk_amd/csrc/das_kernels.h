@@ -88,6 +88,9 @@ hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int
                              int usable, int rows_out, const float *d_gain, int wp, int batch, float *d_packed,
                              hipStream_t stream);
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream);
+// FIR8 on the frame-pair layout (batches): d_entries [pixel_count][usable_pad] x {u32 LDS address, i32 coefficient row},
+// addresses as in the pair shape's plan (pair_plan on a window that reaches off + 262); d_coeffs [101][8]
+hipError_t launch_das_fir8_pairs(const PairArgs &a, const void *d_entries, const float *d_coeffs, hipStream_t stream);
 // stationary shape: every active mic's window of a frame pair in LDS at once (plan->chunk = usable_pad); a
 // workgroup stages the pair once and sweeps tiles_per_wg tiles from it
 bool pair_plan_stationary(int window, int usable, FastPlan *plan);

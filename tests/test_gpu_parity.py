@@ -357,6 +357,31 @@ def test_fir8_mode_vs_oracle(pkg, oracle, table_kind):
             assert util.power_rel_err(power[b], want) < util.POWER_RTOL
 
 
+def test_fir8_batched_frame_pair_shape(pkg, oracle):
+    """AWPU_INTERP_FIR8 on a full grid with a batch: the frame-pair FIR8 sweep (das_fir8_pair_kernel).  One 8x8 array,
+    128x128 grid, three frames (an odd batch: the last pair is half empty), a ragged mic list; sampled pixels against
+    the restated FIR sweep with the reference's measured table, and whole frames against the single-frame calls
+    (the exact-structure kernel: same taps in the same order, same bits before the epilogue)."""
+    xyz = oracle.create_antenna()
+    res = 128
+    off, frac = oracle.compute_delay_lut(xyz, res, res)
+    table = measured_fir_table()
+    X = util.hash_frames(64, 1024, seed=91, batch=3)
+    index = np.array([m for m in range(64) if m % 7 != 3], np.int32)
+    with pkg.Engine(n_pixels=res * res, interp=pkg.binding.INTERP_FIR8, max_batch=3) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(index)
+        eng.set_fir_table(table)
+        batch = eng.process(X)
+        single = np.stack([eng.process(X[b]) for b in range(3)])
+    assert util.power_rel_err(batch, single) < 2e-6
+    pick = np.random.default_rng(2).choice(res * res, 120, replace=False)
+    for b in range(3):
+        want = oracle.das_fir8_f32(X[b], off[pick], frac[pick], table, index)
+        floor = util.NULL_FLOOR * float(batch[b].max())
+        assert float((np.abs(batch[b][pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+
+
 def test_device_heatmap_equals_populate_heatmap(pkg, oracle):
     """the display step on device buffers is byte-identical to the restated
     MIMOWorker::populateHeatmap (mimo.cpp:61-95), per frame, and accepts an external peak."""
