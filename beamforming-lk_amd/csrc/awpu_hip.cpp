@@ -84,6 +84,9 @@ struct awpu_hip {
     awpu::QuadEntry *d_quad1_lut = nullptr; // the same with the single-frame layout's LDS addresses (das_quad1_kernel)
     awpu::LutEntry *d_fir_pair_lut = nullptr;  // FIR8 on the frame-pair layout: {LDS address, coefficient row} per (pixel, mic)
     awpu::FastPlan fir_plan{};
+    void *d_fir_plane_lut = nullptr;           // FIR8 on the four-plane layout: 64-byte entries {plane addresses, coefficients}
+    awpu::FastPlan fir_plane_plan{};
+    std::vector<float> fir;                    // host copy of the [101][8] coefficient table (baked into the plane entries)
     awpu::FastPlan quad_plan{}, quad1_plan{};
     bool quad1_fits = false;
     bool quad_ok = false;         // the table's statistics favour the quad shape (decided in prepare)
@@ -162,6 +165,7 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
     int pair_group = 0;            // AWPU_FAST_PAIRGROUP: frame pairs an XCD works on at a time (quad shape)
     int quad_variant = 0;          // AWPU_QUAD_VARIANT (tuning builds)
     int stationary = -1;           // AWPU_FAST_STATIONARY=0/1: never / always (where it fits) the stationary pair shape
+    int fir_planes = 1;            // AWPU_FIR8_PLANES=0: FIR8 batches on the older lane-strided pair kernel (A/B measurements); 2: the plane kernel for every batch >= 2, however small the grid (tests)
     int wgs = 0;                   // AWPU_FAST_WGS: persistent workgroups of the quad shape (0 = one workgroup per item)
     int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0] (tests)
     EnvKnobs() {
@@ -170,6 +174,7 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
         if (const char *v = std::getenv("AWPU_QUAD_VARIANT")) quad_variant = std::atoi(v);
         if (const char *v = std::getenv("AWPU_GROUP_FORCE_COPY")) group_copy = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_WGS")) wgs = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FIR8_PLANES")) fir_planes = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_STATIONARY")) stationary = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_VARIANT"))
             if (std::sscanf(v, "%d,%d,%d", &fpi, &ppw, &nw) < 2) fpi = ppw = nw = 0;
@@ -190,6 +195,7 @@ void release_device(awpu_hip *h) {
     dev_free(h->d_quad_lut);
     dev_free(h->d_quad1_lut);
     dev_free(h->d_fir_pair_lut);
+    dev_free(h->d_fir_plane_lut);
     dev_free(h->d_index);
     dev_free(h->d_gain);
     dev_free(h->d_calib);
@@ -247,6 +253,7 @@ int prepare(awpu_hip *h) {
     dev_free(h->d_quad_lut);
     dev_free(h->d_quad1_lut);
     dev_free(h->d_fir_pair_lut);
+    dev_free(h->d_fir_plane_lut);
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
                            hipMemcpyHostToDevice));
@@ -623,6 +630,59 @@ int launch_fir8_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_po
     return finish_launch(h, batch, s);
 }
 
+// FIR8 on the four-plane frame-pair layout (das_fir8_plane_kernel): a lane owns four consecutive outputs
+int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
+    struct Entry {
+        uint32_t addr[4], pad[4];
+        float coeff[8];
+    };
+    const awpu::FastPlan &pp = h->fir_plane_plan;
+    const int U = h->usable(), P = h->cfg.pixel_count;
+    // the block sweeps triples of items: every chunk's share of a pixel's row is padded to a multiple of three
+    const int n_chunks = (U + pp.chunk - 1) / pp.chunk, chunk_pad = (pp.chunk + 2) / 3 * 3, row_entries = n_chunks * chunk_pad;
+    if (!h->d_fir_plane_lut) {
+        const uint32_t plane_bytes = (uint32_t) pp.row_bytes / 4;
+        // (two spare entries: the block requests entries two items ahead; null entries read row 0 with zero coefficients)
+        std::vector<Entry> packed((size_t) P * row_entries + 2, Entry{{0, plane_bytes, 2 * plane_bytes, 3 * plane_bytes}, {}, {}});
+        for (int p = 0; p < P; p++) {
+            const int32_t *orow = &h->off[(size_t) p * h->cfg.lut_stride];
+            const float *frow = &h->frac[(size_t) p * h->cfg.lut_stride];
+            for (int m = 0; m < U; m++) {
+                const int id = h->index[m];
+                const int32_t k = (int32_t) (frow[id] * 100.0f + 0.5f);  // delay.cpp:32-33: the coefficient row
+                Entry &e = packed[(size_t) p * row_entries + (size_t) (m / pp.chunk) * chunk_pad + m % pp.chunk];
+                const uint32_t first = (uint32_t) (orow[id] - h->wstart);  // row element of X[off]
+                for (uint32_t c = 0; c < 4; c++)
+                    e.addr[c] = (uint32_t) (m % pp.chunk) * pp.row_bytes + ((first + c) & 3) * plane_bytes + ((first + c) >> 2) * 8;
+                std::memcpy(e.coeff, &h->fir[(size_t) k * 8], sizeof(e.coeff));
+            }
+        }
+        AWPU_HIP_TRY(hipMalloc(&h->d_fir_plane_lut, packed.size() * sizeof(Entry)));
+        AWPU_HIP_TRY(hipMemcpy(h->d_fir_plane_lut, packed.data(), packed.size() * sizeof(Entry), hipMemcpyHostToDevice));
+    }
+    const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * U * pp.wr * 2;
+    if (h->pack_cap < need) {
+        dev_free(h->d_pack);
+        h->pack_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
+        h->pack_cap = need;
+    }
+    awpu::PairArgs pa{};
+    pa.packed = h->d_pack;
+    pa.power = d_power;
+    pa.usable = U;
+    pa.usable_pad = row_entries;
+    pa.pixel_count = P;
+    pa.wp = pp.wr;
+    pa.chunk = pp.chunk;
+    pa.batch = batch;
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_pack_planes(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, U, h->d_gain, pp.wr,
+                                          batch, h->d_pack, s));
+    AWPU_HIP_TRY(awpu::launch_das_fir8_planes(pa, h->d_fir_plane_lut, chunk_pad, env().quad_variant, s));
+    return finish_launch(h, batch, s);
+}
+
 // frame-pair shape: two frames per item, for batches on grids that fill the chip
 int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_frames, int batch, float *d_power,
                  hipStream_t s, int hist_eff, int wstart_eff, int stationary_tiles = 0) {
@@ -774,9 +834,12 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     const int hist_eff = compact ? h->compact_hist : (layout == kRing ? 2048 : h->cfg.hist);
     const int wstart_eff = compact ? 0 : h->wstart;
     if (h->cfg.interp == AWPU_INTERP_FIR8 && h->cfg.math == AWPU_MATH_F32_FAST && layout != kRing && batch >= 2 &&
-        env().pairs != 0 && (long) ((h->cfg.pixel_count + 63) / 64) * ((batch + 1) / 2) >= 256 &&
-        awpu::pair_plan(h->window, h->usable(), &h->fir_plan))
-        return launch_fir8_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+        env().pairs != 0 && ((long) ((h->cfg.pixel_count + 63) / 64) * ((batch + 1) / 2) >= 256 || env().fir_planes == 2)) {
+        if (env().fir_planes && awpu::fir8_plane_plan(h->window, h->usable(), &h->fir_plane_plan))
+            return launch_fir8_planes(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+        if (awpu::pair_plan(h->window, h->usable(), &h->fir_plan))
+            return launch_fir8_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+    }
     if (h->cfg.math != AWPU_MATH_F32_FAST || h->cfg.interp == AWPU_INTERP_FIR8)
         return launch_exact(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
 
@@ -1402,6 +1465,8 @@ int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     if (!h->d_fir) AWPU_HIP_TRY(hipMalloc(&h->d_fir, 101 * 8 * sizeof(float)));
     AWPU_HIP_TRY(hipMemcpy(h->d_fir, coeffs, 101 * 8 * sizeof(float), hipMemcpyHostToDevice));
+    h->fir.assign(coeffs, coeffs + 101 * 8);
+    dev_free(h->d_fir_plane_lut);  // its entries carry the coefficients
     h->have_fir = true;
     return AWPU_OK;
 }

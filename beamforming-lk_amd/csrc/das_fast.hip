@@ -1064,6 +1064,123 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_pair_kernel(PairArgs a, cons
 }
 
 // ---------------------------------------------------------------------------------------
+// FIR8, four-plane frame-pair layout (the default for FIR8 batches): das_fir8_pair_kernel reads 32 LDS elements for
+// 32 FMAs, and the LDS array -- one per CU, 2 cycles per ds_read_b64, shared by four SIMDs that each want a
+// v_pk_fma_f32 every 4 cycles -- then holds the sweep at half the VALU rate.  Here a lane owns four CONSECUTIVE
+// outputs n = 4l..4l+3, so that the eleven samples X[e+4l .. e+4l+10] feed its 32 FMAs: 11 reads per item.  For
+// consecutive lanes to read consecutive 8-byte elements (conflict-free) whatever the delay, pack_planes_kernel
+// stores a row as four planes (sample i in plane i % 4, index i / 4); the 64-byte table entry carries the byte
+// address of each rotated plane and the item's eight coefficients.  Inner loop: sweep_fir8_planes (generated,
+// tools/gen_trip_asm.py: block_fir8).  Chunk pipeline, grid and epilogue arithmetic as in das_fir8_pair_kernel.
+// ---------------------------------------------------------------------------------------
+__global__ void pack_planes_kernel(const float *frames, int n_streams, int hist, int wstart, const int32_t *index,
+                                   const float *gain, int wp, int batch, float *packed) {
+    const int pair = blockIdx.y, s = blockIdx.x, usable = gridDim.x, plane = wp >> 2;
+    f2 *dst = (f2 *) packed + ((size_t) pair * usable + s) * wp;
+    const int fa = min(2 * pair, batch - 1), fb = min(2 * pair + 1, batch - 1);
+    const float *xa = frames + ((size_t) fa * n_streams + index[s]) * hist + wstart;
+    const float *xb = frames + ((size_t) fb * n_streams + index[s]) * hist + wstart;
+    const float gm = gain ? gain[s] : 1.0f;
+    const int valid = min(wp, hist - wstart);
+    for (int t = threadIdx.x; t < wp; t += blockDim.x)
+        dst[(t & 3) * plane + (t >> 2)] = t < valid ? f2{xa[t] * gm, xb[t] * gm} : f2{0.0f, 0.0f};
+}
+
+struct FirPlaneEntry {
+    uint32_t addr[4];  // LDS byte offset, in the chunk's image, of X[off + c] for c = 0..3 (its plane, its index)
+    uint32_t pad[4];
+    float coeff[8];    // the item's row of the coefficient table (delay.cpp:32-33)
+};
+static_assert(sizeof(FirPlaneEntry) == 64, "one s_load_dwordx16 per item");
+
+// lut: [pixel][chunk][chunk_pad] entries, chunk_pad = the chunk length rounded up to a multiple of 3 (null entries:
+// zero coefficients on row 0), a.usable_pad = entries per pixel.
+template <int VAR>
+__global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, const FirPlaneEntry *lut, int chunk_pad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, PPW = 4, kThreads = NW * 64, BUF = kFastLdsBytes;
+    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int pair = blockIdx.x, tile = blockIdx.y;
+    const int pix0 = (tile * NW + wave) * PPW;
+    const size_t row_floats = (size_t) a.wp * 2;
+    const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
+    const unsigned lane_bytes = threadIdx.x * 16;
+    auto dma_chunk = [&](int m0, int mc, int buf) {
+        const unsigned n_bytes = (unsigned) ((size_t) mc * row_floats * 4);
+        const char *src = (const char *) (pair_base + (size_t) m0 * row_floats);
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            if (lane_bytes + k * kThreads * 16 < n_bytes) {
+                const char *base = (const char *) uniform_ptr(src + k * kThreads * 16);
+                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (base + lane_bytes),
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+            }
+        }
+    };
+    f8 acc[PPW];  // acc[pp][2o], acc[pp][2o+1] = out[4l + o] of the pair's two frames
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) acc[pp] = f8{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
+    dma_chunk(0, min(a.chunk, a.usable), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c++) {
+        const int m0 = c * a.chunk;
+        const int mc = __builtin_amdgcn_readfirstlane(min(a.chunk, a.usable - m0));
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
+        const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
+        const FirPlaneEntry *row[PPW];
+#pragma unroll
+        for (int pp = 0; pp < PPW; pp++) {
+            const int p = min(pix0 + pp, a.pixel_count - 1);  // pixels past the grid repeat the last one (not stored)
+            row[pp] = (const FirPlaneEntry *) uniform_ptr(lut + (size_t) p * a.usable_pad + (size_t) c * chunk_pad);
+        }
+#ifdef AWPU_QUAD_VARIANTS
+        if constexpr (VAR == 1) sweep_fir8_planes_v1(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 2) / 3, lane_addr);
+        else if constexpr (VAR == 2) sweep_fir8_planes_v2(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 2) / 3, lane_addr);
+        else if constexpr (VAR == 3) sweep_fir8_planes_v3(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 2) / 3, lane_addr);
+        else
+#endif
+        sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 2) / 3, lane_addr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // epilogue, mimo.cpp:131-137, on consecutive outputs: the neighbours of out[4l+o] are in this lane but for the
+    // first's left one (lane l-1) and the last's right one (lane l+1)
+    const float norm = (float) (kSamples * a.usable);
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) {
+        f2 o[6];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k + 1] = f2{acc[pp][2 * k], acc[pp][2 * k + 1]};
+        o[0].x = __shfl_up(o[4].x, 1);
+        o[0].y = __shfl_up(o[4].y, 1);
+        o[5].x = __shfl_down(o[1].x, 1);
+        o[5].y = __shfl_down(o[1].y, 1);
+        f2 sum = f2{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = 4 * lane + k;
+            const f2 ma = o[k + 1] * 0.5f - 0.25f * (o[k + 2] + o[k]);
+            if (i >= 1 && i <= kSamples - 2) sum += ma * ma;
+        }
+        sum.x = wave_sum(sum.x);
+        sum.y = wave_sum(sum.y);
+        const int p = pix0 + pp;
+        if (lane == 0 && p < a.pixel_count) {
+            a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
+            if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Quad shape (the default for batches on grids whose row length is known and whose neighbouring rows mostly
 // share their integer delays): the frame-pair layout and chunk pipeline of das_pair_kernel, with the
 // arithmetic rearranged so that pixels share work and not only sample reads:
@@ -1647,6 +1764,53 @@ hipError_t launch_das_fir8_pairs(const PairArgs &a, const void *d_entries, const
     if (grid.y > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(das_fir8_pair_kernel<4>, grid, dim3(1024), lds_bytes, stream, a, (const FirEntry *) d_entries, d_coeffs);
     return hipGetLastError();
+}
+
+bool fir8_plane_plan(int window, int usable, FastPlan *plan) {
+    const int wp = (window + 3) & ~3;  // four planes of wp / 4 elements
+    const size_t row_bytes = (size_t) wp * 8;
+    int chunk = (int) ((size_t) kFastLdsBytes / row_bytes);
+    chunk &= ~3;
+    if (chunk > 64) chunk = 64;
+    if (chunk < 4) return false;
+    const int usable_pad = (usable + 3) & ~3;
+    if (chunk > usable_pad) chunk = usable_pad;
+    plan->fpi = 2;
+    plan->wr = wp;
+    plan->chunk = chunk;
+    plan->usable_pad = usable_pad;
+    plan->row_bytes = (int) row_bytes;
+    plan->image_bytes = -3;  // marks the four-plane frame-pair layout
+    return true;
+}
+
+hipError_t launch_pack_planes(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index, int usable,
+                              const float *d_gain, int wp, int batch, float *d_packed, hipStream_t stream) {
+    dim3 grid(usable, (batch + 1) / 2);
+    hipLaunchKernelGGL(pack_planes_kernel, grid, dim3(128), 0, stream, d_frames, n_streams, hist, wstart, d_index, d_gain,
+                       wp, batch, d_packed);
+    return hipGetLastError();
+}
+
+template <int VAR>
+static hipError_t launch_fir8_plane_variant(const PairArgs &a, const void *d_entries, int chunk_pad, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (hipError_t e = allow_lds((const void *) das_fir8_plane_kernel<VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
+    dim3 grid((a.batch + 1) / 2, (a.pixel_count + 63) / 64);
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(das_fir8_plane_kernel<VAR>, grid, dim3(1024), lds_bytes, stream, a, (const FirPlaneEntry *) d_entries, chunk_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, int chunk_pad, int variant, hipStream_t stream) {
+#ifdef AWPU_QUAD_VARIANTS  // tuning builds (tools/gen_trip_asm.py with QUAD_VARIANTS=1): timing-only and alternative blocks
+    if (variant == 1) return launch_fir8_plane_variant<1>(a, d_entries, chunk_pad, stream);
+    if (variant == 2) return launch_fir8_plane_variant<2>(a, d_entries, chunk_pad, stream);
+    if (variant == 3) return launch_fir8_plane_variant<3>(a, d_entries, chunk_pad, stream);
+#endif
+    (void) variant;
+    return launch_fir8_plane_variant<0>(a, d_entries, chunk_pad, stream);
 }
 
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {

@@ -68,9 +68,12 @@ def main(seed: int, cases: int) -> int:
                 eng.set_delay_table(off, frac)
                 eng.set_active_mics(index)
                 eng.set_fir_table(table)
+                gains = rng.uniform(0.5, 2.0, n_streams).astype(np.float32) if case % 3 == 1 else None
+                eng.set_mic_gains(gains)
                 power = eng.process(X)
             for b in range(batch):
-                err = util.power_rel_err(power[b], oracle_py.das_fir8_f32(X[b], off, frac, table, index))
+                Xb = X[b] * gains[:, None] if gains is not None else X[b]
+                err = util.power_rel_err(power[b], oracle_py.das_fir8_f32(Xb, off, frac, table, index))
                 worst = max(worst, err)
                 if not err < util.POWER_RTOL:
                     print(f"FAIL case {case} (fir8): streams {n_streams} hist {hist} P {P} batch {batch} usable {usable} "

@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
     {"AWPU_TEST_MATH": "exact"},                                # the exact-order kernel
     {"AWPU_TEST_PATH": "device"},                               # device-resident frames + two pixel shards per case
     {"AWPU_TEST_INTERP": "fir8"},                               # the 8-tap variant of delay()
+    {"AWPU_TEST_INTERP": "fir8", "AWPU_FIR8_PLANES": "2"},      # ... on the four-plane frame-pair kernel for every batch >= 2
     {"AWPU_TEST_REUSE": "1"},                                   # one handle re-targeted: tables, mic lists, gains
     {"AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_FAST_PAIRCOLS": "1"},  # frame pairs, vertical pixel pairs
     {"AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_FAST_DEBUG": "4096"},   # the block without read sharing
@@ -27,7 +28,7 @@ pytestmark = pytest.mark.gpu
     {"AWPU_FAST_QUADS": "0", "AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},  # pair shape on the same tables
     {"AWPU_FAST_STATIONARY": "1", "AWPU_FAST_PAIRS": "1"},                          # stationary pair shape wherever the window fits the LDS
     {"AWPU_FAST_STATIONARY": "1", "AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_FAST_QUADS": "0", "AWPU_TEST_COINCIDE": "1"},
-], ids=["pairs", "db", "small", "fpi2", "exact", "device", "fir8", "reuse", "pairs_vertical", "pairs_unshared",
+], ids=["pairs", "db", "small", "fpi2", "exact", "device", "fir8", "fir8_planes", "reuse", "pairs_vertical", "pairs_unshared",
         "quads_random", "quads_coincide", "pairs_coincide", "stationary", "stationary_grid"])
 def test_random_tables(env):
     out = subprocess.run([sys.executable, str(REPO / "tests" / "gpu_random_check.py"), "2024", "14"],

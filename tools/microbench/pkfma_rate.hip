@@ -1,0 +1,133 @@
+// pkfma_rate.hip -- what a SIMD sustains on v_pk_fma_f32 streams shaped like the sweep kernels' inner loops.
+// Build: hipcc --offload-arch=gfx950 -O3 -o pkfma_rate pkfma_rate.hip ; run on an MI355X: ./pkfma_rate
+// Each variant runs REPS x 64 instructions per wave, W waves per SIMD on every SIMD of the chip; the figure printed is
+// SIMD cycles per instruction at the 2.4 GHz the peak is quoted on (4.0 = the v_pk_fma_f32 peak).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+constexpr int REPS = 4096;
+
+// 16 accumulator pairs v[8:39], 16 sample pairs from v40 (X) ; variants pick which registers meet in one instruction
+#define BODY16(fmt_fn) fmt_fn(0) fmt_fn(1) fmt_fn(2) fmt_fn(3) fmt_fn(4) fmt_fn(5) fmt_fn(6) fmt_fn(7)
+
+template <int VAR>
+__global__ __launch_bounds__(1024) void rate_kernel(float *out, float seed) {
+    float r = 0.0f;
+    // registers are named explicitly: the point is WHICH registers an instruction reads
+    asm volatile(
+        "v_mov_b32 v8, %[s]\n\tv_mov_b32 v9, %[s]\n\tv_mov_b32 v10, %[s]\n\tv_mov_b32 v11, %[s]\n\t"
+        "v_mov_b32 v12, %[s]\n\tv_mov_b32 v13, %[s]\n\tv_mov_b32 v14, %[s]\n\tv_mov_b32 v15, %[s]\n\t"
+        "v_mov_b32 v16, %[s]\n\tv_mov_b32 v17, %[s]\n\tv_mov_b32 v18, %[s]\n\tv_mov_b32 v19, %[s]\n\t"
+        "v_mov_b32 v20, %[s]\n\tv_mov_b32 v21, %[s]\n\tv_mov_b32 v22, %[s]\n\tv_mov_b32 v23, %[s]\n\t"
+        "v_mov_b32 v40, 0\n\tv_mov_b32 v41, 0\n\tv_mov_b32 v42, 0\n\tv_mov_b32 v43, 0\n\t"
+        "v_mov_b32 v44, 0\n\tv_mov_b32 v45, 0\n\tv_mov_b32 v46, 0\n\tv_mov_b32 v47, 0\n\t"
+        "s_mov_b32 s40, 0x3f800000\n\ts_mov_b32 s41, 0x3f800000\n\t"
+        "s_mov_b32 s36, %[n]\n\t"
+        ".Lloop_%=:\n\t"
+        ".rept 8\n\t"
+        ".if %c[var] == 0\n\t"  // all VGPR, sample pair in the banks the accumulator is NOT in
+        "v_pk_fma_f32 v[8:9], v[40:41], v[42:43], v[8:9]\n\t"
+        "v_pk_fma_f32 v[10:11], v[40:41], v[44:45], v[10:11]\n\t"
+        "v_pk_fma_f32 v[12:13], v[40:41], v[46:47], v[12:13]\n\t"
+        "v_pk_fma_f32 v[14:15], v[40:41], v[44:45], v[14:15]\n\t"
+        "v_pk_fma_f32 v[16:17], v[40:41], v[42:43], v[16:17]\n\t"
+        "v_pk_fma_f32 v[18:19], v[40:41], v[44:45], v[18:19]\n\t"
+        "v_pk_fma_f32 v[20:21], v[40:41], v[46:47], v[20:21]\n\t"
+        "v_pk_fma_f32 v[22:23], v[40:41], v[44:45], v[22:23]\n\t"
+        ".elseif %c[var] == 1\n\t"  // scalar coefficient, sample pair in the accumulator's banks (v8/v40: both 0 mod 4)
+        "v_pk_fma_f32 v[8:9], s[40:41], v[40:41], v[8:9] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[10:11], s[40:41], v[42:43], v[10:11] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[44:45], v[12:13] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[14:15], s[40:41], v[46:47], v[14:15] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[40:41], v[16:17] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[18:19], s[40:41], v[42:43], v[18:19] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[44:45], v[20:21] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[22:23], s[40:41], v[46:47], v[22:23] op_sel_hi:[0,1,1]\n\t"
+        ".elseif %c[var] == 2\n\t"  // scalar coefficient, sample pair in the OTHER banks
+        "v_pk_fma_f32 v[8:9], s[40:41], v[42:43], v[8:9] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[10:11], s[40:41], v[40:41], v[10:11] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[46:47], v[12:13] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[14:15], s[40:41], v[44:45], v[14:15] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[42:43], v[16:17] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[18:19], s[40:41], v[40:41], v[18:19] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[46:47], v[20:21] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[22:23], s[40:41], v[44:45], v[22:23] op_sel_hi:[0,1,1]\n\t"
+        ".elseif %c[var] == 3\n\t"  // the same arithmetic as 16 v_fma_f32
+        "v_fma_f32 v8, s40, v42, v8\n\tv_fma_f32 v9, s40, v43, v9\n\t"
+        "v_fma_f32 v10, s40, v40, v10\n\tv_fma_f32 v11, s40, v41, v11\n\t"
+        "v_fma_f32 v12, s40, v46, v12\n\tv_fma_f32 v13, s40, v47, v13\n\t"
+        "v_fma_f32 v14, s40, v44, v14\n\tv_fma_f32 v15, s40, v45, v15\n\t"
+        "v_fma_f32 v16, s40, v42, v16\n\tv_fma_f32 v17, s40, v43, v17\n\t"
+        "v_fma_f32 v18, s40, v40, v18\n\tv_fma_f32 v19, s40, v41, v19\n\t"
+        "v_fma_f32 v20, s40, v46, v20\n\tv_fma_f32 v21, s40, v47, v21\n\t"
+        "v_fma_f32 v22, s40, v44, v22\n\tv_fma_f32 v23, s40, v45, v23\n\t"
+        ".elseif %c[var] == 4\n\t"  // scalar coefficient picked from the high dword (op_sel), other banks
+        "v_pk_fma_f32 v[8:9], s[40:41], v[42:43], v[8:9] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 v[10:11], s[40:41], v[40:41], v[10:11] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[46:47], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 v[14:15], s[40:41], v[44:45], v[14:15] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[42:43], v[16:17] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 v[18:19], s[40:41], v[40:41], v[18:19] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[46:47], v[20:21] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 v[22:23], s[40:41], v[44:45], v[22:23] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        ".elseif %c[var] == 5\n\t"  // v_pk_add_f32, other banks
+        "v_pk_add_f32 v[8:9], v[8:9], v[42:43]\n\t"
+        "v_pk_add_f32 v[10:11], v[10:11], v[40:41]\n\t"
+        "v_pk_add_f32 v[12:13], v[12:13], v[46:47]\n\t"
+        "v_pk_add_f32 v[14:15], v[14:15], v[44:45]\n\t"
+        "v_pk_add_f32 v[16:17], v[16:17], v[42:43]\n\t"
+        "v_pk_add_f32 v[18:19], v[18:19], v[40:41]\n\t"
+        "v_pk_add_f32 v[20:21], v[20:21], v[46:47]\n\t"
+        "v_pk_add_f32 v[22:23], v[22:23], v[44:45]\n\t"
+        ".endif\n\t"
+        ".endr\n\t"
+        "s_sub_u32 s36, s36, 1\n\t"
+        "s_cmp_lg_u32 s36, 0\n\t"
+        "s_cbranch_scc1 .Lloop_%=\n\t"
+        "v_add_f32 %[r], v8, v10\n\t"
+        "v_add_f32 %[r], %[r], v12\n\t"
+        "v_add_f32 %[r], %[r], v23\n\t"
+        : [r] "=v"(r)
+        : [s] "v"(seed), [n] "s"(REPS), [var] "n"(VAR)
+        : "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23",
+          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "s36", "s40", "s41", "scc");
+    if (r == 12345.0f) out[threadIdx.x] = r;
+}
+
+template <int VAR>
+static void run(const char *what, int per_instr_flops, float *d_out) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    for (int waves_per_simd : {1, 2, 4}) {
+        const int threads = 64 * 4 * waves_per_simd;  // one workgroup per CU
+        hipLaunchKernelGGL(rate_kernel<VAR>, dim3(256), dim3(threads), 0, 0, d_out, 0.0f);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(a));
+        hipLaunchKernelGGL(rate_kernel<VAR>, dim3(256), dim3(threads), 0, 0, d_out, 0.0f);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, a, b));
+        const double instr_per_simd = (double) REPS * 64 * waves_per_simd;
+        const double cyc = ms * 1e-3 * 2.4e9 / instr_per_simd;
+        const double tflops = instr_per_simd * 1024 * 64 * per_instr_flops / (ms * 1e-3) / 1e12;
+        std::printf("%-62s %d waves/SIMD: %6.3f ms  %5.2f cyc/instr  %6.1f TFLOP/s\n", what, waves_per_simd, ms, cyc, tflops);
+    }
+}
+
+int main() {
+    float *d_out;
+    CHECK(hipMalloc(&d_out, 4096));
+    run<0>("v_pk_fma_f32 all-VGPR, sample/acc in different banks", 4, d_out);
+    run<1>("v_pk_fma_f32 SGPR coeff, sample/acc in the SAME banks", 4, d_out);
+    run<2>("v_pk_fma_f32 SGPR coeff, sample/acc in different banks", 4, d_out);
+    run<4>("v_pk_fma_f32 SGPR coeff (high dword via op_sel), different banks", 4, d_out);
+    run<3>("v_fma_f32 SGPR coeff (half the work per instruction)", 2, d_out);
+    run<5>("v_pk_add_f32 different banks", 2, d_out);
+    return 0;
+}
