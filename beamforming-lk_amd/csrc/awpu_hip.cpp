@@ -638,19 +638,18 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
     };
     const awpu::FastPlan &pp = h->fir_plane_plan;
     const int U = h->usable(), P = h->cfg.pixel_count;
-    // the block sweeps triples of items: every chunk's share of a pixel's row is padded to a multiple of three
-    const int n_chunks = (U + pp.chunk - 1) / pp.chunk, chunk_pad = (pp.chunk + 2) / 3 * 3, row_entries = n_chunks * chunk_pad;
+    const int row_entries = pp.usable_pad;  // (a multiple of 4, like the chunk: the block sweeps groups of four items)
     if (!h->d_fir_plane_lut) {
         const uint32_t plane_bytes = (uint32_t) pp.row_bytes / 4;
-        // (two spare entries: the block requests entries two items ahead; null entries read row 0 with zero coefficients)
-        std::vector<Entry> packed((size_t) P * row_entries + 2, Entry{{0, plane_bytes, 2 * plane_bytes, 3 * plane_bytes}, {}, {}});
+        // (three spare entries: the block requests entries three items ahead; null entries read row 0 with zero coefficients)
+        std::vector<Entry> packed((size_t) P * row_entries + 3, Entry{{0, plane_bytes, 2 * plane_bytes, 3 * plane_bytes}, {}, {}});
         for (int p = 0; p < P; p++) {
             const int32_t *orow = &h->off[(size_t) p * h->cfg.lut_stride];
             const float *frow = &h->frac[(size_t) p * h->cfg.lut_stride];
             for (int m = 0; m < U; m++) {
                 const int id = h->index[m];
                 const int32_t k = (int32_t) (frow[id] * 100.0f + 0.5f);  // delay.cpp:32-33: the coefficient row
-                Entry &e = packed[(size_t) p * row_entries + (size_t) (m / pp.chunk) * chunk_pad + m % pp.chunk];
+                Entry &e = packed[(size_t) p * row_entries + m];
                 const uint32_t first = (uint32_t) (orow[id] - h->wstart);  // row element of X[off]
                 for (uint32_t c = 0; c < 4; c++)
                     e.addr[c] = (uint32_t) (m % pp.chunk) * pp.row_bytes + ((first + c) & 3) * plane_bytes + ((first + c) >> 2) * 8;
@@ -679,7 +678,7 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_planes(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, U, h->d_gain, pp.wr,
                                           batch, h->d_pack, s));
-    AWPU_HIP_TRY(awpu::launch_das_fir8_planes(pa, h->d_fir_plane_lut, chunk_pad, env().quad_variant, s));
+    AWPU_HIP_TRY(awpu::launch_das_fir8_planes(pa, h->d_fir_plane_lut, env().quad_variant, s));
     return finish_launch(h, batch, s);
 }
 

@@ -1093,10 +1093,10 @@ struct FirPlaneEntry {
 };
 static_assert(sizeof(FirPlaneEntry) == 64, "one s_load_dwordx16 per item");
 
-// lut: [pixel][chunk][chunk_pad] entries, chunk_pad = the chunk length rounded up to a multiple of 3 (null entries:
-// zero coefficients on row 0), a.usable_pad = entries per pixel.
+// lut: [pixel][usable_pad] entries (+ 3 spare), usable_pad and the chunk multiples of 4 (null entries: zero
+// coefficients on row 0).
 template <int VAR>
-__global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, const FirPlaneEntry *lut, int chunk_pad) {
+__global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, const FirPlaneEntry *lut) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = 16, PPW = 4, kThreads = NW * 64, BUF = kFastLdsBytes;
     constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
@@ -1139,15 +1139,14 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, con
 #pragma unroll
         for (int pp = 0; pp < PPW; pp++) {
             const int p = min(pix0 + pp, a.pixel_count - 1);  // pixels past the grid repeat the last one (not stored)
-            row[pp] = (const FirPlaneEntry *) uniform_ptr(lut + (size_t) p * a.usable_pad + (size_t) c * chunk_pad);
+            row[pp] = (const FirPlaneEntry *) uniform_ptr(lut + (size_t) p * a.usable_pad + m0);
         }
 #ifdef AWPU_QUAD_VARIANTS
-        if constexpr (VAR == 1) sweep_fir8_planes_v1(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 2) / 3, lane_addr);
-        else if constexpr (VAR == 2) sweep_fir8_planes_v2(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 2) / 3, lane_addr);
-        else if constexpr (VAR == 3) sweep_fir8_planes_v3(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 2) / 3, lane_addr);
+        if constexpr (VAR == 1) sweep_fir8_planes_v1(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr);
+        else if constexpr (VAR == 2) sweep_fir8_planes_v2(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr);
         else
 #endif
-        sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 2) / 3, lane_addr);
+        sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -1793,24 +1792,23 @@ hipError_t launch_pack_planes(const float *d_frames, int n_streams, int hist, in
 }
 
 template <int VAR>
-static hipError_t launch_fir8_plane_variant(const PairArgs &a, const void *d_entries, int chunk_pad, hipStream_t stream) {
+static hipError_t launch_fir8_plane_variant(const PairArgs &a, const void *d_entries, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_fir8_plane_kernel<VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
     dim3 grid((a.batch + 1) / 2, (a.pixel_count + 63) / 64);
     if (grid.y > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(das_fir8_plane_kernel<VAR>, grid, dim3(1024), lds_bytes, stream, a, (const FirPlaneEntry *) d_entries, chunk_pad);
+    hipLaunchKernelGGL(das_fir8_plane_kernel<VAR>, grid, dim3(1024), lds_bytes, stream, a, (const FirPlaneEntry *) d_entries);
     return hipGetLastError();
 }
 
-hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, int chunk_pad, int variant, hipStream_t stream) {
+hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, int variant, hipStream_t stream) {
 #ifdef AWPU_QUAD_VARIANTS  // tuning builds (tools/gen_trip_asm.py with QUAD_VARIANTS=1): timing-only and alternative blocks
-    if (variant == 1) return launch_fir8_plane_variant<1>(a, d_entries, chunk_pad, stream);
-    if (variant == 2) return launch_fir8_plane_variant<2>(a, d_entries, chunk_pad, stream);
-    if (variant == 3) return launch_fir8_plane_variant<3>(a, d_entries, chunk_pad, stream);
+    if (variant == 1) return launch_fir8_plane_variant<1>(a, d_entries, stream);
+    if (variant == 2) return launch_fir8_plane_variant<2>(a, d_entries, stream);
 #endif
     (void) variant;
-    return launch_fir8_plane_variant<0>(a, d_entries, chunk_pad, stream);
+    return launch_fir8_plane_variant<0>(a, d_entries, stream);
 }
 
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {

@@ -784,10 +784,10 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, un
 """
 
 
-FIR_ACC, FIR_TMP = 8, 96  # block_fir8: accumulators of the four pixels pinned at v[8:39], temps v96..v121
+FIR_ACC, FIR_TMP = 8, 88  # block_fir8: accumulators of the four pixels pinned at v[8:39], temps v88..v121
 
 
-def block_fir8(name, head=4, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
+def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
     """Four pixels of the staged chunk with the 8-tap table variant of delay() (delay.cpp:31-40) on the frame-pair
     layout stored as four sample planes (sample i of a row lives in plane i % 4 at index i / 4).
 
@@ -797,102 +797,121 @@ def block_fir8(name, head=4, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
     Sample w sits in the plane (e + w) % 4: the table entry carries the four byte addresses of the rotated planes
     c = w % 4 (4 v_add_u32 per item) and w / 4 is an immediate offset of 0, 8 or 16 bytes; consecutive lanes read
     consecutive 8-byte elements, so every read is conflict-free.  The entry also carries the item's eight
-    coefficients: one s_load_dwordx16 per item (64-byte entries), three SGPR sets in rotation, the entry two items
-    ahead requested at the head of an item.  The coefficient of tap t is the low or the high dword of an aligned
-    SGPR pair, picked by op_sel.  Taps accumulate in the reference's order t = 0..7 for every output.
+    coefficients (64-byte entries: addresses in dwords 0..3, coefficients in 8..15).  The coefficient of tap t is
+    the low or the high dword of an aligned SGPR pair, picked by op_sel.  Taps accumulate in the reference's order
+    t = 0..7 for every output.
 
-    The block sweeps its four pixels one after the other, `n3` TRIPLES of items each (the table pads every chunk
-    of a pixel's row to a multiple of three entries, so that the set rotation has the same phase for every pixel),
-    and the stream of entry requests runs on from one pixel's row into the next: a wave meets the scalar-load
-    latency once per block, not once per pixel.
+    Pipeline: four SGPR entry sets in rotation, the entry THREE items ahead requested at the head of an item (two
+    items of time before it is needed: the table streams from L2).  Scalar loads share lgkmcnt with the LDS reads
+    and return out of order, so only an lgkmcnt(0) proves an entry has landed: one per item, at its head -- and the
+    LDS reads are placed so that this drain finds nothing young in flight: samples 0..3 and 4..7 of the NEXT item
+    are requested after this item's FMAs on its own samples 0..3 (22 FMAs before the drain; samples 4..7 have two
+    register sets), samples 8..10 right after the drain (26 FMAs before their first use, waits counted in younger
+    LDS reads only).
 
-    head > 0: the reads of samples 0..head-1 of the NEXT item are issued as soon as this item has spent its own
-    (after 10 of its 32 FMAs when head = 4), so that a wave does not meet the LDS latency once per item.  Waits are
-    counted in younger LDS reads only (scalar loads share the counter but are never budgeted for, see the module
-    docstring); one lgkmcnt(0) per item, at its head, is what proves the next entry has landed."""
-    E = (36, 52, 68)
+    The block sweeps its four pixels one after the other, `n4` groups of four items each (chunks and table rows are
+    multiples of four mics; padding entries carry zero coefficients), and the stream of entry requests runs on from
+    one pixel's row into the next: a wave meets the scalar-load latency once per block, not once per pixel."""
+    E = (36, 48, 60, 72)  # 12 SGPRs per set: +0..3 plane addresses, +4..11 coefficients
     S_OFF_, S_LEFT_, S_PTR = 23, 24, 84  # s[84:85]: the row the entry requests currently run in
-    X = [tmp + 2 * w for w in range(11)]
-    VA = [tmp + 22 + c for c in range(4)]
-    n_tmp = 26
+    X03 = [tmp + 2 * w for w in range(4)]
+    X47 = [[tmp + 8 + 8 * z + 2 * w for w in range(4)] for z in range(2)]
+    X8 = [tmp + 24 + 2 * w for w in range(3)]
+    VA = [tmp + 30 + c for c in range(4)]
+    n_tmp = 34
 
     def accp(pp, o):
         b = acc + 8 * pp + 2 * o
         return f"v[{b}:{b + 1}]"
 
-    def xp(w):
-        return f"v[{X[w]}:{X[w] + 1}]"
+    def xreg(w, z):
+        return X03[w] if w < 4 else (X47[z][w - 4] if w < 8 else X8[w - 8])
+
+    def xp(w, z):
+        r = xreg(w, z)
+        return f"v[{r}:{r + 1}]"
 
     def adds(base):
         return [f"v_add_u32 v{VA[c]}, s{base + c}, %[lane]" for c in range(4)]
 
-    def read(w):
+    def read(w, z):
         off = f" offset:{8 * (w // 4)}" if w >= 4 else ""
         if timing == "nolds":  # (timing-only builds: no LDS traffic)
-            return "s_nop 0"
-        return f"ds_read_b64 {xp(w)}, v{VA[w % 4]}{off}"
+            return None
+        return f"ds_read_b64 {xp(w, z)}, v{VA[w % 4]}{off}"
 
-    def fma(pp, base, o, t, w):
-        sp = base + 8 + (t & ~1)
+    def reads(ws, z):
+        return [r for r in (read(w, z) for w in ws) if r]
+
+    def load(set_base):
+        if timing == "noload":  # (timing-only builds: the first entries over and over)
+            return []
+        return [f"s_load_dwordx4 s[{set_base}:{set_base + 3}], s[{S_PTR}:{S_PTR + 1}], s{S_OFF_}",
+                f"s_add_u32 s{S_OFF_}, s{S_OFF_}, 32",
+                f"s_load_dwordx8 s[{set_base + 4}:{set_base + 11}], s[{S_PTR}:{S_PTR + 1}], s{S_OFF_}",
+                f"s_add_u32 s{S_OFF_}, s{S_OFF_}, 32"]
+
+    def fma(pp, base, o, t, w, z):
+        sp = base + 4 + (t & ~1)
         sel = t & 1
-        return (f"v_pk_fma_f32 {accp(pp, o)}, s[{sp}:{sp + 1}], {xp(w)}, {accp(pp, o)} "
+        return (f"v_pk_fma_f32 {accp(pp, o)}, s[{sp}:{sp + 1}], {xp(w, z)}, {accp(pp, o)} "
                 f"op_sel:[{sel},0,0] op_sel_hi:[{sel},1,1]")
 
+    def fmas(pp, cur, w, z):
+        return [fma(pp, cur, o, w - o, w, z) for o in range(max(0, w - 7), min(3, w) + 1)]
+
     def item(pp, k):
-        cur, nxt, nn = E[k % 3], E[(k + 1) % 3], E[(k + 2) % 3]
-        L = ["s_waitcnt lgkmcnt(0)"]  # the entry after this one has landed (and this item's first samples)
-        if timing != "noload":  # (timing-only builds: "noload" sweeps the first three entries over and over)
-            L += [f"s_load_dwordx16 s[{nn}:{nn + 15}], s[{S_PTR}:{S_PTR + 1}], s{S_OFF_}"]
-        L += [f"s_add_u32 s{S_OFF_}, s{S_OFF_}, 64"]
-        if k == 0 and pp < 3:  # a pixel's last triple: its second and third requests are the next pixel's first entries
+        cur, nxt, far = E[k % 4], E[(k + 1) % 4], E[(k + 3) % 4]
+        z = k & 1
+        L = ["s_waitcnt lgkmcnt(0)"]  # the next entry has landed; so have this item's samples 0..7 (requested long ago)
+        L += load(far)
+        if k == 0 and pp < 3:  # a pixel's last group: its other three requests are the next pixel's first entries
             L += [f"s_cmp_eq_u32 s{S_LEFT_}, 1", f"s_cselect_b64 s[{S_PTR}:{S_PTR + 1}], %[row{pp + 1}], s[{S_PTR}:{S_PTR + 1}]",
                   f"s_cselect_b32 s{S_OFF_}, 0, s{S_OFF_}"]
-        if not head:
-            L += adds(cur)
-        L += [read(w) for w in range(head, 11)]
-        younger = 10 - head  # LDS reads younger than sample `head`'s (the head group landed with the lgkmcnt(0) above)
-        for w in range(11):
-            if w >= head:
+        L += reads(range(8, 11), z)
+        for w in range(4):
+            L += fmas(pp, cur, w, z)
+        L += adds(nxt) + reads(range(0, 4), z ^ 1) + reads(range(4, 8), z ^ 1)
+        for w in range(4, 8):
+            L += fmas(pp, cur, w, z)
+        younger = 10  # samples 9, 10 and the next item's 0..7
+        for w in range(8, 11):
+            if timing != "nolds":
                 L.append(f"s_waitcnt lgkmcnt({younger})")
-                younger -= 1
-            for o in range(max(0, w - 7), min(3, w) + 1):
-                L.append(fma(pp, cur, o, w - o, w))
-            if head and w == head - 1:  # samples 0..head-1 are spent: the next item's first reads take their registers
-                L += adds(nxt) + [read(x) for x in range(head)]
-                younger += head
+            younger -= 1
+            L += fmas(pp, cur, w, z)
         return L
 
-    L = [f"s_mov_b64 s[{S_PTR}:{S_PTR + 1}], %[row0]",
-         f"s_load_dwordx16 s[{E[0]}:{E[0] + 15}], s[{S_PTR}:{S_PTR + 1}], 0x0",
-         f"s_load_dwordx16 s[{E[1]}:{E[1] + 15}], s[{S_PTR}:{S_PTR + 1}], 0x40"]
-    if timing == "noload":
-        L += [f"s_load_dwordx16 s[{E[2]}:{E[2] + 15}], s[{S_PTR}:{S_PTR + 1}], 0x80"]
-    L += [f"s_movk_i32 s{S_OFF_}, 0x80", "s_waitcnt lgkmcnt(0)"]
-    if head:
-        L += adds(E[0]) + [read(x) for x in range(head)]
+    L = [f"s_mov_b64 s[{S_PTR}:{S_PTR + 1}], %[row0]", f"s_mov_b32 s{S_OFF_}, 0"]
+    keep = timing
+    timing = ""
+    for k in range(4 if keep == "noload" else 3):
+        L += load(E[k])
+    timing = keep
+    L += ["s_waitcnt lgkmcnt(0)"] + adds(E[0]) + reads(range(0, 4), 0) + reads(range(4, 8), 0)
     for pp in range(4):
-        L += [f"s_mov_b32 s{S_LEFT_}, %[n3]", f".LF{pp}_%=:"]
-        for k in range(3):
+        L += [f"s_mov_b32 s{S_LEFT_}, %[n4]", f".LF{pp}_%=:"]
+        for k in range(4):
             L += item(pp, k)
         L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", f"s_cbranch_scc1 .LF{pp}_%="]
     L += ["s_waitcnt lgkmcnt(0)"]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
     vregs = list(range(tmp, tmp + n_tmp))
-    sregs = [S_OFF_, S_LEFT_, S_PTR, S_PTR + 1] + list(range(E[0], E[2] + 16))
+    sregs = [S_OFF_, S_LEFT_, S_PTR, S_PTR + 1] + list(range(E[0], E[3] + 12))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
     acc_params = ", ".join(f"f8 &A{pp}" for pp in range(4))
     acc_ops = ", ".join(f'"+{{v[{acc + 8 * pp}:{acc + 8 * pp + 7}]}}"(A{pp})' for pp in range(4))
     rows = ", ".join(f'[row{pp}] "s"(row{pp})' for pp in range(4))
     return f"""// Four pixels of the staged chunk, 8-tap variant, four-plane frame-pair layout: see block_fir8 in
-// tools/gen_trip_asm.py.  row0..row3 = the pixels' 64-byte entries from the chunk's first mic (the chunk's share of
-// a row padded with null entries to 3 * n3); reads two entries past the last swept one of row3.  n3 >= 1.
+// tools/gen_trip_asm.py.  row0..row3 = the pixels' 64-byte entries from the chunk's first mic; sweeps 4 * n4 entries
+// of each (n4 >= 1) and reads three entries past the last swept one of row3.
 // Accumulators (outputs 4l..4l+3, two frames each) pinned at v[{acc}:{acc + 31}], temps v{vregs[0]}..v{vregs[-1]}.
 __device__ __forceinline__ void {name}({acc_params}, const void *row0, const void *row1, const void *row2,
-                                       const void *row3, int n3, unsigned lane_addr) {{
+                                       const void *row3, int n4, unsigned lane_addr) {{
     asm volatile(
 {body}
         : {acc_ops}
-        : {rows}, [n3] "s"(n3), [lane] "v"(lane_addr)
+        : {rows}, [n4] "s"(n4), [lane] "v"(lane_addr)
         : {clobbers});
 }}
 """
@@ -921,11 +940,10 @@ def main():
     if os.environ.get("QUAD_VARIANTS"):  # tuning builds: the priority schemes side by side (AWPU_QUAD_VARIANT picks)
         for v in (0, 3, 4):
             out.append(block_quad(f"sweep_quad_sum_v{v}", prio=v))
-    out.append(block_fir8("sweep_fir8_planes", head=int(os.environ.get("FIR8_HEAD", "4"))))
+    out.append(block_fir8("sweep_fir8_planes"))
     if os.environ.get("QUAD_VARIANTS"):  # tuning builds: what the block costs without its scalar loads / its LDS reads / the read-ahead
         out.append(block_fir8("sweep_fir8_planes_v1", timing="noload"))
         out.append(block_fir8("sweep_fir8_planes_v2", timing="nolds"))
-        out.append(block_fir8("sweep_fir8_planes_v3", head=0))
     lo = 80 - (4 * (DEPTH + 1) + 1) - 3  # shapes with an 80-VGPR budget (6 waves per SIMD)
     out.append(block("sweep_quad_lo", 4, lo))
     out.append(block("sweep_quad_lo_stamped", 4, lo, stamp=True))

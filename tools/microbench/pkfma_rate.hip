@@ -16,6 +16,8 @@ constexpr int REPS = 4096;
 
 template <int VAR>
 __global__ __launch_bounds__(1024) void rate_kernel(float *out, float seed) {
+    __shared__ float lds_buf[2048];  // (variant 7 reads it; the values do not matter)
+    if (seed == 54321.0f) lds_buf[threadIdx.x] = seed;
     float r = 0.0f;
     // registers are named explicitly: the point is WHICH registers an instruction reads
     asm volatile(
@@ -27,6 +29,8 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, float seed) {
         "v_mov_b32 v44, 0\n\tv_mov_b32 v45, 0\n\tv_mov_b32 v46, 0\n\tv_mov_b32 v47, 0\n\t"
         "s_mov_b32 s40, 0x3f800000\n\ts_mov_b32 s41, 0x3f800000\n\t"
         "s_mov_b32 s36, %[n]\n\t"
+        "s_mov_b32 s37, 0\n\t"
+        "v_lshlrev_b32 v56, 3, %[tid]\n\t"
         ".Lloop_%=:\n\t"
         ".rept 8\n\t"
         ".if %c[var] == 0\n\t"  // all VGPR, sample pair in the banks the accumulator is NOT in
@@ -83,6 +87,41 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, float seed) {
         "v_pk_add_f32 v[18:19], v[18:19], v[40:41]\n\t"
         "v_pk_add_f32 v[20:21], v[20:21], v[46:47]\n\t"
         "v_pk_add_f32 v[22:23], v[22:23], v[44:45]\n\t"
+        ".elseif %c[var] == 6\n\t"  // variant 2 with scalar work between the FMAs, as a sweep block has it (8 FMAs + 4 others)
+        "v_pk_fma_f32 v[8:9], s[40:41], v[42:43], v[8:9] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[10:11], s[40:41], v[40:41], v[10:11] op_sel_hi:[0,1,1]\n\t"
+        "s_add_u32 s37, s37, 1\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[46:47], v[12:13] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[14:15], s[40:41], v[44:45], v[14:15] op_sel_hi:[0,1,1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[42:43], v[16:17] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[18:19], s[40:41], v[40:41], v[18:19] op_sel_hi:[0,1,1]\n\t"
+        "s_cmp_eq_u32 s37, 0\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[46:47], v[20:21] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[22:23], s[40:41], v[44:45], v[22:23] op_sel_hi:[0,1,1]\n\t"
+        "s_cselect_b32 s38, 0, s37\n\t"
+        ".elseif %c[var] == 7\n\t"  // variant 2 with LDS reads between the FMAs (3 per 8: the FIR8 plane block's ratio)
+        "v_pk_fma_f32 v[8:9], s[40:41], v[42:43], v[8:9] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[10:11], s[40:41], v[40:41], v[10:11] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b64 v[48:49], v56\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[46:47], v[12:13] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[14:15], s[40:41], v[44:45], v[14:15] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b64 v[50:51], v56 offset:512\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[42:43], v[16:17] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[18:19], s[40:41], v[40:41], v[18:19] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b64 v[52:53], v56 offset:1024\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[46:47], v[20:21] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[22:23], s[40:41], v[44:45], v[22:23] op_sel_hi:[0,1,1]\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        ".elseif %c[var] == 8\n\t"  // variant 2 with one dependent pair per 8 (the same accumulator twice in a row)
+        "v_pk_fma_f32 v[8:9], s[40:41], v[42:43], v[8:9] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[8:9], s[40:41], v[40:41], v[8:9] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[46:47], v[12:13] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[44:45], v[12:13] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[42:43], v[16:17] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[40:41], v[16:17] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[46:47], v[20:21] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[44:45], v[20:21] op_sel_hi:[0,1,1]\n\t"
         ".endif\n\t"
         ".endr\n\t"
         "s_sub_u32 s36, s36, 1\n\t"
@@ -92,9 +131,10 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, float seed) {
         "v_add_f32 %[r], %[r], v12\n\t"
         "v_add_f32 %[r], %[r], v23\n\t"
         : [r] "=v"(r)
-        : [s] "v"(seed), [n] "s"(REPS), [var] "n"(VAR)
+        : [s] "v"(seed), [n] "s"(REPS), [var] "n"(VAR), [tid] "v"(threadIdx.x & 63)
         : "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23",
-          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "s36", "s40", "s41", "scc");
+          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v56", "s36", "s37", "s38",
+          "s40", "s41", "scc");
     if (r == 12345.0f) out[threadIdx.x] = r;
 }
 
@@ -129,5 +169,9 @@ int main() {
     run<4>("v_pk_fma_f32 SGPR coeff (high dword via op_sel), different banks", 4, d_out);
     run<3>("v_fma_f32 SGPR coeff (half the work per instruction)", 2, d_out);
     run<5>("v_pk_add_f32 different banks", 2, d_out);
+    std::printf("-- the figures below count the packed FMAs only (8 per group) --\n");
+    run<6>("8 v_pk_fma_f32 + 4 scalar instructions (add, waitcnt, cmp, cselect)", 4, d_out);
+    run<7>("8 v_pk_fma_f32 + 3 ds_read_b64 + 1 counted waitcnt", 4, d_out);
+    run<8>("8 v_pk_fma_f32, each accumulator twice in a row", 4, d_out);
     return 0;
 }
