@@ -101,32 +101,40 @@ def launcher_selftest(mode: str) -> None:
 # ------------------------------------------------------------------------------------------ legs
 
 
-def cpu_baseline(spec, off, frac, frame, seconds):
+def cpu_baseline(spec, off, frac, frame, seconds, interp="lerp"):
     """The reference's own delay() (oracle/_ref) in the loop nest of mimo.cpp:121-151, one
-    thread, whole frames of the same workload until `seconds` have passed."""
+    thread, whole frames of the same workload until `seconds` have passed.  interp "fir8": the reference built
+    without -mavx2, whose delay() is the 8-tap variant (delay.cpp:31-40) on its own filter.h table."""
     from oracle import oracle_py
 
-    kind = "reference" if oracle_py.ref_available() else "port"
+    variant = "fir" if interp == "fir8" else "avx2"
+    kind = "reference" if oracle_py.ref_available(variant) else "port"
     if kind == "reference":
-        fps, frames = oracle_py.ref_bench(frame, off, frac, None, min_seconds=seconds)
+        fps, frames = oracle_py.ref_bench(frame, off, frac, None, min_seconds=seconds, variant=variant)
     else:
+        table = synthetic_fir_table()
         t0 = time.perf_counter()
         frames = 0
         while True:
-            oracle_py.das_f32(frame, off, frac)
+            if interp == "fir8":
+                oracle_py.das_fir8_f32(frame, off, frac, table)
+            else:
+                oracle_py.das_f32(frame, off, frac)
             frames += 1
             if time.perf_counter() - t0 >= seconds:
                 break
         fps = frames / (time.perf_counter() - t0)
+    flags = "-Ofast -ffast-math, no -mavx2: the 8-tap variant" if interp == "fir8" else "-Ofast -ffast-math -mavx2 -mfma"
     out = {
         "value": fps, "unit": "frames/s", "cores": 1, "kind": kind,
         "sample": f"{frames} whole frames of the same workload ({spec.name}), 1 thread, {os.cpu_count()} host cores "
-                  f"present; the reference's delay.cpp compiled with its own flags (-Ofast -ffast-math -mavx2 -mfma) "
+                  f"present; the reference's delay.cpp compiled with its own flags ({flags}) "
                   f"minus -march=native, so that one .so runs on any host (its AVX2 intrinsics need no more)",
     }
     if kind == "reference":  # beside it: the same kernel with the pixels dealt to the box's CPU share
         threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()))
-        fps_mt, frames_mt, _ = oracle_py.ref_bench_mt(frame, off, frac, threads, min_seconds=max(2.0, seconds / 4))
+        fps_mt, frames_mt, _ = oracle_py.ref_bench_mt(frame, off, frac, threads, min_seconds=max(2.0, seconds / 4),
+                                                      variant=variant)
         out["multi_thread"] = {"value": fps_mt, "unit": "frames/s", "cores": threads,
                                "sample": f"{frames_mt} whole frames, pixels dealt to {threads} threads (the reference's "
                                          f"MIMO worker itself is one thread)"}
@@ -474,7 +482,7 @@ def main():
         eng16.close()
 
     if world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(spec, off, frac, host_first[0], args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(spec, off, frac, host_first[0], args.cpu_seconds, args.interp)
         out["cpu_baseline"]["pixels"] = int(shard.pixel_count)
         out["speedup_vs_cpu_1t"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:

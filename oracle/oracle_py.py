@@ -279,25 +279,26 @@ def delay_fir8(out, signal, fraction, coeffs):
     return out
 
 
-def ref_bench(X, off, frac, index=None, min_seconds=1.0):
-    """frames/s of the reference-kernel loop nest on one thread over the P pixels of `off`."""
+def ref_bench(X, off, frac, index=None, min_seconds=1.0, variant="avx2"):
+    """frames/s of the reference-kernel loop nest on one thread over the P pixels of `off` (variant "fir": the
+    build without -mavx2, whose delay() is the 8-tap table variant)."""
     X, off, frac, index = _sweep_args(X, off, frac, index)
     P = off.shape[0]
     power = np.empty(P, np.float32)
     done = C.c_int(0)
-    fps = ref("avx2").ref_das_bench(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1],
+    fps = ref(variant).ref_das_bench(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1],
                                     _pi(index), index.size, _p32(power), float(min_seconds), C.byref(done))
     return fps, done.value
 
 
-def ref_bench_mt(X, off, frac, threads, index=None, min_seconds=1.0):
+def ref_bench_mt(X, off, frac, threads, index=None, min_seconds=1.0, variant="avx2"):
     """frames/s of the same loop nest with the pixels dealt to `threads` host threads (the reference itself
     runs one); also returns the power it computed, for a check against the one-thread result."""
     X, off, frac, index = _sweep_args(X, off, frac, index)
     P = off.shape[0]
     power = np.empty(P, np.float32)
     done = C.c_int(0)
-    fps = ref("avx2").ref_das_bench_mt(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index),
+    fps = ref(variant).ref_das_bench_mt(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index),
                                        index.size, _p32(power), float(min_seconds), int(threads), C.byref(done))
     return fps, done.value, power
 
