@@ -332,6 +332,29 @@ def test_fir8_golden_vectors(pkg, name):
     assert util.power_rel_err(power, g["power"]) < util.POWER_RTOL
 
 
+@pytest.mark.parametrize("name", FIR8_SWEEPS)
+def test_fir8_golden_vectors_on_the_batch_kernel(pkg, name):
+    """The same reference-produced powers through the kernel FIR8 BATCHES run (das_fir8_plane_kernel: four-plane
+    frame-pair layout, taken once a launch has >= 256 workgroups): the golden's pixels repeated until the grid is
+    that large, two frames (the golden's frame twice) -- every copy of a pixel, in both frames, must give the
+    reference's power."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    ax, ay = g["arrays"]
+    n = 64 * int(ax) * int(ay)
+    X = util.hash_frames(n, int(g["hist"]), seed=int(g["seed"]))[0]
+    P = g["off"].shape[0]
+    reps = -(-(256 * 64 + 1) // P)
+    off, frac = np.tile(g["off"], (reps, 1)), np.tile(g["frac"], (reps, 1))
+    with pkg.Engine(n_pixels=P * reps, n_streams=n, hist=int(g["hist"]), interp=pkg.binding.INTERP_FIR8, max_batch=2) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(g["index"])
+        eng.set_fir_table(measured_fir_table())
+        power = eng.process(np.stack([X, X]))
+    want = np.tile(g["power"], reps)
+    for b in range(2):
+        assert util.power_rel_err(power[b], want) < util.POWER_RTOL
+
+
 @pytest.mark.parametrize("table_kind", ["synthetic", "reference"])
 def test_fir8_mode_vs_oracle(pkg, oracle, table_kind):
     """AWPU_INTERP_FIR8 (delay.cpp:31-40): GPU vs the restated FIR sweep, 64 and 256 mics, with a
@@ -358,7 +381,7 @@ def test_fir8_mode_vs_oracle(pkg, oracle, table_kind):
 
 
 def test_fir8_batched_frame_pair_shape(pkg, oracle):
-    """AWPU_INTERP_FIR8 on a full grid with a batch: the frame-pair FIR8 sweep (das_fir8_pair_kernel).  One 8x8 array,
+    """AWPU_INTERP_FIR8 on a full grid with a batch: the frame-pair FIR8 sweep (das_fir8_plane_kernel).  One 8x8 array,
     128x128 grid, three frames (an odd batch: the last pair is half empty), a ragged mic list; sampled pixels against
     the restated FIR sweep with the reference's measured table, and whole frames against the single-frame calls
     (the exact-structure kernel: same taps in the same order, same bits before the epilogue)."""
