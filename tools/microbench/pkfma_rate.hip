@@ -143,12 +143,13 @@ static void run(const char *what, int per_instr_flops, float *d_out) {
     hipEvent_t a, b;
     CHECK(hipEventCreate(&a));
     CHECK(hipEventCreate(&b));
-    for (int waves_per_simd : {1, 2, 4}) {
-        const int threads = 64 * 4 * waves_per_simd;  // one workgroup per CU
-        hipLaunchKernelGGL(rate_kernel<VAR>, dim3(256), dim3(threads), 0, 0, d_out, 0.0f);
+    for (int waves_per_simd : {1, 2, 4, 8}) {
+        const int threads = 64 * 4 * (waves_per_simd > 4 ? 4 : waves_per_simd);  // one workgroup per CU (two for 8 waves)
+        const int wgs = waves_per_simd > 4 ? 512 : 256;
+        hipLaunchKernelGGL(rate_kernel<VAR>, dim3(wgs), dim3(threads), 0, 0, d_out, 0.0f);
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(a));
-        hipLaunchKernelGGL(rate_kernel<VAR>, dim3(256), dim3(threads), 0, 0, d_out, 0.0f);
+        hipLaunchKernelGGL(rate_kernel<VAR>, dim3(wgs), dim3(threads), 0, 0, d_out, 0.0f);
         CHECK(hipEventRecord(b));
         CHECK(hipEventSynchronize(b));
         float ms = 0;
