@@ -641,8 +641,9 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
     const int row_entries = pp.usable_pad;  // (a multiple of 4, like the chunk: the block sweeps groups of four items)
     if (!h->d_fir_plane_lut) {
         const uint32_t plane_bytes = (uint32_t) pp.row_bytes / 4;
-        // (three spare entries: the block requests entries three items ahead; null entries read row 0 with zero coefficients)
-        std::vector<Entry> packed((size_t) P * row_entries + 3, Entry{{0, plane_bytes, 2 * plane_bytes, 3 * plane_bytes}, {}, {}});
+        // (three spare entries: the block requests entries three items ahead -- and 16 more: its L2 prefetch touches
+        // whole KiB pieces; null entries read row 0 with zero coefficients)
+        std::vector<Entry> packed((size_t) P * row_entries + 3 + 16, Entry{{0, plane_bytes, 2 * plane_bytes, 3 * plane_bytes}, {}, {}});
         for (int p = 0; p < P; p++) {
             const int32_t *orow = &h->off[(size_t) p * h->cfg.lut_stride];
             const float *frow = &h->frac[(size_t) p * h->cfg.lut_stride];
@@ -832,8 +833,11 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     const bool compact = layout == kCompact;
     const int hist_eff = compact ? h->compact_hist : (layout == kRing ? 2048 : h->cfg.hist);
     const int wstart_eff = compact ? 0 : h->wstart;
-    if (h->cfg.interp == AWPU_INTERP_FIR8 && h->cfg.math == AWPU_MATH_F32_FAST && layout != kRing && batch >= 2 &&
-        env().pairs != 0 && ((long) ((h->cfg.pixel_count + 63) / 64) * ((batch + 1) / 2) >= 256 || env().fir_planes == 2)) {
+    // FIR8 with fast math on a launch that fills the chip: the frame-pair kernels.  A single frame (or the odd last
+    // one) is swept as a pair with itself -- half the packed lanes idle, still 1.6 x the rate of das_fir8_kernel.
+    const long fir_wgs = (long) ((h->cfg.pixel_count + 63) / 64) * ((batch + 1) / 2);
+    if (h->cfg.interp == AWPU_INTERP_FIR8 && h->cfg.math == AWPU_MATH_F32_FAST && env().pairs != 0 &&
+        (fir_wgs >= (batch >= 2 ? 256 : 192) || (env().fir_planes == 2 && batch >= 2))) {
         if (env().fir_planes && awpu::fir8_plane_plan(h->window, h->usable(), &h->fir_plane_plan))
             return launch_fir8_planes(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
         if (awpu::pair_plan(h->window, h->usable(), &h->fir_plan))

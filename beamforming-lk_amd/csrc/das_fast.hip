@@ -1141,12 +1141,16 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, con
             const int p = min(pix0 + pp, a.pixel_count - 1);  // pixels past the grid repeat the last one (not stored)
             row[pp] = (const FirPlaneEntry *) uniform_ptr(lut + (size_t) p * a.usable_pad + m0);
         }
+        // the block also touches the next chunk's entries of its pixels (whole KiB pieces from the chunk's end on)
+        const unsigned pfoff = (unsigned) a.chunk * 64u + lane * 16u;
+        const int pfn = c + 1 < n_chunks ? (min(a.chunk, a.usable - m0 - a.chunk) * 64 + 1023) / 1024 : 0;
 #ifdef AWPU_QUAD_VARIANTS
-        if constexpr (VAR == 1) sweep_fir8_planes_v1(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr);
-        else if constexpr (VAR == 2) sweep_fir8_planes_v2(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr);
+        if constexpr (VAR == 1) sweep_fir8_planes_v1(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, pfoff, pfn);
+        else if constexpr (VAR == 2) sweep_fir8_planes_v2(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, pfoff, pfn);
+        else if constexpr (VAR == 3) sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, pfoff, 0);
         else
 #endif
-        sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr);
+        sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, pfoff, pfn);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -1806,6 +1810,7 @@ hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, int 
 #ifdef AWPU_QUAD_VARIANTS  // tuning builds (tools/gen_trip_asm.py with QUAD_VARIANTS=1): timing-only and alternative blocks
     if (variant == 1) return launch_fir8_plane_variant<1>(a, d_entries, stream);
     if (variant == 2) return launch_fir8_plane_variant<2>(a, d_entries, stream);
+    if (variant == 3) return launch_fir8_plane_variant<3>(a, d_entries, stream);  // no table prefetch
 #endif
     (void) variant;
     return launch_fir8_plane_variant<0>(a, d_entries, stream);

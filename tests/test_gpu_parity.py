@@ -651,6 +651,39 @@ def test_single_frames_on_the_headline_grid(pkg, oracle):
     assert float((np.abs(from_host[pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
 
 
+def test_fir8_single_frames_on_the_headline_grid(pkg, oracle):
+    """AWPU_INTERP_FIR8, one frame per call on the full headline grid: such a launch fills the chip, so it runs the
+    batch kernel (das_fir8_plane_kernel) with the frame paired with itself.  From a host buffer, from the ingest
+    ring (row pitch 2048) and as a member of a batch: the same powers to rounding, and the oracle's on sampled pixels."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["headline"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    off = np.minimum(off, 1024 - 263).astype(np.int32)  # (the 8-tap variant reads 6 samples further than the table was made for)
+    table = measured_fir_table()
+    rng = np.random.default_rng(5)
+    ring = np.zeros((spec.n_mics, 1024), np.float32)
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=3, grid_columns=spec.res,
+                    interp=pkg.binding.INTERP_FIR8) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        eng.set_fir_table(table)
+        for b in range(4):
+            stream = rng.integers(-(1 << 21), 1 << 21, size=(256, 256), dtype=np.int32)
+            eng.ingest_block(make_datagrams(stream, counter0=256 * b, n_arrays=4))
+            ring = np.concatenate([ring[:, 256:], oracle.unpack_exposure(stream, spec.n_mics)], axis=1)
+        from_ring = eng.process_ring()
+        from_host = eng.process(ring)
+        batched = eng.process(np.stack([ring, 2.0 * ring, ring]))
+    assert util.power_rel_err(from_ring, from_host) < 2e-6
+    assert util.power_rel_err(batched[0], from_host) < 2e-6 and np.array_equal(batched[1], 4.0 * batched[0])
+    assert util.power_rel_err(batched[2], from_host) < 2e-6  # the odd last frame of a batch
+    pick = np.random.default_rng(6).choice(spec.n_pixels, 100, replace=False)
+    want = oracle.das_fir8_f32(ring, off[pick], frac[pick], table)
+    floor = util.NULL_FLOOR * float(from_host.max())
+    assert float((np.abs(from_host[pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+
+
 @pytest.mark.parametrize("wl,batch", [("headline", 4), ("c3", 2)])
 def test_full_size_properties(pkg, oracle, wl, batch):
     """BASELINE's full sizes (256 mics x 128x128, 512 mics x 128x128), where the oracle would take

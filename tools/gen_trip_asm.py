@@ -819,6 +819,7 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
     X8 = [tmp + 24 + 2 * w for w in range(3)]
     VA = [tmp + 30 + c for c in range(4)]
     n_tmp = 34
+    SINK = tmp - 4  # v[84:87]: destination of the table prefetch (never read)
 
     def accp(pp, o):
         b = acc + 8 * pp + 2 * o
@@ -883,6 +884,13 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
         return L
 
     L = [f"s_mov_b64 s[{S_PTR}:{S_PTR + 1}], %[row0]", f"s_mov_b32 s{S_OFF_}, 0"]
+    # warm the L2 with the NEXT chunk's entries of these four pixels (pfn pieces of 1 KiB per pixel from pfoff =
+    # chunk bytes + 16 * lane; 0 = last chunk): plain loads into a sink nobody reads, drained at the block's end.
+    # A scalar load that misses the L2 costs the wave more than the two items of lead the requests have.
+    for k in range(4):
+        L += [f"s_cmp_lt_u32 %[pfn], {k + 1}", "s_cbranch_scc1 .LFpf_%="]
+        L += [f"global_load_dwordx4 v[{SINK}:{SINK + 3}], %[pfoff], %[row{pp}] offset:{1024 * k}" for pp in range(4)]
+    L += [".LFpf_%=:"]
     keep = timing
     timing = ""
     for k in range(4 if keep == "noload" else 3):
@@ -894,9 +902,9 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
         for k in range(4):
             L += item(pp, k)
         L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", f"s_cbranch_scc1 .LF{pp}_%="]
-    L += ["s_waitcnt lgkmcnt(0)"]
+    L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
-    vregs = list(range(tmp, tmp + n_tmp))
+    vregs = list(range(SINK, tmp + n_tmp))
     sregs = [S_OFF_, S_LEFT_, S_PTR, S_PTR + 1] + list(range(E[0], E[3] + 12))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
     acc_params = ", ".join(f"f8 &A{pp}" for pp in range(4))
@@ -904,14 +912,15 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
     rows = ", ".join(f'[row{pp}] "s"(row{pp})' for pp in range(4))
     return f"""// Four pixels of the staged chunk, 8-tap variant, four-plane frame-pair layout: see block_fir8 in
 // tools/gen_trip_asm.py.  row0..row3 = the pixels' 64-byte entries from the chunk's first mic; sweeps 4 * n4 entries
-// of each (n4 >= 1) and reads three entries past the last swept one of row3.
+// of each (n4 >= 1) and reads three entries past the last swept one of row3; pfn > 0: also touches pfn KiB from
+// byte pfoff of every row (the next chunk's entries: an L2 prefetch).
 // Accumulators (outputs 4l..4l+3, two frames each) pinned at v[{acc}:{acc + 31}], temps v{vregs[0]}..v{vregs[-1]}.
 __device__ __forceinline__ void {name}({acc_params}, const void *row0, const void *row1, const void *row2,
-                                       const void *row3, int n4, unsigned lane_addr) {{
+                                       const void *row3, int n4, unsigned lane_addr, unsigned pfoff, int pfn) {{
     asm volatile(
 {body}
         : {acc_ops}
-        : {rows}, [n4] "s"(n4), [lane] "v"(lane_addr)
+        : {rows}, [n4] "s"(n4), [lane] "v"(lane_addr), [pfoff] "v"(pfoff), [pfn] "s"(pfn)
         : {clobbers});
 }}
 """
