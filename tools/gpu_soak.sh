@@ -1,0 +1,30 @@
+#!/bin/bash
+# broader randomised parity sweep than the test suite runs: every forced kernel shape of tests/test_gpu_random.py
+# with other seeds and more cases (run under gpurun; prints one line per shape and seed)
+set -uo pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export AWPU_NO_BUILD=1
+fail=0
+run() {  # run <label> <seed> <cases> ENV=VAL...
+  local label=$1 seed=$2 cases=$3; shift 3
+  if out=$(env "$@" timeout -k 10 300 python tests/gpu_random_check.py "$seed" "$cases" 2>&1); then
+    echo "ok   $label seed $seed: $(echo "$out" | tail -1)"
+  else
+    echo "FAIL $label seed $seed: $(echo "$out" | tail -3)"; fail=1
+  fi
+}
+for seed in ${SEEDS:-11 12 13}; do
+  run pairs $seed 20 AWPU_FAST_PAIRS=1
+  run quads_random $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1
+  run quads_coincide $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
+  run stationary $seed 20 AWPU_FAST_STATIONARY=1 AWPU_FAST_PAIRS=1
+  run stationary_grid $seed 20 AWPU_FAST_STATIONARY=1 AWPU_FAST_PAIRS=1 AWPU_TEST_GRID=1 AWPU_FAST_QUADS=0 AWPU_TEST_COINCIDE=1
+  run fir8_planes $seed 20 AWPU_TEST_INTERP=fir8 AWPU_FIR8_PLANES=2
+  run fir8 $seed 12 AWPU_TEST_INTERP=fir8
+  run default_grid $seed 20 AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
+  run default $seed 20 X=1
+  run device $seed 12 AWPU_TEST_PATH=device
+  run reuse $seed 10 AWPU_TEST_REUSE=1
+  run exact $seed 10 AWPU_TEST_MATH=exact
+done
+exit $fail
