@@ -31,6 +31,7 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, float seed) {
         "s_mov_b32 s36, %[n]\n\t"
         "s_mov_b32 s37, 0\n\t"
         "v_lshlrev_b32 v56, 3, %[tid]\n\t"
+        "v_lshlrev_b32 v57, 4, %[tid]\n\t"
         ".Lloop_%=:\n\t"
         ".rept 8\n\t"
         ".if %c[var] == 0\n\t"  // all VGPR, sample pair in the banks the accumulator is NOT in
@@ -113,6 +114,56 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, float seed) {
         "v_pk_fma_f32 v[20:21], s[40:41], v[46:47], v[20:21] op_sel_hi:[0,1,1]\n\t"
         "v_pk_fma_f32 v[22:23], s[40:41], v[44:45], v[22:23] op_sel_hi:[0,1,1]\n\t"
         "s_waitcnt lgkmcnt(3)\n\t"
+        ".elseif %c[var] == 9\n\t"  // the same bytes as variant 7 in one ds_read_b128 (16-byte aligned) + one ds_read_b64
+        "v_pk_fma_f32 v[8:9], s[40:41], v[42:43], v[8:9] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[10:11], s[40:41], v[40:41], v[10:11] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b128 v[48:51], v57\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[46:47], v[12:13] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[14:15], s[40:41], v[44:45], v[14:15] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[42:43], v[16:17] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[18:19], s[40:41], v[40:41], v[18:19] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b64 v[52:53], v56 offset:4096\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[46:47], v[20:21] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[22:23], s[40:41], v[44:45], v[22:23] op_sel_hi:[0,1,1]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        ".elseif %c[var] == 12\n\t"  // variant 9 with the ds_read_b128 only 8-byte aligned (an odd element offset)
+        "v_pk_fma_f32 v[8:9], s[40:41], v[42:43], v[8:9] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[10:11], s[40:41], v[40:41], v[10:11] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b128 v[48:51], v57 offset:8\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[46:47], v[12:13] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[14:15], s[40:41], v[44:45], v[14:15] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[42:43], v[16:17] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[18:19], s[40:41], v[40:41], v[18:19] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b64 v[52:53], v56 offset:4096\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[46:47], v[20:21] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[22:23], s[40:41], v[44:45], v[22:23] op_sel_hi:[0,1,1]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        ".elseif %c[var] == 10\n\t"  // four elements in two ds_read2_b64 (elements 512 bytes apart, as the sweeps' k registers are)
+        "v_pk_fma_f32 v[8:9], s[40:41], v[42:43], v[8:9] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[10:11], s[40:41], v[40:41], v[10:11] op_sel_hi:[0,1,1]\n\t"
+        "ds_read2_b64 v[48:51], v56 offset1:64\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[46:47], v[12:13] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[14:15], s[40:41], v[44:45], v[14:15] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[42:43], v[16:17] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[18:19], s[40:41], v[40:41], v[18:19] op_sel_hi:[0,1,1]\n\t"
+        "ds_read2_b64 v[52:55], v56 offset0:128 offset1:192\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[46:47], v[20:21] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[22:23], s[40:41], v[44:45], v[22:23] op_sel_hi:[0,1,1]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        ".elseif %c[var] == 11\n\t"  // the same four elements in four ds_read_b64
+        "v_pk_fma_f32 v[8:9], s[40:41], v[42:43], v[8:9] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b64 v[48:49], v56\n\t"
+        "v_pk_fma_f32 v[10:11], s[40:41], v[40:41], v[10:11] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b64 v[50:51], v56 offset:512\n\t"
+        "v_pk_fma_f32 v[12:13], s[40:41], v[46:47], v[12:13] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[14:15], s[40:41], v[44:45], v[14:15] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[16:17], s[40:41], v[42:43], v[16:17] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b64 v[52:53], v56 offset:1024\n\t"
+        "v_pk_fma_f32 v[18:19], s[40:41], v[40:41], v[18:19] op_sel_hi:[0,1,1]\n\t"
+        "ds_read_b64 v[54:55], v56 offset:1536\n\t"
+        "v_pk_fma_f32 v[20:21], s[40:41], v[46:47], v[20:21] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 v[22:23], s[40:41], v[44:45], v[22:23] op_sel_hi:[0,1,1]\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
         ".elseif %c[var] == 8\n\t"  // variant 2 with one dependent pair per 8 (the same accumulator twice in a row)
         "v_pk_fma_f32 v[8:9], s[40:41], v[42:43], v[8:9] op_sel_hi:[0,1,1]\n\t"
         "v_pk_fma_f32 v[8:9], s[40:41], v[40:41], v[8:9] op_sel_hi:[0,1,1]\n\t"
@@ -133,7 +184,7 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, float seed) {
         : [r] "=v"(r)
         : [s] "v"(seed), [n] "s"(REPS), [var] "n"(VAR), [tid] "v"(threadIdx.x & 63)
         : "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23",
-          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v56", "s36", "s37", "s38",
+          "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "s36", "s37", "s38",
           "s40", "s41", "scc");
     if (r == 12345.0f) out[threadIdx.x] = r;
 }
@@ -174,5 +225,9 @@ int main() {
     run<6>("8 v_pk_fma_f32 + 4 scalar instructions (add, waitcnt, cmp, cselect)", 4, d_out);
     run<7>("8 v_pk_fma_f32 + 3 ds_read_b64 + 1 counted waitcnt", 4, d_out);
     run<8>("8 v_pk_fma_f32, each accumulator twice in a row", 4, d_out);
+    run<9>("8 v_pk_fma_f32 + ds_read_b128 + ds_read_b64 (the bytes of 3 b64)", 4, d_out);
+    run<12>("8 v_pk_fma_f32 + ds_read_b128 at an 8-byte-aligned address + ds_read_b64", 4, d_out);
+    run<11>("8 v_pk_fma_f32 + 4 ds_read_b64", 4, d_out);
+    run<10>("8 v_pk_fma_f32 + 2 ds_read2_b64 (the same 4 elements)", 4, d_out);
     return 0;
 }
