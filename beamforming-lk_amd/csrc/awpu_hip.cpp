@@ -1059,14 +1059,40 @@ int enqueue_host_process(awpu_hip *h, const float *frames, int batch) {
     }
     rc = ensure_power(h, (size_t) h->cfg.pixel_count * batch);
     if (rc != AWPU_OK) return rc;
-    if (compact) {  // rows of compact_hist floats cut out of rows of hist floats: a third of the PCIe bytes
-        AWPU_HIP_TRY(hipMemcpy2DAsync(h->d_frames, (size_t) dev_hist * sizeof(float), frames + h->wstart,
-                                      (size_t) h->cfg.hist * sizeof(float), (size_t) dev_hist * sizeof(float),
-                                      (size_t) batch * h->cfg.n_streams, hipMemcpyHostToDevice, h->stream));
-    } else {
-        AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, frames, need_frames * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    // Large batches go up in pieces on a second stream, so that piece k+1 crosses PCIe while piece k is swept (the
+    // pieces are whole frame pairs: the same arithmetic as one launch).  last_kernel_ms then spans all the sweeps.
+    const int n_pieces = batch >= 128 ? 4 : (batch >= 64 ? 2 : 1);
+    const int piece = ((batch + n_pieces - 1) / n_pieces + 1) & ~1;
+    if (n_pieces > 1) {
+        if (!h->copy_stream) AWPU_HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (hipEvent_t *ev : {&h->ev_copied[0], &h->ev_copied[1]})
+            if (!*ev) AWPU_HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
-    return launch(h, h->d_frames, batch, h->d_power, h->stream, compact ? kCompact : kFull);
+    const bool keep_timing = h->timing;
+    int turn = 0;
+    for (int b0 = 0; b0 < batch; b0 += piece, turn++) {
+        const int nb = std::min(piece, batch - b0);
+        hipStream_t up = n_pieces > 1 ? h->copy_stream : h->stream;
+        float *dst = h->d_frames + (size_t) b0 * h->cfg.n_streams * dev_hist;
+        const float *src = frames + (size_t) b0 * h->cfg.n_streams * h->cfg.hist;
+        if (compact) {  // rows of compact_hist floats cut out of rows of hist floats: a third of the PCIe bytes
+            AWPU_HIP_TRY(hipMemcpy2DAsync(dst, (size_t) dev_hist * sizeof(float), src + h->wstart, (size_t) h->cfg.hist * sizeof(float),
+                                          (size_t) dev_hist * sizeof(float), (size_t) nb * h->cfg.n_streams, hipMemcpyHostToDevice, up));
+        } else {
+            AWPU_HIP_TRY(hipMemcpyAsync(dst, src, (size_t) nb * h->cfg.n_streams * dev_hist * sizeof(float), hipMemcpyHostToDevice, up));
+        }
+        if (n_pieces > 1) {
+            AWPU_HIP_TRY(hipEventRecord(h->ev_copied[turn & 1], up));
+            AWPU_HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_copied[turn & 1], 0));
+            if (keep_timing && b0 == 0) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, h->stream));
+            h->timing = false;
+        }
+        rc = launch(h, dst, nb, h->d_power + (size_t) b0 * h->cfg.pixel_count, h->stream, compact ? kCompact : kFull);
+        h->timing = keep_timing;
+        if (rc != AWPU_OK) return rc;
+    }
+    if (n_pieces > 1 && keep_timing) AWPU_HIP_TRY(hipEventRecord(h->ev_end, h->stream));
+    return AWPU_OK;
 }
 
 // h->d_power [batch][pixel_count] -> host rows `pitch` floats apart (a slab of a wider image), on h->stream

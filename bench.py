@@ -338,6 +338,7 @@ def main():
         eng2 = make_engine(math, per, off_all - win_begin, frac_all, 0, spec.n_pixels)
         mine = tuple(torch.zeros((per, spec.n_mics, hist), dtype=torch.float32, device=dev) for _ in range(2))
         d_power2 = torch.zeros((per, spec.n_pixels), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
         scat = sharding.FrameScatterer(mine, bufs if rank == 0 else None, src=0)
 
         def post2(k):
@@ -416,6 +417,7 @@ def main():
         eng1 = make_engine(math, 1, off, frac, shard.pixel_begin, shard.pixel_count)
         ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         d_p1 = torch.zeros((2, shard.pixel_count), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()  # (the fill runs on torch's stream; `stream` does not wait for it)
         with torch.cuda.stream(stream):
             for k in range(10):
                 eng1.process_device(d_full[k % B].data_ptr(), 1, d_p1[1].data_ptr(), stream.cuda_stream)
@@ -458,6 +460,7 @@ def main():
         nf = min(B, 16)
         eng16 = make_engine(pkg.MATH_BF16_ACC, nf, off, frac, shard.pixel_begin, shard.pixel_count)
         d_p16 = torch.zeros((nf, shard.pixel_count), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
         ev16 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         with torch.cuda.stream(stream):
             eng16.process_device(d_full.data_ptr(), nf, d_p16.data_ptr(), stream.cuda_stream)

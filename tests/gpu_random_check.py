@@ -118,6 +118,7 @@ def main(seed: int, cases: int) -> int:
 
                 d_X = torch.from_numpy(X_in).cuda()
                 d_P = torch.zeros((batch, P), dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()  # (torch fills on its own stream; the engine's stream does not wait for it)
                 eng.process_device(d_X.data_ptr(), batch, d_P.data_ptr())
                 eng.synchronize()
                 power = d_P.cpu().numpy()

@@ -291,6 +291,7 @@ def test_device_pointer_entry_with_torch(pkg, oracle):
     dev = torch.device("cuda:0")
     d_frames = torch.from_numpy(frames).to(dev)
     d_power = torch.zeros((3, spec.n_pixels), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()  # (torch fills on its own stream; the engine's streams do not wait for it)
     eng = pkg.Engine(n_pixels=spec.n_pixels, max_batch=3)
     with eng:
         eng.set_delay_table(off, frac)
@@ -424,6 +425,7 @@ def test_device_heatmap_equals_populate_heatmap(pkg, oracle):
         d_power = torch.from_numpy(power).to(dev)
         d_peak = torch.zeros(3, dtype=torch.float32, device=dev)
         d_pix = torch.zeros((3, spec.n_pixels), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()  # (torch fills on its own stream; the engine's streams do not wait for it)
         eng.heatmap_device(d_power.data_ptr(), spec.n_pixels, 3, d_peak.data_ptr(), d_pix.data_ptr())
         eng.synchronize()
         pix = d_pix.cpu().numpy()
@@ -435,6 +437,7 @@ def test_device_heatmap_equals_populate_heatmap(pkg, oracle):
         assert np.array_equal(pkg.binding.heatmap_u8(power[2]), pix[2])
         # externally supplied peak (what a rank does with the all-reduced maximum of all tiles)
         d_peak.fill_(float(2.0 * power[0].max()))
+        torch.cuda.synchronize()
         eng.heatmap_device(d_power.data_ptr(), spec.n_pixels, 1, d_peak.data_ptr(), d_pix.data_ptr(), peak_given=True)
         eng.synchronize()
         want = np.clip(power[0].astype(np.float32) / np.float32(2.0 * power[0].max()) * 255.0, 0, 255).astype(np.uint8)
@@ -455,8 +458,9 @@ def test_device_upscale_and_colour_table(pkg, oracle):
             img = rng.integers(0, 256, (batch, r, c), dtype=np.uint8)
             d_img = torch.from_numpy(img).to(dev)
             d_out = torch.zeros((batch, R, C_), dtype=torch.uint8, device=dev)
-            eng.upscale_device(d_img.data_ptr(), r, c, batch, d_out.data_ptr(), R, C_)
             d_rgb = torch.zeros((batch, R, C_, 3), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()  # (torch fills on its own stream; the engine's streams do not wait for it)
+            eng.upscale_device(d_img.data_ptr(), r, c, batch, d_out.data_ptr(), R, C_)
             eng.upscale_device(d_img.data_ptr(), r, c, batch, d_rgb.data_ptr(), R, C_, d_colormap_ptr=lut.data_ptr())
             eng.synchronize()
             for b in range(batch):
@@ -767,6 +771,7 @@ def run(devices, batch, **kw):
         eng.set_delay_table(off, frac); eng.set_active_mics(None)
         host = eng.process(frames[:batch])
         d_X = torch.from_numpy(frames[:batch]).cuda(); d_P = torch.zeros((batch, spec.n_pixels), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         st = torch.cuda.Stream()
         for _ in range(3):  # three calls back to back: both fan-out buffers of every part get reused
             eng.process_device(d_X.data_ptr(), batch, d_P.data_ptr(), st.cuda_stream)
@@ -991,6 +996,7 @@ def test_random_display_and_beam_shapes(pkg, oracle):
             d_peak = torch.zeros(batch, dtype=torch.float32, device=dev)
             d_pix = torch.zeros((batch, r * c), dtype=torch.uint8, device=dev)
             d_big = torch.zeros((batch, R, C_), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()  # (torch fills on its own stream; the engine's streams do not wait for it)
             eng.heatmap_device(d_power.data_ptr(), r * c, batch, d_peak.data_ptr(), d_pix.data_ptr())
             eng.upscale_device(d_pix.data_ptr(), r, c, batch, d_big.data_ptr(), R, C_)
             eng.synchronize()
