@@ -655,6 +655,33 @@ def test_single_frames_on_the_headline_grid(pkg, oracle):
     assert float((np.abs(from_host[pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
 
 
+def test_host_batches_upload_in_pieces(pkg, oracle):
+    """awpu_hip_process uploads a batch of 64 frames or more in pieces beside the sweep (130 frames: pieces of 34, 34,
+    34 and 28): every frame must come out as from the device-resident call on the whole batch, and as the oracle's."""
+    import torch
+
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = util.hash_frames(spec.n_mics, 1024, seed=77, batch=130)
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=130, grid_columns=spec.res) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        host = eng.process(frames)
+        assert eng.stats().last_kernel_ms > 0
+        d_X = torch.from_numpy(frames).cuda()
+        d_P = torch.zeros((130, spec.n_pixels), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        eng.process_device(d_X.data_ptr(), 130, d_P.data_ptr())
+        eng.synchronize()
+        again = eng.process(frames[:70])  # two pieces, an odd number of frame pairs in each
+    assert util.power_rel_err(host, d_P.cpu().numpy()) < 2e-6
+    assert np.array_equal(again, host[:70])
+    for b in (0, 33, 34, 67, 101, 102, 129):
+        assert util.power_rel_err(host[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
+
+
 def test_fir8_single_frames_on_the_headline_grid(pkg, oracle):
     """AWPU_INTERP_FIR8, one frame per call on the full headline grid: such a launch fills the chip, so it runs the
     batch kernel (das_fir8_plane_kernel) with the frame paired with itself.  From a host buffer, from the ingest
