@@ -177,35 +177,52 @@ __device__ __forceinline__ void sweep_chunk_stamped(Acc<1> (&acc)[PPW], const Fa
     }
 }
 
+// Sum over the 64 lanes, returned wave-uniform.  All in the VALU's data-parallel-primitive path (gfx9 DPP modes):
+// pairs, quads, half rows and rows by permutations within a row of 16, then row 0 into row 1 and row 2 into row 3
+// (row_bcast:15), rows 0-1 into row 3 (row_bcast:31), and lane 63 holds the total -- no LDS crossbar, no waits,
+// where the __shfl_xor butterfly compiles to six ds_bpermute_b32 round trips.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_take(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
-    return v;
+    v += dpp_take<0xB1>(v);        // quad_perm:[1,0,3,2]
+    v += dpp_take<0x4E>(v);        // quad_perm:[2,3,0,1]
+    v += dpp_take<0x141>(v);       // row_half_mirror
+    v += dpp_take<0x140>(v);       // row_mirror: every lane holds its row's sum
+    v += dpp_take<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3 (the other rows add 0)
+    v += dpp_take<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// Whole-wave rotation by one lane in the VALU's data-parallel-primitive path (gfx9's wave_rol / wave_ror): no LDS
+// crossbar traffic and no waits, where __shfl_up/_down compile to ds_bpermute_b32.
+constexpr int kDppWaveRol1 = 0x134;  // lane l takes lane l+1's value, lane 63 lane 0's
+constexpr int kDppWaveRor1 = 0x13C;  // lane l takes lane l-1's value, lane 0 lane 63's
+template <int CTRL>
+__device__ __forceinline__ float wave_rotate1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
 
 // out[] of one pixel and frame from the skewed accumulators, then mimo.cpp:131-137.
 // `tail` = sum over mics of g * X[off+256], the contribution to out[255].
 __device__ __forceinline__ float finish_pixel(f2 A, f2 Q, f2 C, f2 R, float tail, int lane) {
-    float q_next = __shfl_down(Q.x, 1);    // lane l+1's contribution to out[2l+1]
-    float r_next = __shfl_down(R.x, 1);    // lane l+1's contribution to out[129+2l]
-    const float r_first = __shfl(R.x, 0);  // lane 0's contribution to out[127]
-    if (lane == 63) {
-        q_next = r_first;
-        r_next = tail;
-    }
+    // neighbour exchanges: whole-wave rotations by one lane (see wave_rotate); a rotation's wrap-around element is
+    // the one the other half of the samples needs at the seam
+    const float q_rot = wave_rotate1<kDppWaveRol1>(Q.x);  // lane l+1's contribution to out[2l+1]
+    const float r_rot = wave_rotate1<kDppWaveRol1>(R.x);  // lane l+1's contribution to out[129+2l]; lane 63: lane 0's, to out[127]
+    const float q_next = lane == 63 ? r_rot : q_rot;
+    const float r_next = lane == 63 ? tail : r_rot;
     const float o0 = A.x + Q.y;     // out[2l]
     const float o1 = A.y + q_next;  // out[2l+1]
     const float o2 = C.x + R.y;     // out[128+2l]
     const float o3 = C.y + r_next;  // out[129+2l]
-    // neighbours across lanes
-    const float o1_prev = __shfl_up(o1, 1);    // out[2l-1]
-    float o0_next = __shfl_down(o0, 1);        // out[2l+2]
-    const float o2_first = __shfl(o2, 0);      // out[128]
-    float o3_prev = __shfl_up(o3, 1);          // out[127+2l]
-    const float o1_last = __shfl(o1, 63);      // out[127]
-    const float o2_next = __shfl_down(o2, 1);  // out[130+2l]
-    if (lane == 63) o0_next = o2_first;
-    if (lane == 0) o3_prev = o1_last;
+    const float o1_prev = wave_rotate1<kDppWaveRor1>(o1);  // out[2l-1]; lane 0: out[127]
+    const float o2_next = wave_rotate1<kDppWaveRol1>(o2);  // out[130+2l]; lane 63: out[128]
+    const float o0_rot = wave_rotate1<kDppWaveRol1>(o0);   // out[2l+2]
+    const float o3_rot = wave_rotate1<kDppWaveRor1>(o3);   // out[127+2l]
+    const float o0_next = lane == 63 ? o2_next : o0_rot;
+    const float o3_prev = lane == 0 ? o1_prev : o3_rot;
     const float ma0 = o0 * 0.5f - 0.25f * (o1 + o1_prev);  // i = 2l      (valid for l >= 1)
     const float ma1 = o1 * 0.5f - 0.25f * (o0_next + o0);  // i = 2l+1
     const float ma2 = o2 * 0.5f - 0.25f * (o3 + o3_prev);  // i = 128+2l
@@ -569,38 +586,37 @@ __global__ void pack_pairs_kernel(const float *frames, int n_streams, int hist, 
 
 // out[] of one pixel (both frames at once) from the skewed accumulators, then mimo.cpp:131-137.
 // P[0..3] = A_k: f-terms of samples l+64k; P[4..7] = Q_k: g-terms, belonging to samples l+64k-1.
+// The neighbour exchanges are whole-wave rotations by one lane (wave_rotate1): lane 63's (lane 0's) wrap-around value
+// is exactly the element the neighbouring register needs at its seam, so one rotation per register serves both.
+template <int CTRL>
+__device__ __forceinline__ f2 wave_rotate(f2 v) {
+    return f2{wave_rotate1<CTRL>(v.x), wave_rotate1<CTRL>(v.y)};
+}
+
 __device__ __forceinline__ f2 finish_pixel_pair(const f2 (&P)[8], f2 tail, int lane) {
     f2 o[4];
+    f2 rq = wave_rotate<kDppWaveRol1>(P[4]);  // Q_k one lane down; lane 63 holds Q_k[0]
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        f2 qn;
-        qn.x = __shfl_down(P[4 + k].x, 1);
-        qn.y = __shfl_down(P[4 + k].y, 1);
-        f2 wrap = tail;  // sample 255 takes X[off+256]'s term
-        if (k < 3) {
-            wrap.x = __shfl(P[5 + (k < 3 ? k : 0)].x, 0);
-            wrap.y = __shfl(P[5 + (k < 3 ? k : 0)].y, 0);
-        }
-        if (lane == 63) qn = wrap;
-        o[k] = P[k] + qn;  // out[l + 64k]
+        // lane 63 of register k takes sample 64(k+1)'s term = Q_{k+1}[0]; sample 255 takes X[off+256]'s term
+        const f2 rq_next = k < 3 ? wave_rotate<kDppWaveRol1>(P[k < 3 ? 5 + k : 7]) : tail;
+        o[k] = P[k] + (lane == 63 ? rq_next : rq);  // out[l + 64k]
+        rq = rq_next;
     }
     f2 sum = f2{0.0f, 0.0f};
+    f2 dn = wave_rotate<kDppWaveRol1>(o[0]);  // out[l+1 + 64k]; lane 63: out[64k]
+    f2 up_before = wave_rotate<kDppWaveRor1>(o[0]);  // (k = 0, lane 0: sample 0 is not summed)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        f2 prev, next, wp_, wn_;
-        prev.x = __shfl_up(o[k].x, 1);
-        prev.y = __shfl_up(o[k].y, 1);
-        next.x = __shfl_down(o[k].x, 1);
-        next.y = __shfl_down(o[k].y, 1);
-        wp_.x = __shfl(o[k > 0 ? k - 1 : 0].x, 63);
-        wp_.y = __shfl(o[k > 0 ? k - 1 : 0].y, 63);
-        wn_.x = __shfl(o[k < 3 ? k + 1 : 3].x, 0);
-        wn_.y = __shfl(o[k < 3 ? k + 1 : 3].y, 0);
-        if (lane == 0) prev = wp_;
-        if (lane == 63) next = wn_;
+        const f2 dn_after = k < 3 ? wave_rotate<kDppWaveRol1>(o[k < 3 ? k + 1 : 3]) : dn;  // (k = 3, lane 63: sample 255 is not summed)
+        const f2 up = wave_rotate<kDppWaveRor1>(o[k]);  // out[l-1 + 64k]; lane 0: out[63 + 64k]
+        const f2 next = lane == 63 ? dn_after : dn;
+        const f2 prev = lane == 0 ? up_before : up;
         const int i = lane + 64 * k;
         const f2 ma = o[k] * 0.5f - 0.25f * (next + prev);
         if (i >= 1 && i <= kSamples - 2) sum += ma * ma;
+        dn = dn_after;
+        up_before = up;
     }
     sum.x = wave_sum(sum.x);
     sum.y = wave_sum(sum.y);
