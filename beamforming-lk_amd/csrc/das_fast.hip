@@ -195,6 +195,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Sum over each group of 8 consecutive lanes, left in all 8 (the tail passes give 8 lanes to a pixel), and the value
+// of one lane as a wave-uniform scalar: DPP and v_readlane instead of ds_bpermute_b32.
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_take<0xB1>(v);   // quad_perm:[1,0,3,2]
+    v += dpp_take<0x4E>(v);   // quad_perm:[2,3,0,1]
+    v += dpp_take<0x141>(v);  // row_half_mirror: the other quad of the 8
+    return v;
+}
+__device__ __forceinline__ float lane_value(float v, int lane_index) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_index));
+}
+
 // Whole-wave rotation by one lane in the VALU's data-parallel-primitive path (gfx9's wave_rol / wave_ror): no LDS
 // crossbar traffic and no waits, where __shfl_up/_down compile to ds_bpermute_b32.
 constexpr int kDppWaveRol1 = 0x134;  // lane l takes lane l+1's value, lane 63 lane 0's
@@ -379,9 +391,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
     // combine the 8 partial tail sums of each pixel; lanes 8*pp .. 8*pp+7 then hold pixel pp's
 #pragma unroll
     for (int b = 0; b < FPI; b++) {
-        tail[b] += __shfl_xor(tail[b], 1);
-        tail[b] += __shfl_xor(tail[b], 2);
-        tail[b] += __shfl_xor(tail[b], 4);
+        tail[b] = sum8(tail[b]);
     }
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++) {
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
         if (p < a.pixel_count) {
 #pragma unroll
             for (int b = 0; b < FPI; b++) {
-                const float t = __shfl(tail[b], pp * 8);
+                const float t = lane_value(tail[b], pp * 8);
                 const float sum = finish_pixel(acc[pp].A[b], acc[pp].Q[b], acc[pp].C[b], acc[pp].R[b], t, lane);
                 if (lane == 0 && frame0 + b < a.batch) {
                     a.power[(size_t) (frame0 + b) * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
@@ -526,13 +536,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_db_kernel(FastArgs a) {
         stamp(4, t);
 
         if (last_chunk) {  // this frame's sums are complete: epilogue (mimo.cpp:131-137), then start over
-            tail += __shfl_xor(tail, 1);
-            tail += __shfl_xor(tail, 2);
-            tail += __shfl_xor(tail, 4);
+            tail = sum8(tail);
 #pragma unroll
             for (int pp = 0; pp < PPW; pp++) {
                 const int p = pix0 + pp;
-                const float tl = __shfl(tail, pp * 8);
+                const float tl = lane_value(tail, pp * 8);
                 const float sum = finish_pixel(acc[pp].A[0], acc[pp].Q[0], acc[pp].C[0], acc[pp].R[0], tl, lane);
                 if (lane == 0 && p < a.pixel_count) {
                     a.power[(size_t) (frame0 + fi) * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
@@ -800,19 +808,15 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         o[3] = (unsigned long long) n_chunks * PPW;
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
     }
-    tail.x += __shfl_xor(tail.x, 1);
-    tail.y += __shfl_xor(tail.y, 1);
-    tail.x += __shfl_xor(tail.x, 2);
-    tail.y += __shfl_xor(tail.y, 2);
-    tail.x += __shfl_xor(tail.x, 4);
-    tail.y += __shfl_xor(tail.y, 4);
+    tail.x = sum8(tail.x);
+    tail.y = sum8(tail.y);
     const float norm = (float) (kSamples * a.usable);
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++) {
         const int p = pix[pp];
         f2 tl;
-        tl.x = __shfl(tail.x, pp * 8);
-        tl.y = __shfl(tail.y, pp * 8);
+        tl.x = lane_value(tail.x, pp * 8);
+        tl.y = lane_value(tail.y, pp * 8);
         const f2 sum = finish_pixel_pair(acc[pp], tl, lane);
         if (lane == 0 && live[pp]) {
             a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
@@ -938,17 +942,13 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
                 tail = __builtin_elementwise_fma(f2{e.g, e.g}, x, tail);
             }
         }
-        tail.x += __shfl_xor(tail.x, 1);
-        tail.y += __shfl_xor(tail.y, 1);
-        tail.x += __shfl_xor(tail.x, 2);
-        tail.y += __shfl_xor(tail.y, 2);
-        tail.x += __shfl_xor(tail.x, 4);
-        tail.y += __shfl_xor(tail.y, 4);
+        tail.x = sum8(tail.x);
+        tail.y = sum8(tail.y);
 #pragma unroll
         for (int pp = 0; pp < PPW; pp++) {
             f2 tl;
-            tl.x = __shfl(tail.x, pp * 8);
-            tl.y = __shfl(tail.y, pp * 8);
+            tl.x = lane_value(tail.x, pp * 8);
+            tl.y = lane_value(tail.y, pp * 8);
             const f2 sum = finish_pixel_pair(acc[pp], tl, lane);
             if (lane == 0 && live[pp]) {
                 a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
@@ -1178,10 +1178,8 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, con
         f2 o[6];
 #pragma unroll
         for (int k = 0; k < 4; k++) o[k + 1] = f2{acc[pp][2 * k], acc[pp][2 * k + 1]};
-        o[0].x = __shfl_up(o[4].x, 1);
-        o[0].y = __shfl_up(o[4].y, 1);
-        o[5].x = __shfl_down(o[1].x, 1);
-        o[5].y = __shfl_down(o[1].y, 1);
+        o[0] = wave_rotate<kDppWaveRor1>(o[4]);  // (lane 0's wrap-around value belongs to sample 0, which is not summed)
+        o[5] = wave_rotate<kDppWaveRol1>(o[1]);  // (lane 63's to sample 255)
         f2 sum = f2{0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1418,12 +1416,8 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         }
 
         // ---- this item's powers (the next item's first chunk is in its image already)
-        tail.x += __shfl_xor(tail.x, 1);
-        tail.y += __shfl_xor(tail.y, 1);
-        tail.x += __shfl_xor(tail.x, 2);
-        tail.y += __shfl_xor(tail.y, 2);
-        tail.x += __shfl_xor(tail.x, 4);
-        tail.y += __shfl_xor(tail.y, 4);
+        tail.x = sum8(tail.x);
+        tail.y = sum8(tail.y);
         auto finish = [&](const f8 &A, const f8 &S, int pp) {
             f2 P[8];
 #pragma unroll
@@ -1433,8 +1427,8 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                 P[4 + k] = Hk - Ak;  // sum (1 - f) X
             }
             f2 tl;
-            tl.x = __shfl(tail.x, pp * 8);
-            tl.y = __shfl(tail.y, pp * 8);
+            tl.x = lane_value(tail.x, pp * 8);
+            tl.y = lane_value(tail.y, pp * 8);
             const f2 sum = finish_pixel_pair(P, tl, lane);
             if (lane == 0 && live[pp]) {
                 a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
@@ -1619,15 +1613,13 @@ __global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
         o[3] = (unsigned long long) n_chunks;
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
     }
-    tail += __shfl_xor(tail, 1);
-    tail += __shfl_xor(tail, 2);
-    tail += __shfl_xor(tail, 4);
+    tail = sum8(tail);
     const float norm = (float) (kSamples * a.usable);
     auto finish = [&](const f4 &A, const f4 &S, int slot) {
         const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
         const f2 Ax = f2{A[0], A[1]}, Ay = f2{A[2], A[3]};  // accumulated with f - 1/2 (see QuadEntry)
         const f2 Hx = 0.5f * f2{S[0], S[1]}, Hy = 0.5f * f2{S[2], S[3]};
-        const float tl = __shfl(tail, slot * 8);
+        const float tl = lane_value(tail, slot * 8);
         const float sum = finish_pixel(Hx + Ax, Hx - Ax, Hy + Ay, Hy - Ay, tl, lane);  // sum f X, sum (1 - f) X
         if (lane == 0 && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = sum / norm;
     };
