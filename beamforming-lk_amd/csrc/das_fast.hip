@@ -1372,7 +1372,8 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                 const void *row = uniform_ptr(quad_lut + (size_t) (m0 >> 2) * 16);
                 const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (buf ^ 1) * BUF + wave * 1024);
                 const unsigned n_bytes = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) next_mc4 * row_floats * 4));
-                sweep_quad_sum_dma(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank, uniform_ptr(next_src), dst0, n_bytes, lane_bytes);
+                const unsigned dnp = wave < kQuadDmaWaves ? (n_bytes + kQuadDmaWaves * 1024 - 1) / (kQuadDmaWaves * 1024) : 0;
+                sweep_quad_sum_dma(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank, uniform_ptr(next_src), dst0, n_bytes, lane_bytes, dnp);
             } else {
                 if (g_head > 0) sweep(0, g_head);
                 long long t_dma = DIAG ? __builtin_readcyclecounter() : 0;

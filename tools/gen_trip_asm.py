@@ -409,6 +409,11 @@ __device__ __forceinline__ void {name}(f2 (&P0)[8], f2 (&P1)[8], const void *row
 # the delay is monotone down a column; the slot is prefetched for pixel 3, pixel 2 uses it when its address is
 # the same and otherwise -- rare -- reads into it on the spot, after pixel 3 is done with it), one address
 # register; SGPR sets E0 = s[36:67], E1 = s[68:99]: pixel p, mic i of the trip: f at +8p+2i, address +1.
+# the refill pieces of the quad block's in-block DMA: 1 KiB per issuing wave, QUAD_DMA_WAVES waves take part (waves
+# 0 .. n-1 of the workgroup; the kernel gives the others no pieces)
+DMA_WAVES = int(os.environ.get("QUAD_DMA_WAVES", "16"))
+DMA_STRIDE = DMA_WAVES * 1024
+QUAD_END_PRIO = int(os.environ.get("QUAD_END_PRIO", "3"))  # priority a wave keeps after the quad block (tail pass, barrier, next block's head)
 QUAD_ACC = 30          # first pinned accumulator register; 64 of them
 QUAD_TMP = QUAD_ACC + 64  # 33 temps
 REF = 1                # which pixel of the quad is the reference (a middle one: fewest differing neighbours)
@@ -546,8 +551,8 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
                 f"s_mov_b32 m0, s{S_DST}", "s_nop 0",
                 f"global_load_lds_dwordx4 %[lbytes], s[{S_SB}:{S_SB + 1}]",
                 "s_mov_b64 exec, -1",
-                f"s_add_u32 s{S_SB}, s{S_SB}, 0x4000", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
-                f"s_add_u32 s{S_DST}, s{S_DST}, 0x4000", f"s_sub_u32 s{S_REM}, s{S_REM}, 0x4000",
+                f"s_add_u32 s{S_SB}, s{S_SB}, {hex(DMA_STRIDE)}", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+                f"s_add_u32 s{S_DST}, s{S_DST}, {hex(DMA_STRIDE)}", f"s_sub_u32 s{S_REM}, s{S_REM}, {hex(DMA_STRIDE)}",
                 f"s_add_u32 s{S_K}, s{S_K}, 1", f".Ldskip{u}:"]
 
     def trip_q(par):
@@ -588,7 +593,7 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
     if dma:
         L += [f"s_mov_b32 s{S_M0}, m0",
               f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[dsrc]", f"s_mov_b32 s{S_DST}, %[ddst]", f"s_mov_b32 s{S_REM}, %[dbytes]",
-              f"s_mov_b32 s{S_K}, 0", f"s_add_u32 s{S_NP}, %[dbytes], 0x3fff", f"s_lshr_b32 s{S_NP}, s{S_NP}, 14"]
+              f"s_mov_b32 s{S_K}, 0", f"s_mov_b32 s{S_NP}, %[dnp]"]
     L += load_set(E[0], 0, literal=True)
     L += [f"s_mov_b32 s{S_LEFT_}, %[ng]", f"s_movk_i32 s{S_PF_}, 0x80", "s_waitcnt lgkmcnt(0)"]
     if stamp:
@@ -605,7 +610,7 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
         L += [".LQmore_%=:", f"s_cmp_ge_u32 s{S_K}, s{S_NP}", "s_cbranch_scc1 .LQnomore_%="] + dma_piece() + ["s_branch .LQmore_%=", ".LQnomore_%=:",
               f"s_mov_b32 m0, s{S_M0}"]
     if prio:
-        L += ["s_setprio 0"]
+        L += [f"s_setprio {QUAD_END_PRIO}"]
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
@@ -617,8 +622,8 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
     bases = A + [T] + [V[0], V[2], V[3]]
     acc_params = ", ".join(f"{'f8' if nk == 4 else 'f4'} &{n}" for n in names)
     acc_ops = ", ".join(f'"+{{v[{b}:{b + 2 * nk - 1}]}}"({n})' for n, b in zip(names, bases))
-    dma_params = ", const void *dsrc, unsigned ddst, unsigned dbytes, unsigned lbytes" if dma else ""
-    dma_ops = ', [dsrc] "s"(dsrc), [ddst] "s"(ddst), [dbytes] "s"(dbytes), [lbytes] "v"(lbytes)' if dma else ""
+    dma_params = ", const void *dsrc, unsigned ddst, unsigned dbytes, unsigned lbytes, unsigned dnp" if dma else ""
+    dma_ops = ', [dsrc] "s"(dsrc), [ddst] "s"(ddst), [dbytes] "s"(dbytes), [lbytes] "v"(lbytes), [dnp] "s"(dnp)' if dma else ""
     stamp_params = ", unsigned &t_wait, unsigned &t_all" if stamp else ""
     stamp_ops = ', [t_wait] "=&s"(t_wait), [t_all] "=&s"(t_all)' if stamp else ""
     return f"""// Four vertically adjacent pixels of the staged chunk, ng groups of four mics each (ng >= 1), with the shared
@@ -928,7 +933,8 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row0, const voi
 
 def main():
     hi = 128 - (4 * (DEPTH + 1) + 1) - 3
-    out = ["// GENERATED by tools/gen_trip_asm.py -- do not edit.  See that script for the schedule.", ""]
+    out = ["// GENERATED by tools/gen_trip_asm.py -- do not edit.  See that script for the schedule.", "",
+           f"constexpr int kQuadDmaWaves = {DMA_WAVES};  // waves 0..n-1 of a workgroup issue the quad block's refill pieces", ""]
     out.append(block("sweep_pixel_hi", 1, hi))
     out.append(block("sweep_quad_hi", 4, hi))
     out.append(block("sweep_quad_stamped", 4, hi, stamp=True))
