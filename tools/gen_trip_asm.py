@@ -246,7 +246,7 @@ def block(name, n_pix, vbase, stamp=False, pair_depth=0):
         L += pixel_code(j, n_pix, vbase, accs[j], pair_depth)
     L += [".Ldone_%=:"]
     if PRIO:
-        L += ["s_setprio 0"]
+        L += [f"s_setprio {BLOCK_END_PRIO}"]
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)",
               f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
@@ -365,7 +365,7 @@ def block_shared(name, vbase, stamp=False):
     L += [f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_cmp_lg_u32 s{S_LEFT}, 0", "s_cbranch_scc1 .LT0_%="]
     L += ["s_branch .Ldone_%="] + cold + [".Ldone_%=:"]
     if PRIO:
-        L += ["s_setprio 0"]
+        L += [f"s_setprio {BLOCK_END_PRIO}"]
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)",
               f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
@@ -413,7 +413,8 @@ __device__ __forceinline__ void {name}(f2 (&P0)[8], f2 (&P1)[8], const void *row
 # 0 .. n-1 of the workgroup; the kernel gives the others no pieces)
 DMA_WAVES = int(os.environ.get("QUAD_DMA_WAVES", "16"))
 DMA_STRIDE = DMA_WAVES * 1024
-QUAD_END_PRIO = int(os.environ.get("QUAD_END_PRIO", "3"))  # priority a wave keeps after the quad block (tail pass, barrier, next block's head)
+QUAD_END_PRIO = int(os.environ.get("QUAD_END_PRIO", "3"))
+BLOCK_END_PRIO = int(os.environ.get("BLOCK_END_PRIO", "0"))  # the same for the pair-, single-frame and single-frame quad blocks  # priority a wave keeps after the quad block (tail pass, barrier, next block's head)
 QUAD_ACC = 30          # first pinned accumulator register; 64 of them
 QUAD_TMP = QUAD_ACC + 64  # 33 temps
 REF = 1                # which pixel of the quad is the reference (a middle one: fewest differing neighbours)
@@ -762,7 +763,7 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
     L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQ0_%="]
     L += ["s_branch .LQdone_%="] + cold + [".LQdone_%=:", "s_waitcnt lgkmcnt(0)"]
     if prio:
-        L += ["s_setprio 0"]
+        L += [f"s_setprio {BLOCK_END_PRIO}"]
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
