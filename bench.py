@@ -300,6 +300,31 @@ def main():
 
     run_steps(W)
     fence()
+    # How the batch gets to every rank, untimed: one broadcast per step, or a scatter of 1/N to every rank followed by
+    # an all-gather (every xGMI link carries 1/N instead of the root's ring neighbour carrying all of it).  Which is
+    # faster depends on the collective library's schedule for this topology, so both are timed over a few warm-up
+    # steps and the faster one (the same on every rank: decided on the maximum over ranks) runs the timed region.
+    # BENCH_BCAST=broadcast|scatter_allgather pins it.
+    bcast_choice = {"mode": bcast.mode, "why": "BENCH_BCAST" if "BENCH_BCAST" in os.environ else "single mode"}
+    trial_ranks = 2 if rehearsal else 4  # (two ranks have one link either way: nothing to choose)
+    if world >= trial_ranks and "BENCH_BCAST" not in os.environ and B % world == 0:
+        trial = {}
+        for mode in ("broadcast", "scatter_allgather"):
+            bcast = sharding.FrameBroadcaster(bufs, src=0, mode=mode)
+            run_steps(1)
+            fence()
+            t1 = time.perf_counter()
+            run_steps(max(2, W))
+            fence()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            trial[mode] = float(tt.item()) / max(2, W)
+        best = min(trial, key=trial.get)
+        bcast = sharding.FrameBroadcaster(bufs, src=0, mode=best)
+        bcast_choice = {"mode": best, "why": "faster over the warm-up steps",
+                        "ms_per_step": {m: round(v * 1e3, 4) for m, v in trial.items()}}
+        run_steps(1)
+        fence()
     events = ([torch.cuda.Event(enable_timing=True) for _ in range(K)],
               [torch.cuda.Event(enable_timing=True) for _ in range(K)])
     t0 = time.perf_counter()
@@ -406,6 +431,8 @@ def main():
         }
         if alt is not None:
             out["alt_sharding"] = alt
+        if world > 1:
+            out["config"]["frame_exchange"] = bcast_choice
         if rehearsal:
             out["rehearsal"] = "all ranks on one GPU over gloo: logic check only, not a scaling number"
 
