@@ -203,6 +203,10 @@ __device__ __forceinline__ float sum8(float v) {
     v += dpp_take<0x141>(v);  // row_half_mirror: the other quad of the 8
     return v;
 }
+__device__ __forceinline__ float sum16(float v) {  // the same over each row of 16 lanes
+    v = sum8(v);
+    return v + dpp_take<0x140>(v);  // row_mirror: the other half of the row
+}
 __device__ __forceinline__ float lane_value(float v, int lane_index) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_index));
 }
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
             }
             pair_rows = 1;
         }
-        const int tail_pp = lane >> 3;
+        const int tail_pp = lane >> 4;  // 16 lanes per pixel: one round of the tail pass covers 64 mics
         int tail_pix = pix[0];
         bool tail_lane = false;
 #pragma unroll
@@ -904,10 +908,10 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
             unsigned addr;
             float g;
         };
-        AddrG te[4];  // the tail pass's entries of mics 0..31: requested now, consumed after the sweep
+        AddrG te[4];  // the tail pass's entries of mics 0..63: requested now, consumed after the sweep
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int j = 8 * u + (lane & 7);
+            const int j = 16 * u + (lane & 15);
             te[u] = *(const AddrG *) ((const char *) (tail_row + min(j, a.usable_pad - 1)) + 4);  // fields addr, g
             if (!tail_lane || j >= a.usable_pad) te[u].g = 0.0f;
         }
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
             if constexpr (SHARE) sweep_duo_shared(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
             else sweep_duo_pairs(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
         }
-        // the 257th sample of every window, both frames: lane 8*pp + k takes the mics s = k (mod 8)
+        // the 257th sample of every window, both frames: lane 16*pp + k takes the mics s = k (mod 16)
         f2 tail = f2{0.0f, 0.0f};
         const char *img = (const char *) lds;
 #pragma unroll
@@ -932,23 +936,23 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
             const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
             tail = __builtin_elementwise_fma(f2{te[u].g, te[u].g}, x, tail);
         }
-        for (int j0 = 32; j0 < a.usable_pad; j0 += 32) {
+        for (int j0 = 64; j0 < a.usable_pad; j0 += 64) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int j = j0 + 8 * u + (lane & 7);
+                const int j = j0 + 16 * u + (lane & 15);
                 AddrG e = *(const AddrG *) ((const char *) (tail_row + min(j, a.usable_pad - 1)) + 4);
                 if (!tail_lane || j >= a.usable_pad) e.g = 0.0f;
                 const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
                 tail = __builtin_elementwise_fma(f2{e.g, e.g}, x, tail);
             }
         }
-        tail.x = sum8(tail.x);
-        tail.y = sum8(tail.y);
+        tail.x = sum16(tail.x);
+        tail.y = sum16(tail.y);
 #pragma unroll
         for (int pp = 0; pp < PPW; pp++) {
             f2 tl;
-            tl.x = lane_value(tail.x, pp * 8);
-            tl.y = lane_value(tail.y, pp * 8);
+            tl.x = lane_value(tail.x, pp * 16);
+            tl.y = lane_value(tail.y, pp * 16);
             const f2 sum = finish_pixel_pair(acc[pp], tl, lane);
             if (lane == 0 && live[pp]) {
                 a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
