@@ -655,6 +655,49 @@ def test_single_frames_on_the_headline_grid(pkg, oracle):
     assert float((np.abs(from_host[pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
 
 
+def test_two_handles_from_two_threads(pkg, oracle):
+    """Several AWPUs in one process (the reference runs one per --port): two handles of different shapes used from two
+    threads at the same time (ctypes drops the GIL during a call), first launches included -- the one-time kernel
+    attribute set-up and the tuning knobs are process-wide.  Every result must equal the same handle's result alone."""
+    import threading
+
+    S = pkg.synthetic
+    jobs = []
+    for wl, batch, seed in (("c1", 6, 5), ("c2", 3, 6)):
+        spec = S.WORKLOADS[wl]
+        xyz = S.geometry(spec)
+        off, frac = S.delay_table(spec, xyz)
+        frames = util.hash_frames(spec.n_mics, 1024, seed=seed, batch=batch)
+        jobs.append((spec, off, frac, frames, batch))
+    results = [[], []]
+    errors = []
+
+    def work(k):
+        try:
+            spec, off, frac, frames, batch = jobs[k]
+            with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=batch, grid_columns=spec.res) as eng:
+                eng.set_delay_table(off, frac)
+                eng.set_active_mics(None)
+                for it in range(12):
+                    results[k].append(eng.process(frames) if it % 2 == 0 else eng.process(frames[0])[None])
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        spec, off, frac, frames, batch = jobs[k]
+        for it, got in enumerate(results[k]):
+            ref = results[k][it % 2]
+            assert np.array_equal(got, ref), (k, it)
+        assert util.power_rel_err(results[k][0][0], oracle.das_f32(frames[0], off, frac)) < util.POWER_RTOL
+        assert util.power_rel_err(results[k][1][0], oracle.das_f32(frames[0], off, frac)) < util.POWER_RTOL
+
+
 def test_host_batches_upload_in_pieces(pkg, oracle):
     """awpu_hip_process uploads a batch of 64 frames or more in pieces beside the sweep (130 frames: pieces of 34, 34,
     34 and 28): every frame must come out as from the device-resident call on the whole batch, and as the oracle's."""
