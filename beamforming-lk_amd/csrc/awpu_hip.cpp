@@ -351,7 +351,7 @@ int prepare(awpu_hip *h) {
 
     // The quad shape (das_quad_kernel) shares arithmetic between four vertically adjacent pixels wherever their
     // integer delays coincide with the second pixel's: 20 packed VALU instructions per quad and mic, +8 for every
-    // pixel that differs, against 32 without sharing.  Count it on a sample of the table; take the shape when it
+    // pixel that differs (-4 where the third and fourth differ together), against 32 without sharing.  Count it on a sample of the table; take the shape when it
     // saves VALU work at all once its own address adds are counted (measured: a count of 30.2 -- BASELINE c2 -- is
     // 4 % faster than the pair shape, 29.4 -- c3 -- 8 %, 25.3 -- the headline -- 20 %; AWPU_FAST_QUADS=0/1 forces either).
     h->quad_ok = false;
@@ -361,20 +361,21 @@ int prepare(awpu_hip *h) {
         if (c.math == AWPU_MATH_F32_FAST && c.interp == AWPU_INTERP_LERP && cols > 0 && P % cols == 0 &&
             c.pixel_begin % cols == 0) {
             const int rows = P / cols;
-            long differ = 0, seen = 0;
+            long differ = 0, together = 0, seen = 0;  // `together`: pixels 2 and 3 away from the reference as one (4 less)
             const int n_quads = ((rows + 3) / 4) * cols;
             const int step = std::max(1, n_quads / 2048);
             for (int q = 0; q < n_quads; q += step) {
                 const int r0 = (q / cols) * 4, col = q % cols;
-                const int32_t *ref = &h->off[((size_t) std::min(r0 + 1, rows - 1) * cols + col) * c.lut_stride];
-                for (int k = 0; k < 4; k++) {
-                    if (k == 1) continue;
-                    const int32_t *o = &h->off[((size_t) std::min(r0 + k, rows - 1) * cols + col) * c.lut_stride];
-                    for (int s = 0; s < U; s++) differ += o[h->index[s]] != ref[h->index[s]];
+                const int32_t *o[4];
+                for (int k = 0; k < 4; k++) o[k] = &h->off[((size_t) std::min(r0 + k, rows - 1) * cols + col) * c.lut_stride];
+                for (int s = 0; s < U; s++) {
+                    const int id = h->index[s];
+                    differ += (o[0][id] != o[1][id]) + (o[2][id] != o[1][id]) + (o[3][id] != o[1][id]);
+                    together += o[2][id] != o[1][id] && o[2][id] == o[3][id];
                 }
                 seen += U;
             }
-            h->quad_cost = seen ? 20.0 + 8.0 * (double) differ / (double) seen : 32.0;
+            h->quad_cost = seen ? 20.0 + (8.0 * (double) differ - 4.0 * (double) together) / (double) seen : 32.0;
             h->quad_ok = h->quad_cost < 31.0 && awpu::pair_plan(h->window, U, &h->quad_plan);
             if (env().quads >= 0) h->quad_ok = env().quads != 0 && awpu::pair_plan(h->window, U, &h->quad_plan);
             h->quad1_fits = h->quad_ok && h->gain.empty() &&  // (gains ride on the weights of the other single-frame tables)

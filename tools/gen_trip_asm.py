@@ -414,6 +414,7 @@ __device__ __forceinline__ void {name}(f2 (&P0)[8], f2 (&P1)[8], const void *row
 DMA_WAVES = int(os.environ.get("QUAD_DMA_WAVES", "16"))
 DMA_STRIDE = DMA_WAVES * 1024
 QUAD_END_PRIO = int(os.environ.get("QUAD_END_PRIO", "3"))
+PAIR23 = int(os.environ.get("QUAD_PAIR23", "1"))  # quad blocks: pixels 2 and 3 share one difference where they leave the reference together
 BLOCK_END_PRIO = int(os.environ.get("BLOCK_END_PRIO", "0"))  # the same for the pair-, single-frame and single-frame quad blocks  # priority a wave keeps after the quad block (tail pass, barrier, next block's head)
 QUAD_ACC = 30          # first pinned accumulator register; 64 of them
 QUAD_TMP = QUAD_ACC + 64  # 33 temps
@@ -485,6 +486,7 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
         return f"%=_{COUNTER[0]}"
 
     cold = []
+    skip23 = [None]
 
     def maybe_read_x(p, base, i):
         """issue pixel p's own reads for the mic whose entries sit at (base, i) unless it shares the reference's"""
@@ -514,12 +516,30 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
                          f"s_cbranch_scc1 .Lqhave{u}"] +
                         reads(XS[xz[0]][2], a_of(base, 2, i)) + ["s_waitcnt lgkmcnt(0)", f".Lqhave{u}:"] +
                         own_ops(p, fs, rslot) + [f"s_branch .Lqdone{u}"])
+        elif p == 3 and PAIR23:
+            # Pixels 2 and 3 both away from the reference but together (the pattern a-a-b-b of a delay that steps once
+            # inside the quad): one difference x_b - x_ref serves both shared-sum corrections -- 5 instructions per
+            # register for the two pixels instead of 6.  (The slot is pixel 2's and 3's alone: changed in place.)
+            X3 = XS[xz[0]][3]
+            fs2 = f"s[{f_of(base, 2, i)}:{f_of(base, 2, i) + 1}]"
+            both = []
+            for q, fq in ((3, fs), (2, fs2)):
+                both += [f"v_pk_fma_f32 {pair(A[q], k)}, {fq}, {pair(X3, k)}, {pair(A[q], k)} op_sel_hi:[0,1,1]" for k in range(nk)]
+            both += [f"v_pk_add_f32 {pair(X3, k)}, {pair(X3, k)}, {pair(rslot, k)} neg_lo:[0,1] neg_hi:[0,1]" for k in range(nk)]
+            for q in (3, 2):
+                both += [f"v_pk_add_f32 {pair(V[q], k)}, {pair(V[q], k)}, {pair(X3, k)}" for k in range(nk)]
+            skip23[0] = u
+            cold.extend([f".Lqown{u}:", f"s_cmp_eq_u32 s{a_of(base, 2, i)}, s{a_of(base, 3, i)}", f"s_cbranch_scc1 .Lqboth{u}"] +
+                        own_ops(p, fs, rslot) + [f"s_branch .Lqdone{u}", f".Lqboth{u}:"] + both + [f"s_branch .Lqskip{u}"])
         else:
             cold.extend([f".Lqown{u}:"] + own_ops(p, fs, rslot) + [f"s_branch .Lqdone{u}"])
         L = [f"s_cmp_lg_u32 s{a_of(base, p, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lqown{u}"]
         for k in range(nk):
             L.append(f"v_pk_fma_f32 {pair(A[p], k)}, {fs}, {pair(rslot, k)}, {pair(A[p], k)} op_sel_hi:[0,1,1]")
         L.append(f".Lqdone{u}:")
+        if p == 2 and skip23[0] is not None:  # where pixel 3's combined path rejoins
+            L.append(f".Lqskip{skip23[0]}:")
+            skip23[0] = None
         return L
 
     def ref_ops(base, i, rslot):
@@ -702,10 +722,20 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
         L = []
         # pixel 3: own samples always; the shared sum's correction only where its delay differs
         u = uid()
-        cold.extend([f".Lac{u}:"] + correct(3, X23, R) + [f"s_branch .Lad{u}"])
+        u2 = uid()
+        if PAIR23:
+            # pixels 2 and 3 away from the reference together (a delay that steps once inside the quad): one difference
+            # x_b - x_ref, formed in place (the slot is theirs alone), corrects both shared sums
+            both = (fmas(2, fs(2), X23) +
+                    [f"v_pk_add_f32 {pair(X23, k)}, {pair(X23, k)}, {pair(R, k)} neg_lo:[0,1] neg_hi:[0,1]" for k in range(nk)] +
+                    [f"v_pk_add_f32 {pair(V[q], k)}, {pair(V[q], k)}, {pair(X23, k)}" for q in (3, 2) for k in range(nk)])
+            cold.extend([f".Lac{u}:", f"s_cmp_eq_u32 s{a_of(base, 2, i)}, s{a_of(base, 3, i)}", f"s_cbranch_scc1 .Laf{u}"] +
+                        correct(3, X23, R) + [f"s_branch .Lad{u}", f".Laf{u}:"] + both + [f"s_branch .Lad{u2}"])
+        else:
+            cold.extend([f".Lac{u}:"] + correct(3, X23, R) + [f"s_branch .Lad{u}"])
         L += fmas(3, fs(3), X23) + [f"s_cmp_lg_u32 s{a_of(base, 3, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lac{u}", f".Lad{u}:"]
         # pixel 2: the reference's samples, or pixel 3's, or (rare) its own read on the spot
-        u = uid()
+        u = u2
         cold.extend([f".Lac{u}:",
                      f"s_cmp_eq_u32 s{a_of(base, 2, i)}, s{a_of(base, 3, i)}",
                      f"s_cbranch_scc0 .Lae{u}"] + fmas(2, fs(2), X23) + correct(2, X23, R) + [f"s_branch .Lad{u}",
