@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         }
         const QuadEntry *quad_lut = a.lut + (size_t) quad * groups_total * 16;
         const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
-        const int tail_pp = lane >> 3;  // lanes 8 pp + k: pixel pp of the quad, mics k (mod 8) of the chunk
+        const int tail_pp = lane >> 4;  // lanes 16 pp + k: pixel pp of the quad, mics k (mod 16) of the chunk
         bool tail_lane = false;
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -1329,10 +1329,10 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
             const int buf = step & 1;
             long long t = DIAG ? __builtin_readcyclecounter() : 0;
             // table entries of the tail pass below (the 257th sample): requested now, consumed after the sweep
-            QuadEntry te[4];
+            QuadEntry te[2];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int m = m0 + min(8 * u + ((lane - m0) & 7), mc4 - 1);
+            for (int u = 0; u < 2; u++) {
+                const int m = m0 + min(16 * u + ((lane - m0) & 15), mc4 - 1);
                 te[u] = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
             }
             // The stamped and the tuning builds issue the refill themselves (the production build lets the sweep block
@@ -1394,16 +1394,16 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
             const char *img = (const char *) (lds + buf * (BUF / 4));
             if (!(a.debug & 4)) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {  // mics 0..31 of the chunk (prefetched above)
-                    const bool on = tail_lane && 8 * u + ((lane - m0) & 7) < mc4;
+                for (int u = 0; u < 2; u++) {  // mics 0..31 of the chunk (prefetched above)
+                    const bool on = tail_lane && 16 * u + ((lane - m0) & 15) < mc4;
                     const float g = on ? 0.5f - te[u].f : 0.0f;  // 1 - f
                     const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
                     tail = __builtin_elementwise_fma(f2{g, g}, x, tail);
                 }
                 for (int j0 = 32; j0 < mc4; j0 += 32) {  // chunks of more than 32 mics (narrow windows)
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int jj = j0 + 8 * u + ((lane - m0) & 7);
+                    for (int u = 0; u < 2; u++) {
+                        const int jj = j0 + 16 * u + ((lane - m0) & 15);
                         const int m = m0 + min(jj, mc4 - 1);
                         const QuadEntry e = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
                         const float g = tail_lane && jj < mc4 ? 0.5f - e.f : 0.0f;
@@ -1421,8 +1421,8 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         }
 
         // ---- this item's powers (the next item's first chunk is in its image already)
-        tail.x = sum8(tail.x);
-        tail.y = sum8(tail.y);
+        tail.x = sum16(tail.x);
+        tail.y = sum16(tail.y);
         auto finish = [&](const f8 &A, const f8 &S, int pp) {
             f2 P[8];
 #pragma unroll
@@ -1432,8 +1432,8 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                 P[4 + k] = Hk - Ak;  // sum (1 - f) X
             }
             f2 tl;
-            tl.x = lane_value(tail.x, pp * 8);
-            tl.y = lane_value(tail.y, pp * 8);
+            tl.x = lane_value(tail.x, pp * 16);
+            tl.y = lane_value(tail.y, pp * 16);
             const f2 sum = finish_pixel_pair(P, tl, lane);
             if (lane == 0 && live[pp]) {
                 a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
