@@ -694,7 +694,9 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
     for (int pp = 0; pp < PPW; pp++)
 #pragma unroll
         for (int k = 0; k < 8; k++) acc[pp][k] = f2{0.0f, 0.0f};
-    const int tail_pp = lane >> 3;
+    // tail pass: every lane has a pixel (LPP lanes each); a round covers 32 mics in NU entries per lane
+    constexpr int LPP = 64 / PPW >= 16 ? 16 : 8, NU = 32 / LPP;
+    const int tail_pp = lane / LPP;
     int tail_pix = pix[0];
     bool tail_lane = false;
 #pragma unroll
@@ -749,10 +751,10 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
             unsigned addr;
             float g;
         };
-        AddrG te[4];
+        AddrG te[NU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = 8 * u + ((lane - m0) & 7);
+        for (int u = 0; u < NU; u++) {
+            const int j = LPP * u + ((lane - m0) & (LPP - 1));
             te[u] = *(const AddrG *) ((const char *) (tail_row + m0 + min(j, mc4 - 1)) + 4);  // fields addr, g
             if (!tail_lane || j >= mc4) te[u].g = 0.0f;
         }
@@ -782,14 +784,14 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         const char *img = (const char *) (lds + buf * (BUF / 4));
         if (!(a.debug & 4))
 #pragma unroll
-        for (int u = 0; u < 4; u++) {  // mics 0..31 of the chunk (prefetched above)
+        for (int u = 0; u < NU; u++) {  // mics 0..31 of the chunk (prefetched above)
             const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
             tail = __builtin_elementwise_fma(f2{te[u].g, te[u].g}, x, tail);
         }
         for (int j0 = 32; j0 < mc4; j0 += 32) {  // chunks of more than 32 mics (narrow windows)
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + 8 * u + ((lane - m0) & 7);
+            for (int u = 0; u < NU; u++) {
+                const int j = j0 + LPP * u + ((lane - m0) & (LPP - 1));
                 AddrG e = *(const AddrG *) ((const char *) (tail_row + m0 + min(j, mc4 - 1)) + 4);
                 if (!tail_lane || j >= mc4) e.g = 0.0f;
                 const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
@@ -812,15 +814,15 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         o[3] = (unsigned long long) n_chunks * PPW;
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
     }
-    tail.x = sum8(tail.x);
-    tail.y = sum8(tail.y);
+    tail.x = LPP == 16 ? sum16(tail.x) : sum8(tail.x);
+    tail.y = LPP == 16 ? sum16(tail.y) : sum8(tail.y);
     const float norm = (float) (kSamples * a.usable);
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++) {
         const int p = pix[pp];
         f2 tl;
-        tl.x = lane_value(tail.x, pp * 8);
-        tl.y = lane_value(tail.y, pp * 8);
+        tl.x = lane_value(tail.x, pp * LPP);
+        tl.y = lane_value(tail.y, pp * LPP);
         const f2 sum = finish_pixel_pair(acc[pp], tl, lane);
         if (lane == 0 && live[pp]) {
             a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
@@ -1504,8 +1506,10 @@ __global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
     f4 A0a = {0, 0, 0, 0}, A1a = A0a, A2a = A0a, A3a = A0a, Ta = A0a, V0a = A0a, V2a = A0a, V3a = A0a;
     f4 A0b = A0a, A1b = A0a, A2b = A0a, A3b = A0a, Tb = A0a, V0b = A0a, V2b = A0a, V3b = A0a;
     float tail = 0.0f;
-    // tail pass: lane 8 pp + k takes pixel slot pp (quad pp / 4, pixel pp % 4) and the mics k (mod 8)
-    const int tail_pp = lane >> 3;
+    // tail pass: lane LPP pp + k takes pixel slot pp (quad pp / 4, pixel pp % 4) and the mics k (mod LPP); every lane
+    // has a pixel: 16 lanes each for one quad per wave, 8 for two; a round covers 32 mics in 32 / LPP entries per lane
+    constexpr int LPP = QPW == 1 ? 16 : 8, NU = 32 / LPP;
+    const int tail_pp = lane / LPP;
     const int tail_col = min(col0 + (tail_pp >> 2), cols_pad - 1);
     const bool tail_lane = tail_pp < 4 * QPW && col0 + (tail_pp >> 2) < a.cols && 4 * row4 + (tail_pp & 3) < a.rows;
     const QuadEntry *tail_lut = a.lut + ((size_t) row4 * cols_pad + tail_col) * groups_total * 16;
@@ -1554,10 +1558,10 @@ __global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
         const int buf = c & 1;
         long long t = DIAG ? __builtin_readcyclecounter() : 0;
         // table entries of the tail pass below (the 257th sample): requested now, consumed after the sweep
-        QuadEntry te[4];
+        QuadEntry te[NU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int m = m0 + min(8 * u + ((lane - m0) & 7), mc4 - 1);
+        for (int u = 0; u < NU; u++) {
+            const int m = m0 + min(LPP * u + ((lane - m0) & (LPP - 1)), mc4 - 1);
             te[u] = tail_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
         }
         if (c + 1 < n_chunks && !(a.debug & 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
@@ -1584,22 +1588,22 @@ __global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
         const float *buf_f = lds + buf * (BUF / 4);
         if (!(a.debug & 4))
 #pragma unroll
-            for (int u = 0; u < 4; u++) {  // mics 0..31 of the chunk (prefetched above)
-                const bool on = tail_lane && 8 * u + ((lane - m0) & 7) < mc;
+            for (int u = 0; u < NU; u++) {  // mics 0..31 of the chunk (prefetched above)
+                const bool on = tail_lane && LPP * u + ((lane - m0) & (LPP - 1)) < mc;
                 tail = __builtin_fmaf(on ? 0.5f - te[u].f : 0.0f, buf_f[(te[u].addr + 1024u) >> 2], tail);  // 1 - f
             }
         for (int j0 = 32; j0 < ((a.debug & 4) ? 0 : mc4); j0 += 32) {  // chunks of more than 32 mics (narrow windows)
-            QuadEntry e[4];
-            bool on[4];
+            QuadEntry e[NU];
+            bool on[NU];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + 8 * u + ((lane - m0) & 7);
+            for (int u = 0; u < NU; u++) {
+                const int j = j0 + LPP * u + ((lane - m0) & (LPP - 1));
                 const int m = m0 + min(j, mc4 - 1);
                 e[u] = tail_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
                 on[u] = tail_lane && j < mc;  // padding mics (j >= mc) add nothing
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < NU; u++)
                 tail = __builtin_fmaf(on[u] ? 0.5f - e[u].f : 0.0f, buf_f[(e[u].addr + 1024u) >> 2], tail);  // 1 - f
         }
         if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1618,13 +1622,13 @@ __global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
         o[3] = (unsigned long long) n_chunks;
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
     }
-    tail = sum8(tail);
+    tail = LPP == 16 ? sum16(tail) : sum8(tail);
     const float norm = (float) (kSamples * a.usable);
     auto finish = [&](const f4 &A, const f4 &S, int slot) {
         const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
         const f2 Ax = f2{A[0], A[1]}, Ay = f2{A[2], A[3]};  // accumulated with f - 1/2 (see QuadEntry)
         const f2 Hx = 0.5f * f2{S[0], S[1]}, Hy = 0.5f * f2{S[2], S[3]};
-        const float tl = lane_value(tail, slot * 8);
+        const float tl = lane_value(tail, slot * LPP);
         const float sum = finish_pixel(Hx + Ax, Hx - Ax, Hy + Ay, Hy - Ay, tl, lane);  // sum f X, sum (1 - f) X
         if (lane == 0 && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = sum / norm;
     };
