@@ -755,12 +755,11 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     qa.rows = h->cfg.pixel_count / qa.cols;
     qa.tiles = awpu::quad_tiles(qa.rows, qa.cols);
     qa.n_pairs = (batch + 1) / 2;
-    {   // frame pairs one XCD works on at a time: as many as keep their samples in its 4 MiB L2 beside the table stream;
-        // measured on the BASELINE shapes (two alternating runs each): pairs of up to 768 KiB (256 mics) do best at 8
-        // (headline 4.81 -> 4.75 ms against 4; c2 the same at 4 and 8), pairs of 1.5 MB (512 mics) at 2
+    {   // frame pairs one XCD works on at a time: as many as keep their samples in its 4 MiB L2 beside the table stream.
+        // (Eight pairs at the headline shape, 5.9 MB of samples, run 1.2 % faster than four -- fewer table passes --
+        // but the samples then stream from beyond the L2: 3.2 GB of L2 misses per launch instead of 0.72 GB.  Not taken.)
         const size_t pair_bytes = (size_t) pp.usable_pad * pp.wr * 8;
-        int g = env().pair_group > 0 ? env().pair_group
-                : pair_bytes <= (768u << 10) ? 8 : (int) std::max<size_t>(1, (3u << 20) / pair_bytes);
+        int g = env().pair_group > 0 ? env().pair_group : (int) std::max<size_t>(1, (3u << 20) / pair_bytes);
         g = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;
         while (g > 1 && g > qa.n_pairs) g >>= 1;
         qa.pair_group = g;
