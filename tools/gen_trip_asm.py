@@ -718,6 +718,7 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
 
     def stage(base, i, z):
         R, X0, X23 = Z[z]["R"], Z[z]["X0"], Z[z]["X23"]
+        nobranch = os.environ.get("QUAD1_NOBRANCH") == "1"  # timing-only builds: every pixel taken as coinciding (wrong results)
         fs = lambda p: f"s[{f_of(base, p, i)}:{f_of(base, p, i) + 1}]"
         L = []
         # pixel 3: own samples always; the shared sum's correction only where its delay differs
@@ -733,7 +734,7 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
                         correct(3, X23, R) + [f"s_branch .Lad{u}", f".Laf{u}:"] + both + [f"s_branch .Lad{u2}"])
         else:
             cold.extend([f".Lac{u}:"] + correct(3, X23, R) + [f"s_branch .Lad{u}"])
-        L += fmas(3, fs(3), X23) + [f"s_cmp_lg_u32 s{a_of(base, 3, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lac{u}", f".Lad{u}:"]
+        L += fmas(3, fs(3), X23) + ([] if nobranch else [f"s_cmp_lg_u32 s{a_of(base, 3, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lac{u}"]) + [f".Lad{u}:"]
         # pixel 2: the reference's samples, or pixel 3's, or (rare) its own read on the spot
         u = u2
         cold.extend([f".Lac{u}:",
@@ -741,11 +742,11 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
                      f"s_cbranch_scc0 .Lae{u}"] + fmas(2, fs(2), X23) + correct(2, X23, R) + [f"s_branch .Lad{u}",
                      f".Lae{u}:"] + reads(spot, a_of(base, 2, i)) + ["s_waitcnt lgkmcnt(0)"] + fmas(2, fs(2), spot) + correct(2, spot, R) +
                     [f"s_branch .Lad{u}"])
-        L += [f"s_cmp_lg_u32 s{a_of(base, 2, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lac{u}"] + fmas(2, fs(2), R) + [f".Lad{u}:"]
+        L += ([] if nobranch else [f"s_cmp_lg_u32 s{a_of(base, 2, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lac{u}"]) + fmas(2, fs(2), R) + [f".Lad{u}:"]
         # pixel 0
         u = uid()
         cold.extend([f".Lac{u}:"] + correct(0, X0, R) + [f"s_branch .Lad{u}"])
-        L += fmas(0, fs(0), X0) + [f"s_cmp_lg_u32 s{a_of(base, 0, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lac{u}", f".Lad{u}:"]
+        L += fmas(0, fs(0), X0) + ([] if nobranch else [f"s_cmp_lg_u32 s{a_of(base, 0, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lac{u}"]) + [f".Lad{u}:"]
         # the reference: the shared sum and its own A
         L += [f"v_pk_add_f32 {pair(T, k)}, {pair(T, k)}, {pair(R, k)}" for k in range(nk)] + fmas(REF, fs(REF), R)
         return L
