@@ -88,7 +88,7 @@ _SIGNATURES = {
     "awpu_hip_process_ring": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_ring_snapshot": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_heatmap_u8": (C.c_int, [_f32p, C.c_int32, _u8p]),
-    "awpu_hip_live_block": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _f32p, C.c_int32, C.c_int32, _u8p, C.c_int32,
+    "awpu_hip_live_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _f32p, C.c_int32, C.c_int32, _u8p, C.c_int32,
                                       C.c_int32, C.c_void_p, _u8p]),
     "awpu_hip_steer_table": (C.c_int, [_f32p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
                                        _i32p, _f32p]),
@@ -389,17 +389,28 @@ class Engine:
                                         _f32(out) if want_beams else None), "awpu_hip_beams")
         return power, out
 
-    def live_block(self, wire: bytes, rows: int, cols: int, out_rows: int = 0, out_cols: int = 0,
-                   d_colormap_ptr: int = 0, want_power: bool = True):
+    def live_block(self, wire, rows: int, cols: int, out_rows: int = 0, out_cols: int = 0,
+                   d_colormap_ptr: int = 0, want_power: bool = True, out=None):
         """Block in, images out (awpu_hip_live_block): ingest 256 raw datagrams, sweep the new snapshot, 8-bit
-        heatmap, optional upscale -> (power or None, image [rows, cols], big image or None)."""
+        heatmap, optional upscale -> (power or None, image [rows, cols], big image or None).  `wire`: bytes or a
+        contiguous uint8 array (a receive buffer that is refilled in place); `out` = (power, image, big) arrays of an
+        earlier call to write into again (a display loop keeps its buffers: the library then replays one HIP graph
+        per ring position instead of enqueuing the steps one by one)."""
         if len(wire) != 256 * 1032:
             raise ValueError("wire must be 256 datagrams of 1032 bytes")
-        power = np.empty(self.cfg.n_pixels, np.float32) if want_power else None
-        image = np.empty((rows, cols), np.uint8)
-        big = None
-        if out_rows:
-            big = np.empty((out_rows, out_cols, 3) if d_colormap_ptr else (out_rows, out_cols), np.uint8)
+        if isinstance(wire, np.ndarray):
+            if wire.dtype != np.uint8 or not wire.flags.c_contiguous:
+                raise ValueError("wire array must be contiguous uint8")
+            wire = wire.ctypes.data_as(C.c_void_p)
+        if out is not None:
+            power, image, big = out
+        else:
+            power = np.empty(self.cfg.n_pixels, np.float32) if want_power else None
+            image = np.empty((rows, cols), np.uint8)
+            big = None
+            if out_rows:
+                big = np.empty((out_rows, out_cols, 3) if d_colormap_ptr else (out_rows, out_cols), np.uint8)
+        want_power = power is not None
         _check(self._lib.awpu_hip_live_block(self._h, wire, 1032, _f32(power) if want_power else None, rows, cols,
                                              image.ctypes.data_as(_u8p), out_rows, out_cols, C.c_void_p(d_colormap_ptr),
                                              big.ctypes.data_as(_u8p) if big is not None else None), "awpu_hip_live_block")

@@ -108,6 +108,19 @@ struct awpu_hip {
     unsigned char *d_datagrams = nullptr;  // staging for one block of wire datagrams
     int32_t *d_row_off_ring = nullptr;  // row offsets for frames read out of the ring (pitch 2048)
     int ring_pos = 0;                   // where the next block goes = start of the snapshot
+    // awpu_hip_live_block as a HIP graph: the call's copies and launches captured once per (ring position, caller
+    // buffers, table generation) and replayed with one hipGraphLaunch
+    struct LiveGraph {
+        int ring_pos, stride, rows, cols, out_rows, out_cols;
+        const void *datagrams, *power, *image, *colormap, *big_image;
+        unsigned long long gen;
+        hipGraphExec_t exec;
+    };
+    std::vector<LiveGraph> live_graphs;
+    unsigned long long table_gen = 0;   // bumped whenever prepare() rebuilds the device tables
+    int live_warm = 0;                  // plain live calls made with the current tables AND this call shape (lazy allocations done after one)
+    unsigned long long live_shape = 0;  // the shape those calls had: image sizes, which outputs, colour table or not
+    bool live_graph_broken = false;     // a capture failed on this runtime: never try again
     bool have_fir = false;
     int32_t *d_row_off = nullptr;
     int32_t *d_row_off_compact = nullptr;  // the same for frames uploaded as [streams][compact_hist] windows
@@ -167,12 +180,14 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
     int stationary = -1;           // AWPU_FAST_STATIONARY=0/1: never / always (where it fits) the stationary pair shape
     int fir_planes = 1;            // AWPU_FIR8_PLANES=0: FIR8 batches on the older lane-strided pair kernel (A/B measurements); 2: the plane kernel for every batch >= 2, however small the grid (tests)
     int wgs = 0;                   // AWPU_FAST_WGS: persistent workgroups of the quad shape (0 = one workgroup per item)
+    int live_graph = 1;            // AWPU_LIVE_GRAPH=0: awpu_hip_live_block always enqueues its steps one by one
     int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0] (tests)
     EnvKnobs() {
         if (const char *v = std::getenv("AWPU_FAST_QUADS")) quads = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_PAIRGROUP")) pair_group = std::atoi(v);
         if (const char *v = std::getenv("AWPU_QUAD_VARIANT")) quad_variant = std::atoi(v);
         if (const char *v = std::getenv("AWPU_GROUP_FORCE_COPY")) group_copy = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_LIVE_GRAPH")) live_graph = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_WGS")) wgs = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FIR8_PLANES")) fir_planes = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_STATIONARY")) stationary = std::atoi(v);
@@ -392,6 +407,10 @@ int prepare(awpu_hip *h) {
     st.alg_flops_frame = 4ull * P * U * awpu::kSamples + 6ull * P * (awpu::kSamples - 2);
     st.kernel_variant = c.math;
     h->prepared = true;
+    h->table_gen++;  // graphs of awpu_hip_live_block captured against the old tables are stale
+    h->live_warm = 0;
+    for (auto &g : h->live_graphs) (void) hipGraphExecDestroy(g.exec);
+    h->live_graphs.clear();
     return AWPU_OK;
 }
 
@@ -1287,6 +1306,8 @@ int awpu_hip_destroy(awpu_hip_t *h) {
     (void) hipSetDevice(h->cfg.device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void) hipStreamSynchronize(h->copy_stream);
+    for (auto &g : h->live_graphs) (void) hipGraphExecDestroy(g.exec);
+    h->live_graphs.clear();
     release_device(h);
     for (hipEvent_t ev : {h->ev_begin, h->ev_end, h->ev_fan, h->ev_copied[0], h->ev_copied[1], h->ev_swept[0], h->ev_swept[1], h->ev_done})
         if (ev) (void) hipEventDestroy(ev);
@@ -1609,18 +1630,13 @@ int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_b
     return AWPU_OK;
 }
 
-int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes, float *power, int32_t rows,
-                        int32_t cols, uint8_t *image, int32_t out_rows, int32_t out_cols, const uint8_t *d_colormap,
-                        uint8_t *big_image) {
-    AWPU_CTX(h);
-    if (h && !h->parts.empty()) return invalid("the display step needs the whole grid on one device");
-    int rc = check_ready(h, 1);
-    if (rc != AWPU_OK) return rc;
+namespace {
+
+// the steps of one live block on h->stream, without the final wait
+int enqueue_live_block(awpu_hip *h, const void *datagrams, int32_t stride_bytes, float *power, int32_t rows, int32_t cols,
+                       uint8_t *image, int32_t out_rows, int32_t out_cols, const uint8_t *d_colormap, uint8_t *big_image) {
     const int n = h->cfg.n_pixels;
-    if (h->cfg.pixel_count != n) return invalid("the display step needs the whole grid on this handle");
-    if ((image || big_image) && (rows < 1 || cols < 1 || rows * cols != n)) return invalid("rows x cols must be the grid");
-    if (big_image && (out_rows < rows || out_cols < cols || out_rows > 65535)) return invalid("upscale only: out >= in");
-    rc = enqueue_ingest(h, datagrams, stride_bytes);
+    int rc = enqueue_ingest(h, datagrams, stride_bytes);
     if (rc != AWPU_OK) return rc;
     rc = ensure_power(h, (size_t) n);
     if (rc != AWPU_OK) return rc;
@@ -1647,7 +1663,90 @@ int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_byt
                                         h->stream));
         }
     }
+    return AWPU_OK;
+}
+
+}  // namespace
+
+int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes, float *power, int32_t rows,
+                        int32_t cols, uint8_t *image, int32_t out_rows, int32_t out_cols, const uint8_t *d_colormap,
+                        uint8_t *big_image) {
+    AWPU_CTX(h);
+    if (h && !h->parts.empty()) return invalid("the display step needs the whole grid on one device");
+    int rc = check_ready(h, 1);
+    if (rc != AWPU_OK) return rc;
+    const int n = h->cfg.n_pixels;
+    if (h->cfg.pixel_count != n) return invalid("the display step needs the whole grid on this handle");
+    if ((image || big_image) && (rows < 1 || cols < 1 || rows * cols != n)) return invalid("rows x cols must be the grid");
+    if (big_image && (out_rows < rows || out_cols < cols || out_rows > 65535)) return invalid("upscale only: out >= in");
+    if (!datagrams) return invalid("null argument");
+
+    // A live block is eight small copies and launches: launch-latency bound.  Once every lazily allocated buffer
+    // exists (after two plain calls) the sequence is captured into a HIP graph -- one per ring position and set of
+    // caller buffers, a display loop reuses its own -- and replayed with a single launch.
+    const bool graphs = env().live_graph != 0 && !h->live_graph_broken && h->d_ring != nullptr;
+    // (a call of another shape allocates: upscale taps, a larger display buffer -- not while a capture is open)
+    const unsigned long long shape = ((unsigned long long) (unsigned) rows << 48) ^ ((unsigned long long) (unsigned) cols << 36) ^
+                                     ((unsigned long long) (unsigned) out_rows << 20) ^ ((unsigned long long) (unsigned) out_cols << 4) ^
+                                     (power ? 1u : 0u) ^ (image ? 2u : 0u) ^ (big_image ? 4u : 0u) ^ (d_colormap ? 8u : 0u);
+    if (shape != h->live_shape) {
+        h->live_shape = shape;
+        h->live_warm = 0;
+    }
+    if (graphs && h->live_warm >= 2) {
+        awpu_hip::LiveGraph key{h->ring_pos, stride_bytes, rows, cols, out_rows, out_cols, datagrams, power, image, d_colormap,
+                                big_image, h->table_gen, nullptr};
+        for (const auto &g : h->live_graphs)
+            if (g.ring_pos == key.ring_pos && g.stride == key.stride && g.rows == key.rows && g.cols == key.cols &&
+                g.out_rows == key.out_rows && g.out_cols == key.out_cols && g.datagrams == key.datagrams && g.power == key.power &&
+                g.image == key.image && g.colormap == key.colormap && g.big_image == key.big_image && g.gen == key.gen) {
+                AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+                AWPU_HIP_TRY(hipGraphLaunch(g.exec, h->stream));
+                h->ring_pos = (h->ring_pos + awpu::kSamples) % AWPU_HIST;  // (what enqueue_ingest does on the plain path)
+                h->stats.launches += 1;
+                h->stats.frames += 1;
+                AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
+                return AWPU_OK;
+            }
+        if (h->live_graphs.size() < 64) {  // capture this variant (the stream is idle: every call ends with a wait)
+            AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
+            const bool keep_timing = h->timing;
+            const int keep_pos = h->ring_pos;
+            const auto keep_stats = h->stats;
+            h->timing = false;  // (event records inside a graph would not bracket anything)
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                rc = enqueue_live_block(h, datagrams, stride_bytes, power, rows, cols, image, out_rows, out_cols, d_colormap, big_image);
+                e = hipStreamEndCapture(h->stream, &graph);  // (also on failure: it takes the stream out of capture mode)
+            } else {
+                rc = AWPU_ERR_HIP;
+            }
+            h->timing = keep_timing;
+            h->ring_pos = keep_pos;  // nothing ran yet
+            h->stats = keep_stats;
+            hipGraphExec_t exec = nullptr;
+            if (rc == AWPU_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                key.exec = exec;
+                h->live_graphs.push_back(key);
+            } else {
+                hipStreamCaptureStatus status = hipStreamCaptureStatusNone;  // (an invalidated capture must not outlive this call)
+                if (hipStreamIsCapturing(h->stream, &status) == hipSuccess && status != hipStreamCaptureStatusNone) {
+                    hipGraph_t dead = nullptr;
+                    (void) hipStreamEndCapture(h->stream, &dead);
+                    if (dead) (void) hipGraphDestroy(dead);
+                }
+                (void) hipGetLastError();
+                h->live_graph_broken = true;  // this runtime does not capture the sequence: stay on the plain path
+            }
+            if (graph) (void) hipGraphDestroy(graph);
+            if (!h->live_graph_broken) return awpu_hip_live_block(h, datagrams, stride_bytes, power, rows, cols, image, out_rows, out_cols, d_colormap, big_image);
+        }
+    }
+    rc = enqueue_live_block(h, datagrams, stride_bytes, power, rows, cols, image, out_rows, out_cols, d_colormap, big_image);
+    if (rc != AWPU_OK) return rc;
     AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->live_warm++;
     return AWPU_OK;
 }
 

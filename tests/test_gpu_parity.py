@@ -1018,6 +1018,36 @@ def test_live_block_equals_the_separate_steps(pkg, oracle):
             one.live_block(blocks[0], 8, 16)  # rows x cols is not the grid
 
 
+def test_live_block_replayed_as_a_graph(pkg, oracle):
+    """A display loop keeps its buffers: the receive buffer is refilled in place and the images land in the same
+    arrays block after block.  From the third such call on awpu_hip_live_block replays one captured HIP graph per
+    ring position (eight of them) -- the copies in it must read the buffer's CURRENT contents, and a new delay table
+    must retire the graphs.  24 blocks against the separate entry points, then a table change and 10 more."""
+    rng = np.random.default_rng(56)
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 16, 16)
+    off2, frac2 = oracle.compute_delay_lut(xyz, 16, 16, fov_deg=90.0)
+    wire = np.zeros(256 * 1032, np.uint8)
+    out = (np.zeros(256, np.float32), np.zeros((16, 16), np.uint8), np.zeros((40, 56), np.uint8))
+    with pkg.Engine(n_pixels=256) as one, pkg.Engine(n_pixels=256) as sep:
+        for eng in (one, sep):
+            eng.set_delay_table(off, frac)
+            eng.set_active_mics(None)
+        for b in range(34):
+            if b == 24:
+                for eng in (one, sep):
+                    eng.set_delay_table(off2, frac2)
+            block = make_datagrams(rng.integers(-(1 << 23), 1 << 23, (256, 256), dtype=np.int32), counter0=256 * b)
+            wire[:] = np.frombuffer(block, np.uint8)
+            power, image, big = one.live_block(wire, 16, 16, 40, 56, out=out)
+            assert power is out[0] and image is out[1] and big is out[2]
+            sep.ingest_block(block)
+            want_power = sep.process_ring()
+            assert np.array_equal(power, want_power), b
+            assert np.array_equal(image.ravel(), oracle.heatmap_u8(want_power)), b
+            assert np.array_equal(big, oracle.resize_linear_u8(image, 40, 56)), b
+
+
 @pytest.mark.parametrize("n_streams,usable,P", [(128, 128, 100), (256, 256, 4096), (256, 201, 333), (192, 64, 65)])
 def test_ring_sweep_wider_arrays(pkg, oracle, n_streams, usable, P):
     """The device ring with 2..4 arrays on the wire (the datagram carries up to 256 sensors), ragged mic
