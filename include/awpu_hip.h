@@ -257,7 +257,11 @@ int awpu_hip_ingest_block(awpu_hip_t *h, const void *datagrams, int32_t stride_b
  * ingest the block, sweep the ring's new snapshot, scale to 8 bits, upscale, and bring back what the
  * caller asks for.  Every output is a host buffer and may be NULL: power [n_pixels], image [rows*cols],
  * big_image [out_rows*out_cols] (x3 through d_colormap[256][3], device memory, when that is not NULL).
- * Needs the whole grid on this handle (pixel_count == n_pixels) and rows*cols == n_pixels. */
+ * Needs the whole grid on this handle (pixel_count == n_pixels) and rows*cols == n_pixels.
+ * A display loop that passes the same buffers block after block (a receive buffer refilled in place, its two images)
+ * gets the call replayed as one captured HIP graph per ring position from the third call on: the copies read and
+ * write the buffers' current contents; a new delay table, mic list or set of gains retires the graphs.
+ * AWPU_LIVE_GRAPH=0 in the environment keeps the step-by-step path. */
 int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_bytes, float *power, int32_t rows,
                         int32_t cols, uint8_t *image, int32_t out_rows, int32_t out_cols, const uint8_t *d_colormap,
                         uint8_t *big_image);
