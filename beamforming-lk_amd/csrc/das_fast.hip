@@ -207,6 +207,19 @@ __device__ __forceinline__ float sum16(float v) {  // the same over each row of 
     v = sum8(v);
     return v + dpp_take<0x140>(v);  // row_mirror: the other half of the row
 }
+__device__ __forceinline__ float sum32(float v) {  // over each half of the wave; rows 1 and 3 then hold it
+    v = sum16(v);
+    return v + dpp_take<0x142, 0xa>(v);  // row_bcast:15: row 0's (2's) sum into every lane of row 1 (3)
+}
+template <int LPP>
+__device__ __forceinline__ float sum_lanes(float v) {
+    static_assert(LPP == 8 || LPP == 16 || LPP == 32, "groups of 8, 16 or 32 lanes");
+    return LPP == 8 ? sum8(v) : LPP == 16 ? sum16(v) : sum32(v);
+}
+template <int LPP>
+__device__ __forceinline__ constexpr int sum_lane_of(int group) {  // a lane that holds group `group`'s sum
+    return LPP == 32 ? 32 * group + 16 : LPP * group;
+}
 __device__ __forceinline__ float lane_value(float v, int lane_index) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_index));
 }
@@ -277,13 +290,29 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
 #pragma unroll
         for (int b = 0; b < FPI; b++) acc[pp].A[b] = acc[pp].Q[b] = acc[pp].C[b] = acc[pp].R[b] = f2{0.0f, 0.0f};
 
-    const int tail_pp = lane >> 3;
+    // tail pass (the 257th sample of every window): 8 lanes per pixel whatever the shape -- a lane's partial sum then
+    // runs over the same mics in the same order whatever the chunk size or pixels per wave, so that results do not
+    // depend on the kernel shape (a device group's slabs may run other shapes than the whole grid would); a round
+    // covers 32 mics in NU entries per lane; the first round's entries are requested before the chunk is staged
+    constexpr int LPP = 8, NU = 32 / LPP;
+    const int tail_pp = lane / LPP;
     const bool tail_lane = tail_pp < PPW && pix0 + tail_pp < a.pixel_count;
     const FastEntry *tail_row = a.lut + (size_t) (pix0 + (tail_lane ? tail_pp : 0)) * a.usable_pad;
+    struct AddrG {
+        unsigned addr;
+        float g;
+    };
 
     for (int m0 = 0; m0 < a.usable; m0 += a.chunk) {
         const int mc = min(a.chunk, a.usable - m0);
         const int mc4 = (mc + 3) & ~3;  // the table pads every pixel row to a multiple of 4
+        AddrG te[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int j = LPP * u + ((lane - m0) & (LPP - 1));
+            te[u] = *(const AddrG *) ((const char *) (tail_row + m0 + min(j, mc4 - 1)) + 4);  // fields addr, g
+            if (!tail_lane || j >= mc4) te[u].g = 0.0f;
+        }
         __syncthreads();                // the previous chunk is fully consumed
 
         // ---- stage [frame][mic][copy][wr] floats: copy q = the window shifted by q samples.
@@ -370,19 +399,24 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
                 }
             }
             // ---- the 257th sample of every window (X[off+256], weight g, goes to out[255]): lane
-            // 8*pp + k gathers it for pixel pp and the mics s = k (mod 8) of this chunk.  A lane's
-            // partial sum therefore runs over the same mics in the same order whatever the chunk
-            // size or pixels-per-wave, so results do not depend on the kernel shape.
-            for (int j0 = 0; j0 < mc4; j0 += 32) {  // four passes per trip: their loads overlap
-                FastEntry e[4];
+            // LPP*pp + k gathers it for pixel pp and the mics s = k (mod LPP) of this chunk.
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int j = j0 + 8 * u + ((lane - m0) & 7);
-                    e[u] = tail_row[m0 + min(j, mc4 - 1)];
+            for (int u = 0; u < NU; u++)  // mics 0..31 of the chunk (requested before the staging)
+#pragma unroll
+                for (int b = 0; b < FPI; b++) {
+                    const float x = lds[(te[u].addr + 1024u + (unsigned) (b * FS)) >> 2];
+                    tail[b] = __builtin_fmaf(te[u].g, x, tail[b]);
+                }
+            for (int j0 = 32; j0 < mc4; j0 += 32) {  // chunks of more than 32 mics
+                AddrG e[NU];
+#pragma unroll
+                for (int u = 0; u < NU; u++) {
+                    const int j = j0 + LPP * u + ((lane - m0) & (LPP - 1));
+                    e[u] = *(const AddrG *) ((const char *) (tail_row + m0 + min(j, mc4 - 1)) + 4);
                     if (!tail_lane || j >= mc4) e[u].g = 0.0f;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < NU; u++)
 #pragma unroll
                     for (int b = 0; b < FPI; b++) {
                         const float x = lds[(e[u].addr + 1024u + (unsigned) (b * FS)) >> 2];
@@ -392,10 +426,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
         }
     }
 
-    // combine the 8 partial tail sums of each pixel; lanes 8*pp .. 8*pp+7 then hold pixel pp's
+    // combine the LPP partial tail sums of each pixel
 #pragma unroll
     for (int b = 0; b < FPI; b++) {
-        tail[b] = sum8(tail[b]);
+        tail[b] = sum_lanes<LPP>(tail[b]);
     }
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++) {
@@ -403,7 +437,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
         if (p < a.pixel_count) {
 #pragma unroll
             for (int b = 0; b < FPI; b++) {
-                const float t = lane_value(tail[b], pp * 8);
+                const float t = lane_value(tail[b], sum_lane_of<LPP>(pp));
                 const float sum = finish_pixel(acc[pp].A[b], acc[pp].Q[b], acc[pp].C[b], acc[pp].R[b], t, lane);
                 if (lane == 0 && frame0 + b < a.batch) {
                     a.power[(size_t) (frame0 + b) * a.pixel_count + p] = sum / (float) (kSamples * a.usable);
