@@ -66,6 +66,8 @@ class AwpuError(RuntimeError):
         super().__init__(f"{where}: status {status} ({detail})")
 
 
+PEER_SAME_DEVICE, PEER_DIRECT, PEER_HOST_STAGED = 0, 1, 2
+
 _lib: Optional[C.CDLL] = None
 
 _f32p = C.POINTER(C.c_float)
@@ -114,6 +116,7 @@ _SIGNATURES = {
         [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, _i32p, _f32p],
     ),
     "awpu_hip_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "awpu_hip_group_peer_status": (C.c_int, [C.c_void_p, _i32p, C.c_int32]),
     "awpu_hip_strerror": (C.c_char_p, [C.c_int]),
     "awpu_hip_last_error": (C.c_char_p, []),
     "awpu_hip_abi_version": (C.c_int, []),
@@ -468,6 +471,14 @@ class Engine:
 
     def synchronize(self) -> None:
         _check(self._lib.awpu_hip_synchronize(self._h), "awpu_hip_synchronize")
+
+    def peer_status(self) -> list:
+        """Per device of the group: PEER_SAME_DEVICE / PEER_DIRECT / PEER_HOST_STAGED (awpu_hip_group_peer_status)."""
+        buf = (C.c_int32 * 8)()
+        n = self._lib.awpu_hip_group_peer_status(self._h, buf, 8)
+        if n < 0:
+            _check(n, "group_peer_status")
+        return [int(buf[k]) for k in range(n)]
 
     def stats(self) -> Stats:
         st = Stats()

@@ -115,11 +115,14 @@ struct awpu_hip {
         const void *datagrams, *power, *image, *colormap, *big_image;
         unsigned long long gen;
         hipGraphExec_t exec;
+        unsigned long long last_use;  // live_clock at the last replay: the least recently used graph is evicted
     };
     std::vector<LiveGraph> live_graphs;
     unsigned long long table_gen = 0;   // bumped whenever prepare() rebuilds the device tables
     int live_warm = 0;                  // plain live calls made with the current tables AND this call shape (lazy allocations done after one)
     unsigned long long live_shape = 0;  // the shape those calls had: image sizes, which outputs, colour table or not
+    const void *live_bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // ... and the caller's buffers (a capture bakes them in)
+    unsigned long long live_clock = 0;
     bool live_graph_broken = false;     // a capture failed on this runtime: never try again
     bool have_fir = false;
     int32_t *d_row_off = nullptr;
@@ -141,6 +144,18 @@ struct awpu_hip {
     size_t fan_cap = 0;                     // floats per buffer
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_swept[2] = {nullptr, nullptr}, ev_done = nullptr;
     unsigned fan_turn = 0;
+    // how a part of a group reaches devices[0]: kPeerSame (the same GPU), kPeerDirect (peer copies over xGMI) or
+    // kPeerStaged (no peer access on this node: the window and the tiles cross pinned host memory, explicitly)
+    int peer = 0;
+    float *h_stage[2] = {nullptr, nullptr};  // group: pinned staging of the frames' window for the staged parts
+    size_t stage_cap = 0;                    // floats per buffer
+    int stage_lo = 0, stage_w = 0;           // group: the window [stage_lo, stage_lo + stage_w) of every stream that is staged
+    hipEvent_t ev_staged[2] = {nullptr, nullptr};   // group: window b is in h_stage[b]
+    unsigned stage_turn = 0;
+    float *h_tile[2] = {nullptr, nullptr};   // part (staged): pinned staging of its power tile on the way back
+    size_t tile_cap = 0;
+    hipEvent_t ev_tile_free[2] = {nullptr, nullptr};  // part (staged): the caller's stream has read h_tile[b]
+    bool tile_used[2] = {false, false}, fan_used[2] = {false, false};
     bool in_flight = false;                 // awpu_hip_process_async without its awpu_hip_wait yet
 
     awpu_hip_stats stats{};
@@ -181,7 +196,7 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
     int fir_planes = 1;            // AWPU_FIR8_PLANES=0: FIR8 batches on the older lane-strided pair kernel (A/B measurements); 2: the plane kernel for every batch >= 2, however small the grid (tests)
     int wgs = 0;                   // AWPU_FAST_WGS: persistent workgroups of the quad shape (0 = one workgroup per item)
     int live_graph = 1;            // AWPU_LIVE_GRAPH=0: awpu_hip_live_block always enqueues its steps one by one
-    int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0] (tests)
+    int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0]; 2: and through pinned host memory, the path of a node without peer access (tests)
     EnvKnobs() {
         if (const char *v = std::getenv("AWPU_FAST_QUADS")) quads = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_PAIRGROUP")) pair_group = std::atoi(v);
@@ -195,6 +210,9 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
             if (std::sscanf(v, "%d,%d,%d", &fpi, &ppw, &nw) < 2) fpi = ppw = nw = 0;
         if (const char *v = std::getenv("AWPU_FAST_PAIRS")) pairs = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_DEBUG")) debug = std::atoi(v);
+#ifndef AWPU_TIMING_BUILD
+        debug &= awpu::kDebugSafeBits;  // the wrong-result timing switches do not exist in this build (das_kernels.h)
+#endif
         if (const char *v = std::getenv("AWPU_FAST_FPW")) fpw = std::atoi(v);
     }
 };
@@ -203,7 +221,28 @@ const EnvKnobs &env() {
     return knobs;
 }
 
+// The captured live-block graphs hold raw device pointers (d_power, d_display, d_taps, d_ring, tables, d_pack):
+// whoever frees or reallocates one of those retires the graphs first.  The next live calls run step by step and
+// capture again once the buffers have settled.
+void retire_live_graphs(awpu_hip *h) {
+    for (auto &g : h->live_graphs) (void) hipGraphExecDestroy(g.exec);
+    h->live_graphs.clear();
+    h->live_warm = 0;
+}
+
+// grow-only device buffer shared by the sweep shapes that pack frames (pairs, quads, FIR8 planes)
+int ensure_pack(awpu_hip *h, size_t need) {
+    if (h->pack_cap >= need) return AWPU_OK;
+    retire_live_graphs(h);
+    dev_free(h->d_pack);
+    h->pack_cap = 0;
+    AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
+    h->pack_cap = need;
+    return AWPU_OK;
+}
+
 void release_device(awpu_hip *h) {
+    retire_live_graphs(h);
     dev_free(h->d_lut);
     for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
@@ -233,6 +272,12 @@ void release_device(awpu_hip *h) {
     dev_free(h->d_fan[0]);
     dev_free(h->d_fan[1]);
     h->fan_cap = 0;
+    for (int b = 0; b < 2; b++) {
+        if (h->h_stage[b]) (void) hipHostFree(h->h_stage[b]);
+        if (h->h_tile[b]) (void) hipHostFree(h->h_tile[b]);
+        h->h_stage[b] = h->h_tile[b] = nullptr;
+    }
+    h->stage_cap = h->tile_cap = 0;
     h->beam_cap = h->beam_lut_cap = h->pack_cap = h->frames_cap = h->power_cap = 0;
 }
 
@@ -408,9 +453,7 @@ int prepare(awpu_hip *h) {
     st.kernel_variant = c.math;
     h->prepared = true;
     h->table_gen++;  // graphs of awpu_hip_live_block captured against the old tables are stale
-    h->live_warm = 0;
-    for (auto &g : h->live_graphs) (void) hipGraphExecDestroy(g.exec);
-    h->live_graphs.clear();
+    retire_live_graphs(h);
     return AWPU_OK;
 }
 
@@ -551,6 +594,7 @@ void choose_fast_variant(awpu_hip *h, int batch, int *fpi, int *ppw, int *nw) {
 // layout of d_frames: kFull [batch][n_streams][hist]; kCompact [batch][n_streams][compact_hist] with
 // sample 0 = history sample wstart; kRing one frame read in place from the ingest ring (rows 2048 apart)
 enum FrameLayout { kFull = 0, kCompact = 1, kRing = 2 };
+enum PeerPath { kPeerSame = 0, kPeerDirect = 1, kPeerStaged = 2 };
 
 // a launch is over: close the timing bracket and count it (also on the diagnostic paths)
 int finish_launch(awpu_hip *h, int batch, hipStream_t s) {
@@ -628,12 +672,7 @@ int launch_fir8_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_po
         AWPU_HIP_TRY(hipMemcpy(h->d_fir_pair_lut, packed.data(), packed.size() * sizeof(awpu::LutEntry), hipMemcpyHostToDevice));
     }
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * U * pp.wr * 2;
-    if (h->pack_cap < need) {
-        dev_free(h->d_pack);
-        h->pack_cap = 0;
-        AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
-        h->pack_cap = need;
-    }
+    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
     awpu::PairArgs pa{};
     pa.packed = h->d_pack;
     pa.power = d_power;
@@ -681,12 +720,7 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
         AWPU_HIP_TRY(hipMemcpy(h->d_fir_plane_lut, packed.data(), packed.size() * sizeof(Entry), hipMemcpyHostToDevice));
     }
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * U * pp.wr * 2;
-    if (h->pack_cap < need) {
-        dev_free(h->d_pack);
-        h->pack_cap = 0;
-        AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
-        h->pack_cap = need;
-    }
+    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
     awpu::PairArgs pa{};
     pa.packed = h->d_pack;
     pa.power = d_power;
@@ -708,12 +742,7 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
                  hipStream_t s, int hist_eff, int wstart_eff, int stationary_tiles = 0) {
     const awpu::FastPlan &pp = plut->plan;
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * h->usable() * pp.wr * 2;
-    if (h->pack_cap < need) {
-        dev_free(h->d_pack);
-        h->pack_cap = 0;
-        AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
-        h->pack_cap = need;
-    }
+    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
     awpu::PairArgs pa{};
     pa.packed = h->d_pack;
     pa.lut = plut->d;
@@ -754,12 +783,7 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     if (rc != AWPU_OK) return rc;
     const awpu::FastPlan &pp = h->quad_plan;
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * pp.usable_pad * pp.wr * 2;
-    if (h->pack_cap < need) {
-        dev_free(h->d_pack);
-        h->pack_cap = 0;
-        AWPU_HIP_TRY(hipMalloc(&h->d_pack, need * sizeof(float)));
-        h->pack_cap = need;
-    }
+    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
     awpu::QuadArgs qa{};
     qa.packed = h->d_pack;
     qa.lut = h->d_quad_lut;
@@ -973,6 +997,7 @@ int check_ready(awpu_hip *h, int batch) {
 
 int ensure_power(awpu_hip *h, size_t need_power) {
     if (h->power_cap < need_power) {
+        retire_live_graphs(h);  // (they write through the old pointer)
         dev_free(h->d_power);
         h->power_cap = 0;
         AWPU_HIP_TRY(hipMalloc(&h->d_power, need_power * sizeof(float)));
@@ -1018,6 +1043,7 @@ int create_group(awpu_hip_t **out, const awpu_hip_cfg &c) {
             for (int b = 0; b < 2 && e == hipSuccess; b++) {
                 e = hipEventCreateWithFlags(&part->ev_copied[b], hipEventDisableTiming);
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_swept[b], hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_tile_free[b], hipEventDisableTiming);
             }
             if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_done, hipEventDisableTiming);
             if (e != hipSuccess) rc = hip_fail(e, "group stream/event creation");
@@ -1030,16 +1056,39 @@ int create_group(awpu_hip_t **out, const awpu_hip_cfg &c) {
             return rc;
         }
     }
-    // direct copies between devices[0] and the others (an error here only means "already enabled" or "no peer
-    // path": the copies then go through the host, slower but correct)
-    for (int k = 1; k < G; k++) {
-        if (c.devices[k] == c.devices[0]) continue;
-        if (hipSetDevice(c.devices[0]) == hipSuccess) (void) hipDeviceEnablePeerAccess(c.devices[k], 0);
-        if (hipSetDevice(c.devices[k]) == hipSuccess) (void) hipDeviceEnablePeerAccess(c.devices[0], 0);
+    // Direct copies between devices[0] and the others need peer access both ways.  Asked for and CHECKED: a pair
+    // without it (another PCIe root, IOMMU settings, a container that hides the links) takes the explicit staged path
+    // through pinned host memory -- slower, correct, and said so in awpu_hip_last_error_of / awpu_hip_group_peer_status.
+    std::string staged_note;
+    for (int k = 0; k < G; k++) {
+        awpu_hip *part = g->parts[k];
+        if (c.devices[k] == c.devices[0]) {
+            part->peer = env().group_copy >= 2 ? kPeerStaged : kPeerSame;
+            continue;
+        }
+        int can_out = 0, can_in = 0;
+        hipError_t e_out = hipDeviceCanAccessPeer(&can_out, c.devices[0], c.devices[k]);
+        hipError_t e_in = hipDeviceCanAccessPeer(&can_in, c.devices[k], c.devices[0]);
+        if (e_out == hipSuccess && e_in == hipSuccess && can_out && can_in) {
+            e_out = hipSetDevice(c.devices[0]);
+            if (e_out == hipSuccess) e_out = hipDeviceEnablePeerAccess(c.devices[k], 0);
+            e_in = hipSetDevice(c.devices[k]);
+            if (e_in == hipSuccess) e_in = hipDeviceEnablePeerAccess(c.devices[0], 0);
+        }
+        const auto enabled = [](hipError_t e) { return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled; };
+        part->peer = can_out && can_in && enabled(e_out) && enabled(e_in) && env().group_copy < 2 ? kPeerDirect : kPeerStaged;
+        if (part->peer == kPeerStaged) {
+            staged_note += "device " + std::to_string(c.devices[0]) + " <-> " + std::to_string(c.devices[k]) + ": " +
+                           (!(can_out && can_in) ? std::string("hipDeviceCanAccessPeer says no")
+                                                 : std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(enabled(e_out) ? e_in : e_out)) + "; ";
+        }
     }
     (void) hipGetLastError();
+    if (!staged_note.empty())
+        g->last_error = "device group without peer access (" + staged_note + "): frames and tiles are staged through pinned host memory";
     AWPU_HIP_TRY(hipSetDevice(c.devices[0]));
     hipError_t e = hipEventCreateWithFlags(&g->ev_fan, hipEventDisableTiming);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipEventCreateWithFlags(&g->ev_staged[b], hipEventDisableTiming);
     if (e != hipSuccess) {
         awpu_hip_destroy(g);
         return hip_fail(e, "group event creation");
@@ -1063,6 +1112,14 @@ int for_each_part(awpu_hip *g, F f) {
     }
     return AWPU_OK;
 }
+
+// switches a handle's event bracket off for one asynchronous call and back on whichever way the call ends
+struct TimingOff {
+    awpu_hip *h;
+    bool keep;
+    explicit TimingOff(awpu_hip *h_) : h(h_), keep(h_->timing) { h->timing = false; }
+    ~TimingOff() { h->timing = keep; }
+};
 
 int slab_offset(const awpu_hip *g, const awpu_hip *part) { return part->cfg.pixel_begin - g->cfg.pixel_begin; }
 
@@ -1155,19 +1212,70 @@ int group_process(awpu_hip *g, const float *frames, int batch, float *power) {
 // Frames and power in the memory of devices[0], on the caller's stream there.  The window of every stream that the
 // tables touch travels to each other device by one (2-D) peer copy on that device's copy stream; the slabs are
 // swept concurrently; the tiles return by peer copies on the caller's stream, which thereby waits for all of it.
+// Parts without peer access to devices[0] (kPeerStaged) get the same window through pinned host memory: ONE copy
+// down on the caller's stream for all of them, one copy up per part on its copy stream; their tiles return the
+// same way.  Two buffers everywhere, so that call k+1's copies run beside call k's sweeps.
 int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d_power, hipStream_t stream) {
     const int dev0 = g->cfg.devices[0];
     AWPU_HIP_TRY(hipSetDevice(dev0));
     hipStream_t s = stream ? stream : g->parts[0]->stream;
-    AWPU_HIP_TRY(hipEventRecord(g->ev_fan, s));  // the frames are in place once the caller's stream gets here
     int rc = for_each_part(g, [&](awpu_hip *part) {
         AWPU_CTX(part);
-        int r = check_ready(part, batch);  // (selects the part's device)
+        return check_ready(part, batch);  // (tables packed: every part's window is known)
+    });
+    if (rc != AWPU_OK) return rc;
+    AWPU_HIP_TRY(hipSetDevice(dev0));
+    AWPU_HIP_TRY(hipEventRecord(g->ev_fan, s));  // the frames are in place once the caller's stream gets here
+
+    // ---- staged parts: the union of their windows goes down to pinned memory once
+    int gb = 0;
+    bool any_staged = false;
+    for (awpu_hip *part : g->parts) any_staged |= part->peer == kPeerStaged && !(part->cfg.device == dev0 && !env().group_copy);
+    if (any_staged) {
+        int lo = g->cfg.hist, hi = 0;
+        for (awpu_hip *part : g->parts) {
+            if (part->peer != kPeerStaged) continue;
+            const bool compact = part->compact_hist > 0;
+            lo = std::min(lo, compact ? part->wstart : 0);
+            hi = std::max(hi, compact ? part->wstart + part->compact_hist : part->cfg.hist);
+        }
+        const int w = hi - lo;
+        const size_t need = (size_t) g->cfg.n_streams * w * g->cfg.max_batch;
+        if (g->stage_cap < need || g->stage_lo != lo || g->stage_w != w) {
+            for (awpu_hip *part : g->parts) {  // nobody may still be reading the old staging buffers
+                AWPU_HIP_TRY(hipSetDevice(part->cfg.device));
+                AWPU_HIP_TRY(hipStreamSynchronize(part->copy_stream));
+            }
+            AWPU_HIP_TRY(hipSetDevice(dev0));
+            AWPU_HIP_TRY(hipStreamSynchronize(s));
+            if (g->stage_cap < need) {
+                for (int b = 0; b < 2; b++) {
+                    if (g->h_stage[b]) (void) hipHostFree(g->h_stage[b]);
+                    g->h_stage[b] = nullptr;
+                }
+                g->stage_cap = 0;
+                for (int b = 0; b < 2; b++) AWPU_HIP_TRY(hipHostMalloc(&g->h_stage[b], need * sizeof(float), hipHostMallocPortable));
+                g->stage_cap = need;
+            }
+            g->stage_lo = lo;
+            g->stage_w = w;
+            g->stage_turn = 0;
+        }
+        gb = g->stage_turn++ & 1;
+        if (g->stage_turn > 2)  // h_stage[gb] was read by the staged parts' uploads two calls ago
+            for (awpu_hip *part : g->parts)
+                if (part->peer == kPeerStaged && part->fan_used[gb]) AWPU_HIP_TRY(hipStreamWaitEvent(s, part->ev_copied[gb], 0));
+        AWPU_HIP_TRY(hipMemcpy2DAsync(g->h_stage[gb], (size_t) w * sizeof(float), d_frames + lo, (size_t) g->cfg.hist * sizeof(float),
+                                      (size_t) w * sizeof(float), (size_t) batch * g->cfg.n_streams, hipMemcpyDeviceToHost, s));
+        AWPU_HIP_TRY(hipEventRecord(g->ev_staged[gb], s));
+    }
+
+    rc = for_each_part(g, [&](awpu_hip *part) {
+        AWPU_CTX(part);
+        AWPU_HIP_TRY(hipSetDevice(part->cfg.device));
+        int r = ensure_power(part, (size_t) part->cfg.pixel_count * batch);
         if (r != AWPU_OK) return r;
-        r = ensure_power(part, (size_t) part->cfg.pixel_count * batch);
-        if (r != AWPU_OK) return r;
-        const bool keep = part->timing;
-        part->timing = false;  // asynchronous path: the caller times its own stream
+        TimingOff untimed(part);  // asynchronous path: the caller times its own stream
         if (part->cfg.device == dev0 && !env().group_copy) {  // same GPU: sweep the caller's buffer in place
             AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, g->ev_fan, 0));
             r = launch(part, d_frames, batch, part->d_power, part->stream, kFull);
@@ -1184,21 +1292,47 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
                 AWPU_HIP_TRY(hipMalloc(&part->d_fan[0], need * sizeof(float)));
                 AWPU_HIP_TRY(hipMalloc(&part->d_fan[1], need * sizeof(float)));
                 part->fan_cap = need;
-                part->fan_turn = 0;
+                part->fan_used[0] = part->fan_used[1] = false;
             }
-            const int b = part->fan_turn++ & 1;
-            AWPU_HIP_TRY(hipStreamWaitEvent(part->copy_stream, g->ev_fan, 0));
-            if (part->fan_turn > 2) AWPU_HIP_TRY(hipStreamWaitEvent(part->copy_stream, part->ev_swept[b], 0));  // buffer b is free again
+            const bool staged = part->peer == kPeerStaged;
+            const int b = staged ? gb : (int) (part->fan_turn++ & 1);  // (a staged part follows the staging buffer's turn)
+            if (part->fan_used[b]) AWPU_HIP_TRY(hipStreamWaitEvent(part->copy_stream, part->ev_swept[b], 0));  // buffer b is free again
             const size_t row = (size_t) dev_hist * sizeof(float);
-            AWPU_HIP_TRY(hipMemcpy2DAsync(part->d_fan[b], row, d_frames + (compact ? part->wstart : 0),
-                                          (size_t) part->cfg.hist * sizeof(float), row, (size_t) batch * part->cfg.n_streams,
-                                          hipMemcpyDeviceToDevice, part->copy_stream));
+            if (staged) {
+                AWPU_HIP_TRY(hipStreamWaitEvent(part->copy_stream, g->ev_staged[gb], 0));
+                AWPU_HIP_TRY(hipMemcpy2DAsync(part->d_fan[b], row, g->h_stage[gb] + ((compact ? part->wstart : 0) - g->stage_lo),
+                                              (size_t) g->stage_w * sizeof(float), row, (size_t) batch * part->cfg.n_streams,
+                                              hipMemcpyHostToDevice, part->copy_stream));
+            } else {
+                AWPU_HIP_TRY(hipStreamWaitEvent(part->copy_stream, g->ev_fan, 0));
+                AWPU_HIP_TRY(hipMemcpy2DAsync(part->d_fan[b], row, d_frames + (compact ? part->wstart : 0),
+                                              (size_t) part->cfg.hist * sizeof(float), row, (size_t) batch * part->cfg.n_streams,
+                                              hipMemcpyDeviceToDevice, part->copy_stream));
+            }
+            part->fan_used[b] = true;
             AWPU_HIP_TRY(hipEventRecord(part->ev_copied[b], part->copy_stream));
             AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, part->ev_copied[b], 0));
             r = launch(part, part->d_fan[b], batch, part->d_power, part->stream, compact ? kCompact : kFull);
             if (r == AWPU_OK) AWPU_HIP_TRY(hipEventRecord(part->ev_swept[b], part->stream));
+            if (r == AWPU_OK && staged) {  // the tile's way back starts on the part's own stream: device -> pinned
+                const size_t tile = (size_t) part->cfg.pixel_count * part->cfg.max_batch;
+                if (part->tile_cap < tile) {
+                    AWPU_HIP_TRY(hipStreamSynchronize(part->stream));
+                    for (int k = 0; k < 2; k++) {
+                        if (part->h_tile[k]) (void) hipHostFree(part->h_tile[k]);
+                        part->h_tile[k] = nullptr;
+                    }
+                    part->tile_cap = 0;
+                    for (int k = 0; k < 2; k++) AWPU_HIP_TRY(hipHostMalloc(&part->h_tile[k], tile * sizeof(float), hipHostMallocPortable));
+                    part->tile_cap = tile;
+                    part->tile_used[0] = part->tile_used[1] = false;
+                }
+                if (part->tile_used[b]) AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, part->ev_tile_free[b], 0));
+                AWPU_HIP_TRY(hipMemcpyAsync(part->h_tile[b], part->d_power, (size_t) part->cfg.pixel_count * batch * sizeof(float),
+                                            hipMemcpyDeviceToHost, part->stream));
+                part->tile_used[b] = true;
+            }
         }
-        part->timing = keep;
         if (r == AWPU_OK) AWPU_HIP_TRY(hipEventRecord(part->ev_done, part->stream));
         return r;
     });
@@ -1208,8 +1342,15 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
     for (awpu_hip *part : g->parts) {  // tiles back into the caller's [batch][pixel_count] image
         AWPU_HIP_TRY(hipStreamWaitEvent(s, part->ev_done, 0));
         const size_t row = (size_t) part->cfg.pixel_count * sizeof(float);
-        AWPU_HIP_TRY(hipMemcpy2DAsync(d_power + slab_offset(g, part), pitch, part->d_power, row, row, (size_t) batch,
-                                      hipMemcpyDeviceToDevice, s));
+        const bool staged = part->peer == kPeerStaged && !(part->cfg.device == dev0 && !env().group_copy);
+        if (staged) {
+            AWPU_HIP_TRY(hipMemcpy2DAsync(d_power + slab_offset(g, part), pitch, part->h_tile[gb], row, row, (size_t) batch,
+                                          hipMemcpyHostToDevice, s));
+            AWPU_HIP_TRY(hipEventRecord(part->ev_tile_free[gb], s));
+        } else {
+            AWPU_HIP_TRY(hipMemcpy2DAsync(d_power + slab_offset(g, part), pitch, part->d_power, row, row, (size_t) batch,
+                                          hipMemcpyDeviceToDevice, s));
+        }
     }
     return AWPU_OK;
 }
@@ -1306,10 +1447,9 @@ int awpu_hip_destroy(awpu_hip_t *h) {
     (void) hipSetDevice(h->cfg.device);
     if (h->stream) (void) hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void) hipStreamSynchronize(h->copy_stream);
-    for (auto &g : h->live_graphs) (void) hipGraphExecDestroy(g.exec);
-    h->live_graphs.clear();
     release_device(h);
-    for (hipEvent_t ev : {h->ev_begin, h->ev_end, h->ev_fan, h->ev_copied[0], h->ev_copied[1], h->ev_swept[0], h->ev_swept[1], h->ev_done})
+    for (hipEvent_t ev : {h->ev_begin, h->ev_end, h->ev_fan, h->ev_copied[0], h->ev_copied[1], h->ev_swept[0], h->ev_swept[1], h->ev_done,
+                          h->ev_staged[0], h->ev_staged[1], h->ev_tile_free[0], h->ev_tile_free[1]})
         if (ev) (void) hipEventDestroy(ev);
     if (h->stream) (void) hipStreamDestroy(h->stream);
     if (h->copy_stream) (void) hipStreamDestroy(h->copy_stream);
@@ -1419,11 +1559,13 @@ int awpu_hip_calibrate_device(awpu_hip_t *h, const float *d_frame, int32_t array
 
 int awpu_hip_calibrate_host(awpu_hip_t *h, const float *frame, int32_t array, float reference_power_level,
                              int32_t *index, float *correction, float *median, int32_t *usable) {
+    const bool busy = h && h->in_flight;  // (the staging buffer below is the one an asynchronous call uploads into)
     if (h && !h->parts.empty()) h = h->parts[0];  // not pixel-sharded: a device group answers with its first device
     AWPU_CTX(h);
     if (!h || !frame || !index || !correction || !usable) return invalid("null argument");
     if (array < 0 || (array + 1) * AWPU_ELEMENTS > h->cfg.n_streams) return invalid("array outside the streams");
     if (h->cfg.hist > 16384) return invalid("history too long for the calibration kernel");
+    if (busy) return fail(AWPU_ERR_STATE, "an awpu_hip_process_async call is in flight on this handle: awpu_hip_wait first");
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     // only the array's 64 streams travel; they share the frame staging buffer of awpu_hip_process
     const size_t need = (size_t) AWPU_ELEMENTS * h->cfg.hist;
@@ -1519,6 +1661,8 @@ int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {
     if (!h->d_fir) AWPU_HIP_TRY(hipMalloc(&h->d_fir, 101 * 8 * sizeof(float)));
     AWPU_HIP_TRY(hipMemcpy(h->d_fir, coeffs, 101 * 8 * sizeof(float), hipMemcpyHostToDevice));
     h->fir.assign(coeffs, coeffs + 101 * 8);
+    retire_live_graphs(h);
+    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));  // (a sweep still reading the old plane table)
     dev_free(h->d_fir_plane_lut);  // its entries carry the coefficients
     h->have_fir = true;
     return AWPU_OK;
@@ -1528,6 +1672,7 @@ int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *p
     AWPU_CTX(h);
     if (!h) return invalid("null handle");
     if (!frames || !power) return invalid("null argument");
+    if (h->in_flight) return fail(AWPU_ERR_STATE, "an awpu_hip_process_async call is in flight on this handle: awpu_hip_wait first");
     if (!h->parts.empty()) return group_process(h, frames, batch, power);
     int rc = enqueue_host_process(h, frames, batch);
     if (rc != AWPU_OK) return rc;
@@ -1549,6 +1694,16 @@ int awpu_hip_process_async(awpu_hip_t *h, const float *frames, int32_t batch, fl
             const int r = enqueue_host_process(part, frames, batch);
             return r != AWPU_OK ? r : enqueue_power_to_host(part, batch, power + slab_offset(h, part), pitch);
         });
+        if (rc != AWPU_OK) {  // parts before the failing one hold copies from `frames` and into `power` in flight, and
+            const std::string why = h->last_error;  // the caller is about to hear "failed": finish them before it does
+            for (awpu_hip *part : h->parts)
+                if (hipSetDevice(part->cfg.device) == hipSuccess) {
+                    if (part->copy_stream) (void) hipStreamSynchronize(part->copy_stream);
+                    (void) hipStreamSynchronize(part->stream);
+                }
+            (void) hipGetLastError();
+            note_error(why);
+        }
     } else {
         rc = enqueue_host_process(h, frames, batch);
         if (rc == AWPU_OK) rc = enqueue_power_to_host(h, batch, power, (size_t) h->cfg.pixel_count);
@@ -1575,11 +1730,8 @@ int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch,
     const int rc = check_ready(h, batch);
     if (rc != AWPU_OK) return rc;
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    const bool keep = h->timing;
-    h->timing = false;  // asynchronous path: the caller times its own stream
-    const int rc2 = launch(h, d_frames, batch, d_power, s);
-    h->timing = keep;
-    return rc2;
+    TimingOff untimed(h);  // asynchronous path: the caller times its own stream
+    return launch(h, d_frames, batch, d_power, s);
 }
 
 namespace {
@@ -1647,6 +1799,7 @@ int enqueue_live_block(awpu_hip *h, const void *datagrams, int32_t stride_bytes,
         const size_t channels = d_colormap ? 3 : 1;
         const size_t need = sizeof(float) + (size_t) n + (big_image ? (size_t) out_rows * out_cols * channels : 0);
         if (h->display_cap < need) {
+            retire_live_graphs(h);
             dev_free(h->d_display);
             h->display_cap = 0;
             AWPU_HIP_TRY(hipMalloc(&h->d_display, need));
@@ -1673,6 +1826,7 @@ int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_byt
                         uint8_t *big_image) {
     AWPU_CTX(h);
     if (h && !h->parts.empty()) return invalid("the display step needs the whole grid on one device");
+    if (h && h->in_flight) return fail(AWPU_ERR_STATE, "an awpu_hip_process_async call is in flight on this handle: awpu_hip_wait first");
     int rc = check_ready(h, 1);
     if (rc != AWPU_OK) return rc;
     const int n = h->cfg.n_pixels;
@@ -1689,17 +1843,22 @@ int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_byt
     const unsigned long long shape = ((unsigned long long) (unsigned) rows << 48) ^ ((unsigned long long) (unsigned) cols << 36) ^
                                      ((unsigned long long) (unsigned) out_rows << 20) ^ ((unsigned long long) (unsigned) out_cols << 4) ^
                                      (power ? 1u : 0u) ^ (image ? 2u : 0u) ^ (big_image ? 4u : 0u) ^ (d_colormap ? 8u : 0u);
-    if (shape != h->live_shape) {
+    // Only a caller that comes round with the SAME buffers gains from a graph: a call with other buffers than the
+    // one before it (fresh arrays every block) starts the count again and is never captured.
+    const void *bufs[5] = {datagrams, power, image, d_colormap, big_image};
+    if (shape != h->live_shape || std::memcmp(bufs, h->live_bufs, sizeof(bufs)) != 0) {
         h->live_shape = shape;
+        std::memcpy(h->live_bufs, bufs, sizeof(bufs));
         h->live_warm = 0;
     }
     if (graphs && h->live_warm >= 2) {
         awpu_hip::LiveGraph key{h->ring_pos, stride_bytes, rows, cols, out_rows, out_cols, datagrams, power, image, d_colormap,
-                                big_image, h->table_gen, nullptr};
-        for (const auto &g : h->live_graphs)
+                                big_image, h->table_gen, nullptr, 0};
+        for (auto &g : h->live_graphs)
             if (g.ring_pos == key.ring_pos && g.stride == key.stride && g.rows == key.rows && g.cols == key.cols &&
                 g.out_rows == key.out_rows && g.out_cols == key.out_cols && g.datagrams == key.datagrams && g.power == key.power &&
                 g.image == key.image && g.colormap == key.colormap && g.big_image == key.big_image && g.gen == key.gen) {
+                g.last_use = ++h->live_clock;
                 AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
                 AWPU_HIP_TRY(hipGraphLaunch(g.exec, h->stream));
                 h->ring_pos = (h->ring_pos + awpu::kSamples) % AWPU_HIST;  // (what enqueue_ingest does on the plain path)
@@ -1708,7 +1867,13 @@ int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_byt
                 AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
                 return AWPU_OK;
             }
-        if (h->live_graphs.size() < 64) {  // capture this variant (the stream is idle: every call ends with a wait)
+        if (h->live_graphs.size() >= 64) {  // full: the least recently replayed graph makes room
+            auto lru = std::min_element(h->live_graphs.begin(), h->live_graphs.end(),
+                                        [](const awpu_hip::LiveGraph &a, const awpu_hip::LiveGraph &b) { return a.last_use < b.last_use; });
+            (void) hipGraphExecDestroy(lru->exec);
+            h->live_graphs.erase(lru);
+        }
+        {   // capture this variant (the stream is idle: every call ends with a wait)
             AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
             const bool keep_timing = h->timing;
             const int keep_pos = h->ring_pos;
@@ -1728,6 +1893,7 @@ int awpu_hip_live_block(awpu_hip_t *h, const void *datagrams, int32_t stride_byt
             hipGraphExec_t exec = nullptr;
             if (rc == AWPU_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                 key.exec = exec;
+                key.last_use = ++h->live_clock;
                 h->live_graphs.push_back(key);
             } else {
                 hipStreamCaptureStatus status = hipStreamCaptureStatusNone;  // (an invalidated capture must not outlive this call)
@@ -1822,6 +1988,7 @@ int awpu_hip_upscale_u8_device(awpu_hip_t *h, const uint8_t *d_pix, int32_t rows
         awpu::resize_taps(cols, out_cols, true, taps.data());
         awpu::resize_taps(rows, out_rows, false, taps.data() + out_cols);
         AWPU_HIP_TRY(hipStreamSynchronize(s));  // an earlier launch may still read the old taps
+        retire_live_graphs(h);
         dev_free(h->d_taps);
         AWPU_HIP_TRY(hipMalloc(&h->d_taps, taps.size() * sizeof(awpu::ResizeTap)));
         AWPU_HIP_TRY(hipMemcpy(h->d_taps, taps.data(), taps.size() * sizeof(awpu::ResizeTap), hipMemcpyHostToDevice));
@@ -1876,6 +2043,22 @@ int awpu_hip_synchronize(awpu_hip_t *h) {
     return AWPU_OK;
 }
 
+int awpu_hip_group_peer_status(awpu_hip_t *h, int32_t *status, int32_t n) {
+    AWPU_CTX(h);
+    if (!h || !status || n < 1) return invalid("null argument");
+    const int have = h->parts.empty() ? 1 : (int) h->parts.size();
+    if (n < have) return invalid("status array shorter than the device group");
+    if (h->parts.empty()) {
+        status[0] = AWPU_PEER_SAME_DEVICE;
+    } else {
+        for (int k = 0; k < have; k++)
+            status[k] = h->parts[k]->peer == kPeerSame     ? AWPU_PEER_SAME_DEVICE
+                        : h->parts[k]->peer == kPeerDirect ? AWPU_PEER_DIRECT
+                                                           : AWPU_PEER_HOST_STAGED;
+    }
+    return have;
+}
+
 int awpu_hip_get_stats(awpu_hip_t *h, awpu_hip_stats *stats) {
     AWPU_CTX(h);
     if (!h || !stats) return invalid("null argument");
@@ -1904,3 +2087,9 @@ const char *awpu_hip_last_error_of(awpu_hip_t *h) { return h ? h->last_error.c_s
 int awpu_hip_abi_version(void) { return AWPU_HIP_ABI_VERSION; }
 
 }  // extern "C"
+
+#ifdef AWPU_TIMING_BUILD
+// marker of a build whose AWPU_FAST_DEBUG timing switches are live (wrong results on request): never shipped,
+// tests/test_abi.py::test_shipping_build_has_no_wrong_result_switches looks for it
+extern "C" int awpu_hip_timing_build(void) { return 1; }
+#endif

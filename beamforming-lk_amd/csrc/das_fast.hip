@@ -316,9 +316,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
         __syncthreads();                // the previous chunk is fully consumed
 
         // ---- stage [frame][mic][copy][wr] floats: copy q = the window shifted by q samples.
-        const int rows = (a.debug & 1) && m0 > 0 ? 0 : FPI * mc * 2;  // debug bit 0: stage once
+        const int rows = AWPU_DBG(a, 1) && m0 > 0 ? 0 : FPI * mc * 2;  // debug bit 0: stage once
         const bool inside = a.wstart + 1 + wr <= a.hist;  // every 16-byte piece of every row is readable
-        if (inside && !(a.debug & 64)) {
+        if (inside && !AWPU_DBG(a, 64)) {
             // LDS-DMA, one wave per row: lane l's 16 bytes land at (row base + 1 KiB * k) + 16 l
             for (int r = wave; r < rows; r += NW) {
                 const int b = r / (2 * mc);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_kernel(FastArgs a) {
         }
         __syncthreads();
 
-        if (!(a.debug & 2)) {  // debug bit 1: no sweep (staging only)
+        if (!AWPU_DBG(a, 2)) {  // debug bit 1: no sweep (staging only)
             if constexpr (FPI == 1) {
                 sweep_chunk_trips<PPW>(acc, a.lut, pix0, a.usable_pad, m0, mc4 >> 2, lane_addr);
             } else {
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_db_kernel(FastArgs a) {
         const int c1 = last_chunk ? 0 : c + 1;
         const int fi1 = last_chunk ? fi + 1 : fi;
         long long t = diag ? __builtin_readcyclecounter() : 0;
-        if (step + 1 < n_steps && !(a.debug & 1)) {  // lands in the other buffer during the sweep below
+        if (step + 1 < n_steps && !AWPU_DBG(a, 1)) {  // lands in the other buffer during the sweep below
             dma_chunk(frame0 + fi1, c1 * a.chunk, min(a.chunk, a.usable - c1 * a.chunk), buf ^ 1);
         }
         stamp(0, t);
@@ -549,13 +549,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_db_kernel(FastArgs a) {
         const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
         if constexpr (DIAG) {
             sweep_chunk_stamped<PPW, (WPS > 4)>(acc, a.lut, pix0, a.usable_pad, m0, mc4 >> 2, lane_addr, t_wait, t_all);
-        } else if (!(a.debug & 2)) {
+        } else if (!AWPU_DBG(a, 2)) {
             sweep_chunk_trips<PPW, (WPS > 4)>(acc, a.lut, pix0, a.usable_pad, m0, mc4 >> 2, lane_addr);
         }
         stamp(1, t);
         // the 257th sample of every window: see das_fast_kernel
         const float *buf_f = lds + buf * (BUF / 4);
-        for (int j0 = 0; j0 < ((a.debug & 4) ? 0 : mc4); j0 += 32) {
+        for (int j0 = 0; j0 < (AWPU_DBG(a, 4) ? 0 : mc4); j0 += 32) {
             FastEntry e[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_db_kernel(FastArgs a) {
         stamp(2, t);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next chunk are in LDS
         stamp(3, t);
-        if (!(a.debug & 8)) __syncthreads();
+        if (!AWPU_DBG(a, 8)) __syncthreads();
         stamp(4, t);
 
         if (last_chunk) {  // this frame's sums are complete: epilogue (mimo.cpp:131-137), then start over
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         // The refill of the other image goes out AFTER the requests above: hipcc guards the reuse of their
         // destination registers with s_waitcnt vmcnt(0), which in the other order waited for the DMA just
         // issued -- every wave idle at the head of every chunk until its pieces had landed.
-        if (c + 1 < n_chunks && !(a.debug & 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
+        if (c + 1 < n_chunks && !AWPU_DBG(a, 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
         stamp(0, t);
         const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
 #pragma unroll
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         stamp(1, t);
         // the 257th sample of every window, both frames: lane 8*pp + k takes the mics s = k (mod 8)
         const char *img = (const char *) (lds + buf * (BUF / 4));
-        if (!(a.debug & 4))
+        if (!AWPU_DBG(a, 4))
 #pragma unroll
         for (int u = 0; u < NU; u++) {  // mics 0..31 of the chunk (prefetched above)
             const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         stamp(2, t);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(3, t);
-        if (!(a.debug & 8)) __syncthreads();
+        if (!AWPU_DBG(a, 8)) __syncthreads();
         stamp(4, t);
     }
 
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                 next_src = a.packed + (size_t) pair_next * a.usable_pad * row_floats;
                 next_mc4 = chunk_mics(0);
             }
-            if (a.debug & 1) next_mc4 = 0;
+            if (AWPU_DBG(a, 1)) next_mc4 = 0;
             if constexpr (!DIAG && VAR == 0) {
                 // ... issued by the sweep block itself, one 16 KiB piece per trip (tools/gen_trip_asm.py, dma=True)
                 const void *row = uniform_ptr(quad_lut + (size_t) (m0 >> 2) * 16);
@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
             stamp(1, t);
             // the 257th sample of every window, both frames: X[off+256] with weight 1 - f goes to out[255]
             const char *img = (const char *) (lds + buf * (BUF / 4));
-            if (!(a.debug & 4)) {
+            if (!AWPU_DBG(a, 4)) {
 #pragma unroll
                 for (int u = 0; u < 2; u++) {  // mics 0..31 of the chunk (prefetched above)
                     const bool on = tail_lane && 16 * u + ((lane - m0) & 15) < mc4;
@@ -1452,7 +1452,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
             stamp(2, t);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(3, t);
-            if (!(a.debug & 8)) __syncthreads();
+            if (!AWPU_DBG(a, 8)) __syncthreads();
             stamp(4, t);
         }
 
@@ -1598,7 +1598,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
             const int m = m0 + min(LPP * u + ((lane - m0) & (LPP - 1)), mc4 - 1);
             te[u] = tail_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
         }
-        if (c + 1 < n_chunks && !(a.debug & 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
+        if (c + 1 < n_chunks && !AWPU_DBG(a, 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
         stamp(0, t);
         const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
         const int ng = __builtin_amdgcn_readfirstlane(mc4 >> 2);
@@ -1620,13 +1620,13 @@ __global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
         stamp(1, t);
         // the 257th sample of every window (X[off+256], weight 1 - f, goes to out[255])
         const float *buf_f = lds + buf * (BUF / 4);
-        if (!(a.debug & 4))
+        if (!AWPU_DBG(a, 4))
 #pragma unroll
             for (int u = 0; u < NU; u++) {  // mics 0..31 of the chunk (prefetched above)
                 const bool on = tail_lane && LPP * u + ((lane - m0) & (LPP - 1)) < mc;
                 tail = __builtin_fmaf(on ? 0.5f - te[u].f : 0.0f, buf_f[(te[u].addr + 1024u) >> 2], tail);  // 1 - f
             }
-        for (int j0 = 32; j0 < ((a.debug & 4) ? 0 : mc4); j0 += 32) {  // chunks of more than 32 mics (narrow windows)
+        for (int j0 = 32; j0 < (AWPU_DBG(a, 4) ? 0 : mc4); j0 += 32) {  // chunks of more than 32 mics (narrow windows)
             QuadEntry e[NU];
             bool on[NU];
 #pragma unroll
@@ -1644,7 +1644,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
         stamp(2, t);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(3, t);
-        if (!(a.debug & 8)) __syncthreads();
+        if (!AWPU_DBG(a, 8)) __syncthreads();
         stamp(4, t);
     }
 

@@ -9,6 +9,18 @@ namespace awpu {
 
 constexpr int kSamples = 256;  // N_SAMPLES, src/fpga/streams.hpp:28
 
+// AWPU_FAST_DEBUG bits.  The switches that give WRONG results (timing experiments: what does the kernel cost
+// without its refill / sweep / tail pass / barrier) exist only in builds with -DAWPU_TIMING_BUILD
+// (AWPU_EXTRA_HIPCC_FLAGS); in the shipping library the tests below are the constant 0 and the environment
+// variable cannot reach them (awpu_hip.cpp masks it to kDebugSafeBits).
+constexpr int kDebugNoRefill = 1, kDebugNoSweep = 2, kDebugNoTail = 4, kDebugNoBarrier = 8, kDebugRegStaging = 64;
+constexpr int kDebugSafeBits = 16 | 256 | 512 | 4096;  // stamps, dispatch order, refill by rank, unshared block: same results
+#ifdef AWPU_TIMING_BUILD
+#define AWPU_DBG(a, bit) ((a).debug & (bit))
+#else
+#define AWPU_DBG(a, bit) 0
+#endif
+
 // One table entry per (pixel, active mic s): the integer window start relative to the
 // staged window (off - wstart >= 0) and the fraction.  8 bytes, the size the reference
 // keeps per (pixel, mic) (int offsetDelays + float fractionalDelays, src/dsp/mimo.h:86-88).

@@ -107,6 +107,47 @@ class FrameBroadcaster:
         return self.buffers[k % 2]
 
 
+class LocalCopyExchange:
+    """Stand-in for FrameBroadcaster on ONE device (bench.py's projected_scaling): the same post/wait protocol and
+    the same stream ordering as an asynchronous collective -- the transfer waits for what the caller's stream has
+    enqueued so far, runs on a side stream, and wait() orders the caller's stream after it -- but the bytes come
+    from `arrival`, a local tensor of the batch's shape, instead of over the wire.  It measures everything a rank's
+    step loop costs except the wire itself."""
+
+    mode = "local_copy"
+
+    def __init__(self, buffers: Tuple[torch.Tensor, torch.Tensor], arrival: torch.Tensor):
+        if arrival.shape != buffers[0].shape:
+            raise ValueError("arrival must have the shape of a batch buffer")
+        self.buffers = buffers
+        self.arrival = arrival
+        self.cuda = buffers[0].is_cuda
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=buffers[0].device)
+            self.posted = [torch.cuda.Event(), torch.cuda.Event()]
+            self.landed = [torch.cuda.Event(), torch.cuda.Event()]
+        self._pending = [False, False]
+
+    def post(self, k: int) -> None:
+        b = k % 2
+        if self.cuda:
+            self.posted[b].record(torch.cuda.current_stream(self.buffers[b].device))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.posted[b])
+                self.buffers[b].copy_(self.arrival, non_blocking=True)
+                self.landed[b].record(self.side)
+        else:
+            self.buffers[b].copy_(self.arrival)
+        self._pending[b] = True
+
+    def wait(self, k: int) -> torch.Tensor:
+        b = k % 2
+        if self._pending[b] and self.cuda:
+            torch.cuda.current_stream(self.buffers[b].device).wait_event(self.landed[b])
+        self._pending[b] = False
+        return self.buffers[b]
+
+
 def global_peak(local_peak: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """Display-time normalisation across tiles: MIMOWorker::populateHeatmap scales by the maximum over the
     WHOLE grid (src/dsp/mimo.cpp:62-73), so every rank's per-frame tile maximum [batch] is all-reduced

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AWPU_HIP_ABI_VERSION 2
+#define AWPU_HIP_ABI_VERSION 3
 
 /* compile-time constants of the reference */
 #define AWPU_N_SAMPLES 256 /* src/fpga/streams.hpp:28  N_SAMPLES */
@@ -296,6 +296,17 @@ int awpu_hip_build_delay_table(const float *xyz, int32_t n, int32_t rows, int32_
 /* ---- introspection -------------------------------------------------------------------- */
 
 int awpu_hip_get_stats(awpu_hip_t *h, awpu_hip_stats *stats);
+
+/* How each device of a device group (cfg.n_devices > 1) exchanges frames and power tiles with devices[0]; the
+ * reference has no counterpart (one thread, one array: src/dsp/mimo.cpp:12).  awpu_hip_create asks for peer access
+ * both ways (hipDeviceCanAccessPeer + hipDeviceEnablePeerAccess) and checks the answers: a device without it takes
+ * the explicit path through pinned host memory (correct, PCIe-bound), and awpu_hip_last_error_of(h) says which
+ * pair and why right after creation.  status[k] for k < n_devices; returns the number of entries written
+ * (1 and AWPU_PEER_SAME_DEVICE for a single-device handle) or a negative awpu_status. */
+#define AWPU_PEER_SAME_DEVICE 0 /* devices[k] == devices[0]: the caller's buffers are swept in place */
+#define AWPU_PEER_DIRECT 1      /* peer copies over xGMI */
+#define AWPU_PEER_HOST_STAGED 2 /* no peer access: staged through pinned host memory */
+int awpu_hip_group_peer_status(awpu_hip_t *h, int32_t *status, int32_t n);
 const char *awpu_hip_strerror(int status);
 /* text of the last error seen by this thread ("" if none) */
 const char *awpu_hip_last_error(void);

@@ -6,7 +6,7 @@
  * explicit fmaf() calls that mirror the reference's _mm256_fmadd_ps.
  *
  * Parity pinning: validated against the reference's own src/dsp/delay.cpp
- * compiled in place (oracle/_ref) by tests/test_oracle_vs_ref.py and against
+ * compiled in place (oracle/_ref) by tests/test_oracle_golden.py and against
  * tests/golden/ (generated from that build by tests/golden/make_golden.py).
  */
 #include "das_oracle.h"
@@ -288,6 +288,31 @@ void oracle_das_f64(const float *X, int hist, const int32_t *off, const float *f
                 const double cur = sig[i], nxt = sig[i + 1];
                 out[i] += nxt + f * (cur - nxt);
             }
+        }
+        double p = 0.0;
+        for (int i = 1; i < ORACLE_N_SAMPLES - 1; i++) {
+            const double MA = out[i] * 0.5 - 0.25 * (out[i + 1] + out[i - 1]);
+            p += MA * MA;
+        }
+        power[m] = p / (double) (ORACLE_N_SAMPLES * usable);
+    }
+}
+
+/* The FIR8 sweep (delay.cpp:31-40 inside mimo.cpp:121-151) with every sum in double: the tie-breaker that shows how
+ * far the reference's own fp32 arithmetic is from exact sums (not a restatement: the reference has no fp64 path). */
+void oracle_das_fir8_f64(const float *X, int hist, const int32_t *off, const float *frac, int P,
+                         int lut_stride, const int32_t *index, int usable, const float *coeffs,
+                         double *power) {
+    for (int m = 0; m < P; m++) {
+        double out[ORACLE_N_SAMPLES];
+        for (int i = 0; i < ORACLE_N_SAMPLES; i++) out[i] = 0.0;
+        for (int s = 0; s < usable; s++) {
+            const int id = index[s];
+            const float get_filter = frac[(size_t) m * lut_stride + id] * 100.0f + 0.5f; /* delay.cpp:32-33 */
+            const float *c = coeffs + (size_t) ((int) get_filter) * 8;
+            const float *sig = X + (size_t) id * hist + off[(size_t) m * lut_stride + id];
+            for (int n = 0; n < ORACLE_N_SAMPLES; n++)
+                for (int t = 0; t < 8; t++) out[n] += (double) c[t] * (double) sig[n + t];
         }
         double p = 0.0;
         for (int i = 1; i < ORACLE_N_SAMPLES - 1; i++) {

@@ -87,6 +87,10 @@ void oracle_das_f64(const float *X, int hist, const int32_t *off, const float *f
 void oracle_das_fir8_f32(const float *X, int hist, const int32_t *off, const float *frac, int P,
                          int lut_stride, const int32_t *index, int usable, const float *coeffs,
                          float *power);
+/* the same with every sum in double (tie-breaker only) */
+void oracle_das_fir8_f64(const float *X, int hist, const int32_t *off, const float *frac, int P,
+                         int lut_stride, const int32_t *index, int usable, const float *coeffs,
+                         double *power);
 
 /* MIMOWorker::populateHeatmap with USE_DB 0, src/dsp/mimo.cpp:61-95. */
 /* Particle::beam / Particle::das (src/dsp/particle.cpp:51-103) for n_dir directions; power and beams may be NULL */

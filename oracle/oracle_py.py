@@ -59,6 +59,7 @@ def oracle() -> C.CDLL:
         lib.oracle_das_bf16acc.restype = None
         lib.oracle_das_f64.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f64p]
         lib.oracle_das_fir8_f32.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
+        lib.oracle_das_fir8_f64.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f64p]
         lib.oracle_particle_beams.argtypes = [_f32p, C.c_int, _i32p, _f32p, C.c_int, C.c_int, _i32p, C.c_int, _f32p, _f32p]
         lib.oracle_particle_beams.restype = None
         lib.oracle_heatmap_u8.argtypes = [_f32p, C.c_int, _u8p]
@@ -70,7 +71,7 @@ def oracle() -> C.CDLL:
         for name in ("oracle_create_antenna", "oracle_create_tiled_antenna", "oracle_steering_delays_f32",
                      "oracle_steering_delays_f64", "oracle_compute_delay_lut", "oracle_compute_delays_f64",
                      "oracle_delay_lerp", "oracle_delay_fir8", "oracle_das_f32", "oracle_das_f64",
-                     "oracle_das_fir8_f32", "oracle_heatmap_u8", "oracle_unpack_exposure"):
+                     "oracle_das_fir8_f32", "oracle_das_fir8_f64", "oracle_heatmap_u8", "oracle_unpack_exposure"):
             getattr(lib, name).restype = None
         _oracle = lib
     return _oracle
@@ -237,6 +238,18 @@ def das_fir8_f32(X, off, frac, coeffs, index=None, impl="oracle"):
         assert lib.ref_variant() == 2
         lib.ref_das(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index), index.size,
                     _p32(power), None)
+    return power
+
+
+def das_fir8_f64(X, off, frac, coeffs, index=None) -> np.ndarray:
+    """The FIR8 sweep with every sum in double (tie-breaker: how far is the reference's fp32 from exact)."""
+    X, off, frac, index = _sweep_args(X, off, frac, index)
+    coeffs = np.ascontiguousarray(coeffs, np.float32)
+    assert coeffs.shape == (101, 8) and off.max() + 263 <= X.shape[1]
+    P = off.shape[0]
+    power = np.empty(P, np.float64)
+    oracle().oracle_das_fir8_f64(_p32(X), X.shape[1], _pi(off), _p32(frac), P, off.shape[1], _pi(index), index.size,
+                                 _p32(coeffs), power.ctypes.data_as(_f64p))
     return power
 
 

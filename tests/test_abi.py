@@ -24,7 +24,24 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/awpu_hip.h but not exported"
     assert sorted(pkg.binding.EXPORTED_SYMBOLS) == names
-    assert lib.awpu_hip_abi_version() == 2
+    assert lib.awpu_hip_abi_version() == 3
+
+
+def test_shipping_build_has_no_wrong_result_switches(pkg):
+    """AWPU_FAST_DEBUG's timing switches (no refill / no sweep / no tail pass / no barrier / register staging) give
+    wrong heatmaps; they exist only in -DAWPU_TIMING_BUILD builds.  The default library exports no marker of such a
+    build, its kernels test the constant 0 (das_kernels.h: AWPU_DBG), and the host masks the variable."""
+    lib = pkg.binding.load()
+    assert not hasattr(lib, "awpu_hip_timing_build"), "libawpu_hip.so was built with -DAWPU_TIMING_BUILD"
+    header = (REPO / "beamforming-lk_amd" / "csrc" / "das_kernels.h").read_text()
+    assert "#define AWPU_DBG(a, bit) 0" in header
+    for name in ("das_fast.hip", "das_kernels.hip"):
+        text = (REPO / "beamforming-lk_amd" / "csrc" / name).read_text()
+        # every use of a wrong-result bit goes through the macro (bits 16, 256, 512, 4096 keep the results)
+        for bit in (1, 2, 4, 8, 64):
+            assert not re.search(rf"debug\s*&\s*{bit}\)", text), (name, bit)
+    host = (REPO / "beamforming-lk_amd" / "csrc" / "awpu_hip.cpp").read_text()
+    assert "debug &= awpu::kDebugSafeBits" in host
 
 
 def test_cfg_struct_matches_header(pkg):
@@ -161,6 +178,7 @@ def test_null_arguments_are_refused_not_dereferenced(pkg):
     call("awpu_hip_steering_delays", None, 4, 0.1, 0.2, fp)
     call("awpu_hip_build_delay_table", None, 4, 2, 2, 180.0, 0, 2, ip, fp)
     call("awpu_hip_get_stats", None, None)
+    call("awpu_hip_group_peer_status", None, ip, 1)
     call("awpu_hip_create", None, None)
     untested = set(B.EXPORTED_SYMBOLS) - set(seen) - {"awpu_hip_destroy", "awpu_hip_default_cfg", "awpu_hip_strerror",
                                                       "awpu_hip_last_error", "awpu_hip_last_error_of",

@@ -32,6 +32,21 @@ def run_engine(pkg, X, off, frac, index=None, math="fast", max_batch=None, **kw)
     return (power if X.ndim == 3 else power[0]), st
 
 
+def check_full_grid(oracle, got, frame, off, frac, what, index=None, fir_table=None):
+    """The parity claim in the north star's wording, on EVERY pixel handed in: per-pixel power within 1e-5 relative of
+    the reference's arithmetic (oracle.das_f32 / das_fir8_f32), no floor.  Where the reference's own fp32 sums are
+    further than 3.3e-6 from the exact (fp64) ones at some pixel -- deep beam nulls of large arrays -- the bound is
+    3 x that distance (util.parity_report).  Oracle cost: 2-8 s per full 128x128 frame."""
+    if fir_table is None:
+        r32, r64 = oracle.das_f32(frame, off, frac, index), oracle.das_f64(frame, off, frac, index)
+    else:
+        r32, r64 = oracle.das_fir8_f32(frame, off, frac, fir_table, index), oracle.das_fir8_f64(frame, off, frac, fir_table, index)
+    rep = util.parity_report(got, r32, r64)
+    print(f"parity {what}: {rep}")
+    assert rep["ok"], (what, rep)
+    return rep
+
+
 def test_native_library_is_loaded(pkg):
     """The GPU tests run the in-tree HIP library, not a fallback."""
     lib = pkg.binding.load()
@@ -48,7 +63,7 @@ def test_golden_vectors(pkg, name, math):
     ax, ay = g["arrays"]
     X = util.hash_frames(64 * int(ax) * int(ay), int(g["hist"]), seed=int(g["seed"]))[0]
     power, _ = run_engine(pkg, X, g["off"], g["frac"], g["index"], math=math)
-    assert util.power_rel_err(power, g["power"]) < util.POWER_RTOL
+    assert util.power_rel_err_unfloored(power, g["power"]) < util.POWER_RTOL
 
 
 @pytest.mark.parametrize("math", MATHS)
@@ -62,7 +77,7 @@ def test_full_grid_vs_oracle(pkg, oracle, wl, math):
     X = S.make_frames(xyz, 1, seed=1234)[0]
     power, st = run_engine(pkg, X, off, frac, math=math)
     want = oracle.das_f32(X, off, frac)
-    assert util.power_rel_err(power, want) < util.POWER_RTOL
+    assert util.power_rel_err_unfloored(power, want) < util.POWER_RTOL
     # against fp64 the GPU is in the same error class as the fp32 CPU restatement
     p64 = oracle.das_f64(X, off, frac)
     assert util.power_rel_err(power, p64) < max(3 * util.power_rel_err(want, p64), 5e-6)
@@ -85,7 +100,7 @@ def test_headline_rows_vs_oracle(pkg, oracle, math):
     # n_pixels is the whole grid; the handle owns rows 40..45
     power = run_engine_shard(pkg, X, off, frac, spec.n_pixels, rows[0] * spec.res, math)
     want = oracle.das_f32(X, off, frac)
-    assert util.power_rel_err(power, want) < util.POWER_RTOL
+    assert util.power_rel_err_unfloored(power, want) < util.POWER_RTOL
 
 
 def run_engine_shard(pkg, X, off, frac, n_pixels, pixel_begin, math="fast"):
@@ -127,7 +142,7 @@ def test_batch_equals_single_frames(pkg, oracle, math):
         # a single-frame call may run another kernel shape (the epilogue sums in another order)
         single, _ = run_engine(pkg, frames[b], off, frac, math=math)
         assert util.power_rel_err(batch[b], single) < 2e-6
-        assert util.power_rel_err(batch[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
+        assert util.power_rel_err_unfloored(batch[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
 
 
 @pytest.mark.parametrize("math", MATHS)
@@ -138,7 +153,7 @@ def test_ragged_pixel_counts(pkg, oracle, math, n_pix):
     off, frac = off[5:5 + n_pix], frac[5:5 + n_pix]
     X = util.hash_frames(64, 1024, seed=n_pix)[0]
     power, _ = run_engine(pkg, X, off, frac, math=math)
-    assert util.power_rel_err(power, oracle.das_f32(X, off, frac)) < util.POWER_RTOL
+    assert util.power_rel_err_unfloored(power, oracle.das_f32(X, off, frac)) < util.POWER_RTOL
 
 
 @pytest.mark.parametrize("math", MATHS)
@@ -152,7 +167,7 @@ def test_active_mic_subsets(pkg, oracle, math):
         index = rng.permutation(256)[:usable].astype(np.int32)
         power, st = run_engine(pkg, X, off, frac, index, math=math)
         assert st.usable == usable
-        assert util.power_rel_err(power, oracle.das_f32(X, off, frac, index)) < util.POWER_RTOL
+        assert util.power_rel_err_unfloored(power, oracle.das_f32(X, off, frac, index)) < util.POWER_RTOL
 
 
 @pytest.mark.parametrize("math", MATHS)
@@ -171,7 +186,7 @@ def test_extreme_offsets_and_fractions(pkg, oracle, math):
     X = util.hash_frames(M, hist, seed=77)[0]
     power, st = run_engine(pkg, X, off, frac, math=math)
     assert st.window == hist
-    assert util.power_rel_err(power, oracle.das_f32(X, off, frac)) < util.POWER_RTOL
+    assert util.power_rel_err_unfloored(power, oracle.das_f32(X, off, frac)) < util.POWER_RTOL
     # the same with a ragged mic list and a history that is not a multiple of 4 (regression: the guarded
     # staging of the last, odd group of rows used to clip the unshifted copy to the shifted copy's length,
     # losing the newest sample for entries at the largest legal offset)
@@ -185,7 +200,7 @@ def test_extreme_offsets_and_fractions(pkg, oracle, math):
         power, st = run_engine(pkg, frames[:batch], off, frac, index=index, math=math)
         assert st.window == hist
         want = np.stack([oracle.das_f32(f, off, frac, index) for f in frames[:batch]])
-        assert util.power_rel_err(power, want) < util.POWER_RTOL, batch
+        assert util.power_rel_err_unfloored(power, want) < util.POWER_RTOL, batch
 
 
 @pytest.mark.parametrize("math", MATHS)
@@ -249,7 +264,7 @@ def test_error_paths(pkg, oracle):
             eng.process(np.concatenate([X, X, X]))  # batch 3 > max_batch 2
         assert ei.value.status == B.ERR_INVALID
         ok = eng.process(X)
-        assert util.power_rel_err(ok[0], oracle.das_f32(X[0], off, frac)) < util.POWER_RTOL
+        assert util.power_rel_err_unfloored(ok[0], oracle.das_f32(X[0], off, frac)) < util.POWER_RTOL
 
 
 def test_host_buffer_entry_split_in_two(pkg, oracle):
@@ -304,7 +319,7 @@ def test_device_pointer_entry_with_torch(pkg, oracle):
     got = d_power.cpu().numpy()
     assert np.array_equal(got, host)
     for b in range(3):
-        assert util.power_rel_err(got[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
+        assert util.power_rel_err_unfloored(got[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
 
 
 FIR8_SWEEPS = ["sweep_c1_fir8", "sweep_c1_ragged_fir8", "sweep_headline_fir8", "sweep_c3_fir8"]
@@ -330,7 +345,7 @@ def test_fir8_golden_vectors(pkg, name):
         eng.set_active_mics(g["index"])
         eng.set_fir_table(measured_fir_table())
         power = eng.process(X)
-    assert util.power_rel_err(power, g["power"]) < util.POWER_RTOL
+    assert util.power_rel_err_unfloored(power, g["power"]) < util.POWER_RTOL
 
 
 @pytest.mark.parametrize("name", FIR8_SWEEPS)
@@ -353,7 +368,7 @@ def test_fir8_golden_vectors_on_the_batch_kernel(pkg, name):
         power = eng.process(np.stack([X, X]))
     want = np.tile(g["power"], reps)
     for b in range(2):
-        assert util.power_rel_err(power[b], want) < util.POWER_RTOL
+        assert util.power_rel_err_unfloored(power[b], want) < util.POWER_RTOL
 
 
 @pytest.mark.parametrize("table_kind", ["synthetic", "reference"])
@@ -378,12 +393,12 @@ def test_fir8_mode_vs_oracle(pkg, oracle, table_kind):
             power = eng.process(X)
         for b in range(2):
             want = oracle.das_fir8_f32(X[b], off, frac, table, index)
-            assert util.power_rel_err(power[b], want) < util.POWER_RTOL
+            assert util.power_rel_err_unfloored(power[b], want) < util.POWER_RTOL
 
 
 def test_fir8_batched_frame_pair_shape(pkg, oracle):
     """AWPU_INTERP_FIR8 on a full grid with a batch: the frame-pair FIR8 sweep (das_fir8_plane_kernel).  One 8x8 array,
-    128x128 grid, three frames (an odd batch: the last pair is half empty), a ragged mic list; sampled pixels against
+    128x128 grid, three frames (an odd batch: the last pair is half empty), a ragged mic list; every pixel against
     the restated FIR sweep with the reference's measured table, and whole frames against the single-frame calls
     (the exact-structure kernel: same taps in the same order, same bits before the epilogue)."""
     xyz = oracle.create_antenna()
@@ -399,11 +414,8 @@ def test_fir8_batched_frame_pair_shape(pkg, oracle):
         batch = eng.process(X)
         single = np.stack([eng.process(X[b]) for b in range(3)])
     assert util.power_rel_err(batch, single) < 2e-6
-    pick = np.random.default_rng(2).choice(res * res, 120, replace=False)
     for b in range(3):
-        want = oracle.das_fir8_f32(X[b], off[pick], frac[pick], table, index)
-        floor = util.NULL_FLOOR * float(batch[b].max())
-        assert float((np.abs(batch[b][pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+        check_full_grid(oracle, batch[b], X[b], off, frac, f"fir8 batch frame {b}", index=index, fir_table=table)
 
 
 def test_device_heatmap_equals_populate_heatmap(pkg, oracle):
@@ -558,10 +570,10 @@ def test_mic_gains_equal_prescaled_frames(pkg, oracle):
             eng.set_mic_gains(gains)
             for batch in (1, 4):  # single-frame and frame-pair shapes
                 got = eng.process(frames[:batch])
-                assert util.power_rel_err(got, want[:batch]) <= util.POWER_RTOL, (math, batch)
+                assert util.power_rel_err_unfloored(got, want[:batch]) <= util.POWER_RTOL, (math, batch)
             eng.set_mic_gains(None)  # off again = the reference
             plain = np.stack([oracle.das_f32(f, off, frac, index) for f in frames[:1]])
-            assert util.power_rel_err(eng.process(frames[:1]), plain) <= util.POWER_RTOL
+            assert util.power_rel_err_unfloored(eng.process(frames[:1]), plain) <= util.POWER_RTOL
 
 
 def make_datagrams(stream_block, counter0=0, n_arrays=1):
@@ -615,7 +627,7 @@ def test_wire_ingest_and_ring_sweep(pkg, oracle):
             ring = np.concatenate([ring[:, 256:], block], axis=1)
             assert np.array_equal(eng.ring_snapshot(), ring), f"ring differs after block {b}"
         power = eng.process_ring()
-        assert util.power_rel_err(power, oracle.das_f32(ring, off, frac)) < util.POWER_RTOL
+        assert util.power_rel_err_unfloored(power, oracle.das_f32(ring, off, frac)) < util.POWER_RTOL
         # the ring path and the host-buffer path agree bit for bit on the same snapshot
         assert np.array_equal(power, eng.process(ring))
         # calibration straight off the ring (aw_processing_unit.cpp:102-212): random int24 noise is far
@@ -630,7 +642,7 @@ def test_wire_ingest_and_ring_sweep(pkg, oracle):
 def test_single_frames_on_the_headline_grid(pkg, oracle):
     """One frame per call on the full headline grid with the row length known -- the call MIMOWorker::update makes,
     and (from the ingest ring) the live path: the single-frame quad shape.  Host buffer, device ring and the
-    batched call must agree with the oracle on sampled pixels, and with each other to rounding."""
+    batched call must agree with the oracle on every pixel (unfloored), and with each other to rounding."""
     S = pkg.synthetic
     spec = S.WORKLOADS["headline"]
     xyz = S.geometry(spec)
@@ -649,10 +661,8 @@ def test_single_frames_on_the_headline_grid(pkg, oracle):
         batched = eng.process(np.stack([ring, 2.0 * ring]))
     assert np.array_equal(from_ring, from_host)  # same kernel, same bits, whichever way the frame came in
     assert util.power_rel_err(batched[0], from_host) < 5e-6 and np.array_equal(batched[1], 4.0 * batched[0])
-    pick = np.random.default_rng(4).choice(spec.n_pixels, 160, replace=False)
-    want = oracle.das_f32(ring, off[pick], frac[pick])
-    floor = util.NULL_FLOOR * float(from_host.max())
-    assert float((np.abs(from_host[pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+    check_full_grid(oracle, from_host, ring, off, frac, "headline single frame (quad1 shape)")
+    check_full_grid(oracle, batched[0], ring, off, frac, "headline pair of frames (quad shape)")
 
 
 def test_two_handles_from_two_threads(pkg, oracle):
@@ -694,8 +704,8 @@ def test_two_handles_from_two_threads(pkg, oracle):
         for it, got in enumerate(results[k]):
             ref = results[k][it % 2]
             assert np.array_equal(got, ref), (k, it)
-        assert util.power_rel_err(results[k][0][0], oracle.das_f32(frames[0], off, frac)) < util.POWER_RTOL
-        assert util.power_rel_err(results[k][1][0], oracle.das_f32(frames[0], off, frac)) < util.POWER_RTOL
+        assert util.power_rel_err_unfloored(results[k][0][0], oracle.das_f32(frames[0], off, frac)) < util.POWER_RTOL
+        assert util.power_rel_err_unfloored(results[k][1][0], oracle.das_f32(frames[0], off, frac)) < util.POWER_RTOL
 
 
 def test_host_batches_upload_in_pieces(pkg, oracle):
@@ -722,13 +732,13 @@ def test_host_batches_upload_in_pieces(pkg, oracle):
     assert util.power_rel_err(host, d_P.cpu().numpy()) < 2e-6
     assert np.array_equal(again, host[:70])
     for b in (0, 33, 34, 67, 101, 102, 129):
-        assert util.power_rel_err(host[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
+        assert util.power_rel_err_unfloored(host[b], oracle.das_f32(frames[b], off, frac)) < util.POWER_RTOL
 
 
 def test_fir8_single_frames_on_the_headline_grid(pkg, oracle):
     """AWPU_INTERP_FIR8, one frame per call on the full headline grid: such a launch fills the chip, so it runs the
     batch kernel (das_fir8_plane_kernel) with the frame paired with itself.  From a host buffer, from the ingest
-    ring (row pitch 2048) and as a member of a batch: the same powers to rounding, and the oracle's on sampled pixels."""
+    ring (row pitch 2048) and as a member of a batch: the same powers to rounding, and the oracle's on every pixel."""
     S = pkg.synthetic
     spec = S.WORKLOADS["headline"]
     xyz = S.geometry(spec)
@@ -752,19 +762,17 @@ def test_fir8_single_frames_on_the_headline_grid(pkg, oracle):
     assert util.power_rel_err(from_ring, from_host) < 2e-6
     assert util.power_rel_err(batched[0], from_host) < 2e-6 and np.array_equal(batched[1], 4.0 * batched[0])
     assert util.power_rel_err(batched[2], from_host) < 2e-6  # the odd last frame of a batch
-    pick = np.random.default_rng(6).choice(spec.n_pixels, 100, replace=False)
-    want = oracle.das_fir8_f32(ring, off[pick], frac[pick], table)
-    floor = util.NULL_FLOOR * float(from_host.max())
-    assert float((np.abs(from_host[pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+    check_full_grid(oracle, from_host, ring, off, frac, "headline FIR8 single frame", fir_table=table)
+    check_full_grid(oracle, batched[2], ring, off, frac, "headline FIR8 odd last frame of a batch", fir_table=table)
 
 
 @pytest.mark.parametrize("wl,batch", [("headline", 4), ("c3", 2)])
 def test_full_size_properties(pkg, oracle, wl, batch):
-    """BASELINE's full sizes (256 mics x 128x128, 512 mics x 128x128), where the oracle would take
-    minutes: size-independent properties on the whole grid plus an oracle check on a sample of pixels.
+    """BASELINE's full sizes (256 mics x 128x128, 512 mics x 128x128): EVERY pixel of the first and the last frame of
+    the batch against the oracle, unfloored (the oracle takes 2.5 s / 5 s per whole frame here), with the row length
+    given (quad shape) and without (pixel pairs), plus the size-independent properties:
       * frame 1 = 4 x frame 0  ->  power exactly 16 x (power-of-two scaling is exact in fp32)
-      * the peak pixel looks at the plane-wave source
-      * 200 sampled pixels agree with the oracle to 1e-5."""
+      * the peak pixel looks at the plane-wave source."""
     S = pkg.synthetic
     spec = S.WORKLOADS[wl]
     xyz = S.geometry(spec)
@@ -779,18 +787,15 @@ def test_full_size_properties(pkg, oracle, wl, batch):
     r, c = divmod(int(power[0].argmax()), spec.res)
     er, ec = S.source_pixel(spec)
     assert abs(r - er) <= 1 and abs(c - ec) <= 1
-    pick = np.random.default_rng(1).choice(spec.n_pixels, 200, replace=False)
     for b in (0, batch - 1):
-        want = oracle.das_f32(frames[b], off[pick], frac[pick])
-        got = power[b][pick]
-        floor = util.NULL_FLOOR * float(power[b].max())
-        assert float((np.abs(got - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+        check_full_grid(oracle, power[b], frames[b], off, frac, f"{wl} frame {b}, row length given")
+        check_full_grid(oracle, plain[b], frames[b], off, frac, f"{wl} frame {b}, no row length")
 
 
 def test_c4_rank_slab_of_eight(pkg, oracle):
     """BASELINE configs[3]/[4]: 512 mics x 256x256 sharded over 8 GPUs -- here the slab rank 5 would own
     (rows 160..191, 8192 pixels), a batch of 6 frames as one rank of a batched run would see them.
-    Same size-independent properties as above plus an oracle check on 150 sampled pixels; the second
+    Same size-independent properties as above plus the oracle on every pixel of the slab (unfloored); the second
     handle (rank 6's slab) shows that neighbouring slabs continue each other."""
     sharding = importlib.import_module("beamforming-lk_amd.sharding")
     S = pkg.synthetic
@@ -811,11 +816,8 @@ def test_c4_rank_slab_of_eight(pkg, oracle):
             power = eng.process(frames)
         assert power.shape == (6, 8192)
         assert np.array_equal(power[3], 4.0 * power[0])
-        pick = np.random.default_rng(rank).choice(shard.pixel_count, 150, replace=False)
         for b in (0, 5):
-            want = oracle.das_f32(frames[b], off[pick], frac[pick])
-            floor = util.NULL_FLOOR * float(power[b].max())
-            assert float((np.abs(power[b][pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+            check_full_grid(oracle, power[b], frames[b], off, frac, f"c4 slab of rank {rank}, frame {b}")
         powers.append(power)
     # the last row of one slab and the first row of the next are neighbouring grid rows: smooth across the seam
     seam = np.abs(powers[0][0, -256:] - powers[1][0, :256]) / powers[0][0].max()
@@ -870,6 +872,13 @@ for batch in (1, 6):
             else:
                 assert util.power_rel_err(b, a) < 5e-6, (name, devices, batch)
         assert grp[4].frames == one[4].frames and grp[4].usable == one[4].usable and grp[4].alg_flops_frame == one[4].alg_flops_frame
+staged = os.environ.get("AWPU_GROUP_FORCE_COPY") == "2"
+with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, grid_columns=spec.res, devices=[0, 0, 0]) as eng:
+    want = pkg.binding.PEER_HOST_STAGED if staged else pkg.binding.PEER_SAME_DEVICE
+    assert eng.peer_status() == [want] * 3, eng.peer_status()
+    assert "pinned host memory" not in eng.last_error()  # (equal ordinals have nothing to report; real pairs without peer access do)
+with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics) as eng:
+    assert eng.peer_status() == [pkg.binding.PEER_SAME_DEVICE]
 # uneven slabs (64 rows over 3 devices = 22 + 21 + 21) and a group that owns only part of the grid
 with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, grid_columns=spec.res, devices=[0, 0], pixel_begin=10 * spec.res, pixel_count=7 * spec.res) as eng:
     eng.set_delay_table(off[10 * spec.res:17 * spec.res], frac[10 * spec.res:17 * spec.res]); eng.set_active_mics(None)
@@ -884,7 +893,7 @@ print("GROUP OK")
 """
 
 
-@pytest.mark.parametrize("force_copy,quads", [("0", "0"), ("1", "0"), ("0", ""), ("1", "")])
+@pytest.mark.parametrize("force_copy,quads", [("0", "0"), ("1", "0"), ("2", "0"), ("0", ""), ("1", ""), ("2", "")])
 def test_device_group_equals_one_device(force_copy, quads):
     """awpu_hip_cfg.n_devices > 1 (the multi-GPU split under the C ABI): a handle that spreads the grid's rows over
     two / three engines -- here all on the one GPU of the box, the same code path with devices[k] equal -- gives
@@ -892,7 +901,9 @@ def test_device_group_equals_one_device(force_copy, quads):
     back) and the ingest ring, for one frame and for a batch (quads="0": with the kernel shapes that do not depend
     on the slab; otherwise to rounding, a small slab may run another shape than the whole grid).  force_copy=1 makes
     every part take the copy path of the fan-out (2-D window copies, two buffers per part, events between the copy
-    and the sweep streams) that a part on another GPU takes."""
+    and the sweep streams) that a part on another GPU takes; force_copy=2 the path of a node WITHOUT peer access: the
+    window goes down to pinned host memory once and up to every part, the tiles come back the same way
+    (awpu_hip_group_peer_status then reports AWPU_PEER_HOST_STAGED for every device)."""
     import os, subprocess, sys
     env = dict(os.environ, AWPU_GROUP_FORCE_COPY=force_copy)
     if quads:
@@ -928,7 +939,7 @@ def test_bf16_accumulator_mode(pkg, oracle):
 def test_c5_1024_frames_512_mics_rank_slab(pkg, oracle):
     """BASELINE configs[4] at its real size on one rank: 1024 frames in flight x 512 mics x the slab of a
     256x256 grid that one of 8 GPUs owns (32 rows, 8192 pixels) -- one call, 512 frame pairs.  The oracle checks
-    sampled pixels of the first, a middle and the last frame; frames that repeat give the same bits wherever
+    every pixel of the first, a middle and the last frame (unfloored); frames that repeat give the same bits wherever
     they sit in the batch; the bf16-accumulator mode is run on the same call and its error recorded."""
     sharding = importlib.import_module("beamforming-lk_amd.sharding")
     S = pkg.synthetic
@@ -950,11 +961,8 @@ def test_c5_1024_frames_512_mics_rank_slab(pkg, oracle):
         power = eng.process(frames)
         st = eng.stats()
     assert power.shape == (B, 8192) and st.usable == 512 and st.frames == B
-    pick = np.random.default_rng(5).choice(shard.pixel_count, 48, replace=False)
     for b in (0, 511, 1023):
-        want = oracle.das_f32(frames[b], off[pick], frac[pick])
-        floor = util.NULL_FLOOR * float(power[b].max())
-        assert float((np.abs(power[b][pick] - want) / np.maximum(want, floor)).max()) < util.POWER_RTOL
+        check_full_grid(oracle, power[b], frames[b], off, frac, f"c5 slab, frame {b} of 1024")
     assert np.array_equal(power[64:128], power[:64]) and np.array_equal(power[960:], power[:64])
     # the same call with the bf16 accumulator (a slower kernel: 64 frames of the batch are enough)
     eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, lut_stride=spec.n_mics, max_batch=64,
@@ -966,8 +974,7 @@ def test_c5_1024_frames_512_mics_rank_slab(pkg, oracle):
     err = util.power_rel_err(p16, power[:64])
     print(f"c5 bf16-accumulator max rel err vs the fp32 sweep: {err:.3e}")
     assert 1e-4 < err < 1e-1
-    want16 = oracle.das_bf16acc(frames[63], off[pick], frac[pick])
-    assert float((np.abs(p16[63][pick] - want16) / np.maximum(want16, util.NULL_FLOOR * float(p16[63].max()))).max()) < 2e-6
+    assert util.power_rel_err_unfloored(p16[63], oracle.das_bf16acc(frames[63], off, frac)) < 2e-6  # (its own checker, every pixel)
 
 
 def test_1024_frames_in_flight(pkg, oracle):
@@ -983,7 +990,7 @@ def test_1024_frames_in_flight(pkg, oracle):
     power, _ = run_engine(pkg, frames, off, frac)
     for b in (0, 511, 512, 1023):
         want = oracle.das_f32(frames[b], off, frac)
-        assert util.power_rel_err(power[b], want) < util.POWER_RTOL
+        assert util.power_rel_err_unfloored(power[b], want) < util.POWER_RTOL
     # frames repeat every 8: the same frame gives the same bits wherever it sits in the batch ...
     assert np.array_equal(power[8:16], power[:8]) and np.array_equal(power[1016:], power[:8])
     # ... and agrees with the small-batch call (a different kernel shape: other summation order)
@@ -1048,6 +1055,129 @@ def test_live_block_replayed_as_a_graph(pkg, oracle):
             assert np.array_equal(big, oracle.resize_linear_u8(image, 40, 56)), b
 
 
+def test_live_graphs_are_retired_when_their_buffers_move(pkg, oracle):
+    """The captured live-block graphs bake in device pointers of the handle (power, display, upscale taps, FIR tables).
+    Calls that free or reallocate one of them -- a batched awpu_hip_process on a max_batch > 1 handle (d_power grows), a
+    live call with a larger upscale (d_display, d_taps), awpu_hip_upscale_u8_device with other dimensions (d_taps),
+    awpu_hip_set_fir_table -- must retire the graphs: the display loop goes on, interleaved with all of them, and every
+    block still equals the separate entry points."""
+    import torch
+
+    rng = np.random.default_rng(57)
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 16, 16)
+    wire = np.zeros(256 * 1032, np.uint8)
+    out_a = (np.zeros(256, np.float32), np.zeros((16, 16), np.uint8), np.zeros((40, 56), np.uint8))
+    out_b = (np.zeros(256, np.float32), np.zeros((16, 16), np.uint8), np.zeros((96, 80), np.uint8))
+    frames = util.hash_frames(64, 1024, seed=3, batch=4)
+    d_pix = torch.zeros((16, 16), dtype=torch.uint8, device="cuda:0")
+    d_up = torch.zeros((33, 47), dtype=torch.uint8, device="cuda:0")
+    for interp in (pkg.binding.INTERP_LERP, pkg.binding.INTERP_FIR8):
+        fir = interp == pkg.binding.INTERP_FIR8
+        o = np.minimum(off, 1024 - 263).astype(np.int32) if fir else off
+        with pkg.Engine(n_pixels=256, max_batch=4, interp=interp) as one, pkg.Engine(n_pixels=256, interp=interp) as sep:
+            for eng in (one, sep):
+                eng.set_delay_table(o, frac)
+                eng.set_active_mics(None)
+                if fir:
+                    eng.set_fir_table(util.synthetic_fir_table())
+            b = 0
+
+            def live(out, rows_cols):
+                nonlocal b
+                block = make_datagrams(rng.integers(-(1 << 23), 1 << 23, (256, 256), dtype=np.int32), counter0=256 * b)
+                wire[:] = np.frombuffer(block, np.uint8)
+                power, image, big = one.live_block(wire, 16, 16, *rows_cols, out=out)
+                sep.ingest_block(block)
+                want = sep.process_ring()
+                assert np.array_equal(power, want), b
+                assert np.array_equal(image.ravel(), oracle.heatmap_u8(want)), b
+                assert np.array_equal(big, oracle.resize_linear_u8(image, *rows_cols)), b
+                b += 1
+
+            for _ in range(5):
+                live(out_a, (40, 56))           # warm, captured, replayed
+            p4 = one.process(frames)             # (1) d_power grows from 256 to 4 x 256 floats
+            assert p4.shape == (4, 256) and util.power_rel_err(p4[0], sep.process(frames[0])) < 2e-6
+            for _ in range(5):
+                live(out_a, (40, 56))           # the old key matches again: must not replay a stale graph
+            for _ in range(4):
+                live(out_b, (96, 80))           # (2) a larger display image and other taps
+            for _ in range(4):
+                live(out_a, (40, 56))           # back to the first shape: its graphs were retired with the buffers
+            one.upscale_device(d_pix.data_ptr(), 16, 16, 1, d_up.data_ptr(), 33, 47)  # (3) the taps move again
+            one.synchronize()
+            for _ in range(4):
+                live(out_a, (40, 56))
+            if fir:
+                for eng in (one, sep):          # (4) a new coefficient table: the plane entries are rebuilt
+                    eng.set_fir_table(util.synthetic_fir_table()[::-1].copy())
+                for _ in range(4):
+                    live(out_a, (40, 56))
+
+
+def test_calls_refused_while_an_async_call_is_in_flight(pkg, oracle):
+    """awpu_hip_process, awpu_hip_calibrate_host and awpu_hip_live_block share the staging and power buffers of an
+    awpu_hip_process_async that has not been waited for: AWPU_ERR_STATE until awpu_hip_wait, then they work."""
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 16, 16)
+    frames = util.hash_frames(64, 1024, seed=5, batch=2)
+    wire = make_datagrams(np.zeros((256, 256), np.int32))
+    with pkg.Engine(n_pixels=256, max_batch=2) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        want = eng.process(frames)
+        eng.process_async(frames)
+        for call in (lambda: eng.process(frames), lambda: eng.calibrate_host(frames[0]), lambda: eng.live_block(wire, 16, 16),
+                     lambda: eng.process_async(frames)):
+            with pytest.raises(pkg.AwpuError) as ei:
+                call()
+            assert ei.value.status == pkg.binding.ERR_STATE
+        assert np.array_equal(eng.wait(), want)
+        assert np.array_equal(eng.process(frames), want)
+
+
+DEBUG_CHILD = r"""
+import importlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import util
+pkg = importlib.import_module("beamforming-lk_amd")
+S = pkg.synthetic
+out = []
+for wl, batch, hint in (("c2", 4, True), ("c2", 1, True), ("c2", 3, False), ("c2", 1, False), ("c1", 4, False)):
+    spec = S.WORKLOADS[wl]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = util.hash_frames(spec.n_mics, 1024, seed=31, batch=batch)
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=batch, grid_columns=spec.res if hint else 0) as eng:
+        eng.set_delay_table(off, frac); eng.set_active_mics(None)
+        out.append(eng.process(frames))
+np.savez(sys.argv[2], *out)
+"""
+
+
+def test_timing_switches_are_not_in_the_shipping_library(tmp_path):
+    """AWPU_FAST_DEBUG=1|2|4|8|64 (no refill DMA / no sweep / no tail pass / no chunk barrier / register staging) would
+    give wrong heatmaps; the default build has them compiled out, so with the variable set every sweep shape returns
+    the bits it returns without it."""
+    import os, subprocess, sys
+    outs = []
+    for k, dbg in enumerate(("", "79")):  # 79 = 1 + 2 + 4 + 8 + 64
+        env = dict(os.environ)
+        env.pop("AWPU_FAST_DEBUG", None)
+        if dbg:
+            env["AWPU_FAST_DEBUG"] = dbg
+        path = tmp_path / f"out{k}.npz"
+        r = subprocess.run([sys.executable, "-c", DEBUG_CHILD, str(Path(__file__).resolve().parent.parent), str(path)],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs.append(np.load(path))
+    assert outs[0].files == outs[1].files and len(outs[0].files) == 5
+    for name in outs[0].files:
+        assert outs[0][name].max() > 0 and np.array_equal(outs[0][name], outs[1][name]), name
+
+
 @pytest.mark.parametrize("n_streams,usable,P", [(128, 128, 100), (256, 256, 4096), (256, 201, 333), (192, 64, 65)])
 def test_ring_sweep_wider_arrays(pkg, oracle, n_streams, usable, P):
     """The device ring with 2..4 arrays on the wire (the datagram carries up to 256 sensors), ragged mic
@@ -1071,7 +1201,7 @@ def test_ring_sweep_wider_arrays(pkg, oracle, n_streams, usable, P):
             if b in (0, 3, 4, 8):
                 assert np.array_equal(eng.ring_snapshot(), ring), b
                 power = eng.process_ring()
-                assert util.power_rel_err(power, oracle.das_f32(ring, off, frac, index)) < util.POWER_RTOL, b
+                assert util.power_rel_err_unfloored(power, oracle.das_f32(ring, off, frac, index)) < util.POWER_RTOL, b
         got = eng.calibrate_ring(array=1)
         want = oracle.calibrate(ring[64:128])
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]

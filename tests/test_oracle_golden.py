@@ -283,3 +283,37 @@ def test_bf16_accumulator_restatement(oracle):
     # one mic: the sum is one term, rounded once -- within bf16's half ulp (2^-9) of the fp32 sum, per sample
     one = np.array([11], np.int32)
     assert util.power_rel_err(oracle.das_bf16acc(X, off, frac, one), oracle.das_f32(X, off, frac, one)) < 2.0 ** -7
+
+
+def test_parity_report_is_unfloored():
+    """tests/util.parity_report states the parity claim in the north star's wording (per-pixel, relative, NO floor):
+    a pixel 1e-9 of the frame peak that is off by 2e-5 relative must fail it although the floored metric passes."""
+    import util
+
+    ref = np.array([1.0, 0.5, 1e-9, 2e-5], np.float64)
+    good = ref * (1 + 4e-6)
+    rep = util.parity_report(good, ref, ref * (1 + 1e-6))
+    assert rep["ok"] and rep["pixels_below_floor"] == 2 and rep["pixels_over_1e5"] == 0 and rep["bound"] == 1e-5
+    bad = good.copy()
+    bad[2] = ref[2] * (1 + 2e-5)
+    rep = util.parity_report(bad, ref, ref * (1 + 1e-6))
+    assert not rep["ok"] and rep["pixels_over_1e5"] == 1 and abs(rep["max_rel_unfloored"] - 2e-5) < 1e-9
+    assert util.power_rel_err(bad, ref) < 1e-5  # ... which the floored metric would have let through
+    # where the reference's own fp32 is far from exact sums, the bound follows it: 3 x its distance
+    rep = util.parity_report(bad, ref, ref * (1 + 8e-6))
+    assert abs(rep["bound"] - 2.4e-5) < 1e-9 and rep["ok"]
+    assert util.power_rel_err_unfloored(np.array([0.0, 1.0]), np.array([0.0, 1.0])) == 0.0
+    assert util.power_rel_err_unfloored(np.array([1e-30, 1.0]), np.array([0.0, 1.0])) == np.inf
+
+
+def test_fir8_f64_tiebreaker_is_close_to_the_f32_restatement(oracle):
+    import util
+
+    xyz = oracle.create_antenna()
+    off, frac = oracle.compute_delay_lut(xyz, 8, 8)
+    off = np.minimum(off, 1024 - 263).astype(np.int32)
+    X = util.hash_frames(64, 1024, seed=2)[0]
+    table = util.synthetic_fir_table()
+    p32 = oracle.das_fir8_f32(X, off, frac, table)
+    p64 = oracle.das_fir8_f64(X, off, frac, table)
+    assert 0 < util.power_rel_err_unfloored(p32, p64) < 5e-6

@@ -155,3 +155,23 @@ def test_broadcaster_is_a_noop_without_a_group(pkg):
     t = torch.arange(6.0).reshape(2, 3)
     assert sh.gather_power(t, sh.all_shards(3, 1, 1)) is t
     assert sh.global_peak(t) is t
+
+
+def test_local_copy_exchange_follows_the_broadcaster_protocol(pkg):
+    """bench.py's projected_scaling stand-in for the collective: post(k) delivers `arrival` into buffer k % 2, wait(k)
+    hands that buffer out -- the FrameBroadcaster protocol, so the N > 1 step loop runs unchanged on one device."""
+    sh = importlib.import_module("beamforming-lk_amd.sharding")
+    bufs = tuple(torch.zeros((3, 4, 8)) for _ in range(2))
+    arrival = torch.arange(3 * 4 * 8, dtype=torch.float32).reshape(3, 4, 8)
+    ex = sh.LocalCopyExchange(bufs, arrival)
+    assert ex.mode == "local_copy"
+    ex.post(0)
+    for k in range(5):
+        got = ex.wait(k)
+        assert got is bufs[k % 2] and torch.equal(got, arrival)
+        got.zero_()  # (the sweep may do what it likes with a buffer it was handed)
+        if k + 1 < 5:
+            arrival += 1.0
+            ex.post(k + 1)
+    with pytest.raises(ValueError):
+        sh.LocalCopyExchange(bufs, torch.zeros((2, 4, 8)))

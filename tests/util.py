@@ -32,6 +32,48 @@ def power_rel_err(got: np.ndarray, ref: np.ndarray) -> float:
     return float((np.abs(got - ref) / np.maximum(np.abs(ref), floor)).max())
 
 
+def power_rel_err_unfloored(got: np.ndarray, ref: np.ndarray) -> float:
+    """max_p |got - ref| / |ref|: the north star's wording ("per-pixel power within 1e-5 relative of
+    reference"), no floor.  A pixel whose reference power is exactly 0 must be exactly 0."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    d = np.abs(got - ref)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.where(ref != 0.0, d / np.abs(ref), np.where(d == 0.0, 0.0, np.inf))
+    return float(r.max())
+
+
+def parity_report(got: np.ndarray, ref32: np.ndarray, ref64: np.ndarray | None = None) -> dict:
+    """Everything the parity claim rests on for one frame, on EVERY pixel handed in:
+      max_rel_unfloored / max_rel_floored  GPU vs the fp32 oracle (= the reference's operations)
+      pixels_below_floor                   how many pixels the floored metric treats as absolute
+      ref_f32_vs_f64_unfloored             the reference arithmetic's own distance to exact (fp64) sums
+      gpu_vs_f64_unfloored                 the GPU's distance to the same
+      bound                                max(POWER_RTOL, 3 x ref_f32_vs_f64_unfloored): what `ok` asserts
+      pixels_over_1e5                      pixels whose unfloored error exceeds 1e-5 (0 wherever `ok` without slack)."""
+    got = np.asarray(got, np.float64)
+    ref32 = np.asarray(ref32, np.float64)
+    floor = NULL_FLOOR * np.abs(ref32).max()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rel = np.where(ref32 != 0.0, np.abs(got - ref32) / np.abs(ref32), np.where(got == ref32, 0.0, np.inf))
+    rep = {
+        "pixels": int(got.size),
+        "max_rel_unfloored": float(rel.max()),
+        "max_rel_floored": power_rel_err(got, ref32),
+        "pixels_below_floor": int((np.abs(ref32) < floor).sum()),
+        "pixels_over_1e5": int((rel > POWER_RTOL).sum()),
+    }
+    bound = POWER_RTOL
+    if ref64 is not None:
+        ref64 = np.asarray(ref64, np.float64)
+        rep["ref_f32_vs_f64_unfloored"] = power_rel_err_unfloored(ref32, ref64)
+        rep["gpu_vs_f64_unfloored"] = power_rel_err_unfloored(got, ref64)
+        bound = max(POWER_RTOL, 3.0 * rep["ref_f32_vs_f64_unfloored"])
+    rep["bound"] = bound
+    rep["ok"] = bool(rep["max_rel_unfloored"] <= bound)
+    return rep
+
+
 def synthetic_fir_table() -> np.ndarray:
     """A [101, 8] fractional-delay table in the spirit of the reference's (Blackman-windowed sinc,
     centre tap 3, delays 0..1 in steps of 0.01; math_toolbox/filter_produce.m:89-101,263-264).  The

@@ -2,6 +2,9 @@
 # rocprofv3 evidence for one bench.py command line: kernel stats, SQ counters, HBM-side counters (separate passes)
 # usage: tools/gpu_profile.sh <tag> [bench args...]
 set -euo pipefail
+# One process only: under rocprofv3 the GPU is initialised before bench.py's main() runs, and `--gpus N` would start child
+# ranks from that process (the exec this pool forbids).  Profile one rank's slab instead: `--workload c5`.
+for a in "$@"; do case "$a" in --gpus|--gpus=*) echo "$0: --gpus is not allowed under the profiler; use --workload c5 (one rank's slab)" >&2; exit 2;; esac; done
 : "${GRAFT_REPO_ROOT:?run under gpurun}"
 tag=$1; shift
 out=gpurun_out/$tag

@@ -2,6 +2,9 @@
 # pmc.sh -- collect SQ counters for one bench.py launch set (counters only: no trace domains).
 # usage: tools/pmc.sh <outdir-under-gpurun_out> [bench args...]
 set -euo pipefail
+# One process only: under rocprofv3 the GPU is initialised before bench.py's main() runs, and `--gpus N` would start child
+# ranks from that process (the exec this pool forbids).  Profile one rank's slab instead: `--workload c5`.
+for a in "$@"; do case "$a" in --gpus|--gpus=*) echo "$0: --gpus is not allowed under the profiler; use --workload c5 (one rank's slab)" >&2; exit 2;; esac; done
 : "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run under gpurun)}"
 out=gpurun_out/$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
