@@ -41,7 +41,9 @@ class Cfg(C.Structure):
         ("grid_columns", C.c_int32),
         ("n_devices", C.c_int32),
         ("devices", C.c_int32 * 8),
-        ("reserved", C.c_int32 * 3),
+        ("window_begin", C.c_int32),
+        ("window_end", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -86,6 +88,9 @@ _SIGNATURES = {
     "awpu_hip_wait": (C.c_int, [C.c_void_p]),
     "awpu_hip_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "awpu_hip_synchronize": (C.c_int, [C.c_void_p]),
+    "awpu_hip_packed_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
+    "awpu_hip_pack_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "awpu_hip_process_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "awpu_hip_ingest_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "awpu_hip_process_ring": (C.c_int, [C.c_void_p, _f32p]),
     "awpu_hip_ring_snapshot": (C.c_int, [C.c_void_p, _f32p]),
@@ -253,7 +258,7 @@ class Engine:
     def __init__(self, n_pixels: int, n_streams: int = ELEMENTS, lut_stride: Optional[int] = None,
                  hist: int = HIST, math: int = MATH_F32_FAST, interp: int = INTERP_LERP,
                  max_batch: int = 1, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0,
-                 grid_columns: int = 0, devices=None):
+                 grid_columns: int = 0, devices=None, window=None):
         lib = load()
         cfg = Cfg()
         lib.awpu_hip_default_cfg(C.byref(cfg))
@@ -273,6 +278,8 @@ class Engine:
         cfg.max_batch = max_batch
         cfg.pixel_begin = pixel_begin
         cfg.pixel_count = pixel_count
+        if window is not None:  # (begin, end): history samples staged per stream, the union over the ranks' slabs
+            cfg.window_begin, cfg.window_end = int(window[0]), int(window[1])
         self._h = C.c_void_p()
         _check(lib.awpu_hip_create(C.byref(self._h), C.byref(cfg)), "awpu_hip_create")
         self.cfg = cfg
@@ -370,6 +377,23 @@ class Engine:
         _check(self._lib.awpu_hip_process_device(self._h, C.c_void_p(d_frames_ptr), batch,
                                                  C.c_void_p(d_power_ptr), C.c_void_p(stream)),
                "awpu_hip_process_device")
+
+    def packed_bytes(self, batch: int) -> int:
+        """Bytes of the packed frame-pair buffer for `batch` frames (awpu_hip_packed_bytes); raises AwpuError with
+        status ERR_STATE when this handle's sweep does not take packed frames."""
+        n = C.c_uint64(0)
+        _check(self._lib.awpu_hip_packed_bytes(self._h, batch, C.byref(n)), "awpu_hip_packed_bytes")
+        return int(n.value)
+
+    def pack_frames(self, d_frames_ptr: int, batch: int, d_packed_ptr: int, stream: int = 0) -> None:
+        """The sweep's pack pass on its own (the ingest rank of a multi-GPU job): frames -> packed pairs, on `stream`."""
+        _check(self._lib.awpu_hip_pack_frames(self._h, C.c_void_p(d_frames_ptr), batch, C.c_void_p(d_packed_ptr),
+                                              C.c_void_p(stream)), "awpu_hip_pack_frames")
+
+    def process_packed(self, d_packed_ptr: int, batch: int, d_power_ptr: int, stream: int = 0) -> None:
+        """The sweep on packed frame pairs as they arrive from the ingest rank, on `stream`; asynchronous."""
+        _check(self._lib.awpu_hip_process_packed(self._h, C.c_void_p(d_packed_ptr), batch, C.c_void_p(d_power_ptr),
+                                                 C.c_void_p(stream)), "awpu_hip_process_packed")
 
     def heatmap_device(self, d_power_ptr: int, n: int, batch: int, d_peak_ptr: int, d_pix_ptr: int,
                        peak_given: bool = False, stream: int = 0) -> None:

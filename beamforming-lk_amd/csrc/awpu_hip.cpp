@@ -301,6 +301,10 @@ int prepare(awpu_hip *h) {
     if (lo < 0 || hi + reach > c.hist - 1) {
         return fail(AWPU_ERR_RANGE, "delay table entry reads outside the frame history");
     }
+    if (c.window_end > c.window_begin) {  // a wider window asked for (ranks that exchange packed frames stage the union)
+        lo = std::min(lo, c.window_begin);
+        hi = std::max(hi, c.window_end - reach - 1);
+    }
     h->wstart = lo;
     h->window = hi - lo + reach + 1;
     h->tau_max = awpu::kSamples - lo;
@@ -739,12 +743,13 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
 
 // frame-pair shape: two frames per item, for batches on grids that fill the chip
 int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_frames, int batch, float *d_power,
-                 hipStream_t s, int hist_eff, int wstart_eff, int stationary_tiles = 0) {
+                 hipStream_t s, int hist_eff, int wstart_eff, int stationary_tiles = 0, const float *prepacked = nullptr) {
     const awpu::FastPlan &pp = plut->plan;
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * h->usable() * pp.wr * 2;
-    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
+    if (!prepacked)
+        if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
     awpu::PairArgs pa{};
-    pa.packed = h->d_pack;
+    pa.packed = prepacked ? prepacked : h->d_pack;
     pa.lut = plut->d;
     pa.power = d_power;
     pa.usable = h->usable();
@@ -765,8 +770,9 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
         pa.debug_out = h->d_diag;
     }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
-                                         h->usable(), nullptr, pp.wr, batch, h->d_pack, s));  // gains ride on the table weights here
+    if (!prepacked)
+        AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
+                                             h->usable(), nullptr, pp.wr, batch, h->d_pack, s));  // gains ride on the table weights here
     if (stationary_tiles > 0) {
         AWPU_HIP_TRY(awpu::launch_das_pairs_stationary(pa, stationary_tiles, s));
     } else {
@@ -778,14 +784,16 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
 }
 
 // quad shape: the frame-pair layout swept four vertically adjacent pixels at a time (das_quad_kernel)
-int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
+int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff,
+                 const float *prepacked = nullptr) {
     int rc = build_quad_lut(h, false);
     if (rc != AWPU_OK) return rc;
     const awpu::FastPlan &pp = h->quad_plan;
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * pp.usable_pad * pp.wr * 2;
-    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
+    if (!prepacked)
+        if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
     awpu::QuadArgs qa{};
-    qa.packed = h->d_pack;
+    qa.packed = prepacked ? prepacked : h->d_pack;
     qa.lut = h->d_quad_lut;
     qa.power = d_power;
     qa.usable = h->usable();
@@ -830,8 +838,9 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
         qa.debug_out = h->d_diag;
     }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
-                                         pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, s));
+    if (!prepacked)
+        AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
+                                             pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, s));
     AWPU_HIP_TRY(awpu::launch_das_quads(qa, s));
     rc = finish_launch(h, batch, s);
     if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
@@ -1411,6 +1420,11 @@ int awpu_hip_create(awpu_hip_t **out, const awpu_hip_cfg *cfg) {
     }
     if (c.pixel_begin < 0 || c.pixel_count < 1 || c.pixel_begin + c.pixel_count > c.n_pixels)
         return invalid("pixel shard outside the grid");
+    if (c.window_begin != 0 || c.window_end != 0) {
+        const int reach = c.interp == AWPU_INTERP_FIR8 ? 263 : 257;
+        if (c.window_begin < 0 || c.window_end > c.hist || c.window_end - c.window_begin < reach)
+            return invalid("window_begin/window_end outside the history or narrower than one delay() read");
+    }
 
     if (c.n_devices > 1) return create_group(out, c);
     c.n_devices = 1;
@@ -2026,6 +2040,69 @@ int awpu_hip_resize_linear_u8(const uint8_t *pix, int32_t rows, int32_t cols, ui
             out[(size_t) dy * out_cols + dx] = awpu::resize_combine(sums[dx], sums[(size_t) out_cols + dx], ty.w0, ty.w1);
     }
     return AWPU_OK;
+}
+
+namespace {
+
+// The layout both frame-pair shapes read when usable is a multiple of four and no gains are set:
+// [ceil(batch/2)][usable][wr][2] floats.  AWPU_ERR_STATE when this handle's sweep does not take packed frames.
+int packed_plan(awpu_hip *h, int batch, awpu::FastPlan *plan) {
+    if (!h) return invalid("null handle");
+    if (!h->parts.empty()) return fail(AWPU_ERR_STATE, "packed frames: a device group exchanges its frames itself");
+    const int rc = check_ready(h, batch);
+    if (rc != AWPU_OK) return rc;
+    if (h->cfg.math != AWPU_MATH_F32_FAST || h->cfg.interp != AWPU_INTERP_LERP)
+        return fail(AWPU_ERR_STATE, "packed frames need AWPU_MATH_F32_FAST and AWPU_INTERP_LERP");
+    if (h->usable() % 4 != 0 || !h->gain.empty())
+        return fail(AWPU_ERR_STATE, "packed frames need usable % 4 == 0 and no mic gains (the two pair shapes then read one layout)");
+    if (!awpu::pair_plan(h->window, h->usable(), plan)) return fail(AWPU_ERR_STATE, "the window does not fit the frame-pair image");
+    return AWPU_OK;
+}
+
+}  // namespace
+
+int awpu_hip_packed_bytes(awpu_hip_t *h, int32_t batch, uint64_t *bytes) {
+    AWPU_CTX(h);
+    if (!bytes) return invalid("null argument");
+    awpu::FastPlan plan;
+    const int rc = packed_plan(h, batch, &plan);
+    if (rc != AWPU_OK) return rc;
+    *bytes = (uint64_t) ((batch + 1) / 2) * h->usable() * plan.wr * 2 * sizeof(float);
+    return AWPU_OK;
+}
+
+int awpu_hip_pack_frames(awpu_hip_t *h, const float *d_frames, int32_t batch, float *d_packed, void *stream) {
+    AWPU_CTX(h);
+    if (!d_frames || !d_packed) return invalid("null argument");
+    awpu::FastPlan plan;
+    const int rc = packed_plan(h, batch, &plan);
+    if (rc != AWPU_OK) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    // (Measured: a throttled variant of this pass -- few persistent workgroups, non-temporal accesses -- meant to be gentler
+    // on the sweep it runs beside, slowed that sweep MORE the longer it lasted: 256 / 512 / 1024 workgroups cost the ingest
+    // rank 0.90 / 0.55 / 0.35 ms per 1024-frame step against 0.23 ms for this full-speed pass.  Short and fast wins.)
+    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, h->cfg.hist, h->wstart, h->d_index, h->usable(), h->usable(),
+                                         nullptr, plan.wr, batch, d_packed, s));
+    return AWPU_OK;
+}
+
+int awpu_hip_process_packed(awpu_hip_t *h, const float *d_packed, int32_t batch, float *d_power, void *stream) {
+    AWPU_CTX(h);
+    if (!d_packed || !d_power) return invalid("null argument");
+    awpu::FastPlan plan;
+    int rc = packed_plan(h, batch, &plan);
+    if (rc != AWPU_OK) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    TimingOff untimed(h);  // asynchronous path: the caller times its own stream
+    // the shape awpu_hip_process_device takes for this batch (same rule: same bits), as long as that is a frame-pair shape
+    const bool quad_fills = h->quad_ok && ((long) awpu::quad_tiles(h->cfg.pixel_count / h->cfg.grid_columns, h->cfg.grid_columns) *
+                                               ((batch + 1) / 2) >= 256 || env().quads == 1);
+    if (quad_fills && env().pairs != 0 && h->quad_plan.wr == plan.wr && h->quad_plan.usable_pad == h->usable())
+        return launch_quads(h, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, d_packed);
+    const awpu_hip::FastLut *plut = nullptr;
+    rc = build_fast_lut(h, 2, -1, &plut);
+    if (rc != AWPU_OK) return rc;
+    return launch_pairs(h, plut, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, 0, d_packed);
 }
 
 int awpu_hip_synchronize(awpu_hip_t *h) {

@@ -614,9 +614,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_db_kernel(FastArgs a) {
 // One 16-wave workgroup per CU, two LDS images (chunk c+1 lands while chunk c is swept), 4 pixels
 // per wave; grid = (frame pairs, 64-pixel tiles).
 // ---------------------------------------------------------------------------------------
-__global__ void pack_pairs_kernel(const float *frames, int n_streams, int hist, int wstart, const int32_t *index,
-                                  int usable, const float *gain, int wp, int batch, float *packed) {
-    const int pair = blockIdx.y, s = blockIdx.x, rows_out = gridDim.x;
+__device__ __forceinline__ void pack_one_row(const float *frames, int n_streams, int hist, int wstart, const int32_t *index,
+                                             int usable, const float *gain, int wp, int batch, float *packed, int pair, int s,
+                                             int rows_out) {
     f2 *dst = (f2 *) packed + ((size_t) pair * rows_out + s) * wp;
     if (s >= usable) {  // padding rows (the quad shape sweeps whole groups of four mics): silence
         for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = f2{0.0f, 0.0f};
@@ -628,6 +628,11 @@ __global__ void pack_pairs_kernel(const float *frames, int n_streams, int hist, 
     const float gm = gain ? gain[s] : 1.0f;  // optional per-mic gain (awpu_hip_set_mic_gains); x * 1.0f is x
     const int valid = min(wp, hist - wstart);
     for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = t < valid ? f2{xa[t] * gm, xb[t] * gm} : f2{0.0f, 0.0f};
+}
+
+__global__ void pack_pairs_kernel(const float *frames, int n_streams, int hist, int wstart, const int32_t *index,
+                                  int usable, const float *gain, int wp, int batch, float *packed) {
+    pack_one_row(frames, n_streams, hist, wstart, index, usable, gain, wp, batch, packed, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
 // out[] of one pixel (both frames at once) from the skewed accumulators, then mimo.cpp:131-137.

@@ -21,8 +21,9 @@ class RowShard:
     world: int
     res_rows: int
     res_cols: int
-    row_begin: int
-    row_count: int
+    row_begin: int   # first grid row owned (of the first range when the shard is interleaved)
+    row_count: int   # rows owned in total
+    ranges: Tuple[Tuple[int, int], ...] = ()  # interleaved shards: (first row, rows) of every range, ascending
 
     @property
     def pixel_begin(self) -> int:
@@ -31,6 +32,14 @@ class RowShard:
     @property
     def pixel_count(self) -> int:
         return self.row_count * self.res_cols
+
+    @property
+    def row_ranges(self) -> Tuple[Tuple[int, int], ...]:
+        """(first grid row, rows) of every contiguous run of rows this shard owns, in the order its tile holds them."""
+        return self.ranges if self.ranges else ((self.row_begin, self.row_count),)
+
+    def rows(self) -> List[int]:
+        return [r for b, n in self.row_ranges for r in range(b, b + n)]
 
 
 def shard_rows(res_rows: int, res_cols: int, world: int, rank: int) -> RowShard:
@@ -45,8 +54,29 @@ def shard_rows(res_rows: int, res_cols: int, world: int, rank: int) -> RowShard:
     return RowShard(rank, world, res_rows, res_cols, begin, count)
 
 
-def all_shards(res_rows: int, res_cols: int, world: int) -> List[RowShard]:
-    return [shard_rows(res_rows, res_cols, world, r) for r in range(world)]
+def all_shards(res_rows: int, res_cols: int, world: int, interleaved: bool = False) -> List[RowShard]:
+    f = shard_rows_interleaved if interleaved else shard_rows
+    return [f(res_rows, res_cols, world, r) for r in range(world)]
+
+
+def shard_rows_interleaved(res_rows: int, res_cols: int, world: int, rank: int, group: int = 4) -> RowShard:
+    """Row slabs dealt round-robin in groups of `group` rows: rank r owns row groups r, r + world, r + 2 world, ...
+
+    Why: the sweep's cost per row is not flat over the grid.  The quad shape shares work between four vertically
+    adjacent pixels wherever their integer delays coincide, and they coincide less towards the edge of the sine-space
+    grid (headline shape, 8 contiguous slabs of 16 rows, same GPU: 5.45 ms for an edge slab against 4.93 ms for a
+    middle one; an N-GPU step takes as long as its slowest rank).  Dealt round-robin every rank gets edge and centre
+    groups alike -- with a cost that grows linearly from the centre row outwards the shares are exactly equal -- and
+    a group of four rows is the quad shape's unit, so every quad still is four truly adjacent grid rows.  The rank's
+    table and power tile hold its groups in ascending order; `row_ranges` says which grid rows they are.
+    Falls back to contiguous slabs when there are fewer row groups than ranks."""
+    if not (0 <= rank < world):
+        raise ValueError("rank outside world")
+    n_groups = (res_rows + group - 1) // group
+    if world == 1 or n_groups < world:
+        return shard_rows(res_rows, res_cols, world, rank)
+    ranges = tuple((g * group, min(group, res_rows - g * group)) for g in range(rank, n_groups, world))
+    return RowShard(rank, world, res_rows, res_cols, ranges[0][0], sum(n for _, n in ranges), ranges)
 
 
 class FrameBroadcaster:
@@ -88,13 +118,25 @@ class FrameBroadcaster:
             self._work[k % 2] = [dist.broadcast(buf, src=self.src, group=self.group, async_op=True)]
             return
         per = buf.shape[0] // self.world
-        if self._mine[k % 2] is None:  # this rank's 1/world of the batch, outside `buf` (no aliasing)
+        if dist.get_backend(self.group) != "gloo":
+            # NCCL/RCCL: the root sends every peer its slice straight into that peer's batch buffer (grouped point-to-point
+            # sends), then the in-place all-gather (input = the output's own slice): no staging copy on either side,
+            # stream-ordered one after the other
+            mine = buf[self.rank * per:(self.rank + 1) * per]
+            if self.rank == self.src:  # the root's own slice is in place already; one send per peer, each over its own link
+                ops = [dist.P2POp(dist.isend, buf[r * per:(r + 1) * per], r, self.group) for r in range(self.world) if r != self.src]
+            else:
+                ops = [dist.P2POp(dist.irecv, mine, self.src, self.group)]
+            works = list(dist.batch_isend_irecv(ops))
+            works.append(dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True))
+            self._work[k % 2] = works
+            return
+        if self._mine[k % 2] is None:  # this rank's 1/world of the batch, outside `buf` (gloo does not gather in place)
             self._mine[k % 2] = torch.empty_like(buf[:per])
         mine = self._mine[k % 2]
         chunks = [buf[r * per:(r + 1) * per].contiguous() for r in range(self.world)] if self.rank == self.src else None
         w1 = dist.scatter(mine, chunks, src=self.src, group=self.group, async_op=True)
-        if dist.get_backend(self.group) == "gloo":
-            w1.wait()  # gloo runs async ops on several threads, not in issue order (NCCL/RCCL is stream-ordered)
+        w1.wait()  # gloo runs async ops on several threads, not in issue order (NCCL/RCCL is stream-ordered)
         w2 = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True)
         self._work[k % 2] = [w1, w2]
 
@@ -206,7 +248,8 @@ class FrameScatterer:
 
 def gather_power(local: torch.Tensor, shards: List[RowShard], dst: int = 0,
                  group: Optional[dist.ProcessGroup] = None) -> Optional[torch.Tensor]:
-    """Assemble the [batch, P] heatmap on `dst` from per-rank [batch, pixel_count] tiles.
+    """Assemble the [batch, P] heatmap on `dst` from per-rank [batch, pixel_count] tiles (contiguous or interleaved
+    shards: every tile's rows go where `row_ranges` says).  P = the pixels the shards cover, in grid order.
     Not on the timed data path (each rank can hand its tile to its own consumer)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
@@ -219,4 +262,15 @@ def gather_power(local: torch.Tensor, shards: List[RowShard], dst: int = 0,
     dist.gather(padded, tiles, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([t[:, : s.pixel_count] for t, s in zip(tiles, shards)], dim=1)
+    return assemble_tiles([t[:, : s.pixel_count] for t, s in zip(tiles, shards)], shards)
+
+
+def assemble_tiles(tiles: List[torch.Tensor], shards: List[RowShard]) -> torch.Tensor:
+    """[batch, covered pixels] in grid-row order from the shards' tiles."""
+    cols = shards[0].res_cols
+    owner = sorted((row, k, i) for k, s in enumerate(shards) for i, row in enumerate(s.rows()))
+    batch = tiles[0].shape[0]
+    out = torch.empty((batch, len(owner) * cols), dtype=tiles[0].dtype, device=tiles[0].device)
+    for pos, (_, k, i) in enumerate(owner):
+        out[:, pos * cols:(pos + 1) * cols] = tiles[k][:, i * cols:(i + 1) * cols]
+    return out

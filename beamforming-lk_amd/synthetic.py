@@ -63,6 +63,15 @@ def delay_table(spec: WorkloadSpec, xyz: Optional[np.ndarray] = None, row_begin:
     return binding.build_delay_table(xyz, spec.res, spec.res, spec.fov, row_begin, row_count)
 
 
+def delay_table_for(spec: WorkloadSpec, xyz: Optional[np.ndarray], row_ranges) -> Tuple[np.ndarray, np.ndarray]:
+    """The table rows of a shard (sharding.RowShard.row_ranges: contiguous or interleaved), concatenated in the
+    order the shard's power tile holds them."""
+    parts = [delay_table(spec, xyz, b, n) for b, n in row_ranges]
+    if len(parts) == 1:
+        return parts[0]
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
 def make_frames(xyz: np.ndarray, batch: int, seed: int = 1234, theta: float = SOURCE_THETA,
                 phi: float = SOURCE_PHI, hist: int = binding.HIST) -> np.ndarray:
     """[batch, n_mics, hist] float32: plane wave from (theta, phi) + uniform noise.

@@ -253,9 +253,17 @@ def full_grid_parity(got, frame, off, frac, math="fast", interp="lerp"):
 
 
 class RankJob:
-    """Everything one rank of a `world`-rank run owns: its slab of the grid and of the delay table, its engine, the
-    double-buffered frame exchange and the step loop.  world = 1 is the single-GPU bench.  `stub` replaces the
-    collective by a local copy of the same bytes (projected_scaling: the N > 1 loop on one GPU)."""
+    """Everything one rank of a `world`-rank run owns: its share of the grid's rows and of the delay table, its engine,
+    the double-buffered frame exchange and the step loop.  world = 1 is the single-GPU bench.  `stub` replaces the
+    collective by a local copy of the same bytes (projected_scaling: the N > 1 loop on one GPU).
+
+    Rows.  N > 1: row groups of four dealt round-robin (sharding.shard_rows_interleaved: edge rows cost more than
+    centre rows, an N-GPU step takes as long as its slowest rank); BENCH_SHARDS=contiguous gives plain slabs.
+    Exchange.  "packed" (default where the library offers it): rank 0 runs the sweep's pack pass once per batch, on a
+    side stream beside the previous sweep, the packed frame pairs travel, and every rank sweeps them as they arrive
+    (awpu_hip_pack_frames / awpu_hip_process_packed) -- no window cut on the root, no pack pass on the others.
+    "window" (BENCH_EXCHANGE=window, FIR8, exact math): rank 0 cuts the touched window of every mic out of its
+    snapshots, that travels, every rank runs the whole sweep (pack included) on it."""
 
     def __init__(self, pkg, sharding, torch, dist, args, spec, world, rank, dev, local_rank, B, c5=False, stub=False,
                  frames_src=None):
@@ -263,20 +271,21 @@ class RankJob:
         self.args, self.spec, self.world, self.rank, self.dev, self.B, self.stub = args, spec, world, rank, dev, B, stub
         S = pkg.synthetic
         slabs = C5_SLABS * world if c5 else world
-        self.shard = sharding.shard_rows(spec.res, spec.res, slabs, rank)
-        self.grid_pixels = (sum(sharding.shard_rows(spec.res, spec.res, slabs, r).pixel_count for r in range(world))
-                            if c5 else spec.n_pixels)
+        interleave = world > 1 and not c5 and os.environ.get("BENCH_SHARDS", "interleaved") != "contiguous"
+        self.shards = sharding.all_shards(spec.res, spec.res, slabs, interleaved=interleave)[:world]
+        self.shard = self.shards[rank]
+        self.grid_pixels = sum(s.pixel_count for s in self.shards) if c5 else spec.n_pixels
         self.xyz = S.geometry(spec)
-        off, frac = S.delay_table(spec, self.xyz, self.shard.row_begin, self.shard.row_count)
+        off, frac = S.delay_table_for(spec, self.xyz, self.shard.row_ranges)
+        self.off_abs = off
         self.hist = pkg.binding.HIST
-        self.win_begin = 0
-        exchange = world > 1
-        if exchange:
-            # Only the window [min off, max off + 257) of every mic is ever read, so that
-            # is what travels: rank 0 cuts it out of its 1024-sample snapshots each step and sends
-            # [B][mics][Wc]; every rank sweeps with hist = Wc and offsets relative to the window.
+        self.win_begin, self.win_hist, self.window = 0, pkg.binding.HIST, None
+        self.exchange = None
+        if world > 1:
+            # Only the window [min off, max off + 257) of every mic is ever read, so that is all that
+            # travels, in either exchange format; every rank needs the union over the slabs.
             lo, hi = int(off.min()), int(off.max())
-            if stub:  # the window of the WHOLE grid, as the all-reduce below would find it (one table row per grid row suffices)
+            if stub:  # what the all-reduce below would find (a few table rows across the grid suffice)
                 for r in range(0, spec.res, max(1, spec.res // 16)):
                     o, _ = S.delay_table(spec, self.xyz, r, 1)
                     lo, hi = min(lo, int(o.min())), max(hi, int(o.max()))
@@ -286,15 +295,33 @@ class RankJob:
                 dist.all_reduce(t_lo, op=dist.ReduceOp.MIN)
                 dist.all_reduce(t_hi, op=dist.ReduceOp.MAX)
                 lo, hi = int(t_lo.item()), int(t_hi.item())
-            self.win_begin = lo
             reach = 263 if args.interp == "fir8" else 257
-            self.hist = ((hi - lo + reach + 3) // 4) * 4 + 4
-            off = off - lo
-        self.off, self.frac = off, frac
+            self.win_begin = lo
+            self.win_hist = ((hi - lo + reach + 3) // 4) * 4 + 4
+            self.window = (lo, hi + reach)
+            self.exchange = os.environ.get("BENCH_EXCHANGE", "packed")
+            if args.math != "fast" or args.interp != "lerp" or B % 2:
+                self.exchange = "window"
         self.math = {"fast": pkg.MATH_F32_FAST, "exact": pkg.MATH_F32_EXACT, "bf16": pkg.MATH_BF16_ACC}[args.math]
         self.interp = pkg.binding.INTERP_FIR8 if args.interp == "fir8" else pkg.binding.INTERP_LERP
         self.local_rank = local_rank
-        self.eng = self.make_engine(self.math, B, off, frac, self.shard.pixel_begin, self.shard.pixel_count)
+        self.eng = None
+        self.root_work = True  # (projected_scaling switches it off to time what a rank other than the ingest rank does)
+        if self.exchange == "packed":  # snapshots stay in the ingest layout on rank 0; every rank stages the union window
+            self.eng = self.make_engine(self.math, B, off, frac, self.shard.pixel_begin, self.shard.pixel_count, window=self.window)
+            try:
+                packed_floats = self.eng.packed_bytes(B) // 4
+            except pkg.AwpuError as exc:  # this table / mic list has no packed form: exchange raw windows
+                if exc.status != pkg.binding.ERR_STATE:
+                    raise
+                self.eng.close()
+                self.eng, self.exchange = None, "window"
+        if self.eng is None:
+            if self.exchange == "window":  # every rank sweeps [B][mics][Wc] windows: hist = Wc, offsets relative to the window
+                self.hist = self.win_hist
+                off = off - self.win_begin
+            self.eng = self.make_engine(self.math, B, off, frac, self.shard.pixel_begin, self.shard.pixel_count)
+        self.off, self.frac = off, frac
 
         # frames: DISTINCT_FRAMES synthetic ones generated 64 at a time, repeated up to B, resident in HBM before the clock
         self.d_full = frames_src
@@ -311,27 +338,40 @@ class RankJob:
             for b0 in range(distinct, B, distinct):
                 n = min(distinct, B - b0)
                 self.d_full[b0:b0 + n] = self.d_full[:n]
-        if exchange:
+        # a real (non-null) stream: its handle goes to the C ABI, and the torch events that time the sweep are
+        # recorded on the same stream; `aux` carries the root's pack / window cut and the collectives' enqueue point
+        # (the sweep's stream has the higher priority: where both have work ready, the dispatcher serves the sweep first and
+        # the pack / copy kernels fill what is left)
+        self.stream = torch.cuda.Stream(device=dev, priority=-1)
+        self.aux = torch.cuda.Stream(device=dev, priority=0)
+        self.swept = [torch.cuda.Event(), torch.cuda.Event()]
+        if self.exchange == "packed":
+            pairs = B // 2
+            self.bufs = tuple(torch.zeros((pairs, packed_floats // pairs), dtype=torch.float32, device=dev) for _ in range(2))
+            self.exchange_mb = packed_floats * 4 / 1e6
+        elif self.exchange == "window":
             self.bufs = tuple(torch.zeros((B, spec.n_mics, self.hist), dtype=torch.float32, device=dev) for _ in range(2))
+            self.exchange_mb = B * spec.n_mics * self.hist * 4 / 1e6
         else:
             self.bufs = (self.d_full, self.d_full)
+            self.exchange_mb = 0.0
         self.d_power = torch.zeros((B, self.shard.pixel_count), dtype=torch.float32, device=dev)
         if stub:
-            # stands for the bytes the collective would deliver (the real window, so that the sweep sees real samples)
-            self.arrival = self.d_full[:, :, self.win_begin:self.win_begin + self.hist].contiguous()
+            # stands for the bytes the collective would deliver (the real frames, so that the sweep sees real samples)
+            self.arrival = torch.empty_like(self.bufs[0])
+            torch.cuda.synchronize()
+            self.fill(self.arrival, torch.cuda.current_stream(dev))
             self.bcast = sharding.LocalCopyExchange(self.bufs, self.arrival)
         else:
             self.bcast = sharding.FrameBroadcaster(self.bufs, src=0, mode=os.environ.get("BENCH_BCAST", "broadcast"))
-        # a real (non-null) stream: its handle goes to the C ABI, and the torch events that time
-        # the sweep are recorded on the same stream
-        self.stream = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize()
 
-    def make_engine(self, math_id, max_batch, off_, frac_, begin, count, grid_columns=None):
+    def make_engine(self, math_id, max_batch, off_, frac_, begin, count, grid_columns=None, window=None, hist=None):
         spec = self.spec
         grid_columns = spec.res if grid_columns is None else grid_columns
-        eng_ = self.pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, hist=self.hist, math=math_id, interp=self.interp,
-                               max_batch=max_batch, device=self.local_rank, pixel_begin=begin, pixel_count=count,
+        eng_ = self.pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, hist=hist or self.hist, math=math_id,
+                               interp=self.interp, max_batch=max_batch, device=self.local_rank, pixel_begin=begin,
+                               pixel_count=count, window=window,
                                grid_columns=0 if os.environ.get("BENCH_NO_GRID_HINT") else grid_columns)
         eng_.set_delay_table(off_, frac_)
         eng_.set_active_mics(None)
@@ -339,12 +379,35 @@ class RankJob:
             eng_.set_fir_table(synthetic_fir_table())
         return eng_
 
+    def fill(self, buf, on):
+        """The root's share of a step: the resident snapshots -> the exchange buffer, enqueued on stream `on`."""
+        if self.exchange == "packed":
+            self.eng.pack_frames(self.d_full.data_ptr(), self.B, buf.data_ptr(), on.cuda_stream)
+        else:
+            with self.torch.cuda.stream(on):
+                buf.copy_(self.d_full[:, :, self.win_begin:self.win_begin + self.hist])
+
     def post(self, k):
-        if self.world > 1 and self.rank == 0:  # cut the window out of the resident snapshots (part of the step)
-            self.bufs[k % 2].copy_(self.d_full[:, :, self.win_begin:self.win_begin + self.hist])
-        self.bcast.post(k)
+        """Start batch k on its way into buffer k % 2.  Everything here runs on the side stream: it waits for the sweep
+        that last read the buffer (step k - 2), not for the sweep in progress, so the root's pack pass and the
+        collective run beside sweep k - 1."""
+        if self.exchange is None:
+            return
+        if k >= 2:
+            self.aux.wait_event(self.swept[k % 2])
+        if self.rank == 0 and self.root_work:
+            self.fill(self.bufs[k % 2], self.aux)
+        with self.torch.cuda.stream(self.aux):  # (a collective is ordered after the work of the stream it is called on)
+            self.bcast.post(k)
+
+    def sweep(self, frames):
+        if self.exchange == "packed":
+            self.eng.process_packed(frames.data_ptr(), self.B, self.d_power.data_ptr(), self.stream.cuda_stream)
+        else:
+            self.eng.process_device(frames.data_ptr(), self.B, self.d_power.data_ptr(), self.stream.cuda_stream)
 
     def run_steps(self, n, ev=None):
+        self.aux.wait_stream(self.stream)  # (sweeps of an earlier call may still read the buffers)
         with self.torch.cuda.stream(self.stream):
             self.post(0)
             for k in range(n):
@@ -353,9 +416,10 @@ class RankJob:
                     self.post(k + 1)  # next batch travels while this one is swept
                 if ev is not None:
                     ev[0][k].record(self.stream)
-                self.eng.process_device(frames.data_ptr(), self.B, self.d_power.data_ptr(), self.stream.cuda_stream)
+                self.sweep(frames)
                 if ev is not None:
                     ev[1][k].record(self.stream)
+                self.swept[k % 2].record(self.stream)
 
     def fence(self):
         self.torch.cuda.synchronize()
@@ -435,9 +499,9 @@ def main():
                f"({spec.res // (C5_SLABS * world)} rows) per GPU") if c5 else spec.name
 
     job = RankJob(pkg, sharding, torch, dist, args, spec, world, rank, dev, local_rank, B, c5=c5)
-    shard, hist, off, frac, eng = job.shard, job.hist, job.off, job.frac, job.eng
+    shard, off, frac, eng = job.shard, job.off, job.frac, job.eng
     d_full, d_power, bufs, stream, host_first = job.d_full, job.d_power, job.bufs, job.stream, job.host_first
-    win_begin, grid_pixels, xyz = job.win_begin, job.grid_pixels, job.xyz
+    win_begin, win_hist, grid_pixels, xyz = job.win_begin, job.win_hist, job.grid_pixels, job.xyz
     run_steps, fence = job.run_steps, job.fence
 
     run_steps(W)
@@ -490,7 +554,7 @@ def main():
     st = eng.stats()
     parity = None
     if rank == 0:
-        parity = full_grid_parity(d_power[0].cpu().numpy(), host_first[0], off + win_begin, frac, args.math, args.interp)
+        parity = full_grid_parity(d_power[0].cpu().numpy(), host_first[0], job.off_abs, frac, args.math, args.interp)
         parity["what"] = (f"frame 0 of the timed batch, all {shard.pixel_count} pixels of rank 0's slab, GPU vs oracle.das_f32 "
                           f"(the reference's operations) and vs exact fp64 sums; bound = max(1e-5, 3 x ref_f32_vs_f64_unfloored)")
 
@@ -500,15 +564,16 @@ def main():
     if world > 1 and B % world == 0 and not c5 and os.environ.get("BENCH_ALT", "0") == "1":
         per = B // world
         off_all, frac_all = S.delay_table(spec, xyz, 0, spec.res)
-        eng2 = job.make_engine(job.math, per, off_all - win_begin, frac_all, 0, spec.n_pixels)
-        mine = tuple(torch.zeros((per, spec.n_mics, hist), dtype=torch.float32, device=dev) for _ in range(2))
+        eng2 = job.make_engine(job.math, per, off_all - win_begin, frac_all, 0, spec.n_pixels, hist=win_hist)
+        mine = tuple(torch.zeros((per, spec.n_mics, win_hist), dtype=torch.float32, device=dev) for _ in range(2))
+        full2 = tuple(torch.zeros((B, spec.n_mics, win_hist), dtype=torch.float32, device=dev) for _ in range(2)) if rank == 0 else None
         d_power2 = torch.zeros((per, spec.n_pixels), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
-        scat = sharding.FrameScatterer(mine, bufs if rank == 0 else None, src=0)
+        scat = sharding.FrameScatterer(mine, full2, src=0)
 
         def post2(k):
             if rank == 0:
-                bufs[k % 2].copy_(d_full[:, :, win_begin:win_begin + hist])
+                full2[k % 2].copy_(d_full[:, :, win_begin:win_begin + win_hist])
             scat.post(k)
 
         def run2(n):
@@ -528,9 +593,10 @@ def main():
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         alt = {"sharding": f"whole frames over {world} GPUs ({per} per rank per step, full grid each); rank 0 scatters "
-                           f"{per * spec.n_mics * hist * 4 / 1e6:.1f} MB to each rank per step",
+                           f"{per * spec.n_mics * win_hist * 4 / 1e6:.1f} MB to each rank per step",
                "value": B * K / float(t.item()), "unit": "frames/s", "ms_per_step": float(t.item()) / K * 1e3}
         eng2.close()
+        del full2, mine
 
     out = None
     if rank == 0:
@@ -554,9 +620,13 @@ def main():
                                          f"{B // world} x {world} GPU(s): the batch grows with the number of ranks so that a rank's "
                                          f"launch ({B} frames x 1/{world} of the grid) keeps its one-GPU size"),
                 "distinct_frames": min(B, DISTINCT_FRAMES),
-                "sharding": f"grid rows over {world} GPU(s); per step rank 0 sends the {hist}-sample window "
-                            f"of every mic ({B * spec.n_mics * hist * 4 / 1e6:.1f} MB) to every rank, overlapped with the previous sweep"
-                            if world > 1 else "single GPU",
+                "sharding": (f"grid rows over {world} GPUs, " +
+                             ("row groups of four dealt round-robin (edge and centre rows alike on every rank)" if shard.ranges
+                              else "contiguous slabs") +
+                             f"; per step rank 0 sends the touched window of every mic ({job.exchange_mb:.1f} MB, " +
+                             ("as packed frame pairs: packed once on rank 0, swept as they arrive" if job.exchange == "packed"
+                              else f"{win_hist} samples per mic, cut out of the snapshots") +
+                             ") to every rank, overlapped with the previous sweep") if world > 1 else "single GPU",
                 "alg_bytes_per_frame": full_bytes,
             },
             "roofline": {
@@ -665,11 +735,17 @@ def main():
     # ---- N > 1, opt-in: the assembled heatmap of frame 0 must equal what the shards computed (a collective
     # after the result line, so that a rank that fails here cannot cost the run its line)
     if world > 1 and os.environ.get("BENCH_GATHER_CHECK") == "1":
-        shards = [sharding.shard_rows(spec.res, spec.res, C5_SLABS * world if c5 else world, r) for r in range(world)]
-        full = sharding.gather_power(d_power[:1].contiguous(), shards, dst=0)
+        full = sharding.gather_power(d_power[:1].contiguous(), job.shards, dst=0)
         if rank == 0:
-            ok = full.shape == (1, grid_pixels) and torch.equal(full[0, : shard.pixel_count], d_power[0])
-            print("gather check:", "ok" if ok else "MISMATCH: the assembled heatmap differs from rank 0's tile", file=sys.stderr)
+            cols = spec.res
+            mine = torch.cat([full[0, r * cols:(r + 1) * cols] for r in shard.rows()]) if not c5 else full[0, : shard.pixel_count]
+            ok = full.shape == (1, grid_pixels) and torch.equal(mine, d_power[0])
+            msg = "ok" if ok else "MISMATCH: the assembled heatmap differs from rank 0's tile"
+            if ok and not c5:  # the whole assembled heatmap against the oracle, every pixel, unfloored
+                off_all, frac_all = S.delay_table(spec, xyz, 0, spec.res)
+                rep = full_grid_parity(full[0].cpu().numpy(), host_first[0], off_all, frac_all, args.math, args.interp)
+                msg = f"{'ok' if rep['ok'] else 'PARITY FAILED'}: assembled {world}-rank heatmap vs oracle on {rep['pixels']} pixels: {rep}"
+            print("gather check:", msg, file=sys.stderr)
 
     job.close()
     if world > 1:
@@ -709,7 +785,8 @@ def other_workloads(pkg, sharding, torch, dist, args, dev, local_rank):
 
 def projected_scaling(pkg, sharding, torch, dist, args, spec, dev, local_rank, d_full, B1, fps_one_gpu, ms_one_gpu, ranks=8):
     """What ONE GPU can retire of the 8-GPU unknowns: rank 0's slab of a `ranks`-rank run (1/8 of the rows) through the
-    exact N > 1 step loop -- window cut on the root, double buffer, event waits, the C-ABI call on its own stream --
+    exact N > 1 step loop -- the root's pack pass (or window cut) on the side stream, double buffer, event waits, the C-ABI
+    call on its own stream --
     with the collective replaced by a local copy of the same bytes into the receive buffer (sharding.LocalCopyExchange).
     Everything a rank does per step is in the clock except the wire: xGMI and RCCL's own CU use are NOT projected."""
     B = default_batch(ranks, False) if not args.batch else args.batch
@@ -723,20 +800,27 @@ def projected_scaling(pkg, sharding, torch, dist, args, spec, dev, local_rank, d
     # the same slab without the exchange machinery: resident window, back-to-back launches
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     with torch.cuda.stream(job.stream):
-        job.eng.process_device(job.bufs[0].data_ptr(), B, job.d_power.data_ptr(), job.stream.cuda_stream)
+        job.sweep(job.bufs[0])
         ev[0].record(job.stream)
         for _ in range(4):
-            job.eng.process_device(job.bufs[0].data_ptr(), B, job.d_power.data_ptr(), job.stream.cuda_stream)
+            job.sweep(job.bufs[0])
         ev[1].record(job.stream)
         torch.cuda.synchronize()
     bare_ms = ev[0].elapsed_time(ev[1]) / 4
-    exchange_mb = B * spec.n_mics * job.hist * 4 / 1e6
+    # what the seven ranks that are not the ingest rank do per step: receive and sweep, no pack
+    job.root_work = False
+    elapsed_peer, kernel_peer_ms, _ = job.timed(K, 1)
+    job.root_work = True
+    exchange_mb = job.exchange_mb
     out = {
         "ranks": ranks, "rank": 0, "slab_rows": job.shard.row_count, "slab_pixels": job.shard.pixel_count,
+        "rows": "row groups of four dealt round-robin" if job.shard.ranges else "contiguous slab", "exchange": job.exchange,
         "frames_per_step": B, "steps": K,
         "slab_kernel_ms": kernel_ms,            # the sweep launch inside the loop, by events on its stream
         "slab_kernel_ms_bare": bare_ms,         # the same launch back to back, nothing beside it
-        "step_wall_ms": step_ms,                # wall per step of the whole loop (window cut + stand-in copy + sweep)
+        "step_wall_ms": step_ms,                # wall per step of the whole loop (the root's pack or cut + stand-in copy + sweep)
+        "peer_step_wall_ms": elapsed_peer / K * 1e3,  # the same for a rank other than the ingest rank (no pack / cut)
+        "peer_slab_kernel_ms": kernel_peer_ms,
         "host_enqueue_ms_per_step": t_enqueued / K * 1e3,  # Python + ctypes + event records: hidden while < step_wall_ms
         "host_overhead_ms": max(0.0, step_ms - kernel_ms),  # what the loop adds to the kernel on the device's timeline
         "exchange_mb_per_step": exchange_mb,

@@ -104,7 +104,13 @@ typedef struct {
      * caller's buffer.  awpu_hip_ingest_block feeds every device's ring.  0 or 1 = one device, as before. */
     int32_t n_devices;
     int32_t devices[AWPU_MAX_DEVICES];
-    int32_t reserved[3];
+    /* Optional: history samples [window_begin, window_end) that the handle stages per stream even where its own table
+     * touches fewer (0, 0 = exactly what the table touches: [min off, max off + 257), FIR8 + 263).  Handles that own
+     * different slabs of one grid and exchange PACKED frames (awpu_hip_pack_frames / awpu_hip_process_packed) must
+     * stage the same window, so every rank passes the union over all slabs here.  Results do not depend on it. */
+    int32_t window_begin;
+    int32_t window_end;
+    int32_t reserved[1];
 } awpu_hip_cfg;
 
 typedef struct {
@@ -208,6 +214,26 @@ int awpu_hip_wait(awpu_hip_t *h);
  * [batch][n_streams][hist], d_power [batch][pixel_count]. */
 int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch, float *d_power,
                             void *stream);
+
+/* ---- the sweep split at its pack pass (multi-GPU: the exchange format between ranks) --------------------------
+ * The batched sweep first interleaves the touched window of two consecutive frames sample by sample ("packed frame
+ * pairs": [ceil(batch/2)][usable][wp][2] floats, active-mic order) and then sweeps that buffer.  A
+ * multi-GPU job whose ranks own slabs of one grid needs the pack only ONCE: the ingest rank packs, the
+ * packed buffer is what travels (the same bytes as the raw window), and every rank sweeps it as it arrives --
+ * no window cut on the root, no pack pass on the others.  No reference counterpart (one thread, one array:
+ * src/dsp/mimo.cpp:12, :100-103 is the snapshot this replaces).
+ * Available for AWPU_MATH_F32_FAST + AWPU_INTERP_LERP, usable % 4 == 0, no mic gains, single-device handles; every
+ * rank must have been created with the same n_streams, hist, active mics and cfg.window_begin/window_end.
+ * awpu_hip_process_packed(pack_frames(x)) gives the bits awpu_hip_process_device(x) gives wherever that call sweeps
+ * frame pairs itself (batches that fill the chip: >= 256 workgroups); for smaller batches, where process_device
+ * prefers a single-frame shape, the two agree to fp32 rounding (2e-6).
+ *   _packed_bytes: *bytes = size of the packed buffer for `batch` frames, AWPU_ERR_STATE when the handle's sweep does
+ *                  not take packed frames (the caller then exchanges raw windows and calls awpu_hip_process_device)
+ *   _pack_frames:  d_frames [batch][n_streams][hist] -> d_packed, enqueued on `stream` (NULL = the handle's)
+ *   _process_packed: d_packed -> d_power [batch][pixel_count], enqueued on `stream`; asynchronous */
+int awpu_hip_packed_bytes(awpu_hip_t *h, int32_t batch, uint64_t *bytes);
+int awpu_hip_pack_frames(awpu_hip_t *h, const float *d_frames, int32_t batch, float *d_packed, void *stream);
+int awpu_hip_process_packed(awpu_hip_t *h, const float *d_packed, int32_t batch, float *d_power, void *stream);
 
 /* blocks until everything enqueued through this handle has finished */
 int awpu_hip_synchronize(awpu_hip_t *h);

@@ -160,6 +160,9 @@ def test_null_arguments_are_refused_not_dereferenced(pkg):
     call("awpu_hip_process_async", None, fp, 1, fp)
     call("awpu_hip_wait", None)
     call("awpu_hip_synchronize", None)
+    call("awpu_hip_packed_bytes", None, 2, None)
+    call("awpu_hip_pack_frames", None, None, 2, None, None)
+    call("awpu_hip_process_packed", None, None, 2, None, None)
     call("awpu_hip_ingest_block", None, None, 1032)
     call("awpu_hip_process_ring", None, fp)
     call("awpu_hip_ring_snapshot", None, fp)

@@ -1055,6 +1055,101 @@ def test_live_block_replayed_as_a_graph(pkg, oracle):
             assert np.array_equal(big, oracle.resize_linear_u8(image, 40, 56)), b
 
 
+def test_packed_frames_split_the_sweep_at_its_pack_pass(pkg, oracle):
+    """awpu_hip_pack_frames + awpu_hip_process_packed = awpu_hip_process_device, bit for bit: the multi-GPU exchange
+    format (the ingest rank packs once, every rank sweeps the packed pairs as they arrive).  Quad shape (row length
+    given), pair shape (not given), an odd batch; a handle created with a wider staging window than its table needs
+    (cfg.window_begin/window_end: the union over all ranks' slabs) returns the same bits as one without."""
+    import torch
+
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c2"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 11, seed=44)
+    d_X = torch.from_numpy(frames).cuda()
+    want0 = None
+    for hint, window in ((spec.res, None), (0, None), (spec.res, (int(off.min()) - 20, int(off.max()) + 257 + 9))):
+        for batch in (10, 11, 2):  # 5 and 6 frame pairs x 64 tiles fill the chip; a batch of 2 does not
+            with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=12, grid_columns=hint, window=window) as eng:
+                eng.set_delay_table(off, frac)
+                eng.set_active_mics(None)
+                n = eng.packed_bytes(batch)
+                assert n % 8 == 0 and n >= ((batch + 1) // 2) * spec.n_mics * 257 * 8
+                d_pk = torch.zeros(n // 4, dtype=torch.float32, device="cuda")
+                d_a = torch.zeros((batch, spec.n_pixels), dtype=torch.float32, device="cuda")
+                d_b = torch.zeros_like(d_a)
+                torch.cuda.synchronize()
+                st = torch.cuda.Stream()
+                eng.pack_frames(d_X.data_ptr(), batch, d_pk.data_ptr(), st.cuda_stream)
+                eng.process_packed(d_pk.data_ptr(), batch, d_a.data_ptr(), st.cuda_stream)
+                eng.process_device(d_X.data_ptr(), batch, d_b.data_ptr(), st.cuda_stream)
+                st.synchronize()
+                eng.synchronize()
+            a, b = d_a.cpu().numpy(), d_b.cpu().numpy()
+            if batch >= 10:  # process_device sweeps frame pairs itself: the same kernel on the same packed samples
+                assert a.max() > 0 and np.array_equal(a, b), (hint, window, batch)
+            else:            # process_device prefers a single-frame shape for so small a launch: equal to rounding
+                assert util.power_rel_err(a, b) < 2e-6, (hint, window, batch)
+            if batch == 10 and hint:
+                if want0 is None:
+                    want0 = a
+                    check_full_grid(oracle, a[0], frames[0], off, frac, "c2 through pack_frames + process_packed")
+                else:
+                    assert np.array_equal(a, want0), "a wider staging window changed the bits"
+    # a mic list that is not a multiple of four has no common packed layout: the caller is told, nothing is computed
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=4, grid_columns=spec.res) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(np.arange(253, dtype=np.int32))
+        with pytest.raises(pkg.AwpuError) as ei:
+            eng.packed_bytes(4)
+        assert ei.value.status == pkg.binding.ERR_STATE
+    with pytest.raises(pkg.AwpuError):
+        pkg.Engine(n_pixels=16, window=(900, 1000))  # narrower than one delay() read
+
+
+def test_interleaved_row_groups_tile_the_headline_grid(pkg, oracle):
+    """The N-GPU decomposition bench.py runs: row groups of four dealt round-robin over 8 ranks (every rank gets edge and
+    centre rows alike), every rank staging the union window, rank 0 packing once and every rank sweeping the SAME
+    packed buffer.  Here the 8 ranks run one after the other on one GPU: their tiles, put back where row_ranges says,
+    equal the single-handle heatmap on every pixel to rounding, and the oracle's (unfloored)."""
+    import torch
+
+    sharding = importlib.import_module("beamforming-lk_amd.sharding")
+    S = pkg.synthetic
+    spec = S.WORKLOADS["headline"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 4, seed=61)
+    whole, _ = run_engine(pkg, frames, off, frac, grid_columns=spec.res)
+    window = (int(off.min()), int(off.max()) + 257)
+    shards = sharding.all_shards(spec.res, spec.res, 8, interleaved=True)
+    assert all(s.row_count == 16 and len(s.row_ranges) == 4 for s in shards) and shards[3].row_ranges[1] == (44, 4)
+    d_X = torch.from_numpy(frames).cuda()
+    d_pk, tiles = None, []
+    for s in shards:
+        o, f = S.delay_table_for(spec, xyz, s.row_ranges)
+        rows = np.array(s.rows())
+        assert np.array_equal(o, off.reshape(spec.res, spec.res, -1)[rows].reshape(-1, spec.n_mics))
+        with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=4, pixel_begin=s.pixel_begin,
+                        pixel_count=s.pixel_count, grid_columns=spec.res, window=window) as eng:
+            eng.set_delay_table(o, f)
+            eng.set_active_mics(None)
+            if d_pk is None:  # "rank 0" packs; the others never see the raw frames
+                d_pk = torch.zeros(eng.packed_bytes(4) // 4, dtype=torch.float32, device="cuda")
+                eng.pack_frames(d_X.data_ptr(), 4, d_pk.data_ptr())
+                eng.synchronize()
+            d_P = torch.zeros((4, s.pixel_count), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            eng.process_packed(d_pk.data_ptr(), 4, d_P.data_ptr())
+            eng.synchronize()
+        tiles.append(d_P.cpu())
+    full = sharding.assemble_tiles(tiles, shards).numpy()
+    assert full.shape == whole.shape and util.power_rel_err(full, whole) < 5e-6
+    check_full_grid(oracle, full[0], frames[0], off, frac, "headline assembled from 8 interleaved ranks")
+    check_full_grid(oracle, full[3], frames[3], off, frac, "headline assembled from 8 interleaved ranks, frame 3")
+
+
 def test_live_graphs_are_retired_when_their_buffers_move(pkg, oracle):
     """The captured live-block graphs bake in device pointers of the handle (power, display, upscale taps, FIR tables).
     Calls that free or reallocate one of them -- a batched awpu_hip_process on a max_batch > 1 handle (d_power grows), a

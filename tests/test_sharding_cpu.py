@@ -157,6 +157,31 @@ def test_broadcaster_is_a_noop_without_a_group(pkg):
     assert sh.global_peak(t) is t
 
 
+def test_interleaved_row_groups_tile_the_grid(pkg):
+    """shard_rows_interleaved: row groups of four dealt round-robin -- every row owned once, quads intact (every range
+    is a whole group of four adjacent rows), equal shares, and with a cost that grows linearly from the centre row
+    outwards (what the sweep shows) every rank's cost is the same; assemble_tiles puts the tiles back in grid order."""
+    sh = importlib.import_module("beamforming-lk_amd.sharding")
+    for res, world in [(128, 8), (128, 4), (128, 2), (256, 8), (64, 8), (100, 8), (30, 4), (128, 1)]:
+        shards = sh.all_shards(res, res, world, interleaved=True)
+        rows = sorted(r for s in shards for r in s.rows())
+        assert rows == list(range(res)), (res, world)
+        for s in shards:
+            assert s.row_count == len(s.rows()) and s.pixel_count == s.row_count * res
+            for b, n in s.row_ranges[:-1]:
+                assert world == 1 or (b % 4 == 0 and n == 4)
+        if res % (4 * world) == 0 and world > 1:
+            cost = [sum(abs(r - (res - 1) / 2) for r in s.rows()) for s in shards]
+            assert max(cost) - min(cost) < 1e-9, (res, world, cost)
+            contiguous = [sum(abs(r - (res - 1) / 2) for r in s.rows()) for s in sh.all_shards(res, res, world)]
+            assert world == 2 or max(contiguous) > 1.5 * min(contiguous)
+    assert sh.shard_rows_interleaved(8, 8, 4, 1).row_ranges == ((2, 2),)  # fewer groups than ranks: contiguous slabs
+    shards = sh.all_shards(16, 3, 2, interleaved=True)
+    image = torch.arange(2 * 16 * 3, dtype=torch.float32).reshape(2, 48)
+    tiles = [torch.cat([image[:, r * 3:(r + 1) * 3] for r in s.rows()], dim=1) for s in shards]
+    assert torch.equal(sh.assemble_tiles(tiles, shards), image)
+
+
 def test_local_copy_exchange_follows_the_broadcaster_protocol(pkg):
     """bench.py's projected_scaling stand-in for the collective: post(k) delivers `arrival` into buffer k % 2, wait(k)
     hands that buffer out -- the FrameBroadcaster protocol, so the N > 1 step loop runs unchanged on one device."""
