@@ -688,7 +688,7 @@ int launch_fir8_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_po
     pa.batch = batch;
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, U, U, h->d_gain,
-                                         pp.wr, batch, h->d_pack, s));
+                                         pp.wr, batch, h->d_pack, false, s));
     AWPU_HIP_TRY(awpu::launch_das_fir8_pairs(pa, h->d_fir_pair_lut, h->d_fir, s));
     return finish_launch(h, batch, s);
 }
@@ -772,7 +772,7 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     if (!prepacked)
         AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
-                                             h->usable(), nullptr, pp.wr, batch, h->d_pack, s));  // gains ride on the table weights here
+                                             h->usable(), nullptr, pp.wr, batch, h->d_pack, true, s));  // gains ride on the table weights here
     if (stationary_tiles > 0) {
         AWPU_HIP_TRY(awpu::launch_das_pairs_stationary(pa, stationary_tiles, s));
     } else {
@@ -840,7 +840,7 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     if (!prepacked)
         AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
-                                             pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, s));
+                                             pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, true, s));
     AWPU_HIP_TRY(awpu::launch_das_quads(qa, s));
     rc = finish_launch(h, batch, s);
     if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
@@ -2082,7 +2082,7 @@ int awpu_hip_pack_frames(awpu_hip_t *h, const float *d_frames, int32_t batch, fl
     // on the sweep it runs beside, slowed that sweep MORE the longer it lasted: 256 / 512 / 1024 workgroups cost the ingest
     // rank 0.90 / 0.55 / 0.35 ms per 1024-frame step against 0.23 ms for this full-speed pass.  Short and fast wins.)
     AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, h->cfg.hist, h->wstart, h->d_index, h->usable(), h->usable(),
-                                         nullptr, plan.wr, batch, d_packed, s));
+                                         nullptr, plan.wr, batch, d_packed, true, s));
     return AWPU_OK;
 }
 

@@ -614,6 +614,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_db_kernel(FastArgs a) {
 // One 16-wave workgroup per CU, two LDS images (chunk c+1 lands while chunk c is swept), 4 pixels
 // per wave; grid = (frame pairs, 64-pixel tiles).
 // ---------------------------------------------------------------------------------------
+// FILTER: the rows carry Y[t] = X[t]/2 - (X[t+1] + X[t-1])/4 instead of X[t] -- the reference's moving-average
+// stencil (mimo.cpp:131-134) applied to the SAMPLES.  The stencil and the delay-and-sum are both linear, so
+//     MA[i] = out[i]/2 - (out[i+1] + out[i-1])/4 = sum_m f Y_m[off+i] + (1-f) Y_m[off+i+1]     (i = 1..254)
+// comes straight out of the sweep: the frame-pair kernels need no stencil in their epilogue and no 257th sample
+// (MA[254] needs Y[off+255], whose X[off+256] the pack pass reads like any other sample).  Y[off] and Y[off+256]
+// -- the two that would need samples outside [off, off+256] -- are never used (MA[0] and MA[255] do not exist).
+// In fp32 the filtered samples are a third of the size of the raw ones at the carrier, and so are all rounding
+// errors downstream: against exact sums this order is closer than the reference's own.
+template <bool FILTER>
 __device__ __forceinline__ void pack_one_row(const float *frames, int n_streams, int hist, int wstart, const int32_t *index,
                                              int usable, const float *gain, int wp, int batch, float *packed, int pair, int s,
                                              int rows_out) {
@@ -627,12 +636,26 @@ __device__ __forceinline__ void pack_one_row(const float *frames, int n_streams,
     const float *xb = frames + ((size_t) fb * n_streams + index[s]) * hist + wstart;
     const float gm = gain ? gain[s] : 1.0f;  // optional per-mic gain (awpu_hip_set_mic_gains); x * 1.0f is x
     const int valid = min(wp, hist - wstart);
-    for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = t < valid ? f2{xa[t] * gm, xb[t] * gm} : f2{0.0f, 0.0f};
+    for (int t = threadIdx.x; t < wp; t += blockDim.x) {
+        f2 v = f2{0.0f, 0.0f};
+        if (t < valid) {
+            v = f2{xa[t] * gm, xb[t] * gm};
+            if constexpr (FILTER) {
+                // neighbours outside the row count as 0 (the values they produce are never used, see above)
+                const bool lo = wstart + t > 0, hi = wstart + t + 1 < hist;
+                const f2 nb = f2{(lo ? xa[t - 1] * gm : 0.0f) + (hi ? xa[t + 1] * gm : 0.0f),
+                                 (lo ? xb[t - 1] * gm : 0.0f) + (hi ? xb[t + 1] * gm : 0.0f)};
+                v = __builtin_elementwise_fma(f2{-0.25f, -0.25f}, nb, 0.5f * v);
+            }
+        }
+        dst[t] = v;
+    }
 }
 
+template <bool FILTER>
 __global__ void pack_pairs_kernel(const float *frames, int n_streams, int hist, int wstart, const int32_t *index,
                                   int usable, const float *gain, int wp, int batch, float *packed) {
-    pack_one_row(frames, n_streams, hist, wstart, index, usable, gain, wp, batch, packed, blockIdx.y, blockIdx.x, gridDim.x);
+    pack_one_row<FILTER>(frames, n_streams, hist, wstart, index, usable, gain, wp, batch, packed, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
 // out[] of one pixel (both frames at once) from the skewed accumulators, then mimo.cpp:131-137.
@@ -668,6 +691,25 @@ __device__ __forceinline__ f2 finish_pixel_pair(const f2 (&P)[8], f2 tail, int l
         if (i >= 1 && i <= kSamples - 2) sum += ma * ma;
         dn = dn_after;
         up_before = up;
+    }
+    sum.x = wave_sum(sum.x);
+    sum.y = wave_sum(sum.y);
+    return sum;
+}
+
+// The same for sweeps of PRE-FILTERED samples (pack_one_row<true>): the un-skewed sums ARE the moving average,
+// MA[i] = A[i] + Q[i+1], i = 1..254 -- no stencil, no 257th sample.  P as above.
+__device__ __forceinline__ f2 finish_pixel_pair_filtered(const f2 (&P)[8], int lane) {
+    f2 sum = f2{0.0f, 0.0f};
+    f2 rq = wave_rotate<kDppWaveRol1>(P[4]);  // Q_k one lane down; lane 63 holds Q_k[0]
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        // lane 63 of register k takes sample 64(k+1)'s term = Q_{k+1}[0] (k = 3: MA[255] is not summed)
+        const f2 rq_next = k < 3 ? wave_rotate<kDppWaveRol1>(P[k < 3 ? 5 + k : 7]) : rq;
+        const f2 ma = P[k] + (lane == 63 ? rq_next : rq);  // MA[l + 64k]
+        const int i = lane + 64 * k;
+        if (i >= 1 && i <= kSamples - 2) sum = __builtin_elementwise_fma(ma, ma, sum);
+        rq = rq_next;
     }
     sum.x = wave_sum(sum.x);
     sum.y = wave_sum(sum.y);
@@ -728,24 +770,10 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
     const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
 
     f2 acc[PPW][8];
-    f2 tail = f2{0.0f, 0.0f};
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++)
 #pragma unroll
         for (int k = 0; k < 8; k++) acc[pp][k] = f2{0.0f, 0.0f};
-    // tail pass: every lane has a pixel (LPP lanes each); a round covers 32 mics in NU entries per lane
-    constexpr int LPP = 64 / PPW >= 16 ? 16 : 8, NU = 32 / LPP;
-    const int tail_pp = lane / LPP;
-    int tail_pix = pix[0];
-    bool tail_lane = false;
-#pragma unroll
-    for (int q = 0; q < PPW; q++)
-        if (tail_pp == q) {
-            tail_pix = pix[q];
-            tail_lane = live[q];
-        }
-    if (!tail_lane) tail_pix = pix[0];
-    const FastEntry *tail_row = a.lut + (size_t) tail_pix * a.usable_pad;
 
     // one chunk = rows m0 .. m0+mc of this pair, contiguous in HBM and in the LDS image
     auto dma_chunk = [&](int m0, int mc, int buf) {
@@ -785,21 +813,6 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         const int mc4 = (mc + 3) & ~3;
         const int buf = c & 1;
         long long t = DIAG ? __builtin_readcyclecounter() : 0;
-        // table entries of the tail pass below: requested now, consumed after the sweep
-        struct AddrG {
-            unsigned addr;
-            float g;
-        };
-        AddrG te[NU];
-#pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int j = LPP * u + ((lane - m0) & (LPP - 1));
-            te[u] = *(const AddrG *) ((const char *) (tail_row + m0 + min(j, mc4 - 1)) + 4);  // fields addr, g
-            if (!tail_lane || j >= mc4) te[u].g = 0.0f;
-        }
-        // The refill of the other image goes out AFTER the requests above: hipcc guards the reuse of their
-        // destination registers with s_waitcnt vmcnt(0), which in the other order waited for the DMA just
-        // issued -- every wave idle at the head of every chunk until its pieces had landed.
         if (c + 1 < n_chunks && !AWPU_DBG(a, 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
         stamp(0, t);
         const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
@@ -819,24 +832,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
             }
         }
         stamp(1, t);
-        // the 257th sample of every window, both frames: lane 8*pp + k takes the mics s = k (mod 8)
-        const char *img = (const char *) (lds + buf * (BUF / 4));
-        if (!AWPU_DBG(a, 4))
-#pragma unroll
-        for (int u = 0; u < NU; u++) {  // mics 0..31 of the chunk (prefetched above)
-            const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
-            tail = __builtin_elementwise_fma(f2{te[u].g, te[u].g}, x, tail);
-        }
-        for (int j0 = 32; j0 < mc4; j0 += 32) {  // chunks of more than 32 mics (narrow windows)
-#pragma unroll
-            for (int u = 0; u < NU; u++) {
-                const int j = j0 + LPP * u + ((lane - m0) & (LPP - 1));
-                AddrG e = *(const AddrG *) ((const char *) (tail_row + m0 + min(j, mc4 - 1)) + 4);
-                if (!tail_lane || j >= mc4) e.g = 0.0f;
-                const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
-                tail = __builtin_elementwise_fma(f2{e.g, e.g}, x, tail);
-            }
-        }
+        // (no 257th-sample pass: the rows carry pre-filtered samples, pack_one_row<true>)
         if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         stamp(2, t);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -853,16 +849,11 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         o[3] = (unsigned long long) n_chunks * PPW;
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
     }
-    tail.x = LPP == 16 ? sum16(tail.x) : sum8(tail.x);
-    tail.y = LPP == 16 ? sum16(tail.y) : sum8(tail.y);
     const float norm = (float) (kSamples * a.usable);
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++) {
         const int p = pix[pp];
-        f2 tl;
-        tl.x = lane_value(tail.x, pp * LPP);
-        tl.y = lane_value(tail.y, pp * LPP);
-        const f2 sum = finish_pixel_pair(acc[pp], tl, lane);
+        const f2 sum = finish_pixel_pair_filtered(acc[pp], lane);
         if (lane == 0 && live[pp]) {
             a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
             if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
@@ -934,29 +925,6 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
             }
             pair_rows = 1;
         }
-        const int tail_pp = lane >> 4;  // 16 lanes per pixel: one round of the tail pass covers 64 mics
-        int tail_pix = pix[0];
-        bool tail_lane = false;
-#pragma unroll
-        for (int q = 0; q < PPW; q++)
-            if (tail_pp == q) {
-                tail_pix = pix[q];
-                tail_lane = live[q];
-            }
-        if (!tail_lane) tail_pix = pix[0];
-        const FastEntry *tail_row = a.lut + (size_t) tail_pix * a.usable_pad;
-        struct AddrG {
-            unsigned addr;
-            float g;
-        };
-        AddrG te[4];  // the tail pass's entries of mics 0..63: requested now, consumed after the sweep
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = 16 * u + (lane & 15);
-            te[u] = *(const AddrG *) ((const char *) (tail_row + min(j, a.usable_pad - 1)) + 4);  // fields addr, g
-            if (!tail_lane || j >= a.usable_pad) te[u].g = 0.0f;
-        }
-
         f2 acc[PPW][8];
 #pragma unroll
         for (int pp = 0; pp < PPW; pp++)
@@ -969,32 +937,9 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
             if constexpr (SHARE) sweep_duo_shared(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
             else sweep_duo_pairs(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
         }
-        // the 257th sample of every window, both frames: lane 16*pp + k takes the mics s = k (mod 16)
-        f2 tail = f2{0.0f, 0.0f};
-        const char *img = (const char *) lds;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
-            tail = __builtin_elementwise_fma(f2{te[u].g, te[u].g}, x, tail);
-        }
-        for (int j0 = 64; j0 < a.usable_pad; j0 += 64) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int j = j0 + 16 * u + (lane & 15);
-                AddrG e = *(const AddrG *) ((const char *) (tail_row + min(j, a.usable_pad - 1)) + 4);
-                if (!tail_lane || j >= a.usable_pad) e.g = 0.0f;
-                const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
-                tail = __builtin_elementwise_fma(f2{e.g, e.g}, x, tail);
-            }
-        }
-        tail.x = sum16(tail.x);
-        tail.y = sum16(tail.y);
 #pragma unroll
         for (int pp = 0; pp < PPW; pp++) {
-            f2 tl;
-            tl.x = lane_value(tail.x, pp * 16);
-            tl.y = lane_value(tail.y, pp * 16);
-            const f2 sum = finish_pixel_pair(acc[pp], tl, lane);
+            const f2 sum = finish_pixel_pair_filtered(acc[pp], lane);
             if (lane == 0 && live[pp]) {
                 a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
                 if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + pix[pp]] = sum.y / norm;
@@ -1352,30 +1297,17 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         }
         const QuadEntry *quad_lut = a.lut + (size_t) quad * groups_total * 16;
         const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
-        const int tail_pp = lane >> 4;  // lanes 16 pp + k: pixel pp of the quad, mics k (mod 16) of the chunk
-        bool tail_lane = false;
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (tail_pp == q) tail_lane = live[q];
         // ---- the item after it
         const int item_next = item + wgs_per_xcd;
         int pair_next = 0, tile_next = 0;
         if (item_next < run_end) decode(item_next, pair_next, tile_next);
 
         f8 A0 = {0, 0, 0, 0, 0, 0, 0, 0}, A1 = A0, A2 = A0, A3 = A0, T = A0, V0 = A0, V2 = A0, V3 = A0;
-        f2 tail = f2{0.0f, 0.0f};
         for (int c = 0; c < n_chunks; c++, step++) {
             const int m0 = c * a.chunk;
             const int mc4 = chunk_mics(m0);
             const int buf = step & 1;
             long long t = DIAG ? __builtin_readcyclecounter() : 0;
-            // table entries of the tail pass below (the 257th sample): requested now, consumed after the sweep
-            QuadEntry te[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int m = m0 + min(16 * u + ((lane - m0) & 15), mc4 - 1);
-                te[u] = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
-            }
             // The stamped and the tuning builds issue the refill themselves (the production build lets the sweep block
             // do it piece by piece, below): all pieces at the head of the chunk, from every wave at once (the order
             // of round 1); or, with a.debug & 512, the waves of a SIMD taking turns, rank r sweeping r quarters of
@@ -1431,28 +1363,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                 if (ng - g_head > 0) sweep(g_head, ng - g_head);
             }
             stamp(1, t);
-            // the 257th sample of every window, both frames: X[off+256] with weight 1 - f goes to out[255]
-            const char *img = (const char *) (lds + buf * (BUF / 4));
-            if (!AWPU_DBG(a, 4)) {
-#pragma unroll
-                for (int u = 0; u < 2; u++) {  // mics 0..31 of the chunk (prefetched above)
-                    const bool on = tail_lane && 16 * u + ((lane - m0) & 15) < mc4;
-                    const float g = on ? 0.5f - te[u].f : 0.0f;  // 1 - f
-                    const f2 x = *(const f2 *) (img + te[u].addr + 256 * 8);
-                    tail = __builtin_elementwise_fma(f2{g, g}, x, tail);
-                }
-                for (int j0 = 32; j0 < mc4; j0 += 32) {  // chunks of more than 32 mics (narrow windows)
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int jj = j0 + 16 * u + ((lane - m0) & 15);
-                        const int m = m0 + min(jj, mc4 - 1);
-                        const QuadEntry e = quad_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
-                        const float g = tail_lane && jj < mc4 ? 0.5f - e.f : 0.0f;
-                        const f2 x = *(const f2 *) (img + e.addr + 256 * 8);
-                        tail = __builtin_elementwise_fma(f2{g, g}, x, tail);
-                    }
-                }
-            }
+            // (no 257th-sample pass: the rows carry pre-filtered samples, pack_one_row<true>)
             if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             stamp(2, t);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1462,20 +1373,15 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         }
 
         // ---- this item's powers (the next item's first chunk is in its image already)
-        tail.x = sum16(tail.x);
-        tail.y = sum16(tail.y);
         auto finish = [&](const f8 &A, const f8 &S, int pp) {
             f2 P[8];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const f2 Ak = f2{A[2 * k], A[2 * k + 1]}, Hk = 0.5f * f2{S[2 * k], S[2 * k + 1]};
-                P[k] = Hk + Ak;      // sum f X      (A was accumulated with f - 1/2: see QuadEntry)
-                P[4 + k] = Hk - Ak;  // sum (1 - f) X
+                const f2 Ak = f2{A[2 * k], A[2 * k + 1]}, Sk = f2{S[2 * k], S[2 * k + 1]};
+                P[k] = __builtin_elementwise_fma(f2{0.5f, 0.5f}, Sk, Ak);       // sum f Y      (A was accumulated with f - 1/2: see QuadEntry)
+                P[4 + k] = __builtin_elementwise_fma(f2{0.5f, 0.5f}, Sk, -Ak);  // sum (1 - f) Y
             }
-            f2 tl;
-            tl.x = lane_value(tail.x, pp * 16);
-            tl.y = lane_value(tail.y, pp * 16);
-            const f2 sum = finish_pixel_pair(P, tl, lane);
+            const f2 sum = finish_pixel_pair_filtered(P, lane);
             if (lane == 0 && live[pp]) {
                 a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
                 if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + pix[pp]] = sum.y / norm;
@@ -1767,10 +1673,15 @@ bool pair_plan(int window, int usable, FastPlan *plan) {
 
 hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index,
                              int usable, int rows_out, const float *d_gain, int wp, int batch, float *d_packed,
-                             hipStream_t stream) {
+                             bool filter, hipStream_t stream) {
     dim3 grid(rows_out, (batch + 1) / 2);
-    hipLaunchKernelGGL(pack_pairs_kernel, grid, dim3(128), 0, stream, d_frames, n_streams, hist, wstart, d_index,
-                       usable, d_gain, wp, batch, d_packed);
+    if (filter) {
+        hipLaunchKernelGGL(pack_pairs_kernel<true>, grid, dim3(128), 0, stream, d_frames, n_streams, hist, wstart, d_index,
+                           usable, d_gain, wp, batch, d_packed);
+    } else {
+        hipLaunchKernelGGL(pack_pairs_kernel<false>, grid, dim3(128), 0, stream, d_frames, n_streams, hist, wstart, d_index,
+                           usable, d_gain, wp, batch, d_packed);
+    }
     return hipGetLastError();
 }
 

@@ -95,10 +95,13 @@ inline int pair_tiles(int pixel_count, int cols) {
     return cols > 0 ? ((pixel_count / cols + 1) / 2) * ((cols + 31) / 32) : (pixel_count + 63) / 64;
 }
 bool pair_plan(int window, int usable, FastPlan *plan);
-// rows_out >= usable rows per pair are written (the extra ones zero); d_gain [usable] (or null) scales row s
+// rows_out >= usable rows per pair are written (the extra ones zero); d_gain [usable] (or null) scales row s;
+// filter: the rows carry the moving-average stencil of the samples, Y[t] = X[t]/2 - (X[t+1] + X[t-1])/4 -- what
+// das_pair_kernel, das_pair_stationary_kernel and das_quad_kernel sweep (their epilogue then has no stencil and
+// there is no 257th sample); the FIR8 pair kernel takes raw samples
 hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index,
                              int usable, int rows_out, const float *d_gain, int wp, int batch, float *d_packed,
-                             hipStream_t stream);
+                             bool filter, hipStream_t stream);
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream);
 // FIR8 on the frame-pair layout (batches): d_entries [pixel_count][usable_pad] x {u32 LDS address, i32 coefficient row},
 // addresses as in the pair shape's plan (pair_plan on a window that reaches off + 262); d_coeffs [101][8]
