@@ -1389,8 +1389,9 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         };
         finish(A0, T + V0, 0);
         finish(A1, T, 1);
-        finish(A2, T + V2, 2);
-        finish(A3, T + V3, 3);
+        const f8 S2 = T + V2;
+        finish(A2, S2, 2);
+        finish(A3, (kQuadChain ? S2 : T) + V3, 3);  // (the blocks keep V3 = S3 - S2: tools/gen_trip_asm.py, pixels_23_chain)
         if (item_next >= run_end) break;
         item = item_next;
         pair = pair_next;

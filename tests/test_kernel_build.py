@@ -33,7 +33,8 @@ def test_generated_blocks_are_current():
 
     spec = importlib.util.spec_from_file_location("gen_trip_asm", REPO / "tools" / "gen_trip_asm.py")
     before = (CSRC / "das_fast_trip.inc").read_text()
-    env_backup = {k: os.environ.pop(k) for k in ("QUAD_VARIANTS", "TRIP_PRIO", "TRIP_DEPTH", "PAIR_DEPTH") if k in os.environ}
+    env_backup = {k: os.environ.pop(k) for k in ("QUAD_VARIANTS", "TRIP_PRIO", "TRIP_DEPTH", "PAIR_DEPTH", "QUAD_CHAIN", "QUAD_YMAP", "QUAD_XMAP")
+                  if k in os.environ}
     try:
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)

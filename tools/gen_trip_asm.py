@@ -44,17 +44,17 @@ S_PRIO = 27  # PRIO 3: rotating priority counter (starts at the wave's age rank 
 S_RANK = 26  # the wave's age rank on its SIMD (0 = oldest), constant
 
 
-def select_prio(sel, step):
+def select_prio(sel, step, pmap=(0, 1, 2, 3)):
     """s_setprio takes an immediate, so the priority is chosen by a 4-way branch on s{sel} & 3 after
-    adding `step` to it."""
+    adding `step` to it; pmap[k] = the priority a wave whose s{sel} is k takes."""
     L = []
     if step:
         L += [f"s_add_u32 s{sel}, s{sel}, {step}", f"s_and_b32 s{sel}, s{sel}, 3"]
     for k in range(3):
         L += [f"s_cmp_eq_u32 s{sel}, {k}", f"s_cbranch_scc1 .Lprio{k}_%=_{COUNTER[0]}"]
-    L += ["s_setprio 3", f"s_branch .Lprio_done_%=_{COUNTER[0]}"]
+    L += [f"s_setprio {pmap[3]}", f"s_branch .Lprio_done_%=_{COUNTER[0]}"]
     for k in range(3):
-        L += [f".Lprio{k}_%=_{COUNTER[0]}:", f"s_setprio {k}"]
+        L += [f".Lprio{k}_%=_{COUNTER[0]}:", f"s_setprio {pmap[k]}"]
         if k < 2:
             L += [f"s_branch .Lprio_done_%=_{COUNTER[0]}"]
     L += [f".Lprio_done_%=_{COUNTER[0]}:"]
@@ -439,7 +439,12 @@ QUAD1_ACC = (16, 48)
 QUAD1_TMP = 80
 
 
-def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, dma=False, early_x=False):
+QUAD_YMAP = tuple(int(x) for x in os.environ.get("QUAD_YMAP", "0,1,2,3").split(","))  # frame-pair quad blocks: priority by age rank in the youngest-first trips
+QUAD_XMAP = tuple(int(x) for x in os.environ.get("QUAD_XMAP", "0,1,2,3").split(","))  # ... and by rotating role in the other trips
+CHAIN = int(os.environ.get("QUAD_CHAIN", "1"))  # frame-pair quad blocks: V3 = S3 - S2 (a step in the column costs one difference, wherever it lies)
+
+
+def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, dma=False, early_x=False, chain=False):
     """dma=True: the block also issues the refill of the other LDS image (the next chunk: `dbytes` bytes from `dsrc`,
     16 KiB pieces of 64 lanes x 16 bytes per wave, this wave's first piece landing at LDS address `ddst`), one
     piece at the head of each trip instead of all of them before the sweep: the 16 waves of the workgroup then do not
@@ -542,6 +547,37 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
             skip23[0] = None
         return L
 
+    def pixels_23_chain(base, i, rslot):
+        """Pixels 3 and 2 of mic (base, i) with the shared sums kept as a CHAIN of differences down the column:
+        V2 = S2 - S1 (S1 = T, the reference's), V3 = S3 - S2.  The integer delay is monotone down a column, so the
+        quad's addresses look like a-a-a-a, a-a-a-b, a-a-b-b (or, rarely, a-a-b-c): a step costs one difference
+        x_b - x_a and one add wherever it lies -- the a-a-b-b pattern 4 instructions per register for the two pixels
+        (two FMAs, the difference, one add) where V3 = S3 - S1 needed 5.  The slot X23 holds pixel 3's samples whenever
+        its address differs from the reference's (requested a mic ahead by maybe_read_x)."""
+        X3 = XS[xz[0]][3]
+        u = uid()
+        a1, a2, a3 = a_of(base, REF, i), a_of(base, 2, i), a_of(base, 3, i)
+        f2s = f"s[{f_of(base, 2, i)}:{f_of(base, 2, i) + 1}]"
+        f3s = f"s[{f_of(base, 3, i)}:{f_of(base, 3, i) + 1}]"
+        fma = lambda p, fs, src: [f"v_pk_fma_f32 {pair(A[p], k)}, {fs}, {pair(src, k)}, {pair(A[p], k)} op_sel_hi:[0,1,1]" for k in range(nk)]
+        sub_ref = [f"v_pk_add_f32 {pair(X3, k)}, {pair(X3, k)}, {pair(rslot, k)} neg_lo:[0,1] neg_hi:[0,1]" for k in range(nk)]
+        add_v = lambda p, src: [f"v_pk_add_f32 {pair(V[p], k)}, {pair(V[p], k)}, {pair(src, k)}" for k in range(nk)]
+        sub_v = lambda p, src: [f"v_pk_add_f32 {pair(V[p], k)}, {pair(V[p], k)}, {pair(src, k)} neg_lo:[0,1] neg_hi:[0,1]" for k in range(nk)]
+        spot = reads(X3, a2) + ["s_waitcnt lgkmcnt(0)"]  # pixel 2's own samples, read on the spot (rare)
+        cold.extend(
+            [f".Lq3diff{u}:"] + fma(3, f3s, X3) +
+            [f"s_cmp_eq_u32 s{a2}, s{a3}", f"s_cbranch_scc1 .Lqtog{u}", f"s_cmp_lg_u32 s{a2}, s{a1}", f"s_cbranch_scc1 .Lqtwo{u}"] +
+            # a-a-a-b: the step lies between pixels 2 and 3
+            fma(2, f2s, rslot) + sub_ref + add_v(3, X3) + [f"s_branch .Lq23done{u}"] +
+            # a-a-b-b: between the reference and pixel 2; pixel 3 follows pixel 2 (V3 += 0)
+            [f".Lqtog{u}:"] + fma(2, f2s, X3) + sub_ref + add_v(2, X3) + [f"s_branch .Lq23done{u}"] +
+            # a-a-b-c: two steps
+            [f".Lqtwo{u}:"] + add_v(3, X3) + spot + fma(2, f2s, X3) + sub_v(3, X3) + sub_ref + add_v(2, X3) + [f"s_branch .Lq23done{u}"] +
+            # a-a-b-a (not monotone: rare): pixel 2 alone leaves and pixel 3 comes back
+            [f".Lq2odd{u}:"] + spot + fma(2, f2s, X3) + sub_ref + add_v(2, X3) + sub_v(3, X3) + [f"s_branch .Lq23done{u}"])
+        return ([f"s_cmp_lg_u32 s{a3}, s{a1}", f"s_cbranch_scc1 .Lq3diff{u}"] + fma(3, f3s, rslot) +
+                [f"s_cmp_lg_u32 s{a2}, s{a1}", f"s_cbranch_scc1 .Lq2odd{u}"] + fma(2, f2s, rslot) + [f".Lq23done{u}:"])
+
     def ref_ops(base, i, rslot):
         fs = f"s[{f_of(base, REF, i)}:{f_of(base, REF, i) + 1}]"
         L = []
@@ -580,9 +616,9 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
         cur, nxt = E[par], E[1 - par]
         L = dma_piece() if dma else []
         if prio == 3 or (prio == 5 and par == 0):
-            L += select_prio(S_PRIO, 1)   # the top priority moves on to the next wave of the SIMD
+            L += select_prio(S_PRIO, 1, QUAD_XMAP if nk == 4 else (0, 1, 2, 3))   # the top priority moves on to the next wave of the SIMD
         elif prio == 5:
-            L += select_prio(S_RANK, 0)   # youngest first
+            L += select_prio(S_RANK, 0, QUAD_YMAP if nk == 4 else (0, 1, 2, 3))   # youngest first
         L += load_set(nxt, S_PF_) + [f"s_add_u32 s{S_PF_}, s{S_PF_}, 128"]
         for st in range(4):
             rslot = R[st & 1]
@@ -599,6 +635,9 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
                 L += maybe_read_x(3, nbase, ni) + maybe_read_x(0, nbase, ni)
                 xz[0] = st & 1
                 L += pixel_ops(3, cur, st, rslot) + pixel_ops(2, cur, st, rslot) + pixel_ops(0, cur, st, rslot)
+            elif chain:
+                L += pixels_23_chain(cur, st, rslot) + maybe_read_x(3, nbase, ni)
+                L += pixel_ops(0, cur, st, rslot) + maybe_read_x(0, nbase, ni)
             else:
                 L += pixel_ops(3, cur, st, rslot) + pixel_ops(2, cur, st, rslot) + maybe_read_x(3, nbase, ni)
                 L += pixel_ops(0, cur, st, rslot) + maybe_read_x(0, nbase, ni)
@@ -975,9 +1014,10 @@ def main():
     out.append(block("sweep_duo_pairs_stamped", 2, 128 - (8 * (pd + 1) + 1) - 3, stamp=True, pair_depth=pd))
     out.append(block_shared("sweep_duo_shared", 128 - 25 - 3))
     out.append(block_shared("sweep_duo_shared_stamped", 128 - 25 - 3, stamp=True))
-    out.append(block_quad("sweep_quad_sum"))
-    out.append(block_quad("sweep_quad_sum_dma", dma=True))
-    out.append(block_quad("sweep_quad_sum_stamped", stamp=True))
+    out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
+    out.append(block_quad("sweep_quad_sum", chain=CHAIN))
+    out.append(block_quad("sweep_quad_sum_dma", dma=True, chain=CHAIN))
+    out.append(block_quad("sweep_quad_sum_stamped", stamp=True, chain=CHAIN))
     for q, base in enumerate(QUAD1_ACC):  # single-frame layout, first / second quad of a wave
         out.append(block_quad_ar(f"sweep_quad1_sum_{'ab'[q]}", nk=2, acc=base, tmp=QUAD1_TMP))
     out.append(block_quad_ar("sweep_quad1_sum_a_stamped", stamp=True, nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP))
@@ -986,7 +1026,7 @@ def main():
             out.append(block_quad(f"sweep_quad1_early_{'ab'[q]}", nk=2, acc=base, tmp=QUAD1_TMP, early_x=True))
     if os.environ.get("QUAD_VARIANTS"):  # tuning builds: the priority schemes side by side (AWPU_QUAD_VARIANT picks)
         for v in (0, 3, 4):
-            out.append(block_quad(f"sweep_quad_sum_v{v}", prio=v))
+            out.append(block_quad(f"sweep_quad_sum_v{v}", prio=v, chain=CHAIN))
     out.append(block_fir8("sweep_fir8_planes"))
     if os.environ.get("QUAD_VARIANTS"):  # tuning builds: what the block costs without its scalar loads / its LDS reads / the read-ahead
         out.append(block_fir8("sweep_fir8_planes_v1", timing="noload"))

@@ -6,7 +6,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export AWPU_NO_BUILD=1
 cp beamforming-lk_amd/libawpu_hip.so $out/keep.so
-for rep in 1 2 3; do
+for rep in $(seq 1 ${REPS:-3}); do
 for v in "$@"; do
   cp tools/ab/$v beamforming-lk_amd/libawpu_hip.so
   timeout -k 10 200 python bench.py --cpu-seconds 0 --no-extras ${BENCH_ARGS:-} > $out/${v}_$rep.json 2> $out/${v}_$rep.err
