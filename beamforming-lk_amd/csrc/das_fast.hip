@@ -230,7 +230,10 @@ constexpr int kDppWaveRol1 = 0x134;  // lane l takes lane l+1's value, lane 63 l
 constexpr int kDppWaveRor1 = 0x13C;  // lane l takes lane l-1's value, lane 0 lane 63's
 template <int CTRL>
 __device__ __forceinline__ float wave_rotate1(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    // (every lane of a whole-wave rotation receives a value, so `old` is never seen: passing the source itself
+    // spares the v_mov_b32 0 that a constant `old` costs before every rotation)
+    const int bits = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(bits, bits, CTRL, 0xf, 0xf, false));
 }
 
 // out[] of one pixel and frame from the skewed accumulators, then mimo.cpp:131-137.
