@@ -30,4 +30,9 @@ for f in glob.glob(out + "/*/*/*counter_collection.csv"):
         if "das_" not in row["Kernel_Name"]: continue
         tot[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
 for k in sorted(tot): print(f"{k:28s} {tot[k]/n[k]:18.1f}   (avg over {n[k]} launches)")
+# calibrated on the kernels' own access patterns (profiles/r03_fetch_calibration.txt): one missed 128-byte line = one TCC_MISS
+if "TCC_MISS_sum" in tot and "WRITE_SIZE" in tot:
+    miss, wr, fetch = tot["TCC_MISS_sum"] / n["TCC_MISS_sum"], tot["WRITE_SIZE"] / n["WRITE_SIZE"], tot["FETCH_SIZE"] / n["FETCH_SIZE"]
+    print(f"# traffic = 128 B x TCC_MISS_sum + 1024 B x WRITE_SIZE = {128 * miss + 1024 * wr:.0f} bytes per launch "
+          f"(2 x FETCH_SIZE + WRITE_SIZE, the correction for pure 16-byte-per-lane streams: {2048 * fetch + 1024 * wr:.0f})")
 PY
