@@ -84,7 +84,7 @@ struct awpu_hip {
     awpu::QuadEntry *d_quad1_lut = nullptr; // the same with the single-frame layout's LDS addresses (das_quad1_kernel)
     awpu::LutEntry *d_fir_pair_lut = nullptr;  // FIR8 on the frame-pair layout: {LDS address, coefficient row} per (pixel, mic)
     awpu::FastPlan fir_plan{};
-    void *d_fir_plane_lut = nullptr;           // FIR8 on the four-plane layout: 64-byte entries {plane addresses, coefficients}
+    void *d_fir_plane_lut = nullptr;           // FIR8 on the four-plane layout: one dword per (pixel, mic): address, plane, coefficient row
     awpu::FastPlan fir_plane_plan{};
     std::vector<float> fir;                    // host copy of the [101][8] coefficient table (baked into the plane entries)
     awpu::FastPlan quad_plan{}, quad1_plan{};
@@ -695,33 +695,27 @@ int launch_fir8_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_po
 
 // FIR8 on the four-plane frame-pair layout (das_fir8_plane_kernel): a lane owns four consecutive outputs
 int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
-    struct Entry {
-        uint32_t addr[4], pad[4];
-        float coeff[8];
-    };
     const awpu::FastPlan &pp = h->fir_plane_plan;
     const int U = h->usable(), P = h->cfg.pixel_count;
     const int row_entries = pp.usable_pad;  // (a multiple of 4, like the chunk: the block sweeps groups of four items)
     if (!h->d_fir_plane_lut) {
         const uint32_t plane_bytes = (uint32_t) pp.row_bytes / 4;
-        // (three spare entries: the block requests entries three items ahead -- and 16 more: its L2 prefetch touches
-        // whole KiB pieces; null entries read row 0 with zero coefficients)
-        std::vector<Entry> packed((size_t) P * row_entries + 3 + 16, Entry{{0, plane_bytes, 2 * plane_bytes, 3 * plane_bytes}, {}, {}});
+        // one dword per (pixel, mic); four spare: the block requests entries four items ahead.  Null entries (the
+        // padding of a row, the spares) read row 0 with the zero coefficient row.
+        std::vector<uint32_t> packed((size_t) P * row_entries + 4 + 64, awpu::fir8_plane_word(0, 0, awpu::kFir8ZeroRow));
         for (int p = 0; p < P; p++) {
             const int32_t *orow = &h->off[(size_t) p * h->cfg.lut_stride];
             const float *frow = &h->frac[(size_t) p * h->cfg.lut_stride];
             for (int m = 0; m < U; m++) {
                 const int id = h->index[m];
                 const int32_t k = (int32_t) (frow[id] * 100.0f + 0.5f);  // delay.cpp:32-33: the coefficient row
-                Entry &e = packed[(size_t) p * row_entries + m];
                 const uint32_t first = (uint32_t) (orow[id] - h->wstart);  // row element of X[off]
-                for (uint32_t c = 0; c < 4; c++)
-                    e.addr[c] = (uint32_t) (m % pp.chunk) * pp.row_bytes + ((first + c) & 3) * plane_bytes + ((first + c) >> 2) * 8;
-                std::memcpy(e.coeff, &h->fir[(size_t) k * 8], sizeof(e.coeff));
+                const uint32_t addr = (uint32_t) (m % pp.chunk) * pp.row_bytes + (first & 3) * plane_bytes + (first >> 2) * 8;
+                packed[(size_t) p * row_entries + m] = awpu::fir8_plane_word(addr, first & 3, (uint32_t) k);
             }
         }
-        AWPU_HIP_TRY(hipMalloc(&h->d_fir_plane_lut, packed.size() * sizeof(Entry)));
-        AWPU_HIP_TRY(hipMemcpy(h->d_fir_plane_lut, packed.data(), packed.size() * sizeof(Entry), hipMemcpyHostToDevice));
+        AWPU_HIP_TRY(hipMalloc(&h->d_fir_plane_lut, packed.size() * sizeof(uint32_t)));
+        AWPU_HIP_TRY(hipMemcpy(h->d_fir_plane_lut, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * U * pp.wr * 2;
     if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
@@ -737,7 +731,7 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_planes(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, U, h->d_gain, pp.wr,
                                           batch, h->d_pack, s));
-    AWPU_HIP_TRY(awpu::launch_das_fir8_planes(pa, h->d_fir_plane_lut, env().quad_variant, s));
+    AWPU_HIP_TRY(awpu::launch_das_fir8_planes(pa, h->d_fir_plane_lut, h->d_fir, env().quad_variant, s));
     return finish_launch(h, batch, s);
 }
 
@@ -1672,13 +1666,14 @@ int awpu_hip_set_fir_table(awpu_hip_t *h, const float *coeffs) {
     if (!h || !coeffs) return invalid("null argument");
     if (!h->parts.empty()) return for_each_part(h, [&](awpu_hip *part) { return awpu_hip_set_fir_table(part, coeffs); });
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
-    if (!h->d_fir) AWPU_HIP_TRY(hipMalloc(&h->d_fir, 101 * 8 * sizeof(float)));
+    // (on the device: the caller's 101 rows followed by zero rows up to kFir8CoeffRows -- the plane kernel's padding
+    // entries name row 101, and its entry requests run a few items past a row's end, where any 7-bit row may stand)
+    if (!h->d_fir) AWPU_HIP_TRY(hipMalloc(&h->d_fir, awpu::kFir8CoeffRows * 8 * sizeof(float)));
+    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));  // (a sweep still reading the old coefficients)
+    AWPU_HIP_TRY(hipMemset(h->d_fir, 0, awpu::kFir8CoeffRows * 8 * sizeof(float)));
     AWPU_HIP_TRY(hipMemcpy(h->d_fir, coeffs, 101 * 8 * sizeof(float), hipMemcpyHostToDevice));
     h->fir.assign(coeffs, coeffs + 101 * 8);
-    retire_live_graphs(h);
-    AWPU_HIP_TRY(hipStreamSynchronize(h->stream));  // (a sweep still reading the old plane table)
-    dev_free(h->d_fir_plane_lut);  // its entries carry the coefficients
-    h->have_fir = true;
+    h->have_fir = true;  // (the plane table names coefficient rows, it does not carry them: nothing to rebuild)
     return AWPU_OK;
 }
 

@@ -1095,17 +1095,18 @@ __global__ void pack_planes_kernel(const float *frames, int n_streams, int hist,
         dst[(t & 3) * plane + (t >> 2)] = t < valid ? f2{xa[t] * gm, xb[t] * gm} : f2{0.0f, 0.0f};
 }
 
-struct FirPlaneEntry {
-    uint32_t addr[4];  // LDS byte offset, in the chunk's image, of X[off + c] for c = 0..3 (its plane, its index)
-    uint32_t pad[4];
-    float coeff[8];    // the item's row of the coefficient table (delay.cpp:32-33)
-};
-static_assert(sizeof(FirPlaneEntry) == 64, "one s_load_dwordx16 per item");
+// One dword per (pixel, mic): bits 0..17 the LDS byte offset, in the chunk's image, of X[off] (its plane, its index),
+// bits 18..19 that plane, bits 20..26 the coefficient row (delay.cpp:32-33; row 101 = zeros, for padding entries);
+// the block derives the other three plane addresses and fetches the coefficients from `coeffs` (block_fir8).
+typedef uint32_t FirPlaneEntry;
+__host__ __device__ constexpr uint32_t fir_plane_entry(uint32_t addr, uint32_t plane, uint32_t k) {
+    return (addr & 0x3ffffu) | ((plane & 3u) << 18) | ((k & 0x7fu) << 20);
+}
 
-// lut: [pixel][usable_pad] entries (+ 3 spare), usable_pad and the chunk multiples of 4 (null entries: zero
-// coefficients on row 0).
+// lut: [pixel][usable_pad] entries (+ 4 spare), usable_pad and the chunk multiples of 4 (null entries: coefficient
+// row 101 on row 0); coeffs [128][8]: the caller's 101 rows, then zeros.
 template <int VAR>
-__global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, const FirPlaneEntry *lut) {
+__global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, const FirPlaneEntry *lut, const float *coeffs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = 16, PPW = 4, kThreads = NW * 64, BUF = kFastLdsBytes;
     constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
@@ -1150,16 +1151,18 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, con
             const int p = min(pix0 + pp, a.pixel_count - 1);  // pixels past the grid repeat the last one (not stored)
             row[pp] = (const FirPlaneEntry *) uniform_ptr(lut + (size_t) p * a.usable_pad + m0);
         }
-        // the block also touches the next chunk's entries of its pixels (whole KiB pieces from the chunk's end on)
-        const unsigned pfoff = (unsigned) a.chunk * 64u + lane * 16u;
-        const int pfn = c + 1 < n_chunks ? (min(a.chunk, a.usable - m0 - a.chunk) * 64 + 1023) / 1024 : 0;
+        // the block also touches the next chunk's entries of its pixels (256 bytes from the chunk's end on: 64 entries)
+        const unsigned pfoff = (unsigned) a.chunk * 4u + lane * 4u;
+        const int pfn = __builtin_amdgcn_readfirstlane(c + 1 < n_chunks ? 1 : 0);
+        const unsigned plane_bytes = (unsigned) a.wp * 2u;  // a staged row is wp 8-byte elements in four planes
+        const void *coef = uniform_ptr(coeffs);
 #ifdef AWPU_QUAD_VARIANTS
-        if constexpr (VAR == 1) sweep_fir8_planes_v1(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, pfoff, pfn);
-        else if constexpr (VAR == 2) sweep_fir8_planes_v2(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, pfoff, pfn);
-        else if constexpr (VAR == 3) sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, pfoff, 0);
+        if constexpr (VAR == 1) sweep_fir8_planes_v1(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn);
+        else if constexpr (VAR == 2) sweep_fir8_planes_v2(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn);
+        else if constexpr (VAR == 3) sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, 0);
         else
 #endif
-        sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, pfoff, pfn);
+        sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -1767,24 +1770,24 @@ hipError_t launch_pack_planes(const float *d_frames, int n_streams, int hist, in
 }
 
 template <int VAR>
-static hipError_t launch_fir8_plane_variant(const PairArgs &a, const void *d_entries, hipStream_t stream) {
+static hipError_t launch_fir8_plane_variant(const PairArgs &a, const void *d_entries, const float *d_coeffs, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_fir8_plane_kernel<VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
     dim3 grid((a.batch + 1) / 2, (a.pixel_count + 63) / 64);
     if (grid.y > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(das_fir8_plane_kernel<VAR>, grid, dim3(1024), lds_bytes, stream, a, (const FirPlaneEntry *) d_entries);
+    hipLaunchKernelGGL(das_fir8_plane_kernel<VAR>, grid, dim3(1024), lds_bytes, stream, a, (const FirPlaneEntry *) d_entries, d_coeffs);
     return hipGetLastError();
 }
 
-hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, int variant, hipStream_t stream) {
+hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, const float *d_coeffs, int variant, hipStream_t stream) {
 #ifdef AWPU_QUAD_VARIANTS  // tuning builds (tools/gen_trip_asm.py with QUAD_VARIANTS=1): timing-only and alternative blocks
-    if (variant == 1) return launch_fir8_plane_variant<1>(a, d_entries, stream);
-    if (variant == 2) return launch_fir8_plane_variant<2>(a, d_entries, stream);
-    if (variant == 3) return launch_fir8_plane_variant<3>(a, d_entries, stream);  // no table prefetch
+    if (variant == 1) return launch_fir8_plane_variant<1>(a, d_entries, d_coeffs, stream);
+    if (variant == 2) return launch_fir8_plane_variant<2>(a, d_entries, d_coeffs, stream);
+    if (variant == 3) return launch_fir8_plane_variant<3>(a, d_entries, d_coeffs, stream);  // no table prefetch
 #endif
     (void) variant;
-    return launch_fir8_plane_variant<0>(a, d_entries, stream);
+    return launch_fir8_plane_variant<0>(a, d_entries, d_coeffs, stream);
 }
 
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {

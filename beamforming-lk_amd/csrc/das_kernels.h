@@ -107,13 +107,18 @@ hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream);
 // addresses as in the pair shape's plan (pair_plan on a window that reaches off + 262); d_coeffs [101][8]
 hipError_t launch_das_fir8_pairs(const PairArgs &a, const void *d_entries, const float *d_coeffs, hipStream_t stream);
 // The same on the four-plane layout (a lane owns four consecutive outputs: 11 LDS reads per 32 FMAs).  Rows packed by
-// launch_pack_planes, `wr` a multiple of 4 (fir8_plane_plan); d_entries [pixel_count][usable_pad] + 3 spare
-// 64-byte entries {addr[4], pad[4], coeff[8]}: addr[c] = the LDS byte offset of X[off + c] in its chunk's image; the
-// entries that pad a row to usable_pad carry zero coefficients and row 0's addresses.
+// launch_pack_planes, `wr` a multiple of 4 (fir8_plane_plan); d_entries [pixel_count][usable_pad] + 4 spare dwords,
+// one per (pixel, mic): fir8_plane_word(LDS byte offset of X[off] in its chunk's image, its plane, coefficient row);
+// the entries that pad a row to usable_pad carry coefficient row kFir8ZeroRow and row 0's address.  d_coeffs: the
+// [kFir8CoeffRows][8] coefficient table on the device, the caller's 101 rows followed by zeros.
+constexpr int kFir8ZeroRow = 101, kFir8CoeffRows = 128;
+inline uint32_t fir8_plane_word(uint32_t addr, uint32_t plane, uint32_t k) {
+    return (addr & 0x3ffffu) | ((plane & 3u) << 18) | ((k & 0x7fu) << 20);
+}
 bool fir8_plane_plan(int window, int usable, FastPlan *plan);
 hipError_t launch_pack_planes(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index, int usable,
                               const float *d_gain, int wp, int batch, float *d_packed, hipStream_t stream);
-hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, int variant, hipStream_t stream);
+hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, const float *d_coeffs, int variant, hipStream_t stream);
 // stationary shape: every active mic's window of a frame pair in LDS at once (plan->chunk = usable_pad); a
 // workgroup stages the pair once and sweeps tiles_per_wg tiles from it
 bool pair_plan_stationary(int window, int usable, FastPlan *plan);

@@ -870,32 +870,44 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
     Lane l owns the four CONSECUTIVE outputs n = 4l .. 4l+3, so an item (pixel x mic, two frames) needs the eleven
     samples X[e + 4l + w], w = 0..10, and gives 32 v_pk_fma_f32 for 11 ds_read_b64 -- against 32 reads when a lane
     owns outputs 64 apart (the LDS array, shared by the four SIMDs, then limits the sweep at half the VALU rate).
-    Sample w sits in the plane (e + w) % 4: the table entry carries the four byte addresses of the rotated planes
-    c = w % 4 (4 v_add_u32 per item) and w / 4 is an immediate offset of 0, 8 or 16 bytes; consecutive lanes read
-    consecutive 8-byte elements, so every read is conflict-free.  The entry also carries the item's eight
-    coefficients (64-byte entries: addresses in dwords 0..3, coefficients in 8..15).  The coefficient of tap t is
-    the low or the high dword of an aligned SGPR pair, picked by op_sel.  Taps accumulate in the reference's order
-    t = 0..7 for every output.
+    Sample w sits in the plane (e + w) % 4: an item needs the four byte addresses of the rotated planes c = w % 4
+    (4 v_add_u32 per item) and w / 4 is an immediate offset of 0, 8 or 16 bytes; consecutive lanes read consecutive
+    8-byte elements, so every read is conflict-free.  The coefficient of tap t is the low or the high dword of an
+    aligned SGPR pair, picked by op_sel.  Taps accumulate in the reference's order t = 0..7 for every output.
 
-    Pipeline: four SGPR entry sets in rotation, the entry THREE items ahead requested at the head of an item (two
-    items of time before it is needed: the table streams from L2).  Scalar loads share lgkmcnt with the LDS reads
-    and return out of order, so only an lgkmcnt(0) proves an entry has landed: one per item, at its head -- and the
-    LDS reads are placed so that this drain finds nothing young in flight: samples 0..3 and 4..7 of the NEXT item
-    are requested after this item's FMAs on its own samples 0..3 (22 FMAs before the drain; samples 4..7 have two
-    register sets), samples 8..10 right after the drain (26 FMAs before their first use, waits counted in younger
-    LDS reads only).
+    Table (round 3: 4 bytes per item where round 2 had 64): ONE dword per (pixel, mic),
+        bits 0..17  the LDS byte address of X[off] (plane r = first % 4, index first / 4 of the mic's row),
+        bits 18..19 r,   bits 20..26 the coefficient row k (delay.cpp:32-33; row 101 = zeros, for padding mics);
+    the other three plane addresses follow in the scalar ALU -- addr[c] = addr[0] + c PB, minus 4 PB - 8 where r + c
+    wraps past plane 3 (PB = bytes of one plane) -- and the eight coefficients come by a second, dependent scalar
+    load from the 3.2 KB coefficient table, which lives in the scalar cache.  The 512-mic 128x128 table shrinks from
+    537 MB, re-streamed from beyond the L2 by every group of workgroups, to 33.5 MB.
+
+    Pipeline per item i, at its head, after the one lgkmcnt(0) that proves everything requested earlier has landed:
+    request the entry of item i+4; take the entry of item i+3 (requested an item ago) apart and request its
+    coefficients (four sets of 8 SGPRs in rotation: they are needed from item i+2's address adds ... no, from item i+3's
+    FMAs on); compute the four addresses of item i+1 (single set: the v_adds of this item consume them).  Scalar
+    loads share lgkmcnt with the LDS reads and return out of order, so only an lgkmcnt(0) proves a load has landed:
+    one per item -- and the LDS reads are placed so that this drain finds nothing young in flight: samples 0..3 and
+    4..7 of the NEXT item are requested after this item's FMAs on its own samples 0..3 (22 FMAs before the drain;
+    samples 4..7 have two register sets), samples 8..10 right after the drain (26 FMAs before their first use, waits
+    counted in younger LDS reads only).
 
     The block sweeps its four pixels one after the other, `n4` groups of four items each (chunks and table rows are
-    multiples of four mics; padding entries carry zero coefficients), and the stream of entry requests runs on from
-    one pixel's row into the next: a wave meets the scalar-load latency once per block, not once per pixel."""
-    E = (36, 48, 60, 72)  # 12 SGPRs per set: +0..3 plane addresses, +4..11 coefficients
+    multiples of four mics; padding entries point at the zero coefficient row), and the stream of entry requests
+    runs on from one pixel's row into the next: a wave meets the scalar-load latency once per block."""
+    ENT = 36                      # s[36:39]: ring of four entry dwords, entry i in s[36 + i % 4]
+    CO = (40, 48, 56, 64)         # coefficient sets, item i uses CO[i % 4]
+    AD = 72                       # s[72:75]: the plane addresses of the item whose reads are being issued
+    S_PB, S_PB2, S_PB3, S_ADJ = 76, 77, 78, 79   # c * PB and 8 - 4 PB
+    S_T, S_R, S_K = 80, 81, 82
     S_OFF_, S_LEFT_, S_PTR = 23, 24, 84  # s[84:85]: the row the entry requests currently run in
     X03 = [tmp + 2 * w for w in range(4)]
     X47 = [[tmp + 8 + 8 * z + 2 * w for w in range(4)] for z in range(2)]
     X8 = [tmp + 24 + 2 * w for w in range(3)]
     VA = [tmp + 30 + c for c in range(4)]
     n_tmp = 34
-    SINK = tmp - 4  # v[84:87]: destination of the table prefetch (never read)
+    SINK = tmp - 4  # v84: destination of the table prefetch (never read)
 
     def accp(pp, o):
         b = acc + 8 * pp + 2 * o
@@ -908,8 +920,18 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
         r = xreg(w, z)
         return f"v[{r}:{r + 1}]"
 
-    def adds(base):
-        return [f"v_add_u32 v{VA[c]}, s{base + c}, %[lane]" for c in range(4)]
+    def addresses(ent):
+        """the four plane addresses of the item whose entry sits in s{ent} -> s[AD:AD+3]"""
+        L = [f"s_and_b32 s{AD}, s{ent}, 0x3ffff", f"s_bfe_u32 s{S_R}, s{ent}, 0x20012"]  # address; r = bits 18..19
+        for c, pb in ((1, S_PB), (2, S_PB2), (3, S_PB3)):
+            L += [f"s_add_u32 s{AD + c}, s{AD}, s{pb}",
+                  f"s_cmp_ge_u32 s{S_R}, {4 - c}",             # r + c >= 4: the plane index wraps, the element index steps
+                  f"s_cselect_b32 s{S_T}, s{S_ADJ}, 0",
+                  f"s_add_u32 s{AD + c}, s{AD + c}, s{S_T}"]
+        return L
+
+    def adds():
+        return [f"v_add_u32 v{VA[c]}, s{AD + c}, %[lane]" for c in range(4)]
 
     def read(w, z):
         off = f" offset:{8 * (w // 4)}" if w >= 4 else ""
@@ -920,16 +942,20 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
     def reads(ws, z):
         return [r for r in (read(w, z) for w in ws) if r]
 
-    def load(set_base):
+    def load_entry(slot):
         if timing == "noload":  # (timing-only builds: the first entries over and over)
             return []
-        return [f"s_load_dwordx4 s[{set_base}:{set_base + 3}], s[{S_PTR}:{S_PTR + 1}], s{S_OFF_}",
-                f"s_add_u32 s{S_OFF_}, s{S_OFF_}, 32",
-                f"s_load_dwordx8 s[{set_base + 4}:{set_base + 11}], s[{S_PTR}:{S_PTR + 1}], s{S_OFF_}",
-                f"s_add_u32 s{S_OFF_}, s{S_OFF_}, 32"]
+        return [f"s_load_dword s{ENT + slot}, s[{S_PTR}:{S_PTR + 1}], s{S_OFF_}", f"s_add_u32 s{S_OFF_}, s{S_OFF_}, 4"]
+
+    def load_coeffs(ent, cset):
+        if timing == "noload":
+            return []
+        return [f"s_bfe_u32 s{S_K}, s{ent}, 0x70014",   # k = bits 20..26
+                f"s_lshl_b32 s{S_K}, s{S_K}, 5",        # 32 bytes per coefficient row
+                f"s_load_dwordx8 s[{cset}:{cset + 7}], %[coef], s{S_K}"]
 
     def fma(pp, base, o, t, w, z):
-        sp = base + 4 + (t & ~1)
+        sp = base + (t & ~1)
         sel = t & 1
         return (f"v_pk_fma_f32 {accp(pp, o)}, s[{sp}:{sp + 1}], {xp(w, z)}, {accp(pp, o)} "
                 f"op_sel:[{sel},0,0] op_sel_hi:[{sel},1,1]")
@@ -938,17 +964,19 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
         return [fma(pp, cur, o, w - o, w, z) for o in range(max(0, w - 7), min(3, w) + 1)]
 
     def item(pp, k):
-        cur, nxt, far = E[k % 4], E[(k + 1) % 4], E[(k + 3) % 4]
+        cur = CO[k % 4]
         z = k & 1
-        L = ["s_waitcnt lgkmcnt(0)"]  # the next entry has landed; so have this item's samples 0..7 (requested long ago)
-        L += load(far)
-        if k == 0 and pp < 3:  # a pixel's last group: its other three requests are the next pixel's first entries
+        L = ["s_waitcnt lgkmcnt(0)"]  # everything requested before this item has landed; so have its samples 0..7
+        if k == 0 and pp < 3:  # a pixel's last group: the entry four items on is the next pixel's first
             L += [f"s_cmp_eq_u32 s{S_LEFT_}, 1", f"s_cselect_b64 s[{S_PTR}:{S_PTR + 1}], %[row{pp + 1}], s[{S_PTR}:{S_PTR + 1}]",
                   f"s_cselect_b32 s{S_OFF_}, 0, s{S_OFF_}"]
+        L += load_entry(k % 4)                                # entry of item i + 4 (this item's slot is free)
+        L += load_coeffs(ENT + (k + 3) % 4, CO[(k + 3) % 4])  # coefficients of item i + 3 (its entry landed an item ago)
         L += reads(range(8, 11), z)
+        L += addresses(ENT + (k + 1) % 4)                     # plane addresses of item i + 1
         for w in range(4):
             L += fmas(pp, cur, w, z)
-        L += adds(nxt) + reads(range(0, 4), z ^ 1) + reads(range(4, 8), z ^ 1)
+        L += adds() + reads(range(0, 4), z ^ 1) + reads(range(4, 8), z ^ 1)
         for w in range(4, 8):
             L += fmas(pp, cur, w, z)
         younger = 10  # samples 9, 10 and the next item's 0..7
@@ -959,20 +987,22 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
             L += fmas(pp, cur, w, z)
         return L
 
-    L = [f"s_mov_b64 s[{S_PTR}:{S_PTR + 1}], %[row0]", f"s_mov_b32 s{S_OFF_}, 0"]
-    # warm the L2 with the NEXT chunk's entries of these four pixels (pfn pieces of 1 KiB per pixel from pfoff =
-    # chunk bytes + 16 * lane; 0 = last chunk): plain loads into a sink nobody reads, drained at the block's end.
-    # A scalar load that misses the L2 costs the wave more than the two items of lead the requests have.
-    for k in range(4):
-        L += [f"s_cmp_lt_u32 %[pfn], {k + 1}", "s_cbranch_scc1 .LFpf_%="]
-        L += [f"global_load_dwordx4 v[{SINK}:{SINK + 3}], %[pfoff], %[row{pp}] offset:{1024 * k}" for pp in range(4)]
+    L = [f"s_mov_b64 s[{S_PTR}:{S_PTR + 1}], %[row0]", f"s_mov_b32 s{S_OFF_}, 0",
+         f"s_mov_b32 s{S_PB}, %[pb]", f"s_lshl_b32 s{S_PB2}, s{S_PB}, 1", f"s_add_u32 s{S_PB3}, s{S_PB2}, s{S_PB}",
+         f"s_lshl_b32 s{S_ADJ}, s{S_PB}, 2", f"s_sub_u32 s{S_ADJ}, 8, s{S_ADJ}"]
+    # warm the L2 with the NEXT chunk's entries of these four pixels (one dword per lane from pfoff = chunk bytes +
+    # 4 * lane: a chunk is at most 64 entries; pfn = 0: last chunk): plain loads into a sink nobody reads, drained at
+    # the block's end.  A scalar load that misses the L2 costs the wave more than the lead the requests have.
+    L += ["s_cmp_lt_u32 %[pfn], 1", "s_cbranch_scc1 .LFpf_%="]
+    L += [f"global_load_dword v{SINK}, %[pfoff], %[row{pp}]" for pp in range(4)]
     L += [".LFpf_%=:"]
     keep = timing
     timing = ""
+    L += [f"s_load_dwordx4 s[{ENT}:{ENT + 3}], s[{S_PTR}:{S_PTR + 1}], 0x0", f"s_mov_b32 s{S_OFF_}, 16", "s_waitcnt lgkmcnt(0)"]
     for k in range(4 if keep == "noload" else 3):
-        L += load(E[k])
+        L += load_coeffs(ENT + k, CO[k])
     timing = keep
-    L += ["s_waitcnt lgkmcnt(0)"] + adds(E[0]) + reads(range(0, 4), 0) + reads(range(4, 8), 0)
+    L += addresses(ENT) + ["s_waitcnt lgkmcnt(0)"] + adds() + reads(range(0, 4), 0) + reads(range(4, 8), 0)
     for pp in range(4):
         L += [f"s_mov_b32 s{S_LEFT_}, %[n4]", f".LF{pp}_%=:"]
         for k in range(4):
@@ -981,22 +1011,24 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
     L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
     vregs = list(range(SINK, tmp + n_tmp))
-    sregs = [S_OFF_, S_LEFT_, S_PTR, S_PTR + 1] + list(range(E[0], E[3] + 12))
+    sregs = [S_OFF_, S_LEFT_, S_PTR, S_PTR + 1] + list(range(ENT, S_K + 1))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
     acc_params = ", ".join(f"f8 &A{pp}" for pp in range(4))
     acc_ops = ", ".join(f'"+{{v[{acc + 8 * pp}:{acc + 8 * pp + 7}]}}"(A{pp})' for pp in range(4))
     rows = ", ".join(f'[row{pp}] "s"(row{pp})' for pp in range(4))
     return f"""// Four pixels of the staged chunk, 8-tap variant, four-plane frame-pair layout: see block_fir8 in
-// tools/gen_trip_asm.py.  row0..row3 = the pixels' 64-byte entries from the chunk's first mic; sweeps 4 * n4 entries
-// of each (n4 >= 1) and reads three entries past the last swept one of row3; pfn > 0: also touches pfn KiB from
-// byte pfoff of every row (the next chunk's entries: an L2 prefetch).
+// tools/gen_trip_asm.py.  row0..row3 = the pixels' 4-byte entries from the chunk's first mic; sweeps 4 * n4 entries
+// of each (n4 >= 1) and reads four entries past the last swept one of row3; coef = the [102][8] coefficient table
+// (row 101 zeros), pb = bytes of one sample plane of a staged row; pfn > 0: also touches the 256 bytes from byte pfoff
+// of every row (the next chunk's entries: an L2 prefetch).
 // Accumulators (outputs 4l..4l+3, two frames each) pinned at v[{acc}:{acc + 31}], temps v{vregs[0]}..v{vregs[-1]}.
 __device__ __forceinline__ void {name}({acc_params}, const void *row0, const void *row1, const void *row2,
-                                       const void *row3, int n4, unsigned lane_addr, unsigned pfoff, int pfn) {{
+                                       const void *row3, int n4, unsigned lane_addr, const void *coef, unsigned pb,
+                                       unsigned pfoff, int pfn) {{
     asm volatile(
 {body}
         : {acc_ops}
-        : {rows}, [n4] "s"(n4), [lane] "v"(lane_addr), [pfoff] "v"(pfoff), [pfn] "s"(pfn)
+        : {rows}, [n4] "s"(n4), [lane] "v"(lane_addr), [coef] "s"(coef), [pb] "s"(pb), [pfoff] "v"(pfoff), [pfn] "s"(pfn)
         : {clobbers});
 }}
 """
