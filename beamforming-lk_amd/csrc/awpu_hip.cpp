@@ -82,13 +82,15 @@ struct awpu_hip {
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     awpu::QuadEntry *d_quad_lut = nullptr;  // quad-major table of the quad shape (das_quad_kernel)
     awpu::QuadEntry *d_quad1_lut = nullptr; // the same with the single-frame layout's LDS addresses (das_quad1_kernel)
+    awpu::QuadEntry *d_quadh_lut = nullptr; // the same with the halves layout's LDS addresses (das_quadh_kernel)
     awpu::LutEntry *d_fir_pair_lut = nullptr;  // FIR8 on the frame-pair layout: {LDS address, coefficient row} per (pixel, mic)
     awpu::FastPlan fir_plan{};
     void *d_fir_plane_lut = nullptr;           // FIR8 on the four-plane layout: one dword per (pixel, mic): address, plane, coefficient row
     awpu::FastPlan fir_plane_plan{};
     std::vector<float> fir;                    // host copy of the [101][8] coefficient table (baked into the plane entries)
-    awpu::FastPlan quad_plan{}, quad1_plan{};
+    awpu::FastPlan quad_plan{}, quad1_plan{}, quadh_plan{};
     bool quad1_fits = false;
+    bool quadh_fits = false;      // single frames on the halves layout (das_quadh_kernel)
     bool quad_ok = false;         // the table's statistics favour the quad shape (decided in prepare)
     double quad_cost = 0.0;       // its expected packed VALU instructions per quad and mic (32 = no sharing at all)
     int32_t *d_index = nullptr;
@@ -196,12 +198,14 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
     int fir_planes = 1;            // AWPU_FIR8_PLANES=0: FIR8 batches on the older lane-strided pair kernel (A/B measurements); 2: the plane kernel for every batch >= 2, however small the grid (tests)
     int wgs = 0;                   // AWPU_FAST_WGS: persistent workgroups of the quad shape (0 = one workgroup per item)
     int live_graph = 1;            // AWPU_LIVE_GRAPH=0: awpu_hip_live_block always enqueues its steps one by one
+    int halves = -1;               // AWPU_FAST_HALVES=0/1: never / always (where the quad table is built) sweep single frames on the halves layout
     int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0]; 2: and through pinned host memory, the path of a node without peer access (tests)
     EnvKnobs() {
         if (const char *v = std::getenv("AWPU_FAST_QUADS")) quads = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_PAIRGROUP")) pair_group = std::atoi(v);
         if (const char *v = std::getenv("AWPU_QUAD_VARIANT")) quad_variant = std::atoi(v);
         if (const char *v = std::getenv("AWPU_GROUP_FORCE_COPY")) group_copy = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FAST_HALVES")) halves = std::atoi(v);
         if (const char *v = std::getenv("AWPU_LIVE_GRAPH")) live_graph = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_WGS")) wgs = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FIR8_PLANES")) fir_planes = std::atoi(v);
@@ -248,6 +252,7 @@ void release_device(awpu_hip *h) {
     h->fast_luts.clear();
     dev_free(h->d_quad_lut);
     dev_free(h->d_quad1_lut);
+    dev_free(h->d_quadh_lut);
     dev_free(h->d_fir_pair_lut);
     dev_free(h->d_fir_plane_lut);
     dev_free(h->d_index);
@@ -316,6 +321,7 @@ int prepare(awpu_hip *h) {
     h->fast_luts.clear();
     dev_free(h->d_quad_lut);
     dev_free(h->d_quad1_lut);
+    dev_free(h->d_quadh_lut);
     dev_free(h->d_fir_pair_lut);
     dev_free(h->d_fir_plane_lut);
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
@@ -419,6 +425,7 @@ int prepare(awpu_hip *h) {
     // saves VALU work at all once its own address adds are counted (measured: a count of 30.2 -- BASELINE c2 -- is
     // 4 % faster than the pair shape, 29.4 -- c3 -- 8 %, 25.3 -- the headline -- 20 %; AWPU_FAST_QUADS=0/1 forces either).
     h->quad_ok = false;
+    h->quadh_fits = false;
     h->quad_cost = 0.0;
     {
         const int cols = c.grid_columns;
@@ -445,6 +452,8 @@ int prepare(awpu_hip *h) {
             h->quad1_fits = h->quad_ok && h->gain.empty() &&  // (gains ride on the weights of the other single-frame tables)
                             awpu::fast_plan(h->window, U, 1, awpu::kFastLdsBytes - awpu::kQuad1ZeroBytes, &h->quad1_plan) &&
                             awpu::fast_db_fits(h->quad1_plan);
+            // the halves layout: a row holds the window less 128 samples, as (sample, sample + 128) pairs (its pack pass applies the gains)
+            h->quadh_fits = h->quad_ok && awpu::pair_plan(h->window - 128, U, &h->quadh_plan);
         }
     }
 
@@ -516,11 +525,13 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
 // address), quads = groups of four grid rows x columns padded to whole 16-column tiles.  Pixels past the grid
 // carry weight 0 and the address of the nearest pixel inside it (they then follow the shared path and add
 // nothing); padding mics (usable rounded up to 4) carry weight 0 and the address of their own, zero, row.
-int build_quad_lut(awpu_hip *h, bool single) {
-    awpu::QuadEntry *&d_lut = single ? h->d_quad1_lut : h->d_quad_lut;
+enum QuadLayout { kQuadPairs = 0, kQuadSingle = 1, kQuadHalves = 2 };
+int build_quad_lut(awpu_hip *h, int layout) {
+    const bool single = layout == kQuadSingle;
+    awpu::QuadEntry *&d_lut = single ? h->d_quad1_lut : (layout == kQuadHalves ? h->d_quadh_lut : h->d_quad_lut);
     if (d_lut) return AWPU_OK;
     const auto &c = h->cfg;
-    const awpu::FastPlan &plan = single ? h->quad1_plan : h->quad_plan;
+    const awpu::FastPlan &plan = single ? h->quad1_plan : (layout == kQuadHalves ? h->quadh_plan : h->quad_plan);
     const int U = h->usable(), cols = c.grid_columns, rows = c.pixel_count / cols;
     const int groups = plan.usable_pad / 4;
     const int cols_pad = (cols + 15) / 16 * 16, rows4 = (rows + 3) / 4;
@@ -780,7 +791,7 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
 // quad shape: the frame-pair layout swept four vertically adjacent pixels at a time (das_quad_kernel)
 int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff,
                  const float *prepacked = nullptr) {
-    int rc = build_quad_lut(h, false);
+    int rc = build_quad_lut(h, kQuadPairs);
     if (rc != AWPU_OK) return rc;
     const awpu::FastPlan &pp = h->quad_plan;
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * pp.usable_pad * pp.wr * 2;
@@ -844,7 +855,7 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
 // quad shape for single frames (das_quad1_kernel): frames read in place, qpw quads per wave
 int launch_quads1(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff,
                   const int32_t *d_row_off, int qpw) {
-    int rc = build_quad_lut(h, true);
+    int rc = build_quad_lut(h, kQuadSingle);
     if (rc != AWPU_OK) return rc;
     const awpu::FastPlan &pp = h->quad1_plan;
     awpu::Quad1Args qa{};
@@ -876,6 +887,44 @@ int launch_quads1(awpu_hip *h, const float *d_frames, int batch, float *d_power,
     rc = finish_launch(h, batch, s);
     if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
     return dump_diag(h, n_waves, 16, "quads1", s);
+}
+
+// quad shape for single frames on the halves layout (das_quadh_kernel): a pack + filter pre-pass, then the sweep
+int launch_quadsh(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int pitch, int hist_eff, int wstart_eff,
+                  int qpw) {
+    int rc = build_quad_lut(h, kQuadHalves);
+    if (rc != AWPU_OK) return rc;
+    const awpu::FastPlan &pp = h->quadh_plan;
+    const size_t need = std::max((size_t) h->cfg.max_batch, (size_t) batch) * pp.usable_pad * pp.wr * 2;
+    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
+    awpu::QuadhArgs qa{};
+    qa.packed = h->d_pack;
+    qa.lut = h->d_quadh_lut;
+    qa.power = d_power;
+    qa.usable = h->usable();
+    qa.usable_pad = pp.usable_pad;
+    qa.pixel_count = h->cfg.pixel_count;
+    qa.wp = pp.wr;
+    qa.chunk = pp.chunk;
+    qa.batch = batch;
+    qa.cols = h->cfg.grid_columns;
+    qa.rows = h->cfg.pixel_count / qa.cols;
+    qa.debug = env().debug;
+    qa.debug_out = nullptr;
+    size_t n_waves = 0;
+    if (qa.debug & 16) {
+        n_waves = (size_t) 16 * batch * awpu::quad1_tiles(qa.rows, qa.cols, qpw);
+        rc = ensure_diag(h, n_waves * 12);
+        if (rc != AWPU_OK) return rc;
+        qa.debug_out = h->d_diag;
+    }
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_pack_halves(d_frames, h->cfg.n_streams, pitch, hist_eff, wstart_eff, h->d_index, h->usable(),
+                                          pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, s));
+    AWPU_HIP_TRY(awpu::launch_das_quadh(qa, qpw, s));
+    rc = finish_launch(h, batch, s);
+    if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
+    return dump_diag(h, n_waves, 16, "quadsh", s);
 }
 
 int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int layout = kFull) {
@@ -925,7 +974,17 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         // else (an allocation or copy that failed) is the caller's to know about
         if (rc != AWPU_ERR_INVALID) return rc;
     }
-    // ---- single frames on a grid whose table favours the quad shape (AWPU_FAST_VARIANT set: the older shapes)
+    // ---- single frames on a grid whose table favours the quad shape (AWPU_FAST_VARIANT set: the older shapes): the
+    // halves layout behind a pack + filter pre-pass (AWPU_FAST_HALVES=0: the in-place layout of round 2)
+    if (h->quadh_fits && env().fpi == 0 && env().halves != 0) {
+        const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
+        const int qpw = (long) awpu::quad1_tiles(rows, cols, 2) * batch >= 256 ? 2 : 1;
+        if ((long) awpu::quad1_tiles(rows, cols, qpw) * batch >= 192 || env().quads == 1 || env().halves == 1) {
+            // pitch between streams: the ring's rows are 2048 floats apart; the history a stream offers the filter is hist_eff
+            const int pitch = hist_eff;
+            return launch_quadsh(h, d_frames, batch, d_power, s, pitch, layout == kRing ? AWPU_HIST : hist_eff, wstart_eff, qpw);
+        }
+    }
     if (h->quad1_fits && env().fpi == 0 && wstart_eff + 1 + h->quad1_plan.wr <= hist_eff) {
         const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
         const int qpw = (long) awpu::quad1_tiles(rows, cols, 2) * batch >= 256 ? 2 : 1;

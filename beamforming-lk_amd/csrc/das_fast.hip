@@ -1596,6 +1596,179 @@ __global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
     }
 }
 // ---------------------------------------------------------------------------------------
+// Quad shape for single frames on the HALVES layout (round 3; the default for calls of one frame where the quad table
+// pays): a pre-pass (pack_halves_kernel) writes, per active mic, the touched window as 8-byte elements
+//     element t = (Y[wstart + t], Y[wstart + t + 128]),      Y = the pre-filtered samples of pack_one_row<true>,
+// i.e. the two HALVES of the 256-sample block ride in the two lanes of every packed instruction, as the two frames of a
+// pair do in das_quad_kernel.  Lane l owns samples l and l + 64 of either half: register pair 0 = (sample l, 128 + l),
+// pair 1 = (64 + l, 192 + l).  Against das_quad1_kernel's layout (adjacent samples in the packed lanes, the window staged
+// twice so that odd delays stay 8-byte aligned):
+//   * any integer delay is 8-byte aligned: no parity copies -- a mic's row is (W - 128) x 8 bytes instead of 2 x W x 4
+//     (headline: 1760 against 2784), 44 mics per chunk instead of 28, 6 chunks instead of 10;
+//   * a chunk is contiguous in HBM: the refill is one linear stream that the sweep block issues itself, one 16 KiB
+//     piece per trip (sweep_quad1_sum_a_dma) -- no row table, no queue of 80 LDS-DMA instructions at the CU's address
+//     unit right after every barrier;
+//   * pre-filtered samples: no 257th-sample pass, and the epilogue is rotation, squares, wave sum.
+// The block (always-read schedule), the quad-major table and the tile geometry are das_quad1_kernel's; the table
+// carries this layout's LDS addresses (slot x row bytes + (off - wstart) x 8).  grid = (frames, tiles).
+// ---------------------------------------------------------------------------------------
+__global__ void pack_halves_kernel(const float *frames, int n_streams, int pitch, int hist, int wstart, const int32_t *index,
+                                   int usable, const float *gain, int wp, float *packed) {
+    const int frame = blockIdx.y, s = blockIdx.x, rows_out = gridDim.x;
+    f2 *dst = (f2 *) packed + ((size_t) frame * rows_out + s) * wp;
+    if (s >= usable) {  // padding rows (whole groups of four mics are swept): silence
+        for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = f2{0.0f, 0.0f};
+        return;
+    }
+    const float *x = frames + ((size_t) frame * n_streams + index[s]) * pitch;
+    const float gm = gain ? gain[s] : 1.0f;
+    auto y = [&](int i) -> float {  // the filtered sample at history index i; neighbours outside the history count as 0
+        if (i < 0 || i >= hist) return 0.0f;  // (values that would need them are never used: pack_one_row)
+        const float lo = i > 0 ? x[i - 1] * gm : 0.0f, hi = i + 1 < hist ? x[i + 1] * gm : 0.0f;
+        return __builtin_fmaf(-0.25f, lo + hi, 0.5f * (x[i] * gm));
+    };
+    for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = f2{y(wstart + t), y(wstart + t + 128)};
+}
+
+template <int QPW, bool DIAG>
+__global__ __launch_bounds__(1024, 4) void das_quadh_kernel(QuadhArgs a) {
+    static_assert(QPW == 1 || QPW == 2, "one or two quads per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
+    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int frame = blockIdx.x;
+    const int tile = blockIdx.y;
+
+    const int tile_cols = NW * QPW;
+    const int tiles_per_row4 = (a.cols + tile_cols - 1) / tile_cols;
+    const int cols_pad = (a.cols + 15) / 16 * 16;  // the table's quads: columns padded to 16 (quad_count)
+    const int row4 = tile / tiles_per_row4;
+    const int col0 = (tile - row4 * tiles_per_row4) * tile_cols + wave * QPW;
+    const int groups_total = a.usable_pad >> 2;
+    const size_t row_floats = (size_t) a.wp * 2;
+    const float *frame_base = a.packed + (size_t) frame * a.usable_pad * row_floats;
+    const unsigned lane_bytes = threadIdx.x * 16;
+    auto chunk_mics = [&](int m0) { return (min(a.chunk, a.usable - m0) + 3) & ~3; };
+    auto dma_chunk = [&](const float *src, int mc4, int buf) {  // (first chunk, and the stamped build's refills)
+        const unsigned n_bytes = (unsigned) ((size_t) mc4 * row_floats * 4);
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            if (lane_bytes + k * kThreads * 16 < n_bytes) {
+                const char *base = (const char *) uniform_ptr((const char *) src + k * kThreads * 16);
+                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (base + lane_bytes),
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+            }
+        }
+    };
+
+    f4 A0a = {0, 0, 0, 0}, A1a = A0a, A2a = A0a, A3a = A0a, Ta = A0a, V0a = A0a, V2a = A0a, V3a = A0a;
+    f4 A0b = A0a, A1b = A0a, A2b = A0a, A3b = A0a, Tb = A0a, V0b = A0a, V2b = A0a, V3b = A0a;
+
+    unsigned t_wait = 0, t_all = 0;
+    const long long t_begin = __builtin_readcyclecounter();
+    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
+    dma_chunk(frame_base, chunk_mics(0), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    unsigned t_ph[5] = {0, 0, 0, 0, 0};
+    auto stamp = [&](int k, long long &t) {
+        if (DIAG) {
+            const long long n = __builtin_readcyclecounter();
+            t_ph[k] += (unsigned) (n - t);
+            t = n;
+        }
+    };
+    const int rank = wave >> 2;
+    for (int c = 0; c < n_chunks; c++) {
+        const int m0 = c * a.chunk;
+        const int mc4 = chunk_mics(m0);
+        const int buf = c & 1;
+        long long t = DIAG ? __builtin_readcyclecounter() : 0;
+        const float *next_src = frame_base + (size_t) (m0 + a.chunk) * row_floats;
+        const int next_mc4 = c + 1 < n_chunks ? chunk_mics(m0 + a.chunk) : 0;
+        const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
+        const int ng = __builtin_amdgcn_readfirstlane(mc4 >> 2);
+        {
+            const void *row = uniform_ptr(a.lut + (((size_t) row4 * cols_pad + min(col0, cols_pad - 1)) * groups_total + (m0 >> 2)) * 16);
+            if constexpr (DIAG) {
+                if (next_mc4) dma_chunk(next_src, next_mc4, buf ^ 1);
+                stamp(0, t);
+                unsigned dw = 0, da = 0;
+                sweep_quad1_sum_a_stamped(A0a, A1a, A2a, A3a, Ta, V0a, V2a, V3a, row, ng, lane_addr, rank, dw, da);
+                t_wait += dw;
+                t_all += da;
+            } else {  // the block issues the refill of the other image itself, one 16 KiB piece per trip
+                const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (buf ^ 1) * BUF + wave * 1024);
+                const unsigned n_bytes = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) next_mc4 * row_floats * 4));
+                const unsigned dnp = wave < kQuadDmaWaves ? (n_bytes + kQuadDmaWaves * 1024 - 1) / (kQuadDmaWaves * 1024) : 0;
+                sweep_quad1_sum_a_dma(A0a, A1a, A2a, A3a, Ta, V0a, V2a, V3a, row, ng, lane_addr, rank, uniform_ptr(next_src), dst0,
+                                      n_bytes, lane_bytes, dnp);
+            }
+        }
+        if constexpr (QPW == 2) {
+            const void *row = uniform_ptr(a.lut + (((size_t) row4 * cols_pad + min(col0 + 1, cols_pad - 1)) * groups_total + (m0 >> 2)) * 16);
+            sweep_quad1_sum_b(A0b, A1b, A2b, A3b, Tb, V0b, V2b, V3b, row, ng, lane_addr, rank);
+        }
+        stamp(1, t);
+        stamp(2, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3, t);
+        __syncthreads();
+        stamp(4, t);
+    }
+
+    if (DIAG && a.debug_out && lane == 0) {
+        unsigned long long *o = a.debug_out + 12 * ((size_t) (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+        o[0] = t_wait;
+        o[1] = t_all;
+        o[2] = (unsigned long long) (__builtin_readcyclecounter() - t_begin);
+        o[3] = (unsigned long long) n_chunks;
+        for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
+    }
+    // epilogue: the un-skewed sums ARE the moving average (pre-filtered samples): MA[i] = P[i] + G[i+1], i = 1..254, with
+    // P = sum f Y = S/2 + A, G = sum (1 - f) Y = S/2 - A (A was accumulated with f - 1/2).  Sample order of a lane's four
+    // values: pair 0 low (l), pair 1 low (64 + l), pair 0 high (128 + l), pair 1 high (192 + l).
+    const float norm = (float) (kSamples * a.usable);
+    auto finish = [&](const f4 &A, const f4 &S, int slot) {
+        const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
+        const float Av[4] = {A[0], A[2], A[1], A[3]}, Sv[4] = {S[0], S[2], S[1], S[3]};  // in sample order
+        float P[4], G[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            P[r] = __builtin_fmaf(0.5f, Sv[r], Av[r]);
+            G[r] = __builtin_fmaf(0.5f, Sv[r], -Av[r]);
+        }
+        float sum = 0.0f;
+        float rq = wave_rotate1<kDppWaveRol1>(G[0]);  // G_r one lane down; lane 63 holds G_r[0]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float rq_next = r < 3 ? wave_rotate1<kDppWaveRol1>(G[r < 3 ? r + 1 : 3]) : rq;
+            const float ma = P[r] + (lane == 63 ? rq_next : rq);  // MA[l + 64 r]
+            const int i = lane + 64 * r;
+            if (i >= 1 && i <= kSamples - 2) sum = __builtin_fmaf(ma, ma, sum);
+            rq = rq_next;
+        }
+        sum = wave_sum(sum);
+        if (lane == 0 && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = sum / norm;
+    };
+    finish(A0a, Ta + V0a, 0);
+    finish(A1a, Ta, 1);
+    finish(A2a, Ta + V2a, 2);
+    finish(A3a, Ta + V3a, 3);
+    if constexpr (QPW == 2) {
+        finish(A0b, Tb + V0b, 4);
+        finish(A1b, Tb, 5);
+        finish(A2b, Tb + V2b, 6);
+        finish(A3b, Tb + V3b, 7);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // host side: geometry of the LDS image and the launch
 // ---------------------------------------------------------------------------------------
 bool fast_plan(int window, int usable, int fpi, int image_bytes, FastPlan *plan) {
@@ -1844,6 +2017,32 @@ int fast_image_bytes(int nw) { return nw == 24 ? kFastLdsBytesSmall : kFastLdsBy
 
 bool fast_db_fits(const FastPlan &plan) {
     return (size_t) 2 * plan.usable_pad * sizeof(int) <= (size_t) kFastSideBytes;
+}
+
+template <int QPW, bool DIAG>
+static hipError_t launch_quadh_variant(const QuadhArgs &a, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (hipError_t e = allow_lds((const void *) das_quadh_kernel<QPW, DIAG>, lds_bytes, attr_set); e != hipSuccess) return e;
+    dim3 grid(a.batch, quad1_tiles(a.rows, a.cols, QPW));
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((das_quadh_kernel<QPW, DIAG>), grid, dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_das_quadh(const QuadhArgs &a, int qpw, hipStream_t stream) {
+    if (a.debug & 16) return qpw == 2 ? launch_quadh_variant<2, true>(a, stream) : launch_quadh_variant<1, true>(a, stream);
+    return qpw == 2 ? launch_quadh_variant<2, false>(a, stream) : launch_quadh_variant<1, false>(a, stream);
+}
+
+hipError_t launch_pack_halves(const float *d_frames, int n_streams, int pitch, int hist, int wstart, const int32_t *d_index, int usable,
+                              int rows_out, const float *d_gain, int wp, int batch, float *d_packed, hipStream_t stream) {
+    // one thread per element where a row allows (a row is 130 .. 400 elements): the pass is a few microseconds of latency
+    // in front of a 55 us sweep, not bandwidth
+    const int threads = wp <= 256 ? 256 : 512;
+    hipLaunchKernelGGL(pack_halves_kernel, dim3(rows_out, batch), dim3(threads), 0, stream, d_frames, n_streams, pitch, hist, wstart,
+                       d_index, usable, d_gain, wp, d_packed);
+    return hipGetLastError();
 }
 
 hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream) {

@@ -163,6 +163,24 @@ struct Quad1Args {
 inline int quad1_tiles(int rows, int cols, int qpw) { return ((rows + 3) / 4) * ((cols + 16 * qpw - 1) / (16 * qpw)); }
 hipError_t launch_das_quads1(const Quad1Args &a, int qpw, hipStream_t stream);
 
+// ---- single frames on the halves layout (das_quadh_kernel): the two halves of the 256-sample block in the two packed
+// lanes, pre-filtered; rows packed by launch_pack_halves, table = the quad-major table with this layout's addresses
+// (pair_plan on a window of window - 128 samples)
+struct QuadhArgs {
+    const float *packed;      // [batch][usable_pad][wp][2]: element t = (Y[wstart + t], Y[wstart + t + 128])
+    const QuadEntry *lut;
+    float *power;             // [batch][pixel_count]
+    int32_t usable, usable_pad, pixel_count, wp, chunk, batch;
+    int32_t cols, rows;
+    unsigned long long *debug_out;
+    int32_t debug;
+};
+hipError_t launch_das_quadh(const QuadhArgs &a, int qpw, hipStream_t stream);
+// `pitch` = floats between two streams of a frame (hist, or 2048 in the ingest ring), `hist` = samples of a stream's
+// history (neighbours of the filter outside it count as 0), wstart = first history sample of the window
+hipError_t launch_pack_halves(const float *d_frames, int n_streams, int pitch, int hist, int wstart, const int32_t *d_index, int usable,
+                              int rows_out, const float *d_gain, int wp, int batch, float *d_packed, hipStream_t stream);
+
 // LDS image geometry for a window of `window` samples; false if it cannot fit.
 bool fast_plan(int window, int usable, int fpi, int image_bytes, FastPlan *plan);
 int fast_image_bytes(int nw);

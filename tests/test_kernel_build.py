@@ -33,7 +33,7 @@ def test_generated_blocks_are_current():
 
     spec = importlib.util.spec_from_file_location("gen_trip_asm", REPO / "tools" / "gen_trip_asm.py")
     before = (CSRC / "das_fast_trip.inc").read_text()
-    env_backup = {k: os.environ.pop(k) for k in ("QUAD_VARIANTS", "TRIP_PRIO", "TRIP_DEPTH", "PAIR_DEPTH", "QUAD_CHAIN", "QUAD_YMAP", "QUAD_XMAP")
+    env_backup = {k: os.environ.pop(k) for k in ("QUAD_VARIANTS", "TRIP_PRIO", "TRIP_DEPTH", "PAIR_DEPTH", "QUAD_CHAIN", "QUAD_YMAP", "QUAD_XMAP", "QUAD1_TIMING_SKIP", "QUAD1_NOBRANCH", "QUAD1_EARLY_X")
                   if k in os.environ}
     try:
         mod = importlib.util.module_from_spec(spec)
@@ -47,7 +47,7 @@ def test_generated_blocks_are_current():
 
 # the shapes launch() can pick without a tuning knob (awpu_hip.cpp); stamped (diagnostic) builds and the shapes only
 # AWPU_FAST_VARIANT reaches are not timed and may spill
-PRODUCTION = [r"das_quad_kernelILb0ELi0E", r"das_quad1_kernelILi[12]ELb0E", r"das_pair_kernelILi4ELb0ELb[01]E",
+PRODUCTION = [r"das_quad_kernelILb0ELi0E", r"das_quad1_kernelILi[12]ELb0E", r"das_quadh_kernelILi[12]ELb0E", r"das_pair_kernelILi4ELb0ELb[01]E",
               r"das_pair_stationary_kernelILb[01]E", r"das_fast_db_kernelILi16ELi[48]ELi\d+ELi4ELb0E",
               r"das_fast_kernelILi8ELi[24]ELi1ELi4E", r"das_fir8_plane_kernelILi0E"]
 

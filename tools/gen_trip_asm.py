@@ -701,7 +701,7 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, un
 """
 
 
-def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP):
+def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP, dma=False):
     """The quad block for the single-frame layout, "always read" schedule.  With two register pairs per
     accumulator a mic's share of the work is only ~13 VALU instructions, too short a stage to hide an LDS read
     that is issued -- conditionally, late in the previous stage -- only when a pixel's integer delay differs from
@@ -710,8 +710,13 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
     FMAs always take their own samples, and only the correction of the shared sum (V_p += x_p - x_ref) stays
     conditional.  Pixel 2 takes the reference's samples, or pixel 3's when it carries pixel 3's address, or --
     rare -- reads on the spot.  LDS reads per mic and quad: 3 groups instead of 1.7 on average (the LDS has the
-    room: the quad arithmetic needs a third of the reads of the older shapes); VALU instructions: the same."""
+    room: the quad arithmetic needs a third of the reads of the older shapes); VALU instructions: the same.
+
+    dma=True (the halves layout of das_quadh_kernel, whose chunks are contiguous in HBM): the block also issues the
+    refill of the other LDS image, one 16 KiB piece at the head of each trip, exactly as block_quad does."""
     prio = PRIO if prio is None else prio
+    assert not (dma and stamp), "the stamped builds keep the refill outside the block (s28..s31 hold the stamps)"
+    S_SB, S_DST, S_REM, S_K, S_NP, S_M0 = 20, 25, 28, 29, 30, 31
     w = 2 * nk
     A = [acc + w * p for p in range(4)]
     T = acc + 4 * w
@@ -753,7 +758,9 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
                 [f"v_pk_add_f32 {pair(V[p], k)}, {pair(V[p], k)}, {pair(ref, k)} neg_lo:[0,1] neg_hi:[0,1]" for k in range(nk)])
 
     def issue(z, base, i):
-        return reads(Z[z]["R"], a_of(base, REF, i)) + reads(Z[z]["X0"], a_of(base, 0, i)) + reads(Z[z]["X23"], a_of(base, 3, i))
+        skip = os.environ.get("QUAD1_TIMING_SKIP", "")  # timing-only builds (wrong results): "0" = no X0 reads, "03" = neither X0 nor X23
+        return (reads(Z[z]["R"], a_of(base, REF, i)) + ([] if "0" in skip else reads(Z[z]["X0"], a_of(base, 0, i))) +
+                ([] if "3" in skip else reads(Z[z]["X23"], a_of(base, 3, i))))
 
     def stage(base, i, z):
         R, X0, X23 = Z[z]["R"], Z[z]["X0"], Z[z]["X23"]
@@ -798,9 +805,22 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
                 f"s_add_u32 s{S_TMP}, s{off}, 64",
                 f"s_load_dwordx16 s[{base + 16}:{base + 31}], %[ptr], s{S_TMP}"]
 
+    def dma_piece():
+        """one 16 KiB piece of the refill, if any is left"""
+        u = uid()
+        return [f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Ldskip{u}",
+                f"v_cmp_gt_u32 vcc, s{S_REM}, %[lbytes]",  # lanes whose 16 bytes lie inside the chunk
+                "s_mov_b64 exec, vcc",                      # (the block runs with all 64 lanes on: restored to -1 below)
+                f"s_mov_b32 m0, s{S_DST}", "s_nop 0",
+                f"global_load_lds_dwordx4 %[lbytes], s[{S_SB}:{S_SB + 1}]",
+                "s_mov_b64 exec, -1",
+                f"s_add_u32 s{S_SB}, s{S_SB}, {hex(DMA_STRIDE)}", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+                f"s_add_u32 s{S_DST}, s{S_DST}, {hex(DMA_STRIDE)}", f"s_sub_u32 s{S_REM}, s{S_REM}, {hex(DMA_STRIDE)}",
+                f"s_add_u32 s{S_K}, s{S_K}, 1", f".Ldskip{u}:"]
+
     def trip_q(par):
         cur, nxt = E[par], E[1 - par]
-        L = []
+        L = dma_piece() if dma else []
         if prio == 3 or (prio == 5 and par == 0):
             L += select_prio(S_PRIO, 1)
         elif prio == 5:
@@ -809,7 +829,8 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
         for st in range(4):
             if st < 3:
                 L += issue((st + 1) & 1, cur, st + 1)
-                L.append(f"s_waitcnt lgkmcnt({3 * nk})")  # all but the three read groups just issued
+                n_groups = 3 - len(os.environ.get("QUAD1_TIMING_SKIP", ""))
+                L.append(f"s_waitcnt lgkmcnt({n_groups * nk})")  # all but the three read groups just issued
             else:
                 L.append("s_waitcnt lgkmcnt(0)")  # this mic's samples, and the next trip's entries
                 L += issue(0, nxt, 0)
@@ -822,6 +843,10 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
     L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
     if prio == 4:
         L += select_prio(S_RANK, 0)
+    if dma:
+        L += [f"s_mov_b32 s{S_M0}, m0",
+              f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[dsrc]", f"s_mov_b32 s{S_DST}, %[ddst]", f"s_mov_b32 s{S_REM}, %[dbytes]",
+              f"s_mov_b32 s{S_K}, 0", f"s_mov_b32 s{S_NP}, %[dnp]"]
     L += load_set(E[0], 0, literal=True)
     L += [f"s_mov_b32 s{S_LEFT_}, %[ng]", f"s_movk_i32 s{S_PF_}, 0x80", "s_waitcnt lgkmcnt(0)"]
     if stamp:
@@ -832,14 +857,20 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
     L += trip_q(1)
     L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQ0_%="]
     L += ["s_branch .LQdone_%="] + cold + [".LQdone_%=:", "s_waitcnt lgkmcnt(0)"]
+    if dma:  # pieces a short chunk had no trip for
+        L += [".LQmore_%=:", f"s_cmp_ge_u32 s{S_K}, s{S_NP}", "s_cbranch_scc1 .LQnomore_%="] + dma_piece() + ["s_branch .LQmore_%=", ".LQnomore_%=:",
+              f"s_mov_b32 m0, s{S_M0}"]
     if prio:
         L += [f"s_setprio {BLOCK_END_PRIO}"]
     if stamp:
         L += [f"s_memtime s[{S_T1}:{S_T1 + 1}]", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 %[t_all], s{S_T1}, s{S_T0}"]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
     vregs = list(range(tmp, tmp + n_tmp))
-    sregs = sorted({S_TMP, S_PF_, S_LEFT_, S_RANK, S_PRIO, S_T0, S_T0 + 1, S_T1, S_T1 + 1}) + list(range(36, 100))
-    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
+    sregs = sorted({S_TMP, S_PF_, S_LEFT_, S_RANK, S_PRIO, S_T0, S_T0 + 1, S_T1, S_T1 + 1} |
+                   ({S_SB, S_SB + 1, S_DST, S_REM, S_K, S_NP, S_M0} if dma else set())) + list(range(36, 100))
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'] + (['"vcc"'] if dma else []))
+    dma_params = ", const void *dsrc, unsigned ddst, unsigned dbytes, unsigned lbytes, unsigned dnp" if dma else ""
+    dma_ops = ', [dsrc] "s"(dsrc), [ddst] "s"(ddst), [dbytes] "s"(dbytes), [lbytes] "v"(lbytes), [dnp] "s"(dnp)' if dma else ""
     names = [f"A{p}" for p in range(4)] + ["T"] + [f"V{p}" for p in (0, 2, 3)]
     bases = A + [T] + [V[0], V[2], V[3]]
     vt = "f8" if nk == 4 else "f4"
@@ -850,11 +881,11 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
     return f"""// Four vertically adjacent pixels of the staged chunk, single-frame layout, shared integer-delay sum, reads always
 // one stage ahead: see block_quad_ar in tools/gen_trip_asm.py.  `row` = the quad's entries of the chunk's first
 // group in the quad-major table; reads one group past the last.  Accumulators pinned from v{acc}, temps v{vregs[0]}..v{vregs[-1]}.
-__device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, unsigned lane_addr, int rank{stamp_params}) {{
+__device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, unsigned lane_addr, int rank{dma_params}{stamp_params}) {{
     asm volatile(
 {body}
         : {acc_ops}{stamp_ops}
-        : [ptr] "s"(row), [ng] "s"(ng), [lane] "v"(lane_addr), [rank] "s"(rank)
+        : [ptr] "s"(row), [ng] "s"(ng), [lane] "v"(lane_addr), [rank] "s"(rank){dma_ops}
         : {clobbers});
 }}
 """
@@ -1053,6 +1084,7 @@ def main():
     for q, base in enumerate(QUAD1_ACC):  # single-frame layout, first / second quad of a wave
         out.append(block_quad_ar(f"sweep_quad1_sum_{'ab'[q]}", nk=2, acc=base, tmp=QUAD1_TMP))
     out.append(block_quad_ar("sweep_quad1_sum_a_stamped", stamp=True, nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP))
+    out.append(block_quad_ar("sweep_quad1_sum_a_dma", nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP, dma=True))  # das_quadh_kernel
     if os.environ.get("QUAD1_EARLY_X"):  # tuning builds: conditional reads at the head of the stage (measured: 79 vs 71 us)
         for q, base in enumerate(QUAD1_ACC):
             out.append(block_quad(f"sweep_quad1_early_{'ab'[q]}", nk=2, acc=base, tmp=QUAD1_TMP, early_x=True))
