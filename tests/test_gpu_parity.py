@@ -1347,3 +1347,30 @@ def test_random_display_and_beam_shapes(pkg, oracle):
         want_p, want_b = oracle.particle_beams(X, off, frac, index)
         assert np.array_equal(beams, want_b), (n_streams, hist, n_dir, usable)
         assert util.power_rel_err(power, want_p) < 2e-6
+
+
+def test_bench_two_ranks_on_one_gpu_assemble_the_oracle_heatmap():
+    """bench.py's N > 1 path end to end, rehearsed with two ranks on the one GPU of the box over gloo (BENCH_REHEARSAL=1:
+    a logic check, not a measurement): row groups dealt round-robin, rank 0 packs on its side stream, the packed frame
+    pairs travel, both ranks sweep them, the collective trial picks a schedule, and the heatmap assembled from the two
+    tiles equals the oracle's on EVERY pixel, unfloored (BENCH_GATHER_CHECK=1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    repo = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_REHEARSAL="1", BENCH_GATHER_CHECK="1")
+    for exchange in ("packed", "window"):
+        env["BENCH_EXCHANGE"] = exchange
+        proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "2", "--warmup", "1",
+                               "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=600)
+        assert proc.returncode == 0, proc.stderr[-3000:]
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, proc.stdout[-2000:]
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["frames_per_step"] == 256
+        assert rec["parity"]["ok"] and rec["parity"]["pixels"] == 2048  # rank 0's share: 32 of the 64 rows
+        assert ("packed frame pairs" in rec["config"]["sharding"]) == (exchange == "packed")
+        assert "gather check: ok" in proc.stderr, proc.stderr[-3000:]
