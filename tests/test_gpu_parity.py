@@ -1360,7 +1360,8 @@ def test_bench_two_ranks_on_one_gpu_assemble_the_oracle_heatmap():
     import sys
 
     repo = Path(__file__).resolve().parent.parent
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AWPU_NO_BUILD")}  # (not under a profiler here)
     env.update(BENCH_REHEARSAL="1", BENCH_GATHER_CHECK="1")
     for exchange in ("packed", "window"):
         env["BENCH_EXCHANGE"] = exchange
