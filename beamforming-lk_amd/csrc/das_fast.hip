@@ -1309,6 +1309,24 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         if (item_next < run_end) decode(item_next, pair_next, tile_next);
 
         f8 A0 = {0, 0, 0, 0, 0, 0, 0, 0}, A1 = A0, A2 = A0, A3 = A0, T = A0, V0 = A0, V2 = A0, V3 = A0;
+        if constexpr (!DIAG && VAR == 0) {
+            // The production build sweeps the whole item in ONE block: chunk loop, refill, vmcnt wait and workgroup barrier
+            // inside the asm (sweep_quad_item), so that a chunk begins on table entries that are in SGPRs already.
+            const int buf = step & 1;
+            unsigned lane_addr = lds_base + buf * BUF + lane * 8;
+            const int ngf = __builtin_amdgcn_readfirstlane(chunk_mics(0) >> 2);
+            const int ngl = __builtin_amdgcn_readfirstlane(chunk_mics((n_chunks - 1) * a.chunk) >> 2);
+            const unsigned dbf = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) a.chunk * row_floats * 4));
+            const unsigned dbl = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) ngl * 4 * row_floats * 4));
+            const bool more = item_next < run_end;
+            const float *nsrc = more ? a.packed + (size_t) pair_next * a.usable_pad * row_floats : pair_base;
+            const unsigned dbn = __builtin_amdgcn_readfirstlane(more ? (unsigned) ((size_t) chunk_mics(0) * row_floats * 4) : 0u);
+            const unsigned ddst = __builtin_amdgcn_readfirstlane(lds_base + (buf ^ 1) * BUF + wave * 1024);
+            const int delta = __builtin_amdgcn_readfirstlane(buf ? -BUF : BUF);
+            sweep_quad_item(A0, A1, A2, A3, T, V0, V2, V3, uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
+                            lane_addr, rank, uniform_ptr(pair_base), dbf, dbl, uniform_ptr(nsrc), dbn, ddst, delta, lane_bytes, wave);
+            step += n_chunks;
+        } else
         for (int c = 0; c < n_chunks; c++, step++) {
             const int m0 = c * a.chunk;
             const int mc4 = chunk_mics(m0);

@@ -444,7 +444,7 @@ QUAD_XMAP = tuple(int(x) for x in os.environ.get("QUAD_XMAP", "0,1,2,3").split("
 CHAIN = int(os.environ.get("QUAD_CHAIN", "1"))  # frame-pair quad blocks: V3 = S3 - S2 (a step in the column costs one difference, wherever it lies)
 
 
-def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, dma=False, early_x=False, chain=False):
+def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, dma=False, early_x=False, chain=False, item=False):
     """dma=True: the block also issues the refill of the other LDS image (the next chunk: `dbytes` bytes from `dsrc`,
     16 KiB pieces of 64 lanes x 16 bytes per wave, this wave's first piece landing at LDS address `ddst`), one
     piece at the head of each trip instead of all of them before the sweep: the 16 waves of the workgroup then do not
@@ -644,6 +644,8 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
             L += ref_ops(cur, st, rslot)
         return L
 
+    if item:
+        return _block_quad_item(name, locals())
     L = []
     if stamp:
         L += [f"s_memtime s[{S_T0}:{S_T0 + 1}]", "s_waitcnt lgkmcnt(0)"]
@@ -696,6 +698,114 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, un
 {body}
         : {acc_ops}{stamp_ops}
         : [ptr] "s"(row), [ng] "s"(ng), [lane] "v"(lane_addr), [rank] "s"(rank){dma_ops}
+        : {clobbers});
+}}
+"""
+
+
+def _block_quad_item(name, env):
+    """The quad block for a WHOLE item (frame pair x tile): the chunk loop, the wait for the refill and the workgroup
+    barrier live inside the block.  A chunk's trips run exactly as in block_quad(dma=True); at a chunk's end the block
+    drains its reads, issues what is left of the refill, waits for its own pieces (vmcnt(0)), meets the workgroup at
+    s_barrier, flips to the other LDS image and goes on -- with the NEXT chunk's first table entries already in
+    SGPRs (the table of a quad is contiguous across chunks, and the running prefetch has fetched them during the last
+    trip), where a block per chunk began by waiting for its first two scalar loads with every wave of the workgroup in
+    the same place.  The refill runs one chunk ahead across the whole item and on into the next item's first chunk.
+    Inputs (all wave-uniform): ngf / ngl = groups of four mics in a full / in the last chunk, nch = chunks,
+    isrc = chunk 0's rows in HBM (chunk c's follow dbf bytes apart), dbf / dbl = bytes of a full / the last chunk,
+    nsrc, dbn = the next item's first chunk (dbn = 0: none), ddst = this wave's first LDS-DMA destination in the image
+    that chunk 0 does NOT occupy, delta = (that image) - (chunk 0's image) in bytes."""
+    g = env
+    S_SB, S_DST, S_REM, S_K, S_NP, S_M0 = g["S_SB"], g["S_DST"], g["S_REM"], g["S_K"], g["S_NP"], g["S_M0"]
+    S_TMP, S_PF_, S_LEFT_ = g["S_TMP"], g["S_PF_"], g["S_LEFT_"]
+    E, R, REF_ = g["E"], g["R"], REF
+    reads, maybe_read_x, trip_q, load_set, dma_piece, a_of, cold, uid = (g["reads"], g["maybe_read_x"], g["trip_q"], g["load_set"],
+                                                                        g["dma_piece"], g["a_of"], g["cold"], g["uid"])
+    nk, acc, tmp, A, T, V, prio = g["nk"], g["acc"], g["tmp"], g["A"], g["T"], g["V"], g["prio"]
+    S_CH, S_DELTA = 100, 35  # chunks left (this one included); byte distance to the OTHER image, sign flipping per chunk
+    assert nk == 4 and g["dma"] and not g["stamp"]
+
+    def first_reads(base):
+        g["xz"][0] = 0
+        return reads(R[0], a_of(base, REF_, 0)) + maybe_read_x(3, base, 0) + maybe_read_x(0, base, 0)
+
+    def refill_params(first):
+        """S_SB / S_REM / S_NP / S_K for the refill that runs beside the chunk about to be swept; S_CH = chunks left with
+        that chunk included.  first: S_SB holds chunk 0's source; else S_SB / S_DST have advanced S_K pieces."""
+        u = uid()
+        L = []
+        if not first:
+            L += [f"s_lshl_b32 s{S_TMP}, s{S_K}, {DMA_STRIDE.bit_length() - 1}",   # undo the pieces' advance
+                  f"s_sub_u32 s{S_SB}, s{S_SB}, s{S_TMP}", f"s_subb_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+                  f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_TMP}",
+                  f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_DELTA}",            # the refill alternates images like the sweep, one ahead
+                  f"s_sub_u32 s{S_DELTA}, 0, s{S_DELTA}"]
+        L += [f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cbranch_scc1 .Lrnext{u}",
+              # another chunk of this item follows the one about to be swept: its rows lie dbf bytes on
+              f"s_add_u32 s{S_SB}, s{S_SB}, %[dbf]", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+              f"s_mov_b32 s{S_REM}, %[dbf]", f"s_cmp_eq_u32 s{S_CH}, 2", f"s_cselect_b32 s{S_REM}, %[dbl], s{S_REM}",
+              f"s_branch .Lrset{u}", f".Lrnext{u}:",
+              # the chunk about to be swept is the item's last: the refill is the next item's first chunk (or nothing)
+              f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[nsrc]", f"s_mov_b32 s{S_REM}, %[dbn]",
+              f".Lrset{u}:",
+              f"s_mov_b32 s{S_K}, 0", f"s_add_u32 s{S_NP}, s{S_REM}, {DMA_STRIDE - 1}",
+              f"s_lshr_b32 s{S_NP}, s{S_NP}, {DMA_STRIDE.bit_length() - 1}"]
+        if DMA_WAVES < 16:
+            L += [f"s_cmp_ge_u32 %[wave], {DMA_WAVES}", f"s_cselect_b32 s{S_NP}, 0, s{S_NP}"]
+        return L
+
+    def boundary(next_set, resume):
+        u = uid()
+        L = ["s_waitcnt lgkmcnt(0)",  # this chunk's last samples, and the reads issued for a trip that does not come
+             f".LQmore{u}:", f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .LQnomore{u}"] + dma_piece() + [f"s_branch .LQmore{u}", f".LQnomore{u}:"]
+        L += ["s_waitcnt vmcnt(0)", "s_barrier",  # my pieces of the next chunk have landed; so has everybody's, and all are done with this image
+              f"s_sub_u32 s{S_CH}, s{S_CH}, 1", f"s_cmp_eq_u32 s{S_CH}, 0", "s_cbranch_scc1 .LQexit_%=",
+              f"v_add_u32 %[lane], s{S_DELTA}, %[lane]"]  # the sweep moves to the image just filled
+        L += refill_params(first=False)
+        L += [f"s_mov_b32 s{S_LEFT_}, %[ngf]", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cselect_b32 s{S_LEFT_}, %[ngl], s{S_LEFT_}"]
+        L += first_reads(next_set) + [f"s_branch {resume}"]
+        return L
+
+    L = [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    if prio == 4:
+        L += select_prio(S_RANK, 0)
+    L += [f"s_mov_b32 s{S_M0}, m0", f"s_mov_b32 s{S_CH}, %[nch]", f"s_mov_b32 s{S_DELTA}, %[delta]",
+          f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[isrc]", f"s_mov_b32 s{S_DST}, %[ddst]"]
+    L += refill_params(first=True)
+    L += load_set(E[0], 0, literal=True)
+    L += [f"s_mov_b32 s{S_LEFT_}, %[ngf]", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cselect_b32 s{S_LEFT_}, %[ngl], s{S_LEFT_}",
+          f"s_movk_i32 s{S_PF_}, 0x80", "s_waitcnt lgkmcnt(0)"]
+    L += first_reads(E[0])
+    L += [".LQ0_%=:"] + trip_q(0)
+    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_eq_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQbndA_%="]
+    L += [".LQ1_%=:"] + trip_q(1)
+    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LQ0_%="]
+    L += boundary(E[0], ".LQ0_%=")                    # the chunk ended on a trip out of set 1: the next begins on set 0
+    L += [".LQbndA_%=:"] + boundary(E[1], ".LQ1_%=")  # ... on a trip out of set 0: the next begins on set 1
+    L += cold
+    L += [".LQexit_%=:", f"s_mov_b32 m0, s{S_M0}"]
+    if prio:
+        L += [f"s_setprio {QUAD_END_PRIO}"]
+    body = "\n".join(f'        "{l}\\n\\t"' for l in L)
+    vregs = list(range(tmp, tmp + 8 * nk + 1))
+    sregs = sorted({S_TMP, S_PF_, S_LEFT_, S_RANK, S_PRIO, S_SB, S_SB + 1, S_DST, S_REM, S_K, S_NP, S_M0, S_CH, S_DELTA}) + list(range(36, 100))
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"', '"vcc"', '"memory"'])
+    names = [f"A{p}" for p in range(4)] + ["T"] + [f"V{p}" for p in (0, 2, 3)]
+    bases = A + [T] + [V[0], V[2], V[3]]
+    acc_params = ", ".join(f"f8 &{n}" for n in names)
+    acc_ops = ", ".join(f'"+{{v[{b}:{b + 2 * nk - 1}]}}"({n})' for n, b in zip(names, bases))
+    return f"""// A whole item (frame pair x tile) of the quad shape: chunk loop, refill, vmcnt wait and workgroup barrier inside the
+// block (_block_quad_item in tools/gen_trip_asm.py).  `row` = the quad's entries of the item's first group (contiguous
+// across chunks); lane_addr is the sweep's LDS address in chunk 0's image on entry and wherever the last flip left it
+// on exit (the caller tracks the image by the chunk count).  Executes nch s_barrier instructions.
+__device__ __forceinline__ void {name}({acc_params}, const void *row, int ngf, int ngl, int nch, unsigned &lane_addr, int rank,
+                                       const void *isrc, unsigned dbf, unsigned dbl, const void *nsrc, unsigned dbn, unsigned ddst,
+                                       int delta, unsigned lbytes, int wave) {{
+    asm volatile(
+{body}
+        : {acc_ops}, [lane] "+v"(lane_addr)
+        : [ptr] "s"(row), [ngf] "s"(ngf), [ngl] "s"(ngl), [nch] "s"(nch), [rank] "s"(rank), [isrc] "s"(isrc), [dbf] "s"(dbf), [dbl] "s"(dbl),
+          [nsrc] "s"(nsrc), [dbn] "s"(dbn), [ddst] "s"(ddst), [delta] "s"(delta), [lbytes] "v"(lbytes), [wave] "s"(wave)
         : {clobbers});
 }}
 """
@@ -1080,6 +1190,7 @@ def main():
     out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))
     out.append(block_quad("sweep_quad_sum_dma", dma=True, chain=CHAIN))
+    out.append(block_quad("sweep_quad_item", dma=True, chain=CHAIN, item=True))  # the production batch kernel: one block per item
     out.append(block_quad("sweep_quad_sum_stamped", stamp=True, chain=CHAIN))
     for q, base in enumerate(QUAD1_ACC):  # single-frame layout, first / second quad of a wave
         out.append(block_quad_ar(f"sweep_quad1_sum_{'ab'[q]}", nk=2, acc=base, tmp=QUAD1_TMP))
