@@ -20,7 +20,7 @@ OPENCV_CFLAGS ?= -Itests/host/mock_opencv
 lib: $(LIB)
 
 $(LIB): $(KERNEL_SRC) $(CSRC)/das_kernels.h $(CSRC)/das_fast_trip.inc include/awpu_hip.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-result -x hip \
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-result -Werror=inline-asm -x hip \
 	    -Iinclude -I$(CSRC) $(KERNEL_SRC) -o $@
 
 # the hand-scheduled inner loops are generated (tools/gen_trip_asm.py documents the schedule and its knobs)

@@ -60,6 +60,7 @@ def _compile(verbose: bool) -> Path:
         "-shared",
         "-Wall",
         "-Wno-unused-result",
+        "-Werror=inline-asm",  # e.g. a reserved register on a hand-written block's clobber list: undefined behaviour, not a warning
         "-x", "hip",
         f"-I{REPO / 'include'}",
         f"-I{CSRC}",

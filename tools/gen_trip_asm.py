@@ -722,7 +722,7 @@ def _block_quad_item(name, env):
     reads, maybe_read_x, trip_q, load_set, dma_piece, a_of, cold, uid = (g["reads"], g["maybe_read_x"], g["trip_q"], g["load_set"],
                                                                         g["dma_piece"], g["a_of"], g["cold"], g["uid"])
     nk, acc, tmp, A, T, V, prio = g["nk"], g["acc"], g["tmp"], g["A"], g["T"], g["V"], g["prio"]
-    S_CH, S_DELTA = 100, 35  # chunks left (this one included); byte distance to the OTHER image, sign flipping per chunk
+    S_CH, S_DELTA = 19, 35  # chunks left (this one included); byte distance to the OTHER image, sign flipping per chunk
     assert nk == 4 and g["dma"] and not g["stamp"]
 
     def first_reads(base):
