@@ -1375,3 +1375,25 @@ def test_bench_two_ranks_on_one_gpu_assemble_the_oracle_heatmap():
         assert rec["parity"]["ok"] and rec["parity"]["pixels"] == 2048  # rank 0's share: 32 of the 64 rows
         assert ("packed frame pairs" in rec["config"]["sharding"]) == (exchange == "packed")
         assert "gather check: ok" in proc.stderr, proc.stderr[-3000:]
+
+
+def test_dc_offset_frames_batched_sweep_is_closer_to_exact_than_the_reference(pkg, oracle):
+    """Samples with a DC offset (an ADC bias the wire format does not remove): the reference sums 256 mics' worth of
+    the offset into every out[i] and lets its moving-average stencil cancel it again -- in fp32 that cancellation costs
+    it several digits (its distance to exact fp64 sums grows a hundredfold).  The batched sweep applies the stencil to
+    the samples first, so the offset never enters a sum: its result stays at fp32 precision of the
+    exact one.  Parity against the reference's arithmetic then holds within the reference's own error, which is what
+    util.parity_report's bound (3 x ref_f32_vs_f64) says; and the GPU is the closer of the two to exact."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c2"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 10, seed=71) + np.float32(0.25)
+    power, _ = run_engine(pkg, frames, off, frac, grid_columns=spec.res)
+    for b in (0, 9):
+        r32, r64 = oracle.das_f32(frames[b], off, frac), oracle.das_f64(frames[b], off, frac)
+        rep = util.parity_report(power[b], r32, r64)
+        print(f"parity DC-offset frame {b}: {rep}")
+        assert rep["ok"], rep
+        assert rep["ref_f32_vs_f64_unfloored"] > 1e-5  # the reference's own cancellation noise ...
+        assert rep["gpu_vs_f64_unfloored"] < 0.2 * rep["ref_f32_vs_f64_unfloored"]  # ... which the pre-filtered sweep does not have
