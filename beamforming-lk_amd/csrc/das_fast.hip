@@ -1368,24 +1368,16 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                 next_mc4 = chunk_mics(0);
             }
             if (AWPU_DBG(a, 1)) next_mc4 = 0;
-            if constexpr (!DIAG && VAR == 0) {
-                // ... issued by the sweep block itself, one 16 KiB piece per trip (tools/gen_trip_asm.py, dma=True)
-                const void *row = uniform_ptr(quad_lut + (size_t) (m0 >> 2) * 16);
-                const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds_base + (buf ^ 1) * BUF + wave * 1024);
-                const unsigned n_bytes = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) next_mc4 * row_floats * 4));
-                const unsigned dnp = wave < kQuadDmaWaves ? (n_bytes + kQuadDmaWaves * 1024 - 1) / (kQuadDmaWaves * 1024) : 0;
-                sweep_quad_sum_dma(A0, A1, A2, A3, T, V0, V2, V3, row, ng, lane_addr, rank, uniform_ptr(next_src), dst0, n_bytes, lane_bytes, dnp);
-            } else {
-                if (g_head > 0) sweep(0, g_head);
-                long long t_dma = DIAG ? __builtin_readcyclecounter() : 0;
-                if (next_mc4) dma_chunk(next_src, next_mc4, buf ^ 1);
-                if (DIAG) {
-                    const long long n = __builtin_readcyclecounter();
-                    t_ph[0] += (unsigned) (n - t_dma);
-                    t += n - t_dma;  // (the sweep's share below excludes it)
-                }
-                if (ng - g_head > 0) sweep(g_head, ng - g_head);
+            // (the stamped and the tuning builds: one block per chunk, the refill issued here, outside the block)
+            if (g_head > 0) sweep(0, g_head);
+            long long t_dma = DIAG ? __builtin_readcyclecounter() : 0;
+            if (next_mc4) dma_chunk(next_src, next_mc4, buf ^ 1);
+            if (DIAG) {
+                const long long n = __builtin_readcyclecounter();
+                t_ph[0] += (unsigned) (n - t_dma);
+                t += n - t_dma;  // (the sweep's share below excludes it)
             }
+            if (ng - g_head > 0) sweep(g_head, ng - g_head);
             stamp(1, t);
             // (no 257th-sample pass: the rows carry pre-filtered samples, pack_one_row<true>)
             if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -1189,7 +1189,6 @@ def main():
     out.append(block_shared("sweep_duo_shared_stamped", 128 - 25 - 3, stamp=True))
     out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))
-    out.append(block_quad("sweep_quad_sum_dma", dma=True, chain=CHAIN))
     out.append(block_quad("sweep_quad_item", dma=True, chain=CHAIN, item=True))  # the production batch kernel: one block per item
     out.append(block_quad("sweep_quad_sum_stamped", stamp=True, chain=CHAIN))
     for q, base in enumerate(QUAD1_ACC):  # single-frame layout, first / second quad of a wave
