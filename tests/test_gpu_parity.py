@@ -1397,3 +1397,45 @@ def test_dc_offset_frames_batched_sweep_is_closer_to_exact_than_the_reference(pk
         assert rep["ok"], rep
         assert rep["ref_f32_vs_f64_unfloored"] > 1e-5  # the reference's own cancellation noise ...
         assert rep["gpu_vs_f64_unfloored"] < 0.2 * rep["ref_f32_vs_f64_unfloored"]  # ... which the pre-filtered sweep does not have
+
+
+def test_packed_entry_points_refuse_what_they_cannot_sweep(pkg, oracle):
+    """awpu_hip_packed_bytes / pack_frames / process_packed: argument and state errors come back as statuses, nothing
+    is launched -- a batch beyond max_batch, no table yet, the exact-order and FIR8 modes, mic gains."""
+    import torch
+
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    d = torch.zeros(1 << 20, dtype=torch.float32, device="cuda")
+    B = pkg.binding
+    with pkg.Engine(n_pixels=spec.n_pixels, max_batch=4, grid_columns=spec.res) as eng:
+        with pytest.raises(pkg.AwpuError) as ei:  # no table, no mic list yet
+            eng.packed_bytes(2)
+        assert ei.value.status == B.ERR_STATE
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        assert eng.packed_bytes(4) == 2 * 64 * eng.packed_bytes(2) // (1 * 64)  # two pairs = twice one pair
+        with pytest.raises(pkg.AwpuError) as ei:
+            eng.packed_bytes(5)  # beyond max_batch
+        assert ei.value.status == B.ERR_INVALID
+        with pytest.raises(pkg.AwpuError):
+            eng.pack_frames(0, 2, d.data_ptr())
+        with pytest.raises(pkg.AwpuError):
+            eng.process_packed(d.data_ptr(), 2, 0)
+        eng.set_mic_gains(np.full(64, 2.0, np.float32))
+        with pytest.raises(pkg.AwpuError) as ei:  # gains are applied by the sweep's own pack pass, not by a shared one
+            eng.packed_bytes(2)
+        assert ei.value.status == B.ERR_STATE
+        eng.set_mic_gains(None)
+        assert eng.packed_bytes(2) > 0
+    for kw in (dict(math=pkg.MATH_F32_EXACT), dict(interp=B.INTERP_FIR8)):
+        with pkg.Engine(n_pixels=spec.n_pixels, max_batch=4, **kw) as eng:
+            eng.set_delay_table(np.minimum(off, 1024 - 263).astype(np.int32), frac)
+            eng.set_active_mics(None)
+            if "interp" in kw:
+                eng.set_fir_table(util.synthetic_fir_table())
+            with pytest.raises(pkg.AwpuError) as ei:
+                eng.packed_bytes(2)
+            assert ei.value.status == B.ERR_STATE
