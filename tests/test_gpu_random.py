@@ -28,8 +28,10 @@ pytestmark = pytest.mark.gpu
     {"AWPU_FAST_QUADS": "0", "AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},  # pair shape on the same tables
     {"AWPU_FAST_STATIONARY": "1", "AWPU_FAST_PAIRS": "1"},                          # stationary pair shape wherever the window fits the LDS
     {"AWPU_FAST_STATIONARY": "1", "AWPU_FAST_PAIRS": "1", "AWPU_TEST_GRID": "1", "AWPU_FAST_QUADS": "0", "AWPU_TEST_COINCIDE": "1"},
+    {"AWPU_FAST_QUADS": "1", "AWPU_TEST_GRID": "1", "AWPU_FAST_PAIRS": "0"},                             # single-frame quad shape on the halves layout for every call
+    {"AWPU_FAST_QUADS": "1", "AWPU_TEST_GRID": "1", "AWPU_FAST_PAIRS": "0", "AWPU_FAST_HALVES": "0", "AWPU_TEST_COINCIDE": "1"},  # ... round 2's in-place kernel
 ], ids=["pairs", "db", "small", "fpi2", "exact", "device", "fir8", "fir8_planes", "reuse", "pairs_vertical", "pairs_unshared",
-        "quads_random", "quads_coincide", "pairs_coincide", "stationary", "stationary_grid"])
+        "quads_random", "quads_coincide", "pairs_coincide", "stationary", "stationary_grid", "quadh_every_call", "quad1_in_place"])
 def test_random_tables(env):
     out = subprocess.run([sys.executable, str(REPO / "tests" / "gpu_random_check.py"), "2024", "14"],
                          env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)

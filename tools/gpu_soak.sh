@@ -19,6 +19,8 @@ for seed in ${SEEDS:-11 12 13}; do
   run quads_coincide $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
   run stationary $seed 20 AWPU_FAST_STATIONARY=1 AWPU_FAST_PAIRS=1
   run stationary_grid $seed 20 AWPU_FAST_STATIONARY=1 AWPU_FAST_PAIRS=1 AWPU_TEST_GRID=1 AWPU_FAST_QUADS=0 AWPU_TEST_COINCIDE=1
+  run quadh_every_call $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1 AWPU_FAST_PAIRS=0
+  run quad1_in_place $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1 AWPU_FAST_PAIRS=0 AWPU_FAST_HALVES=0 AWPU_TEST_COINCIDE=1
   run fir8_planes $seed 20 AWPU_TEST_INTERP=fir8 AWPU_FIR8_PLANES=2
   run fir8 $seed 12 AWPU_TEST_INTERP=fir8
   run default_grid $seed 20 AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
