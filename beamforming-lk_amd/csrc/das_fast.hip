@@ -1106,14 +1106,32 @@ __host__ __device__ constexpr uint32_t fir_plane_entry(uint32_t addr, uint32_t p
 // lut: [pixel][usable_pad] entries (+ 4 spare), usable_pad and the chunk multiples of 4 (null entries: coefficient
 // row 101 on row 0); coeffs [128][8]: the caller's 101 rows, then zeros.
 template <int VAR>
-__global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, const FirPlaneEntry *lut, const float *coeffs) {
+__global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, const FirPlaneEntry *lut, const float *coeffs, int n_tiles,
+                                                                 int pair_group) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = 16, PPW = 4, kThreads = NW * 64, BUF = kFastLdsBytes;
     constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
-    const int pair = blockIdx.x, tile = blockIdx.y;
+    // Item order as in das_quad_kernel: the (frame pair, tile) items, ordered (pair group, tile, pair), are cut into 8
+    // contiguous runs, one per XCD (blockIdx & 7: round-robin placement, assumed for speed only), so that the workgroups an
+    // XCD runs side by side sweep `pair_group` frame pairs x consecutive tiles: the pairs' packed samples stay in that
+    // XCD's L2 instead of 32 different pairs streaming through it.
+    const int n_pairs = (a.batch + 1) / 2;
+    const int total = n_pairs * n_tiles;
+    const int per_xcd = (total + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int) (blockIdx.x >> 3) >= per_xcd || item >= total) return;  // (uniform for the workgroup)
+    int pair, tile;
+    {
+        const int full_items = (n_pairs / pair_group) * pair_group * n_tiles;  // items of whole pair groups
+        const int ga = item < full_items ? pair_group : n_pairs % pair_group;  // the last group may be smaller
+        const int rem = item < full_items ? item : item - full_items;
+        const int grp = rem / (n_tiles * ga), in = rem - grp * n_tiles * ga;
+        tile = in / ga;
+        pair = (item < full_items ? grp * pair_group : n_pairs - ga) + (in - tile * ga);
+    }
     const int pix0 = (tile * NW + wave) * PPW;
     const size_t row_floats = (size_t) a.wp * 2;
     const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
@@ -1957,9 +1975,16 @@ static hipError_t launch_fir8_plane_variant(const PairArgs &a, const void *d_ent
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_fir8_plane_kernel<VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
-    dim3 grid((a.batch + 1) / 2, (a.pixel_count + 63) / 64);
-    if (grid.y > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(das_fir8_plane_kernel<VAR>, grid, dim3(1024), lds_bytes, stream, a, (const FirPlaneEntry *) d_entries, d_coeffs);
+    const int n_pairs = (a.batch + 1) / 2, n_tiles = (a.pixel_count + 63) / 64;
+    // frame pairs an XCD works on at a time: as many as keep their packed samples in its 4 MiB L2 beside the table slices
+    const size_t pair_bytes = (size_t) a.usable * a.wp * 8;
+    int g = (int) std::max<size_t>(1, (3u << 20) / pair_bytes);
+    g = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;
+    while (g > 1 && g > n_pairs) g >>= 1;
+    const long total = (long) n_pairs * n_tiles;
+    const long per_xcd = (total + 7) / 8;
+    hipLaunchKernelGGL(das_fir8_plane_kernel<VAR>, dim3((unsigned) (8 * per_xcd)), dim3(1024), lds_bytes, stream, a,
+                       (const FirPlaneEntry *) d_entries, d_coeffs, n_tiles, g);
     return hipGetLastError();
 }
 
