@@ -158,14 +158,14 @@ class LocalCopyExchange:
 
     mode = "local_copy"
 
-    def __init__(self, buffers: Tuple[torch.Tensor, torch.Tensor], arrival: torch.Tensor):
+    def __init__(self, buffers: Tuple[torch.Tensor, torch.Tensor], arrival: torch.Tensor, priority: int = 0):
         if arrival.shape != buffers[0].shape:
             raise ValueError("arrival must have the shape of a batch buffer")
         self.buffers = buffers
         self.arrival = arrival
         self.cuda = buffers[0].is_cuda
         if self.cuda:
-            self.side = torch.cuda.Stream(device=buffers[0].device)
+            self.side = torch.cuda.Stream(device=buffers[0].device, priority=priority)
             self.posted = [torch.cuda.Event(), torch.cuda.Event()]
             self.landed = [torch.cuda.Event(), torch.cuda.Event()]
         self._pending = [False, False]

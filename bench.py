@@ -339,11 +339,14 @@ class RankJob:
                 n = min(distinct, B - b0)
                 self.d_full[b0:b0 + n] = self.d_full[:n]
         # a real (non-null) stream: its handle goes to the C ABI, and the torch events that time the sweep are
-        # recorded on the same stream; `aux` carries the root's pack / window cut and the collectives' enqueue point
-        # (the sweep's stream has the higher priority: where both have work ready, the dispatcher serves the sweep first and
-        # the pack / copy kernels fill what is left)
-        self.stream = torch.cuda.Stream(device=dev, priority=-1)
-        self.aux = torch.cuda.Stream(device=dev, priority=0)
+        # recorded on the same stream; `aux` carries the root's pack / window cut and the collectives' enqueue point.
+        # Both at the default priority: measured through projected_scaling (tools/gpu_prio.sh, two alternating runs on one
+        # box), step wall of the root / of a peer: sweep above aux 4.99-5.03 / 4.68-4.69 ms, aux above sweep 4.99-5.00 /
+        # 4.55-4.59, equal 4.93-4.95 / 4.55-4.56 -- a starved side stream delivers the next batch late, a starved sweep
+        # is simply slower.  BENCH_STREAM_PRIO="sweep,aux" overrides for tuning runs.
+        prio = [int(x) for x in os.environ.get("BENCH_STREAM_PRIO", "0,0").split(",")]
+        self.stream = torch.cuda.Stream(device=dev, priority=prio[0])
+        self.aux = torch.cuda.Stream(device=dev, priority=prio[1])
         self.swept = [torch.cuda.Event(), torch.cuda.Event()]
         if self.exchange == "packed":
             pairs = B // 2
@@ -361,7 +364,7 @@ class RankJob:
             self.arrival = torch.empty_like(self.bufs[0])
             torch.cuda.synchronize()
             self.fill(self.arrival, torch.cuda.current_stream(dev))
-            self.bcast = sharding.LocalCopyExchange(self.bufs, self.arrival)
+            self.bcast = sharding.LocalCopyExchange(self.bufs, self.arrival, priority=prio[1])
         else:
             self.bcast = sharding.FrameBroadcaster(self.bufs, src=0, mode=os.environ.get("BENCH_BCAST", "broadcast"))
         torch.cuda.synchronize()
