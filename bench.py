@@ -756,24 +756,26 @@ def main():
 
 
 def other_workloads(pkg, sharding, torch, dist, args, dev, local_rank):
-    """The other BASELINE shapes in the same driver-timed run, compactly: 3 timed steps each (1 warm-up), the sweep
+    """The other BASELINE shapes in the same driver-timed run, compactly: a few timed steps each, the sweep
     launch timed by events on its stream, parity of frame 0 on every pixel."""
     S = pkg.synthetic
     out = []
-    for name, batch in (("c2", 128), ("c3", 128), ("c5", 1024)):
+    # (steps, warm-up): the short launches get more of both -- three c2 steps after one warm-up step ran 17 % below the
+    # rate of a 20-step run of the same workload (profiles/r03_bench_c2.json: the clocks and the caches had not settled)
+    for name, batch, K, W in (("c2", 128, 12, 6), ("c3", 128, 4, 2), ("c5", 1024, 3, 1)):
         c5 = name == "c5"
         spec = S.WORKLOADS["c4" if c5 else name]
         t0 = time.perf_counter()
         sub = argparse.Namespace(**vars(args))
         job = RankJob(pkg, sharding, torch, dist, sub, spec, 1, 0, dev, local_rank, batch, c5=c5)
-        elapsed, kernel_ms, _ = job.timed(3, 1)
+        elapsed, kernel_ms, _ = job.timed(K, W)
         st = job.eng.stats()
         par = full_grid_parity(job.d_power[0].cpu().numpy(), job.host_first[0], job.off, job.frac)
         flops = int(st.alg_flops_frame) * batch
         out.append({
             "workload": (f"c5: one rank's slab of 8 of 512 mics x 256x256 ({job.shard.pixel_count} pixels), {batch} frames in flight"
                          if c5 else spec.name),
-            "frames_per_step": batch, "steps": 3, "value": batch * 3 / elapsed, "unit": "frames/s",
+            "frames_per_step": batch, "steps": K, "warmup": W, "value": batch * K / elapsed, "unit": "frames/s",
             "kernel_ms": kernel_ms, "valu_frac": flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
             "hbm_frac": int(st.alg_bytes_frame) * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "parity_max_rel_unfloored": par["max_rel_unfloored"], "parity_bound": par["bound"], "parity_ok": par["ok"],

@@ -1439,3 +1439,25 @@ def test_packed_entry_points_refuse_what_they_cannot_sweep(pkg, oracle):
             with pytest.raises(pkg.AwpuError) as ei:
                 eng.packed_bytes(2)
             assert ei.value.status == B.ERR_STATE
+
+
+@pytest.mark.parametrize("res,fov", [(100, 180.0), (33, 180.0), (50, 90.0)])
+def test_reference_cli_default_grid(pkg, oracle, res, fov):
+    """The shape the reference ships: one 8x8 array, `--mimo-res 100`, `--fov 180` (src/main.cpp:38-41,53-56 ->
+    MIMOWorker(pipeline, antennas[0], &running, 100, 100, fov), aw_processing_unit.cpp:74): rows and columns that are no
+    multiple of the kernels' 4-row x 16-column tiles, an odd grid (whose centre pixel looks straight ahead: mimo.cpp:38-39
+    divides by a norm of ~1e-17 there) and a narrower field of view.  One frame per call (MIMOWorker::update) and a batch
+    of three, with the row length given and withheld: every pixel against the oracle, unfloored."""
+    xyz = pkg.create_antenna()
+    off, frac = pkg.build_delay_table(xyz, res, res, fov)
+    assert off.shape == (res * res, 64) and off.min() >= 256 - 29 and off.max() <= 256
+    frames = pkg.synthetic.make_frames(xyz, 3, seed=77)
+    for cols in (res, 0):
+        with pkg.Engine(n_pixels=res * res, n_streams=64, max_batch=3, grid_columns=cols) as eng:
+            eng.set_delay_table(off, frac)
+            eng.set_active_mics(None)
+            single = eng.process(frames[:1])[0]
+            batch = eng.process(frames)
+        check_full_grid(oracle, single, frames[0], off, frac, f"{res}x{res} fov {fov} single frame, grid_columns={cols}")
+        check_full_grid(oracle, batch[2], frames[2], off, frac, f"{res}x{res} fov {fov} last of three, grid_columns={cols}")
+        assert util.power_rel_err(batch[0], single) < 5e-6
