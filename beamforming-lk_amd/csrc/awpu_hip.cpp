@@ -624,10 +624,10 @@ int dump_diag(awpu_hip *h, size_t n_waves, int wg_waves, const char *tag, hipStr
     AWPU_HIP_TRY(hipStreamSynchronize(s));
     std::vector<unsigned long long> hb(n_waves * 12);
     AWPU_HIP_TRY(hipMemcpy(hb.data(), h->d_diag, hb.size() * 8, hipMemcpyDeviceToHost));
-    double v[9] = {0};
+    double v[10] = {0};
     std::vector<double> sw(wg_waves, 0), ba(wg_waves, 0);
     for (size_t i = 0; i < n_waves; i++) {
-        for (int k = 0; k < 9; k++) v[k] += (double) hb[12 * i + k];
+        for (int k = 0; k < 10; k++) v[k] += (double) hb[12 * i + k];
         sw[i % wg_waves] += (double) hb[12 * i + 5];
         ba[i % wg_waves] += (double) hb[12 * i + 8];
     }
@@ -635,6 +635,9 @@ int dump_diag(awpu_hip *h, size_t n_waves, int wg_waves, const char *tag, hipStr
                  "first table wait %.0f) tail %.0f dma-wait %.0f barrier %.0f | per block %.0f\n", tag, n_waves, v[2] / n_waves,
                  v[4] / n_waves, v[5] / n_waves, v[1] / n_waves, 100 * v[1] / v[2], v[0] / n_waves, v[6] / n_waves,
                  v[7] / n_waves, v[8] / n_waves, v[1] / v[3]);
+    if (v[9] > 0)  // shader cycles over the 100 MHz real-time counter, both stamped by every wave (MI355X_MICROARCH.md, DVFS give-back item 6)
+        std::fprintf(stderr, "[awpu diag %s] in-kernel clock %.3f GHz (cycles %.0f / real time %.2f us per wave)\n", tag, v[2] / v[9] * 0.1,
+                     v[2] / n_waves, v[9] / n_waves * 0.01);
     std::fprintf(stderr, "[awpu diag %s] wave slot sweep/barrier kcycles:", tag);
     for (int k = 0; k < wg_waves; k++)
         std::fprintf(stderr, " %d:%.0f/%.0f", k, sw[k] * wg_waves / n_waves / 1e3, ba[k] * wg_waves / n_waves / 1e3);

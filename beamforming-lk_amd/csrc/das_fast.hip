@@ -1290,6 +1290,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
 
     unsigned t_wait = 0, t_all = 0, n_blocks = 0;
     const long long t_begin = __builtin_readcyclecounter();
+    const unsigned long long rt_begin = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz: the in-kernel clock's yardstick
     unsigned t_ph[5] = {0, 0, 0, 0, 0};
     auto stamp = [&](int k, long long &t) {
         if (DIAG) {
@@ -1439,6 +1440,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         o[2] = (unsigned long long) (__builtin_readcyclecounter() - t_begin);
         o[3] = n_blocks;
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
+        o[9] = __builtin_amdgcn_s_memrealtime() - rt_begin;
     }
 }
 

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
@@ -18,10 +19,11 @@ constexpr int REPS = 8192;
 #define DS(r, off) "ds_read_b64 v[" #r ":" #r "+1], v56 offset:" #off "\n\t"
 
 template <int VAR>
-__global__ __launch_bounds__(1024, 4) void mix_kernel(float *out, float seed) {
+__global__ __launch_bounds__(1024, 4) void mix_kernel(float *out, float seed, unsigned long long *stamps) {
     __shared__ float lds_buf[4096];
     if (seed == 54321.0f) lds_buf[threadIdx.x] = seed;
     float r = 0.0f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     asm volatile(
         ".irp n,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39\n\tv_mov_b32 v\\n, %[s]\n\t.endr\n\t"
         ".irp n,64,65,66,67,68,69,70,71,72,73,74,75,76,77,78,79,80,81,82,83,84,85,86,87,88,89,90,91,92,93,94,95\n\tv_mov_b32 v\\n, %[s]\n\t.endr\n\t"
@@ -69,6 +71,11 @@ __global__ __launch_bounds__(1024, 4) void mix_kernel(float *out, float seed) {
           "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74",
           "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
           "v95", "s36", "s40", "s41", "scc");
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (stamps && threadIdx.x == 0) {  // in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6)
+        stamps[2 * blockIdx.x] = c1 - c0;
+        stamps[2 * blockIdx.x + 1] = r1 - r0;
+    }
     if (r == 12345.0f) out[threadIdx.x] = r;
 }
 
@@ -79,19 +86,27 @@ static void run(const char *what, int n_pk, int n_mf, float *d_out) {
     CHECK(hipEventCreate(&b));
     for (int waves_per_simd : {1, 2, 3, 4}) {
         const int threads = 64 * 4 * waves_per_simd;  // one workgroup per CU
-        hipLaunchKernelGGL(mix_kernel<VAR>, dim3(256), dim3(threads), 0, 0, d_out, 0.0f);
+        static unsigned long long *d_stamps = nullptr;
+        if (!d_stamps) CHECK(hipMalloc(&d_stamps, 512 * sizeof(unsigned long long)));
+        for (int warm = 0; warm < 150; warm++) hipLaunchKernelGGL(mix_kernel<VAR>, dim3(256), dim3(threads), 0, 0, d_out, 0.0f, nullptr);
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(a));
-        hipLaunchKernelGGL(mix_kernel<VAR>, dim3(256), dim3(threads), 0, 0, d_out, 0.0f);
+        hipLaunchKernelGGL(mix_kernel<VAR>, dim3(256), dim3(threads), 0, 0, d_out, 0.0f, d_stamps);
         CHECK(hipEventRecord(b));
         CHECK(hipEventSynchronize(b));
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, a, b));
+        unsigned long long h_st[512];
+        CHECK(hipMemcpy(h_st, d_stamps, sizeof h_st, hipMemcpyDeviceToHost));
+        double ghz[256];
+        for (int i = 0; i < 256; i++) ghz[i] = (double) h_st[2 * i] / (double) h_st[2 * i + 1] * 0.1;
+        std::sort(ghz, ghz + 256);
         const double groups_per_simd = (double) REPS * waves_per_simd;
         const double cyc = ms * 1e-3 * 2.4e9 / groups_per_simd;
+        const double cyc_real = ms * 1e-3 * ghz[128] * 1e9 / groups_per_simd;
         const double lane_fma = groups_per_simd * 1024 * (128.0 * n_pk + 256.0 * n_mf);
-        std::printf("%-58s %d waves/SIMD: %7.3f ms  %6.1f cyc/group (pk-only floor %3d, mfma-only floor %3d)  %6.1f TFLOP/s\n", what, waves_per_simd, ms,
-                    cyc, 4 * n_pk, 8 * n_mf, 2 * lane_fma / (ms * 1e-3) / 1e12);
+        std::printf("%-44s %d waves/SIMD: %7.3f ms  %6.1f cyc/group at 2.4 GHz, %6.1f at the in-kernel clock of %.2f GHz (floors: pk %3d, mfma %3d)  %6.1f TFLOP/s\n",
+                    what, waves_per_simd, ms, cyc, cyc_real, ghz[128], 4 * n_pk, 8 * n_mf, 2 * lane_fma / (ms * 1e-3) / 1e12);
     }
 }
 
