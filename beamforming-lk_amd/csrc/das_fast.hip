@@ -1180,6 +1180,9 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, con
         else if constexpr (VAR == 3) sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, 0);
         else
 #endif
+        if (plane_bytes == kFirStaticPlaneBytes)  // (uniform: rows staged at the pitch the one-address block is generated for, fir8_plane_plan)
+            sweep_fir8_planes_static(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn);
+        else
         sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1947,7 +1950,13 @@ hipError_t launch_das_fir8_pairs(const PairArgs &a, const void *d_entries, const
 }
 
 bool fir8_plane_plan(int window, int usable, FastPlan *plan) {
-    const int wp = (window + 3) & ~3;  // four planes of wp / 4 elements
+    int wp = (window + 3) & ~3;  // four planes of wp / 4 elements
+    // windows of 321..384 samples (every BASELINE shape but the single 8x8 array) are staged at the plane pitch the
+    // one-address block is generated for (sweep_fir8_planes_static: 33 instead of 36 VALU instructions per item);
+    // AWPU_FIR8_STATIC=0 keeps the natural pitch for A/B runs
+    static const bool allow_static = !(std::getenv("AWPU_FIR8_STATIC") && std::atoi(std::getenv("AWPU_FIR8_STATIC")) == 0);
+    const int wp_static = (int) (kFirStaticPlaneBytes / 2);
+    if (allow_static && wp > wp_static - 64 && wp <= wp_static) wp = wp_static;
     const size_t row_bytes = (size_t) wp * 8;
     int chunk = (int) ((size_t) kFastLdsBytes / row_bytes);
     chunk &= ~3;

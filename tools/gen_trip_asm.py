@@ -1001,10 +1001,11 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, un
 """
 
 
-FIR_ACC, FIR_TMP = 8, 88  # block_fir8: accumulators of the four pixels pinned at v[8:39], temps v88..v121
+FIR_ACC, FIR_TMP = 8, 88  # block_fir8: accumulators of the four pixels pinned at v[8:39], temps v88..v121 (static pitch: ..v124)
+FIR_STATIC_PB = 768       # sweep_fir8_planes_static: rows of 384 samples (windows of 321..384: every BASELINE shape but c1)
 
 
-def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
+def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing="", static_pb=0):
     """Four pixels of the staged chunk with the 8-tap table variant of delay() (delay.cpp:31-40) on the frame-pair
     layout stored as four sample planes (sample i of a row lives in plane i % 4 at index i / 4).
 
@@ -1036,7 +1037,15 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
 
     The block sweeps its four pixels one after the other, `n4` groups of four items each (chunks and table rows are
     multiples of four mics; padding entries point at the zero coefficient row), and the stream of entry requests
-    runs on from one pixel's row into the next: a wave meets the scalar-load latency once per block."""
+    runs on from one pixel's row into the next: a wave meets the scalar-load latency once per block.
+
+    static_pb > 0 (late round 3): the block for rows staged with a plane pitch of exactly `static_pb` bytes.  With the
+    pitch a constant, every sample's offset from the row's plane 0 is an immediate once r is known -- sample w sits in
+    plane (r + w) % 4 at index q + l + (r + w) / 4, i.e. at (row base + 8 q + 8 l) + [(r + w) % 4] pitch + 8 [(r + w) / 4] --
+    so an item needs ONE v_add_u32 instead of four, and its eleven reads go out together, in one of four copies picked by
+    two scalar compares on r (the next item's samples 8..10 get a second register set).  33 VALU instructions per item
+    instead of 36; the compares cost the wave ~100 cycles of its own time per item, of the ~860 its share of the SIMD
+    gives it.  Same table entries (the block subtracts r * pitch from the address field), same sums."""
     ENT = 36                      # s[36:39]: ring of four entry dwords, entry i in s[36 + i % 4]
     CO = (40, 48, 56, 64)         # coefficient sets, item i uses CO[i % 4]
     AD = 72                       # s[72:75]: the plane addresses of the item whose reads are being issued
@@ -1048,6 +1057,10 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
     X8 = [tmp + 24 + 2 * w for w in range(3)]
     VA = [tmp + 30 + c for c in range(4)]
     n_tmp = 34
+    if static_pb:
+        X8 = [[tmp + 24 + 6 * z + 2 * w for w in range(3)] for z in range(2)]  # samples 8..10: two sets as well
+        VA = [tmp + 36]
+        n_tmp = 37
     SINK = tmp - 4  # v84: destination of the table prefetch (never read)
 
     def accp(pp, o):
@@ -1055,6 +1068,8 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
         return f"v[{b}:{b + 1}]"
 
     def xreg(w, z):
+        if static_pb and w >= 8:
+            return X8[z][w - 8]
         return X03[w] if w < 4 else (X47[z][w - 4] if w < 8 else X8[w - 8])
 
     def xp(w, z):
@@ -1082,6 +1097,27 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
 
     def reads(ws, z):
         return [r for r in (read(w, z) for w in ws) if r]
+
+    def addresses_static(ent):
+        """plane-0 address (row base + 8 q) of the item whose entry sits in s{ent} -> s{AD}; r -> s{S_R}"""
+        return [f"s_and_b32 s{AD}, s{ent}, 0x3ffff", f"s_bfe_u32 s{S_R}, s{ent}, 0x20012",
+                f"s_mul_i32 s{S_T}, s{S_R}, {static_pb}", f"s_sub_u32 s{AD}, s{AD}, s{S_T}"]
+
+    def reads_static(z, r):
+        L = []
+        for w in range(11):
+            off = ((r + w) % 4) * static_pb + 8 * ((r + w) // 4)
+            L.append(f"ds_read_b64 {xp(w, z)}, v{VA[0]}" + (f" offset:{off}" if off else ""))
+        return L
+
+    def dispatch_reads(z):
+        """all eleven reads of the item whose r sits in s{S_R}, into register set z"""
+        COUNTER[0] += 1
+        u = f"%=_{COUNTER[0]}"
+        return ([f"s_cmp_lt_u32 s{S_R}, 2", f"s_cbranch_scc1 .LFr01{u}", f"s_cmp_eq_u32 s{S_R}, 2", f"s_cbranch_scc1 .LFr2{u}"] +
+                reads_static(z, 3) + [f"s_branch .LFrj{u}", f".LFr2{u}:"] + reads_static(z, 2) + [f"s_branch .LFrj{u}", f".LFr01{u}:",
+                f"s_cmp_eq_u32 s{S_R}, 0", f"s_cbranch_scc1 .LFr0{u}"] + reads_static(z, 1) + [f"s_branch .LFrj{u}", f".LFr0{u}:"] +
+                reads_static(z, 0) + [f".LFrj{u}:"])
 
     def load_entry(slot):
         if timing == "noload":  # (timing-only builds: the first entries over and over)
@@ -1113,6 +1149,14 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
                   f"s_cselect_b32 s{S_OFF_}, 0, s{S_OFF_}"]
         L += load_entry(k % 4)                                # entry of item i + 4 (this item's slot is free)
         L += load_coeffs(ENT + (k + 3) % 4, CO[(k + 3) % 4])  # coefficients of item i + 3 (its entry landed an item ago)
+        if static_pb:
+            L += addresses_static(ENT + (k + 1) % 4)          # plane-0 address and r of item i + 1
+            for w in range(4):
+                L += fmas(pp, cur, w, z)
+            L += [f"v_add_u32 v{VA[0]}, s{AD}, %[lane]"] + dispatch_reads(z ^ 1)  # all eleven samples of item i + 1
+            for w in range(4, 11):
+                L += fmas(pp, cur, w, z)
+            return L
         L += reads(range(8, 11), z)
         L += addresses(ENT + (k + 1) % 4)                     # plane addresses of item i + 1
         for w in range(4):
@@ -1143,7 +1187,10 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing=""):
     for k in range(4 if keep == "noload" else 3):
         L += load_coeffs(ENT + k, CO[k])
     timing = keep
-    L += addresses(ENT) + ["s_waitcnt lgkmcnt(0)"] + adds() + reads(range(0, 4), 0) + reads(range(4, 8), 0)
+    if static_pb:
+        L += addresses_static(ENT) + ["s_waitcnt lgkmcnt(0)", f"v_add_u32 v{VA[0]}, s{AD}, %[lane]"] + dispatch_reads(0)
+    else:
+        L += addresses(ENT) + ["s_waitcnt lgkmcnt(0)"] + adds() + reads(range(0, 4), 0) + reads(range(4, 8), 0)
     for pp in range(4):
         L += [f"s_mov_b32 s{S_LEFT_}, %[n4]", f".LF{pp}_%=:"]
         for k in range(4):
@@ -1202,6 +1249,8 @@ def main():
         for v in (0, 3, 4):
             out.append(block_quad(f"sweep_quad_sum_v{v}", prio=v, chain=CHAIN))
     out.append(block_fir8("sweep_fir8_planes"))
+    out += [f"constexpr unsigned kFirStaticPlaneBytes = {FIR_STATIC_PB};  // sweep_fir8_planes_static: the plane pitch it is generated for", ""]
+    out.append(block_fir8("sweep_fir8_planes_static", static_pb=FIR_STATIC_PB))
     if os.environ.get("QUAD_VARIANTS"):  # tuning builds: what the block costs without its scalar loads / its LDS reads / the read-ahead
         out.append(block_fir8("sweep_fir8_planes_v1", timing="noload"))
         out.append(block_fir8("sweep_fir8_planes_v2", timing="nolds"))
