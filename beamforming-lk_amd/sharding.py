@@ -128,6 +128,12 @@ class FrameBroadcaster:
             else:
                 ops = [dist.P2POp(dist.irecv, mine, self.src, self.group)]
             works = list(dist.batch_isend_irecv(ops))
+            # The all-gather must not start before this rank's slice has arrived.  Batched point-to-point ops run on the
+            # collectives' stream in current PyTorch, but that is an implementation detail: wait() here only orders the
+            # calling stream (the side stream) after them -- no host block -- and the all-gather below is ordered after
+            # the calling stream.
+            for w in works:
+                w.wait()
             works.append(dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True))
             self._work[k % 2] = works
             return
