@@ -16,6 +16,7 @@ from .binding import (  # noqa: F401
     AwpuError,
     Engine,
     build_delay_table,
+    build_delay_table_device,
     create_antenna,
     create_tiled_antenna,
     heatmap_u8,
@@ -25,7 +26,7 @@ from .binding import (  # noqa: F401
 )
 
 __all__ = [
-    "Engine", "AwpuError", "MATH_F32_EXACT", "MATH_F32_FAST", "MATH_BF16_ACC", "build_delay_table",
+    "Engine", "AwpuError", "MATH_F32_EXACT", "MATH_F32_FAST", "MATH_BF16_ACC", "build_delay_table", "build_delay_table_device",
     "create_antenna", "create_tiled_antenna", "steering_delays", "heatmap_u8", "resize_linear_u8", "steer_table", "binding",
     "synthetic", "_build",
 ]

@@ -120,6 +120,10 @@ _SIGNATURES = {
         C.c_int,
         [_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, _i32p, _f32p],
     ),
+    "awpu_hip_build_delay_table_device": (
+        C.c_int,
+        [C.c_int32, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, _i32p, _f32p],
+    ),
     "awpu_hip_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "awpu_hip_group_peer_status": (C.c_int, [C.c_void_p, _i32p, C.c_int32]),
     "awpu_hip_strerror": (C.c_char_p, [C.c_int]),
@@ -210,6 +214,19 @@ def build_delay_table(xyz: np.ndarray, rows: int, columns: int, fov_deg: float =
     frac = np.empty((row_count * columns, n), np.float32)
     _check(load().awpu_hip_build_delay_table(_f32(xyz), n, rows, columns, fov_deg, row_begin,
                                              row_count, _i32(off), _f32(frac)), "build_delay_table")
+    return off, frac
+
+
+def build_delay_table_device(xyz: np.ndarray, rows: int, columns: int, fov_deg: float = 180.0,
+                             row_begin: int = 0, row_count: Optional[int] = None, device: int = 0):
+    """The same table, its rows x columns x n part computed on HIP device `device` (bit-identical to build_delay_table)."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    n = xyz.shape[1]
+    row_count = rows - row_begin if row_count is None else row_count
+    off = np.empty((row_count * columns, n), np.int32)
+    frac = np.empty((row_count * columns, n), np.float32)
+    _check(load().awpu_hip_build_delay_table_device(device, _f32(xyz), n, rows, columns, fov_deg, row_begin,
+                                                    row_count, _i32(off), _f32(frac)), "build_delay_table_device")
     return off, frac
 
 

@@ -2193,6 +2193,49 @@ int awpu_hip_group_peer_status(awpu_hip_t *h, int32_t *status, int32_t n) {
     return have;
 }
 
+int awpu_hip_build_delay_table_device(int32_t device, const float *xyz, int32_t n, int32_t rows, int32_t columns, float fov_deg,
+                                      int32_t row_begin, int32_t row_count, int32_t *off, float *frac) {
+    if (!xyz || !off || !frac || n <= 0 || rows <= 0 || columns <= 0) return invalid("null or non-positive argument");
+    if (row_begin < 0 || row_count < 0 || row_begin + row_count > rows) return invalid("rows outside the grid");
+    if (row_count == 0) return AWPU_OK;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+        return fail(AWPU_ERR_NO_DEVICE, "no such HIP device (the host builder awpu_hip_build_delay_table needs none)");
+    hipDeviceProp_t prop;
+    AWPU_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(AWPU_ERR_NO_DEVICE, "device is not gfx950 (MI355X); kernels are built for gfx950 only");
+    AWPU_HIP_TRY(hipSetDevice(device));
+    const size_t P = (size_t) row_count * columns;
+    std::vector<float> rot(P * 12);
+    awpu::pixel_rotations(rows, columns, fov_deg, row_begin, row_count, rot.data());
+    float *d_xyz = nullptr, *d_rot = nullptr, *d_frac = nullptr;
+    int32_t *d_off = nullptr;
+    auto body = [&]() -> int {
+        AWPU_HIP_TRY(hipMalloc(&d_xyz, (size_t) 3 * n * sizeof(float)));
+        AWPU_HIP_TRY(hipMalloc(&d_rot, rot.size() * sizeof(float)));
+        AWPU_HIP_TRY(hipMalloc(&d_off, P * n * sizeof(int32_t)));
+        AWPU_HIP_TRY(hipMalloc(&d_frac, P * n * sizeof(float)));
+        AWPU_HIP_TRY(hipMemcpy(d_xyz, xyz, (size_t) 3 * n * sizeof(float), hipMemcpyHostToDevice));
+        AWPU_HIP_TRY(hipMemcpy(d_rot, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice));
+        // one launch per 32 768 pixels (the grid's x dimension is not the limit; this bounds a launch's run time)
+        for (size_t p0 = 0; p0 < P; p0 += 32768) {
+            const int np = (int) std::min<size_t>(32768, P - p0);
+            AWPU_HIP_TRY(awpu::launch_delay_table(d_xyz, n, d_rot + p0 * 12, np, awpu::samples_per_metre(), d_off + p0 * n, d_frac + p0 * n,
+                                                  nullptr));
+        }
+        AWPU_HIP_TRY(hipMemcpy(off, d_off, P * n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        AWPU_HIP_TRY(hipMemcpy(frac, d_frac, P * n * sizeof(float), hipMemcpyDeviceToHost));
+        return AWPU_OK;
+    };
+    const int rc = body();
+    dev_free(d_xyz);
+    dev_free(d_rot);
+    dev_free(d_off);
+    dev_free(d_frac);
+    return rc;
+}
+
 int awpu_hip_get_stats(awpu_hip_t *h, awpu_hip_stats *stats) {
     AWPU_CTX(h);
     if (!h || !stats) return invalid("null argument");

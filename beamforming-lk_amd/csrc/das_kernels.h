@@ -208,6 +208,15 @@ hipError_t launch_heatmap(const float *d_power, int n, int batch, float *d_peak,
 hipError_t launch_das_beams(const float *d_frame, const LutEntry *d_entries, int usable, int n_dir, float *d_power,
                             float *d_beams, hipStream_t stream);
 
+// geometry_host.cpp: the per-pixel half of computeDelayLUT for the device builder (rot [row_count * columns][12])
+void pixel_rotations(int rows, int columns, float fov_deg, int row_begin, int row_count, float *rot);
+float samples_per_metre();  // (float) (48828 / 340), antenna.cpp:90
+
+// computeDelayLUT's P x n part on the device (das_kernels.hip, delay_table_kernel): d_rot [n_pixels][12] = Rz(phi)
+// row-major + row z of Ry(-theta), d_xyz [3][n]; d_off / d_frac [n_pixels][n]
+hipError_t launch_delay_table(const float *d_xyz, int n, const float *d_rot, int n_pixels, float scale, int32_t *d_off, float *d_frac,
+                              hipStream_t stream);
+
 // mean square of `hist` samples of each of `n` rows (pitch floats apart), summed in sample order
 // (calibration, aw_processing_unit.cpp:133-143)
 hipError_t launch_stream_power(const float *d_rows, int pitch, int hist, int n, float *d_out, hipStream_t stream);

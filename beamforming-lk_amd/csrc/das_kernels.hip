@@ -309,6 +309,49 @@ __global__ __launch_bounds__(256) void stream_power_kernel(const float *rows, in
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// MIMOWorker::computeDelayLUT on the device (src/dsp/mimo.cpp:20-59; SURVEY 8b, "optionally ... so the LUT can be
+// generated on device").  The per-pixel part -- the sine-space grid, asin / atan2 and the rotation entries, all in
+// double with the host's libm -- stays on the host (a few thousand pixels); what the device does is the P x n part:
+// steer() and compute_delays() of src/geometry/antenna.cpp:89-107 for every (pixel, mic) with the host builder's
+// operations in the host builder's order (contraction into FMAs switched off for this kernel),
+// the minimum over the mics (exact in any order), and the split of mimo.cpp:46-54.  Bit-identical to
+// awpu_hip_build_delay_table by construction; one workgroup per pixel.
+// rot: [P][12] = the nine entries of Rz(phi) row-major, then row z of Ry(-theta).
+// ---------------------------------------------------------------------------------------
+__global__ void delay_table_kernel(const float *xyz, int n, const float *rot, float scale, int32_t *off, float *frac) {
+#pragma clang fp contract(off)  // the host builder's x86 code has no FMA: a contracted a*b + c would round once instead of twice
+    __shared__ float lowest_of_wave[4];
+    const int p = blockIdx.x;
+    const float *m = rot + (size_t) p * 12;
+    auto delay = [&](int i) {  // steer() + compute_delays() before the minimum is removed, antenna.cpp:89-107
+        const float p0 = xyz[i], p1 = xyz[n + i], p2 = xyz[2 * n + i];
+        float t[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) t[r] = m[3 * r] * p0 + m[3 * r + 1] * p1 + m[3 * r + 2] * p2;
+        const float z = m[9] * t[0] + m[10] * t[1] + m[11] * t[2];
+        return z * scale;
+    };
+    float lowest = __builtin_inff();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lowest = fminf(lowest, delay(i));
+    for (int d = 32; d >= 1; d >>= 1) lowest = fminf(lowest, __shfl_xor(lowest, d));
+    if ((threadIdx.x & 63) == 0) lowest_of_wave[threadIdx.x >> 6] = lowest;
+    __syncthreads();
+    lowest = fminf(fminf(lowest_of_wave[0], lowest_of_wave[1]), fminf(lowest_of_wave[2], lowest_of_wave[3]));
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {  // (recomputed: the same operations give the same bits)
+        const float tau = delay(i) - lowest;
+        const float whole = truncf(tau);  // modf((double) tau, &whole): exact in float as well
+        frac[(size_t) p * n + i] = tau - whole;
+        off[(size_t) p * n + i] = kSamples - (int) whole;
+    }
+}
+
+hipError_t launch_delay_table(const float *d_xyz, int n, const float *d_rot, int n_pixels, float scale, int32_t *d_off, float *d_frac,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(delay_table_kernel, dim3(n_pixels), dim3(256), 0, stream, d_xyz, n, d_rot, scale, d_off, d_frac);
+    return hipGetLastError();
+}
+
 hipError_t launch_stream_power(const float *d_rows, int pitch, int hist, int n, float *d_out, hipStream_t stream) {
     hipLaunchKernelGGL(stream_power_kernel, dim3(n), dim3(256), sizeof(float) * hist, stream, d_rows, pitch, hist, d_out);
     return hipGetLastError();

@@ -65,6 +65,40 @@ void element_position(int r, int c, int rows, int columns, float distance, float
 
 }  // namespace
 
+namespace awpu {
+
+// The per-pixel half of computeDelayLUT (mimo.cpp:21-43) for the device builder: for every pixel of grid rows
+// [row_begin, row_begin + row_count) the twelve floats steering_delays() would build from (theta, phi) -- Rz((float) phi)
+// row-major, then row z of Ry(-(float) theta).  Same expressions, same libm as awpu_hip_build_delay_table.
+void pixel_rotations(int rows, int columns, float fov_deg, int row_begin, int row_count, float *rot) {
+    const double fov = static_cast<double>(fov_deg) * (M_PI / 180.0);
+    const double sep_rows = std::sin(fov / 2.0) / (static_cast<double>(rows) / 2.0);
+    const double sep_cols = std::sin(fov / 2.0) / (static_cast<double>(columns) / 2.0);
+    size_t k = 0;
+    for (int r = row_begin; r < row_begin + row_count; r++) {
+        for (int c = 0; c < columns; c++, k++) {
+            double y = r * sep_rows - rows * sep_rows / 2.0 + sep_rows / 2.0;
+            double x = c * sep_cols - columns * sep_cols / 2.0 + sep_cols / 2.0;
+            double norm = std::sqrt(x * x + y * y);
+            x /= norm;
+            y /= norm;
+            if (norm > 1.0) norm = 1.0;
+            const double theta = std::asin(norm);
+            const double phi = std::atan2(y, x);
+            const Rot rz = rotate_z(static_cast<float>(phi));
+            const Rot ry = rotate_y(-static_cast<float>(theta));
+            float *m = rot + k * 12;
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) m[3 * a + b] = rz.m[a][b];
+            for (int b = 0; b < 3; b++) m[9 + b] = ry.m[2][b];
+        }
+    }
+}
+
+float samples_per_metre() { return static_cast<float>(kSampleRate / kPropagationSpeed); }
+
+}  // namespace awpu
+
 extern "C" {
 
 int awpu_hip_create_antenna(int32_t columns, int32_t rows, float distance, float *xyz) {

@@ -319,6 +319,16 @@ int awpu_hip_build_delay_table(const float *xyz, int32_t n, int32_t rows, int32_
                                float fov_deg, int32_t row_begin, int32_t row_count, int32_t *off,
                                float *frac);
 
+/* The same table generated on the device ("optionally ... so the LUT can be generated on device"): the
+ * per-pixel angles and rotation entries (double, the host's libm: rows * columns values) stay on the host, the
+ * rows * columns * n part -- steer() / compute_delays() of src/geometry/antenna.cpp:89-107 and the split of
+ * src/dsp/mimo.cpp:46-54 -- runs on HIP device `device` with the host builder's operations in the host builder's order.
+ * off / frac are host arrays as above and receive the SAME BITS awpu_hip_build_delay_table writes (c4, 65 536 pixels x
+ * 512 mics: 0.12 s on one core of the GPU box's host, 0.022 s here, most of it the copy back).
+ * AWPU_ERR_NO_DEVICE without a gfx950 device: the host builder needs none. */
+int awpu_hip_build_delay_table_device(int32_t device, const float *xyz, int32_t n, int32_t rows, int32_t columns,
+                                      float fov_deg, int32_t row_begin, int32_t row_count, int32_t *off, float *frac);
+
 /* ---- introspection -------------------------------------------------------------------- */
 
 int awpu_hip_get_stats(awpu_hip_t *h, awpu_hip_stats *stats);

@@ -63,6 +63,20 @@ def test_no_cpu_fallback_without_device(pkg):
     assert ei.value.status == pkg.binding.ERR_NO_DEVICE
 
 
+def test_device_table_builder_without_device(pkg):
+    """awpu_hip_build_delay_table_device needs a gfx950 device and says so; it never falls back to the host builder."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device path is exercised on CPU-only boxes")
+    xyz = pkg.create_antenna()
+    with pytest.raises(pkg.AwpuError) as ei:
+        pkg.build_delay_table_device(xyz, 8, 8)
+    assert ei.value.status == pkg.binding.ERR_NO_DEVICE
+    lib = pkg.binding.load()
+    assert lib.awpu_hip_build_delay_table_device(0, None, 64, 8, 8, 180.0, 0, 8, None, None) == pkg.binding.ERR_INVALID
+
+
 def test_product_does_not_import_oracle():
     """The oracle is test infrastructure: no product source may reference it."""
     for path in (REPO / "beamforming-lk_amd").rglob("*"):
@@ -180,6 +194,7 @@ def test_null_arguments_are_refused_not_dereferenced(pkg):
     call("awpu_hip_create_tiled_antenna", 0, 1, 0.02, fp)
     call("awpu_hip_steering_delays", None, 4, 0.1, 0.2, fp)
     call("awpu_hip_build_delay_table", None, 4, 2, 2, 180.0, 0, 2, ip, fp)
+    call("awpu_hip_build_delay_table_device", 0, None, 4, 2, 2, 180.0, 0, 2, ip, fp)
     call("awpu_hip_get_stats", None, None)
     call("awpu_hip_group_peer_status", None, ip, 1)
     call("awpu_hip_create", None, None)

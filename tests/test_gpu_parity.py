@@ -1461,3 +1461,20 @@ def test_reference_cli_default_grid(pkg, oracle, res, fov):
         check_full_grid(oracle, single, frames[0], off, frac, f"{res}x{res} fov {fov} single frame, grid_columns={cols}")
         check_full_grid(oracle, batch[2], frames[2], off, frac, f"{res}x{res} fov {fov} last of three, grid_columns={cols}")
         assert util.power_rel_err(batch[0], single) < 5e-6
+
+
+@pytest.mark.parametrize("arrays,res,fov,rows", [((1, 1), 100, 180.0, None), ((1, 1), 33, 180.0, None), ((4, 1), 128, 180.0, None),
+                                                 ((4, 2), 256, 180.0, (96, 40)), ((4, 2), 64, 90.0, None), ((3, 1), 50, 120.0, (7, 9))])
+def test_device_table_builder_equals_the_host_builder(pkg, arrays, res, fov, rows):
+    """awpu_hip_build_delay_table_device (MIMOWorker::computeDelayLUT with its pixels x mics part on the GPU, SURVEY 8b)
+    writes the bits awpu_hip_build_delay_table writes: the reference's own shape, an odd grid, the headline table, a slab
+    of c4's rows, a narrower field of view, a mic count that is no multiple of the kernel's 256 threads."""
+    xyz = pkg.create_tiled_antenna(*arrays) if arrays != (1, 1) else pkg.create_antenna()
+    rb, rc = rows if rows else (0, res)
+    off_h, frac_h = pkg.build_delay_table(xyz, res, res, fov, rb, rc)
+    off_d, frac_d = pkg.build_delay_table_device(xyz, res, res, fov, rb, rc)
+    assert off_d.shape == off_h.shape == (rc * res, xyz.shape[1])
+    assert np.array_equal(off_d, off_h)
+    assert np.array_equal(frac_d.view(np.uint32), frac_h.view(np.uint32))
+    assert off_d.max() <= 256 and frac_d.min() >= 0.0 and frac_d.max() < 1.0
+    assert (off_d == 256).any(axis=1).all()  # every pixel's nearest mic has delay 0 (antenna.cpp:93-96)
