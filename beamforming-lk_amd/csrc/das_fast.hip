@@ -1181,9 +1181,9 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, con
         else
 #endif
         if (plane_bytes == kFirStaticPlaneBytes)  // (uniform: rows staged at the pitch the one-address block is generated for, fir8_plane_plan)
-            sweep_fir8_planes_static(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn);
+            sweep_fir8_planes_static(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn, wave >> 2);
         else
-        sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn);
+        sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn, wave >> 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }

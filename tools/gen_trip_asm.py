@@ -1005,7 +1005,16 @@ FIR_ACC, FIR_TMP = 8, 88  # block_fir8: accumulators of the four pixels pinned a
 FIR_STATIC_PB = 768       # sweep_fir8_planes_static: rows of 384 samples (windows of 321..384: every BASELINE shape but c1)
 
 
-def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing="", static_pb=0):
+# block_fir8 wave priorities (s_setprio, as in the quad blocks): 0 none; 1 the top priority rotates through the four waves of
+# the SIMD once per group of four items; 2 rotation and youngest-first alternate within a group; 3 static youngest-first;
+# 4 / 5 rotation every two items / every item; 6 rotation and youngest-first item by item; 7 rotation on even groups,
+# youngest-first on odd ones (8: pairs of groups; 11: by pixel); 10 rotation every other group only.  Measured on c3 (512 mics x
+# 128x128, 128 frames per launch, alternating runs on one box, ms per launch): 0: 45.79, 3: 45.60, 1: 44.05, 5: 44.03,
+# 4: 43.93, 6: 43.95, 2: 43.82, 10: 43.58 | 7: 42.87, 8: 42.92, 11: 42.89 (a second box: 7: 43.24 against 2: 43.74).
+FIR_PRIO = int(os.environ.get("FIR_PRIO", "7"))
+
+
+def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing="", static_pb=0, prio=None):
     """Four pixels of the staged chunk with the 8-tap table variant of delay() (delay.cpp:31-40) on the frame-pair
     layout stored as four sample planes (sample i of a row lives in plane i % 4 at index i / 4).
 
@@ -1046,6 +1055,7 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing="", static_pb=0):
     two scalar compares on r (the next item's samples 8..10 get a second register set).  33 VALU instructions per item
     instead of 36; the compares cost the wave ~100 cycles of its own time per item, of the ~860 its share of the SIMD
     gives it.  Same table entries (the block subtracts r * pitch from the address field), same sums."""
+    prio = FIR_PRIO if prio is None else prio
     ENT = 36                      # s[36:39]: ring of four entry dwords, entry i in s[36 + i % 4]
     CO = (40, 48, 56, 64)         # coefficient sets, item i uses CO[i % 4]
     AD = 72                       # s[72:75]: the plane addresses of the item whose reads are being issued
@@ -1149,6 +1159,31 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing="", static_pb=0):
                   f"s_cselect_b32 s{S_OFF_}, 0, s{S_OFF_}"]
         L += load_entry(k % 4)                                # entry of item i + 4 (this item's slot is free)
         L += load_coeffs(ENT + (k + 3) % 4, CO[(k + 3) % 4])  # coefficients of item i + 3 (its entry landed an item ago)
+        if prio == 1 and k == 0:
+            L += select_prio(S_PRIO, 1)       # the top priority moves on to the next wave of the SIMD
+        elif prio == 2 and k == 0:
+            L += select_prio(S_PRIO, 1)
+        elif prio == 2 and k == 2:
+            L += select_prio(S_RANK, 0)       # youngest first
+        elif prio == 4 and k in (0, 2):
+            L += select_prio(S_PRIO, 1)
+        elif prio == 5:
+            L += select_prio(S_PRIO, 1)
+        elif prio == 6:
+            L += select_prio(S_PRIO, 1) if k in (0, 2) else select_prio(S_RANK, 0)
+        elif prio == 10 and k == 0:            # rotation every other group only
+            COUNTER[0] += 1
+            u7 = f"%=_{COUNTER[0]}"
+            COUNTER[0] += 1
+            L += [f"s_bitcmp1_b32 s{S_LEFT_}, 0", f"s_cbranch_scc1 .LFpz{u7}"] + select_prio(S_PRIO, 1) + [f".LFpz{u7}:"]
+        elif prio == 11 and k == 0:            # by pixel: even pixels rotate each group, odd pixels run youngest-first
+            L += select_prio(S_PRIO, 1) if pp % 2 == 0 else (select_prio(S_RANK, 0) if True else [])
+        elif prio in (7, 8) and k == 0:        # rotation every other group (8: every other pair of groups), youngest-first in between
+            COUNTER[0] += 1
+            u7 = f"%=_{COUNTER[0]}"
+            COUNTER[0] += 1
+            L += ([f"s_bitcmp1_b32 s{S_LEFT_}, {1 if prio == 8 else 0}", f"s_cbranch_scc1 .LFpy{u7}"] + select_prio(S_PRIO, 1) +
+                  [f"s_branch .LFpz{u7}", f".LFpy{u7}:"] + select_prio(S_RANK, 0) + [f".LFpz{u7}:"])
         if static_pb:
             L += addresses_static(ENT + (k + 1) % 4)          # plane-0 address and r of item i + 1
             for w in range(4):
@@ -1172,8 +1207,12 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing="", static_pb=0):
             L += fmas(pp, cur, w, z)
         return L
 
-    L = [f"s_mov_b64 s[{S_PTR}:{S_PTR + 1}], %[row0]", f"s_mov_b32 s{S_OFF_}, 0",
-         f"s_mov_b32 s{S_PB}, %[pb]", f"s_lshl_b32 s{S_PB2}, s{S_PB}, 1", f"s_add_u32 s{S_PB3}, s{S_PB2}, s{S_PB}",
+    L = [f"s_mov_b64 s[{S_PTR}:{S_PTR + 1}], %[row0]", f"s_mov_b32 s{S_OFF_}, 0"]
+    if prio:
+        L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    if prio == 3:
+        L += select_prio(S_RANK, 0)
+    L += [f"s_mov_b32 s{S_PB}, %[pb]", f"s_lshl_b32 s{S_PB2}, s{S_PB}, 1", f"s_add_u32 s{S_PB3}, s{S_PB2}, s{S_PB}",
          f"s_lshl_b32 s{S_ADJ}, s{S_PB}, 2", f"s_sub_u32 s{S_ADJ}, 8, s{S_ADJ}"]
     # warm the L2 with the NEXT chunk's entries of these four pixels (one dword per lane from pfoff = chunk bytes +
     # 4 * lane: a chunk is at most 64 entries; pfn = 0: last chunk): plain loads into a sink nobody reads, drained at
@@ -1197,9 +1236,11 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing="", static_pb=0):
             L += item(pp, k)
         L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", f"s_cbranch_scc1 .LF{pp}_%="]
     L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]
+    if prio:
+        L += ["s_setprio 0"]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
     vregs = list(range(SINK, tmp + n_tmp))
-    sregs = [S_OFF_, S_LEFT_, S_PTR, S_PTR + 1] + list(range(ENT, S_K + 1))
+    sregs = [S_OFF_, S_LEFT_, S_PTR, S_PTR + 1] + list(range(ENT, S_K + 1)) + ([S_RANK, S_PRIO] if prio else [])
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
     acc_params = ", ".join(f"f8 &A{pp}" for pp in range(4))
     acc_ops = ", ".join(f'"+{{v[{acc + 8 * pp}:{acc + 8 * pp + 7}]}}"(A{pp})' for pp in range(4))
@@ -1212,11 +1253,11 @@ def block_fir8(name, acc=FIR_ACC, tmp=FIR_TMP, timing="", static_pb=0):
 // Accumulators (outputs 4l..4l+3, two frames each) pinned at v[{acc}:{acc + 31}], temps v{vregs[0]}..v{vregs[-1]}.
 __device__ __forceinline__ void {name}({acc_params}, const void *row0, const void *row1, const void *row2,
                                        const void *row3, int n4, unsigned lane_addr, const void *coef, unsigned pb,
-                                       unsigned pfoff, int pfn) {{
+                                       unsigned pfoff, int pfn, int rank = 0) {{
     asm volatile(
 {body}
         : {acc_ops}
-        : {rows}, [n4] "s"(n4), [lane] "v"(lane_addr), [coef] "s"(coef), [pb] "s"(pb), [pfoff] "v"(pfoff), [pfn] "s"(pfn)
+        : {rows}, [n4] "s"(n4), [lane] "v"(lane_addr), [coef] "s"(coef), [pb] "s"(pb), [pfoff] "v"(pfoff), [pfn] "s"(pfn), [rank] "s"(rank)
         : {clobbers});
 }}
 """
@@ -1252,8 +1293,8 @@ def main():
     out += [f"constexpr unsigned kFirStaticPlaneBytes = {FIR_STATIC_PB};  // sweep_fir8_planes_static: the plane pitch it is generated for", ""]
     out.append(block_fir8("sweep_fir8_planes_static", static_pb=FIR_STATIC_PB))
     if os.environ.get("QUAD_VARIANTS"):  # tuning builds: what the block costs without its scalar loads / its LDS reads / the read-ahead
-        out.append(block_fir8("sweep_fir8_planes_v1", timing="noload"))
-        out.append(block_fir8("sweep_fir8_planes_v2", timing="nolds"))
+        out.append(block_fir8("sweep_fir8_planes_v1", timing="noload", prio=0))
+        out.append(block_fir8("sweep_fir8_planes_v2", timing="nolds", prio=0))
     lo = 80 - (4 * (DEPTH + 1) + 1) - 3  # shapes with an 80-VGPR budget (6 waves per SIMD)
     out.append(block("sweep_quad_lo", 4, lo))
     out.append(block("sweep_quad_lo_stamped", 4, lo, stamp=True))
