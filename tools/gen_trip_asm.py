@@ -441,6 +441,10 @@ QUAD1_TMP = 80
 
 QUAD_YMAP = tuple(int(x) for x in os.environ.get("QUAD_YMAP", "0,1,2,3").split(","))  # frame-pair quad blocks: priority by age rank in the youngest-first trips
 QUAD_XMAP = tuple(int(x) for x in os.environ.get("QUAD_XMAP", "0,1,2,3").split(","))  # ... and by rotating role in the other trips
+# frame-pair quad blocks, tuning (see trip_q): the priority scheme alternating per pair of trips (1) or per two pairs (2) instead of
+# trip by trip (0).  Measured, headline, alternating runs on one box: 4.470 / 4.497 / 4.520 ms per launch -- coarser is worse here
+# (the FIR8 blocks, whose items are eight times longer, want it the other way round: FIR_PRIO).
+QUAD_PRIO_COARSE = int(os.environ.get("QUAD_PRIO_COARSE", "0"))
 CHAIN = int(os.environ.get("QUAD_CHAIN", "1"))  # frame-pair quad blocks: V3 = S3 - S2 (a step in the column costs one difference, wherever it lies)
 
 
@@ -615,7 +619,16 @@ def block_quad(name, stamp=False, prio=None, nk=4, acc=QUAD_ACC, tmp=QUAD_TMP, d
     def trip_q(par):
         cur, nxt = E[par], E[1 - par]
         L = dma_piece() if dma else []
-        if prio == 3 or (prio == 5 and par == 0):
+        if QUAD_PRIO_COARSE and prio == 5 and nk == 4:
+            # coarser alternation (tuning): the scheme changes every QUAD_PRIO_COARSE-th pair of trips -- rotation while bit
+            # `QUAD_PRIO_COARSE` of the groups-left counter is clear, youngest-first while it is set -- and is applied once per pair
+            if par == 0:
+                COUNTER[0] += 1
+                uc = f"%=_{COUNTER[0]}"
+                COUNTER[0] += 1
+                L += ([f"s_bitcmp1_b32 s{S_LEFT_}, {QUAD_PRIO_COARSE}", f"s_cbranch_scc1 .LQpy{uc}"] + select_prio(S_PRIO, 1, QUAD_XMAP) +
+                      [f"s_branch .LQpz{uc}", f".LQpy{uc}:"] + select_prio(S_RANK, 0, QUAD_YMAP) + [f".LQpz{uc}:"])
+        elif prio == 3 or (prio == 5 and par == 0):
             L += select_prio(S_PRIO, 1, QUAD_XMAP if nk == 4 else (0, 1, 2, 3))   # the top priority moves on to the next wave of the SIMD
         elif prio == 5:
             L += select_prio(S_RANK, 0, QUAD_YMAP if nk == 4 else (0, 1, 2, 3))   # youngest first
