@@ -33,7 +33,7 @@ def test_generated_blocks_are_current():
 
     spec = importlib.util.spec_from_file_location("gen_trip_asm", REPO / "tools" / "gen_trip_asm.py")
     before = (CSRC / "das_fast_trip.inc").read_text()
-    env_backup = {k: os.environ.pop(k) for k in ("QUAD_VARIANTS", "TRIP_PRIO", "TRIP_DEPTH", "PAIR_DEPTH", "QUAD_CHAIN", "QUAD_YMAP", "QUAD_XMAP", "QUAD1_TIMING_SKIP", "QUAD1_NOBRANCH", "QUAD1_EARLY_X", "FIR_PRIO", "QUAD_PRIO_COARSE")
+    env_backup = {k: os.environ.pop(k) for k in ("QUAD_VARIANTS", "TRIP_PRIO", "TRIP_DEPTH", "PAIR_DEPTH", "QUAD_CHAIN", "QUAD_YMAP", "QUAD_XMAP", "QUAD1_TIMING_SKIP", "QUAD1_NOBRANCH", "QUAD1_EARLY_X", "FIR_PRIO", "QUAD_PRIO_COARSE", "QUAD1_PRIO_COARSE")
                   if k in os.environ}
     try:
         mod = importlib.util.module_from_spec(spec)

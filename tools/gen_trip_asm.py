@@ -445,6 +445,10 @@ QUAD_XMAP = tuple(int(x) for x in os.environ.get("QUAD_XMAP", "0,1,2,3").split("
 # trip by trip (0).  Measured, headline, alternating runs on one box: 4.470 / 4.497 / 4.520 ms per launch -- coarser is worse here
 # (the FIR8 blocks, whose items are eight times longer, want it the other way round: FIR_PRIO).
 QUAD_PRIO_COARSE = int(os.environ.get("QUAD_PRIO_COARSE", "0"))
+# the same knob for the single-frame quad blocks (block_quad_ar).  Measured, headline, one frame per call, alternating runs on one
+# box, frames/s: trip by trip 14.1 k | per pair of trips 13.9 k | per two pairs 13.8 k | rotation only (TRIP_PRIO=3) 13.5 k | static
+# youngest-first (4) 13.6 k | no priorities (0) 13.3 k
+QUAD1_PRIO_COARSE = int(os.environ.get("QUAD1_PRIO_COARSE", "0"))
 CHAIN = int(os.environ.get("QUAD_CHAIN", "1"))  # frame-pair quad blocks: V3 = S3 - S2 (a step in the column costs one difference, wherever it lies)
 
 
@@ -944,7 +948,14 @@ def block_quad_ar(name, stamp=False, prio=None, nk=2, acc=QUAD1_ACC[0], tmp=QUAD
     def trip_q(par):
         cur, nxt = E[par], E[1 - par]
         L = dma_piece() if dma else []
-        if prio == 3 or (prio == 5 and par == 0):
+        if QUAD1_PRIO_COARSE and prio == 5:  # tuning: the scheme changes per pair of trips (1) / two pairs (2), applied once per pair
+            if par == 0:
+                COUNTER[0] += 1
+                uc = f"%=_{COUNTER[0]}"
+                COUNTER[0] += 1
+                L += ([f"s_bitcmp1_b32 s{S_LEFT_}, {QUAD1_PRIO_COARSE}", f"s_cbranch_scc1 .LQpy{uc}"] + select_prio(S_PRIO, 1) +
+                      [f"s_branch .LQpz{uc}", f".LQpy{uc}:"] + select_prio(S_RANK, 0) + [f".LQpz{uc}:"])
+        elif prio == 3 or (prio == 5 and par == 0):
             L += select_prio(S_PRIO, 1)
         elif prio == 5:
             L += select_prio(S_RANK, 0)
