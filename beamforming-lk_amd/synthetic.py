@@ -50,6 +50,8 @@ WORKLOADS = {
     "headline": WorkloadSpec("headline: 256 mics x 128x128 x 256", 4, 1, 128),
     "c3": WorkloadSpec("c3: 512 mics x 128x128 x 256", 4, 2, 128),
     "c4": WorkloadSpec("c4: 512 mics x 256x256 x 256", 4, 2, 256),
+    # what the reference ships: one 8x8 array, --mimo-res 100, --fov 180 (src/main.cpp:38-41,53-56)
+    "ref_default": WorkloadSpec("reference default: 64 mics x 100x100 x 256", 1, 1, 100),
 }
 
 

@@ -724,6 +724,7 @@ def main():
         }
         eng16.close()
 
+        out["reference_default"] = reference_default(pkg, torch, args, dev, local_rank)
         out["workloads"] = other_workloads(pkg, sharding, torch, dist, args, dev, local_rank)
         out["projected_scaling"] = projected_scaling(pkg, sharding, torch, dist, args, spec, dev, local_rank, d_full, B,
                                                      fps_one_gpu=out["value"], ms_one_gpu=out["ms_per_step"])
@@ -753,6 +754,58 @@ def main():
     job.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def reference_default(pkg, torch, args, dev, local_rank):
+    """The configuration the reference ships and runs live: ONE 8x8 array, a 100x100 grid (src/main.cpp:38-41: --mimo-res
+    100), one frame per call (MIMOWorker::update, once per 256-sample block = every 5.24 ms at 48 828 Hz).  The device time
+    per frame, the reference's own delay() on one host thread beside it, and what each makes of the real-time budget."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["ref_default"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 4, seed=args.seed)
+    d_frames = torch.from_numpy(frames).to(dev)
+    d_p = torch.zeros((2, spec.n_pixels), dtype=torch.float32, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    n = 400
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=1, device=local_rank, grid_columns=spec.res) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            for k in range(20):
+                eng.process_device(d_frames[k % 4].data_ptr(), 1, d_p[1].data_ptr(), stream.cuda_stream)
+            ev[0].record(stream)
+            for k in range(n):
+                eng.process_device(d_frames[k % 4].data_ptr(), 1, d_p[1].data_ptr(), stream.cuda_stream)
+            ev[1].record(stream)
+            eng.process_device(d_frames[0].data_ptr(), 1, d_p[0].data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+        # one synchronous call on a host buffer: what MIMOWorker::update would wait for (upload, sweep, read-back)
+        eng.process(frames[:1])
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.process(frames[:1])
+        host_call_ms = (time.perf_counter() - t0) / 20 * 1e3
+    ms = ev[0].elapsed_time(ev[1]) / n
+    par = full_grid_parity(d_p[0].cpu().numpy(), frames[0], off, frac)
+    block_ms = 256 / 48828.0 * 1e3
+    out = {
+        "workload": spec.name + ", one frame per call (src/main.cpp:38-41,53-56; aw_processing_unit.cpp:74)",
+        "ms_per_frame_device": ms, "value": 1e3 / ms, "unit": "frames/s",
+        "ms_per_host_call": host_call_ms,
+        "realtime_block_ms": block_ms, "fraction_of_realtime_budget": host_call_ms / block_ms,
+        "parity_max_rel_unfloored": par["max_rel_unfloored"], "parity_ok": par["ok"], "pixels_checked": par["pixels"],
+        "note": "device time per frame from back-to-back device-pointer calls; ms_per_host_call = awpu_hip_process on a pageable "
+                "host frame (upload + sweep + read-back), the call MIMOWorker::update would make every 5.24 ms",
+    }
+    if args.cpu_seconds > 0:
+        cpu = cpu_baseline(spec, off, frac, frames[0], min(3.0, args.cpu_seconds))
+        out["cpu_reference_1t"] = {"value": cpu["value"], "unit": "frames/s", "ms_per_frame": 1e3 / cpu["value"],
+                                   "fraction_of_realtime_budget": 1e3 / cpu["value"] / block_ms, "kind": cpu["kind"]}
+    return out
 
 
 def other_workloads(pkg, sharding, torch, dist, args, dev, local_rank):
