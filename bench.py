@@ -28,7 +28,9 @@ At N = 1 the line also carries, next to the batched `value`:
   "single_frame"      one frame per call, the regime the reference's live display runs in
   "pcie_inclusive"    awpu_hip_process on pageable host buffers, upload and read-back inside the clock; never `value`
   "bf16"              the bf16-accumulator mode on the same frames: its ERROR against the fp32 sweep
-  "workloads"         c2, c3 and the c5 slab, 3 steps each: kernel ms, VALU fraction, full-grid parity
+  "reference_default" the shape the reference ships (64 mics, 100x100, one frame per call) with its CPU time and the
+                      5.24 ms real-time budget of a block beside it
+  "workloads"         c2, c3 and the c5 slab, a few steps each: kernel ms, VALU fraction, full-grid parity
   "projected_scaling" rank 0's slab of an 8-rank run through the N > 1 step loop, the collective replaced by a local
                       copy of the same bytes: what one GPU can say about the 8-GPU step (NOT a scaling measurement)
   "cpu_baseline"      the reference's own compiled delay() on the host
