@@ -94,7 +94,11 @@ class FrameBroadcaster:
     """
 
     def __init__(self, buffers: Tuple[torch.Tensor, torch.Tensor], src: int = 0,
-                 group: Optional[dist.ProcessGroup] = None, mode: str = "broadcast"):
+                 group: Optional[dist.ProcessGroup] = None, mode: str = "broadcast", point_to_point: Optional[bool] = None):
+        # point_to_point: the scatter step as grouped sends / receives straight into the batch buffer + an in-place
+        # all-gather (what runs over RCCL).  None = by backend (gloo: scatter into a side buffer + out-of-place gather);
+        # True lets the CPU tests run the RCCL schedule over gloo.
+        self.point_to_point = point_to_point
         self.buffers = buffers
         self.src = src
         self.group = group
@@ -118,7 +122,8 @@ class FrameBroadcaster:
             self._work[k % 2] = [dist.broadcast(buf, src=self.src, group=self.group, async_op=True)]
             return
         per = buf.shape[0] // self.world
-        if dist.get_backend(self.group) != "gloo":
+        p2p = self.point_to_point if self.point_to_point is not None else dist.get_backend(self.group) != "gloo"
+        if p2p:
             # NCCL/RCCL: the root sends every peer its slice straight into that peer's batch buffer (grouped point-to-point
             # sends), then the in-place all-gather (input = the output's own slice): no staging copy on either side,
             # stream-ordered one after the other
@@ -134,7 +139,14 @@ class FrameBroadcaster:
             # the calling stream.
             for w in works:
                 w.wait()
-            works.append(dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True))
+            gather = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True)
+            if dist.get_backend(self.group) == "gloo":
+                # (tests: gloo runs concurrent collectives on several threads in any order, and a second wait() on one of
+                # its finished send / receive works never returns: finish here, keep nothing)
+                gather.wait()
+                works = []
+            else:
+                works.append(gather)
             self._work[k % 2] = works
             return
         if self._mine[k % 2] is None:  # this rank's 1/world of the batch, outside `buf` (gloo does not gather in place)

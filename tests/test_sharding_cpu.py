@@ -33,7 +33,7 @@ def test_shard_rows_tile_the_grid(pkg):
         sh.shard_rows(4, 4, 8, 0)
 
 
-def _worker(rank, world, port, res, batch, steps, out_dir, mode="broadcast"):
+def _worker(rank, world, port, res, batch, steps, out_dir, mode="broadcast", p2p=None):
     import sys
     from pathlib import Path
 
@@ -51,8 +51,8 @@ def _worker(rank, world, port, res, batch, steps, out_dir, mode="broadcast"):
     sl = slice(shard.pixel_begin, shard.pixel_begin + shard.pixel_count)
     rng = np.random.default_rng(100)
     bufs = tuple(torch.zeros((batch, 64, 1024), dtype=torch.float32) for _ in range(2))
-    bc = sh.FrameBroadcaster(bufs, src=0, mode=mode)
-    assert bc.active
+    bc = sh.FrameBroadcaster(bufs, src=0, mode=mode, point_to_point=p2p)
+    assert bc.active and bc.mode == mode
     results = []
     all_frames = [rng.uniform(-0.01, 0.01, size=(batch, 64, 1024)).astype(np.float32) for _ in range(steps)]
     if rank == 0:
@@ -91,6 +91,16 @@ def _worker(rank, world, port, res, batch, steps, out_dir, mode="broadcast"):
 def test_broadcast_and_gather_world2(tmp_path, world, res, mode):
     port = free_port()
     mp.spawn(_worker, args=(world, port, res, 2, 3, str(tmp_path), mode), nprocs=world, join=True)
+    assert np.load(tmp_path / "ok.npy")[0]
+
+
+@pytest.mark.parametrize("world,res,batch", [(4, 8, 4), (3, 9, 6)])
+def test_rccl_exchange_schedule_over_gloo(tmp_path, world, res, batch):
+    """The schedule the N > 1 bench runs over RCCL -- the root's slices sent point to point straight into every peer's
+    batch buffer, then the in-place all-gather, ordered after the receives -- on more than two ranks, over gloo:
+    every rank ends up with rank 0's frames, three steps through the double buffer."""
+    port = free_port()
+    mp.spawn(_worker, args=(world, port, res, batch, 3, str(tmp_path), "scatter_allgather", True), nprocs=world, join=True)
     assert np.load(tmp_path / "ok.npy")[0]
 
 
