@@ -63,6 +63,7 @@ C5_SLABS = 8               # configs[4] shards the 256x256 grid over 8 GPUs
 FRAMES_PER_RANK_STEP = 128  # default batch = this x world: a rank's launch keeps its one-GPU size
 DISTINCT_FRAMES = 128      # synthetic frames generated; larger batches repeat them (every copy is swept in full)
 RENDEZVOUS_TIMEOUT_S = 180
+RUN_TIMEOUT_S = 900        # N > 1: everything after the rendezvous, per rank
 
 
 def parse_args(argv=None):
@@ -503,6 +504,11 @@ def main():
     wl_name = (f"c5: 512 mics x 256x256 x 256, {B} frames in flight, one rank's slab of {C5_SLABS * world} "
                f"({spec.res // (C5_SLABS * world)} rows) per GPU") if c5 else spec.name
 
+    # N > 1: a collective that never completes (a rank that died, a link that hangs) ends this rank with status 4 instead
+    # of sitting in the driver's own limit; generous -- table builds, K steps and the exchange trial fit many times over
+    run_guard = Watchdog(RUN_TIMEOUT_S, f"the {world}-rank run") if world > 1 else None
+    if run_guard:
+        run_guard.__enter__()
     job = RankJob(pkg, sharding, torch, dist, args, spec, world, rank, dev, local_rank, B, c5=c5)
     shard, off, frac, eng = job.shard, job.off, job.frac, job.eng
     d_full, d_power, bufs, stream, host_first = job.d_full, job.d_power, job.bufs, job.stream, job.host_first
@@ -754,6 +760,8 @@ def main():
             print("gather check:", msg, file=sys.stderr)
 
     job.close()
+    if run_guard:
+        run_guard.__exit__(None, None, None)
     if world > 1:
         dist.destroy_process_group()
 
