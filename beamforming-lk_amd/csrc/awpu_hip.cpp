@@ -742,6 +742,14 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
     pa.wp = pp.wr;
     pa.chunk = pp.chunk;
     pa.batch = batch;
+    // vertical pixel quads (samples shared between pixels of one column with the same integer delay) where the grid's row
+    // length is known and the rows are staged at the pitch that block is generated for; AWPU_FIR8_SHARE=0: consecutive pixels
+    {
+        static const bool allow = !(std::getenv("AWPU_FIR8_SHARE") && std::atoi(std::getenv("AWPU_FIR8_SHARE")) == 0);
+        const int cols = h->cfg.grid_columns;
+        if (allow && cols > 0 && P % cols == 0 && h->cfg.pixel_begin % cols == 0 && (uint32_t) pp.wr * 2u == awpu::kFirStaticPlaneBytesHost)
+            pa.cols = cols;
+    }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_planes(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, U, h->d_gain, pp.wr,
                                           batch, h->d_pack, s));

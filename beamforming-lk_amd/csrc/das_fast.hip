@@ -113,6 +113,7 @@ __device__ __forceinline__ void sweep_group(Acc<FPI> &acc, const EntryGroup &e, 
 }
 
 #include "das_fast_trip.inc"
+static_assert(kFirStaticPlaneBytes == kFirStaticPlaneBytesHost, "das_kernels.h and tools/gen_trip_asm.py disagree on the FIR8 plane pitch");
 
 // The items of one wave for one staged chunk: PPW pixels x ng groups of four, one frame per
 // item, each pixel through one hand-scheduled asm block (das_fast_trip.inc).
@@ -1132,7 +1133,27 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, con
         tile = in / ga;
         pair = (item < full_items ? grp * pair_group : n_pairs - ga) + (in - tile * ga);
     }
-    const int pix0 = (tile * NW + wave) * PPW;
+    // Which pixels this wave sweeps.  With the grid's row length known (a.cols > 0: set by the host only together with the
+    // static plane pitch) a workgroup takes 4 rows x 16 columns and a wave the four VERTICALLY adjacent pixels of one
+    // column, whose integer delays mostly coincide (sweep_fir8_planes_shared reuses the samples); otherwise four
+    // consecutive pixels.  Slots past the grid repeat a pixel inside it and are not stored.
+    int pix[PPW];
+    bool live[PPW];
+    if (a.cols > 0) {
+        const int tiles_per_row4 = (a.cols + NW - 1) / NW, rows = a.pixel_count / a.cols;
+        const int row4 = tile / tiles_per_row4, col = (tile - row4 * tiles_per_row4) * NW + wave;
+#pragma unroll
+        for (int q = 0; q < PPW; q++) {
+            live[q] = 4 * row4 + q < rows && col < a.cols;
+            pix[q] = min(4 * row4 + q, rows - 1) * a.cols + min(col, a.cols - 1);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < PPW; q++) {
+            live[q] = (tile * NW + wave) * PPW + q < a.pixel_count;
+            pix[q] = min((tile * NW + wave) * PPW + q, a.pixel_count - 1);
+        }
+    }
     const size_t row_floats = (size_t) a.wp * 2;
     const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
     const unsigned lane_bytes = threadIdx.x * 16;
@@ -1165,10 +1186,7 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, con
         const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
         const FirPlaneEntry *row[PPW];
 #pragma unroll
-        for (int pp = 0; pp < PPW; pp++) {
-            const int p = min(pix0 + pp, a.pixel_count - 1);  // pixels past the grid repeat the last one (not stored)
-            row[pp] = (const FirPlaneEntry *) uniform_ptr(lut + (size_t) p * a.usable_pad + m0);
-        }
+        for (int pp = 0; pp < PPW; pp++) row[pp] = (const FirPlaneEntry *) uniform_ptr(lut + (size_t) pix[pp] * a.usable_pad + m0);
         // the block also touches the next chunk's entries of its pixels (256 bytes from the chunk's end on: 64 entries)
         const unsigned pfoff = (unsigned) a.chunk * 4u + lane * 4u;
         const int pfn = __builtin_amdgcn_readfirstlane(c + 1 < n_chunks ? 1 : 0);
@@ -1180,7 +1198,9 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, con
         else if constexpr (VAR == 3) sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, 0);
         else
 #endif
-        if (plane_bytes == kFirStaticPlaneBytes)  // (uniform: rows staged at the pitch the one-address block is generated for, fir8_plane_plan)
+        if (a.cols > 0)  // (uniform) vertical pixel quads: samples shared between pixels with the same integer delay
+            sweep_fir8_planes_shared(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], mc, lane_addr, coef, pfoff, pfn, wave >> 2);
+        else if (plane_bytes == kFirStaticPlaneBytes)  // (uniform: rows staged at the pitch the one-address block is generated for, fir8_plane_plan)
             sweep_fir8_planes_static(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn, wave >> 2);
         else
         sweep_fir8_planes(acc[0], acc[1], acc[2], acc[3], row[0], row[1], row[2], row[3], (mc + 3) / 4, lane_addr, coef, plane_bytes, pfoff, pfn, wave >> 2);
@@ -1206,8 +1226,8 @@ __global__ __launch_bounds__(1024, 4) void das_fir8_plane_kernel(PairArgs a, con
         }
         sum.x = wave_sum(sum.x);
         sum.y = wave_sum(sum.y);
-        const int p = pix0 + pp;
-        if (lane == 0 && p < a.pixel_count) {
+        const int p = pix[pp];
+        if (lane == 0 && live[pp]) {
             a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
             if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
         }
@@ -1986,7 +2006,9 @@ static hipError_t launch_fir8_plane_variant(const PairArgs &a, const void *d_ent
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_fir8_plane_kernel<VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
-    const int n_pairs = (a.batch + 1) / 2, n_tiles = (a.pixel_count + 63) / 64;
+    const int n_pairs = (a.batch + 1) / 2;
+    const int n_tiles = a.cols > 0 ? ((a.pixel_count / a.cols + 3) / 4) * ((a.cols + 15) / 16) : (a.pixel_count + 63) / 64;
+    if (a.cols > 0 && (unsigned) a.wp * 2u != kFirStaticPlaneBytes) return hipErrorInvalidValue;  // (the shared block is generated for that pitch)
     // frame pairs an XCD works on at a time: as many as keep their packed samples in its 4 MiB L2 beside the table slices
     const size_t pair_bytes = (size_t) a.usable * a.wp * 8;
     int g = (int) std::max<size_t>(1, (3u << 20) / pair_bytes);

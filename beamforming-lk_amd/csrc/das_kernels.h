@@ -118,6 +118,7 @@ inline uint32_t fir8_plane_word(uint32_t addr, uint32_t plane, uint32_t k) {
 bool fir8_plane_plan(int window, int usable, FastPlan *plan);
 hipError_t launch_pack_planes(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index, int usable,
                               const float *d_gain, int wp, int batch, float *d_packed, hipStream_t stream);
+constexpr uint32_t kFirStaticPlaneBytesHost = 768;  // = kFirStaticPlaneBytes of das_fast_trip.inc (static_assert in das_fast.hip)
 hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, const float *d_coeffs, int variant, hipStream_t stream);
 // stationary shape: every active mic's window of a frame pair in LDS at once (plan->chunk = usable_pad); a
 // workgroup stages the pair once and sweeps tiles_per_wg tiles from it

@@ -1478,3 +1478,35 @@ def test_device_table_builder_equals_the_host_builder(pkg, arrays, res, fov, row
     assert np.array_equal(frac_d.view(np.uint32), frac_h.view(np.uint32))
     assert off_d.max() <= 256 and frac_d.min() >= 0.0 and frac_d.max() < 1.0
     assert (off_d == 256).any(axis=1).all()  # every pixel's nearest mic has delay 0 (antenna.cpp:93-96)
+
+
+@pytest.mark.parametrize("arrays,res,batch", [((4, 1), 128, 3), ((4, 2), 66, 8), ((4, 1), 100, 5)])
+def test_fir8_vertical_quads_share_samples_bit_for_bit(pkg, oracle, arrays, res, batch):
+    """The FIR8 batch kernel with the grid's row length given sweeps four vertically adjacent pixels mic by mic and reuses
+    the samples between pixels whose integer delays coincide (sweep_fir8_planes_shared); without the hint it sweeps four
+    consecutive pixels one after the other.  Per pixel the items and the taps run in the same order either way: the powers
+    are the same bits -- on a full grid, on grids whose rows are no multiple of four and columns no multiple of 16 (batches
+    large enough for the plane kernel: 256 workgroups), on a ragged mic list with per-mic gains, odd batches included -- and
+    match the restated FIR sweep on every pixel."""
+    xyz = pkg.create_tiled_antenna(*arrays)
+    n = xyz.shape[1]
+    off, frac = pkg.build_delay_table(xyz, res, res)
+    table = measured_fir_table()
+    X = util.hash_frames(n, 1024, seed=17 + res, batch=batch)
+    index = np.array([m for m in range(n) if m % 11 != 5], np.int32)
+    gains = (1.0 + 0.25 * np.sin(np.arange(n))).astype(np.float32)
+    out = {}
+    for cols in (res, 0):
+        with pkg.Engine(n_pixels=res * res, n_streams=n, interp=pkg.binding.INTERP_FIR8, max_batch=batch, grid_columns=cols) as eng:
+            eng.set_delay_table(off, frac)
+            eng.set_active_mics(index)
+            eng.set_fir_table(table)
+            plain = eng.process(X)
+            eng.set_mic_gains(gains)
+            gained = eng.process(X)
+        out[cols] = (plain, gained)
+    assert np.array_equal(out[res][0], out[0][0]) and np.array_equal(out[res][1], out[0][1])
+    for b in (0, batch - 1):
+        check_full_grid(oracle, out[res][0][b], X[b], off, frac, f"fir8 shared {res}x{res} frame {b}", index=index, fir_table=table)
+    scaled = X * gains[None, :, None]
+    check_full_grid(oracle, out[res][1][0], scaled[0], off, frac, f"fir8 shared {res}x{res} with gains", index=index, fir_table=table)

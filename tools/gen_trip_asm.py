@@ -1287,6 +1287,145 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row0, const voi
 """
 
 
+FIR_SH_TMP = 80  # block_fir8_shared: sample sets A / B at v80..v101 / v102..v123, address v124, prefetch sink v76
+
+
+def block_fir8_shared(name, acc=FIR_ACC, tmp=FIR_SH_TMP, pb=None, prio=None):
+    """The FIR8 block for four VERTICALLY ADJACENT pixels swept mic by mic (late round 3): within a mic the four items
+    go pixel 0, 1, 2, 3, and an item whose table entry carries the same LDS address and plane as the item before it --
+    the same integer delay; only the coefficient row differs -- takes the eleven samples that are in registers already: no
+    address add, no dispatch on the plane, no LDS read.  Vertical neighbours share their integer delay for 63 % (c3) to
+    83 % (headline) of the mics, so an item needs 3.6 .. 5.8 LDS reads where block_fir8 issues 11.
+
+    Two sample register sets A and B (22 registers each).  An item's FMAs read the set `sigma` its samples are in; a
+    following item that does not share them has its eleven reads issued into the OTHER set beside these FMAs and flips
+    sigma.  Which set an item reads is known only at run time, so every item position has its FMAs twice (from A, from B)
+    behind one scalar branch on sigma.  Everything else is block_fir8(static_pb): one table dword per (pixel, mic) (entries of
+    the four pixels' rows at one running offset), one v_add_u32 and eleven immediate-offset reads per NEW set of samples in
+    one of four copies by the plane r, coefficients by a dependent scalar load three items ahead, one lgkmcnt(0) per item.
+    Per pixel the items run in mic order and the taps in the reference's order: the sums are block_fir8's, bit for bit."""
+    pb = FIR_STATIC_PB if pb is None else pb
+    prio = FIR_PRIO if prio is None else prio
+    ENT = 36
+    CO = (40, 48, 56, 64)
+    AD, S_KEYN, S_KEY, S_SH, S_SIG = 72, 73, 74, 75, 76
+    S_T, S_R, S_K = 80, 81, 82
+    S_OFF_, S_LEFT_ = 23, 24
+    XS = (tmp, tmp + 22)
+    VA = tmp + 44
+    SINK = tmp - 4
+
+    def uid():
+        COUNTER[0] += 1
+        return f"%=_{COUNTER[0]}"
+
+    def accp(pp, o):
+        b = acc + 8 * pp + 2 * o
+        return f"v[{b}:{b + 1}]"
+
+    def xp(w, st):
+        r = XS[st] + 2 * w
+        return f"v[{r}:{r + 1}]"
+
+    def fmas(pp, ws, st):
+        L = []
+        for w in ws:
+            for o in range(max(0, w - 7), min(3, w) + 1):
+                t = w - o
+                sp = CO[pp] + (t & ~1)
+                sel = t & 1
+                L.append(f"v_pk_fma_f32 {accp(pp, o)}, s[{sp}:{sp + 1}], {xp(w, st)}, {accp(pp, o)} op_sel:[{sel},0,0] op_sel_hi:[{sel},1,1]")
+        return L
+
+    def reads(st, r):
+        L = []
+        for w in range(11):
+            off = ((r + w) % 4) * pb + 8 * ((r + w) // 4)
+            L.append(f"ds_read_b64 {xp(w, st)}, v{VA}" + (f" offset:{off}" if off else ""))
+        return L
+
+    def issue(st):
+        """the eleven samples of the item whose plane-0 address sits in s{AD} and whose plane in s{S_R}, into set st"""
+        u = uid()
+        return ([f"v_add_u32 v{VA}, s{AD}, %[lane]",
+                 f"s_cmp_lt_u32 s{S_R}, 2", f"s_cbranch_scc1 .LSr01{u}", f"s_cmp_eq_u32 s{S_R}, 2", f"s_cbranch_scc1 .LSr2{u}"] +
+                reads(st, 3) + [f"s_branch .LSrj{u}", f".LSr2{u}:"] + reads(st, 2) + [f"s_branch .LSrj{u}", f".LSr01{u}:",
+                f"s_cmp_eq_u32 s{S_R}, 0", f"s_cbranch_scc1 .LSr0{u}"] + reads(st, 1) + [f"s_branch .LSrj{u}", f".LSr0{u}:"] +
+                reads(st, 0) + [f".LSrj{u}:"])
+
+    def key_of(ent):
+        """key (address + plane: bits 0..19), plane-0 address and plane of the item whose entry sits in s{ent}"""
+        return [f"s_and_b32 s{S_KEYN}, s{ent}, 0xfffff",
+                f"s_and_b32 s{AD}, s{S_KEYN}, 0x3ffff", f"s_lshr_b32 s{S_R}, s{S_KEYN}, 18",
+                f"s_mul_i32 s{S_T}, s{S_R}, {pb}", f"s_sub_u32 s{AD}, s{AD}, s{S_T}"]
+
+    def load_coeffs(ent, cset):
+        return [f"s_bfe_u32 s{S_K}, s{ent}, 0x70014", f"s_lshl_b32 s{S_K}, s{S_K}, 5",
+                f"s_load_dwordx8 s[{cset}:{cset + 7}], %[coef], s{S_K}"]
+
+    def body(pp, st):
+        u = uid()
+        return (fmas(pp, range(0, 4), st) +
+                [f"s_cmp_eq_u32 s{S_SH}, 1", f"s_cbranch_scc1 .LSkeep{u}"] + issue(st ^ 1) + [f"s_xor_b32 s{S_SIG}, s{S_SIG}, 1", f".LSkeep{u}:"] +
+                fmas(pp, range(4, 11), st))
+
+    def item(pp):
+        u = uid()
+        L = ["s_waitcnt lgkmcnt(0)",
+             f"s_load_dword s{ENT + pp}, %[row{pp}], s{S_OFF_}"]        # entry of item i + 4 = (next mic, this pixel)
+        L += load_coeffs(ENT + (pp + 3) % 4, CO[(pp + 3) % 4])         # coefficients of item i + 3
+        if prio == 7 and pp == 0:
+            up = uid()
+            L += ([f"s_bitcmp1_b32 s{S_LEFT_}, 0", f"s_cbranch_scc1 .LSpy{up}"] + select_prio(S_PRIO, 1) +
+                  [f"s_branch .LSpz{up}", f".LSpy{up}:"] + select_prio(S_RANK, 0) + [f".LSpz{up}:"])
+        elif prio in (1, 2) and pp == 0:
+            L += select_prio(S_PRIO, 1)
+        L += key_of(ENT + (pp + 1) % 4)                                  # item i + 1: does it share this item's samples?
+        L += [f"s_cmp_eq_u32 s{S_KEYN}, s{S_KEY}", f"s_cselect_b32 s{S_SH}, 1, 0", f"s_mov_b32 s{S_KEY}, s{S_KEYN}",
+              f"s_cmp_eq_u32 s{S_SIG}, 0", f"s_cbranch_scc0 .LSb{u}"]
+        L += body(pp, 0) + [f"s_branch .LSj{u}", f".LSb{u}:"] + body(pp, 1) + [f".LSj{u}:"]
+        return L
+
+    L = [f"s_mov_b32 s{S_OFF_}, 0", f"s_mov_b32 s{S_SIG}, 0"]
+    if prio:
+        L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    # warm the L2 with the NEXT chunk's entries of these four pixels (as block_fir8 does)
+    L += ["s_cmp_lt_u32 %[pfn], 1", f"s_cbranch_scc1 .LSpf_%="]
+    L += [f"global_load_dword v{SINK}, %[pfoff], %[row{pp}]" for pp in range(4)]
+    L += [".LSpf_%=:"]
+    L += [f"s_load_dword s{ENT + pp}, %[row{pp}], 0x0" for pp in range(4)] + [f"s_mov_b32 s{S_OFF_}, 4", "s_waitcnt lgkmcnt(0)"]
+    for k in range(3):
+        L += load_coeffs(ENT + k, CO[k])
+    L += key_of(ENT) + [f"s_mov_b32 s{S_KEY}, s{S_KEYN}", "s_waitcnt lgkmcnt(0)"] + issue(0)
+    L += [f"s_mov_b32 s{S_LEFT_}, %[n]", ".LSloop_%=:"]
+    for pp in range(4):
+        L += item(pp)
+    L += [f"s_add_u32 s{S_OFF_}, s{S_OFF_}, 4", f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LSloop_%="]
+    L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]
+    if prio:
+        L += ["s_setprio 0"]
+    body_txt = "\n".join(f'        "{l}\\n\\t"' for l in L)
+    vregs = list(range(SINK, VA + 1))
+    sregs = [S_OFF_, S_LEFT_] + list(range(ENT, S_K + 1)) + ([S_RANK, S_PRIO] if prio else [])
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
+    acc_params = ", ".join(f"f8 &A{pp}" for pp in range(4))
+    acc_ops = ", ".join(f'"+{{v[{acc + 8 * pp}:{acc + 8 * pp + 7}]}}"(A{pp})' for pp in range(4))
+    rows = ", ".join(f'[row{pp}] "s"(row{pp})' for pp in range(4))
+    return f"""// Four vertically adjacent pixels of the staged chunk, 8-tap variant, swept mic by mic with the samples shared between
+// pixels whose entries carry the same address and plane: see block_fir8_shared in tools/gen_trip_asm.py.  row0..row3 = the
+// pixels' 4-byte entries from the chunk's first mic; sweeps n mics (n >= 1) and reads one entry past the last of every row;
+// rows staged at a plane pitch of {pb} bytes.  Accumulators pinned at v[{acc}:{acc + 31}], temps v{vregs[0]}..v{vregs[-1]}.
+__device__ __forceinline__ void {name}({acc_params}, const void *row0, const void *row1, const void *row2,
+                                       const void *row3, int n, unsigned lane_addr, const void *coef, unsigned pfoff, int pfn, int rank) {{
+    asm volatile(
+{body_txt}
+        : {acc_ops}
+        : {rows}, [n] "s"(n), [lane] "v"(lane_addr), [coef] "s"(coef), [pfoff] "v"(pfoff), [pfn] "s"(pfn), [rank] "s"(rank)
+        : {clobbers});
+}}
+"""
+
+
 def main():
     hi = 128 - (4 * (DEPTH + 1) + 1) - 3
     out = ["// GENERATED by tools/gen_trip_asm.py -- do not edit.  See that script for the schedule.", "",
@@ -1316,6 +1455,7 @@ def main():
     out.append(block_fir8("sweep_fir8_planes"))
     out += [f"constexpr unsigned kFirStaticPlaneBytes = {FIR_STATIC_PB};  // sweep_fir8_planes_static: the plane pitch it is generated for", ""]
     out.append(block_fir8("sweep_fir8_planes_static", static_pb=FIR_STATIC_PB))
+    out.append(block_fir8_shared("sweep_fir8_planes_shared"))
     if os.environ.get("QUAD_VARIANTS"):  # tuning builds: what the block costs without its scalar loads / its LDS reads / the read-ahead
         out.append(block_fir8("sweep_fir8_planes_v1", timing="noload", prio=0))
         out.append(block_fir8("sweep_fir8_planes_v2", timing="nolds", prio=0))

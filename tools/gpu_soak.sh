@@ -22,6 +22,7 @@ for seed in ${SEEDS:-11 12 13}; do
   run quadh_every_call $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1 AWPU_FAST_PAIRS=0
   run quad1_in_place $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1 AWPU_FAST_PAIRS=0 AWPU_FAST_HALVES=0 AWPU_TEST_COINCIDE=1
   run fir8_planes $seed 20 AWPU_TEST_INTERP=fir8 AWPU_FIR8_PLANES=2
+  run fir8_planes_grid $seed 20 AWPU_TEST_INTERP=fir8 AWPU_FIR8_PLANES=2 AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
   run fir8 $seed 12 AWPU_TEST_INTERP=fir8
   run default_grid $seed 20 AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
   run default $seed 20 X=1
