@@ -91,8 +91,9 @@ typedef struct {
     int32_t pixel_begin;
     int32_t pixel_count; /* 0 = all n_pixels */
     /* optional hint: pixels per row of the steering grid (MIMOWorker's `columns`, mimo.cpp:8), 0 = unknown.
-     * Results do not depend on it; the batched sweep uses it to give a wave vertically adjacent pixels,
-     * whose integer delays coincide for most mics (one sample read then serves both).  Ignored unless
+     * The sweeps use it to give a wave vertically adjacent pixels, whose integer delays coincide for most mics (shared
+     * sums and sample reads: the quad shapes, the FIR8 shared-sample block).  Results with and without it agree within the
+     * fast sweep's fp32 rounding (another order of the same sums; FIR8 and the exact mode: bit for bit).  Ignored unless
      * pixel_begin and pixel_count are whole rows. */
     int32_t grid_columns;
     /* Device group: with n_devices > 1 the handle spreads its pixels over devices[0 .. n_devices-1]
