@@ -32,7 +32,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="c1,c2,headline,c3,c4slab")
     ap.add_argument("--out", default="")
+    ap.add_argument("--interp", default="lerp", choices=["lerp", "fir8"], help="fir8: the 8-tap variant of delay() (batch and single shapes; a Blackman-windowed-sinc table)")
     args = ap.parse_args()
+    fir = args.interp == "fir8"
+    table = util.synthetic_fir_table() if fir else None
     pkg = importlib.import_module("beamforming-lk_amd")
     sharding = importlib.import_module("beamforming-lk_amd.sharding")
     from oracle import oracle_py
@@ -55,17 +58,23 @@ def main():
         refs = []
         t0 = time.perf_counter()
         for b in (0, 3):
-            refs.append((b, oracle_py.das_f32(frames[b], off, frac), oracle_py.das_f64(frames[b], off, frac)))
+            if fir:
+                refs.append((b, oracle_py.das_fir8_f32(frames[b], off, frac, table), oracle_py.das_fir8_f64(frames[b], off, frac, table)))
+            else:
+                refs.append((b, oracle_py.das_f32(frames[b], off, frac), oracle_py.das_f64(frames[b], off, frac)))
         t_or = time.perf_counter() - t0
         for mode, math, batch, hint in (("batch", "fast", 4, True), ("batch", "fast", 4, False),
                                         ("single", "fast", 1, True), ("single", "fast", 1, False),
                                         ("exact", "exact", 1, False)):
             eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=batch,
                              math=pkg.MATH_F32_FAST if math == "fast" else pkg.MATH_F32_EXACT,
+                             interp=pkg.binding.INTERP_FIR8 if fir else pkg.binding.INTERP_LERP,
                              pixel_begin=begin, pixel_count=count, grid_columns=spec.res if hint else 0)
             with eng:
                 eng.set_delay_table(off, frac)
                 eng.set_active_mics(None)
+                if fir:
+                    eng.set_fir_table(table)
                 for b, r32, r64 in refs:
                     if batch == 1:
                         got = eng.process(frames[b:b + 1])[0]
@@ -75,7 +84,7 @@ def main():
                         got = power[0]
                         assert np.array_equal(power[3], power[0]), "the same frame in another slot of a pair differs"
                     rep = util.parity_report(got, r32, r64)
-                    rep.update({"workload": wl, "mode": mode, "grid_columns": hint,
+                    rep.update({"workload": wl, "interp": args.interp, "mode": mode, "grid_columns": hint,
                                 "frame": "plane wave + noise" if b == 0 else "hash noise"})
                     records.append(rep)
                     print(json.dumps(rep), flush=True)
