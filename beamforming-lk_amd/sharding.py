@@ -167,6 +167,73 @@ class FrameBroadcaster:
         return self.buffers[k % 2]
 
 
+class RawScatterExchange:
+    """The third way to get a batch to every rank: spread the ROOT's pack pass over the ranks.
+
+    post(k): the root sends rank r the r-th slice of the RAW frames (contiguous snapshots, no window cut, no pack pass on
+    the root: its share of a step is then the share of every other rank), every rank packs its slice into its slot of
+    packed buffer k % 2 (`pack(raw frames [per, ...], packed slot [per / 2, ...])`: awpu_hip_pack_frames on the calling
+    stream) and an in-place all-gather completes every rank's packed buffer.  wait(k) returns that buffer.
+    Against FrameBroadcaster's scatter + all-gather the wire carries the raw snapshots once more (1024 / W times the
+    window's bytes to each peer), which is why bench.py times the schedules against each other on the node before it
+    picks one.  The batch must divide by twice the world size (whole frame pairs per rank).
+
+    raw: this rank's two receive buffers [per, ...] (the root needs none: it packs from `full` in place);
+    full: the root's whole batch of raw frames [batch, ...], or a callable k -> that tensor."""
+
+    mode = "raw_scatter"
+
+    def __init__(self, packed: Tuple[torch.Tensor, torch.Tensor], raw: Optional[Tuple[torch.Tensor, torch.Tensor]], full, pack,
+                 src: int = 0, group: Optional[dist.ProcessGroup] = None):
+        self.packed, self.raw, self.full, self.pack, self.src, self.group = packed, raw, full, pack, src, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        pairs = packed[0].shape[0]
+        if pairs % self.world:
+            raise ValueError("the frame pairs of a batch must divide by the world size")
+        self.pairs_per = pairs // self.world
+        self.per = 2 * self.pairs_per
+        if self.rank != src and (raw is None or raw[0].shape[0] != self.per):
+            raise ValueError("every rank but the source needs two raw buffers of batch / world frames")
+        self._work = [None, None]
+
+    def post(self, k: int) -> None:
+        b = k % 2
+        gloo = dist.get_backend(self.group) == "gloo"
+        if self.rank == self.src:
+            full = self.full(k) if callable(self.full) else self.full
+            ops = [dist.P2POp(dist.isend, full[r * self.per:(r + 1) * self.per], r, self.group) for r in range(self.world) if r != self.src]
+            mine_raw = full[self.src * self.per:(self.src + 1) * self.per]
+        else:
+            ops = [dist.P2POp(dist.irecv, self.raw[b], self.src, self.group)]
+            mine_raw = self.raw[b]
+        works = list(dist.batch_isend_irecv(ops)) if ops else []
+        if self.rank != self.src:  # (the pack below reads what the receive delivers: order the calling stream after it)
+            for w in works:
+                w.wait()
+            if gloo:
+                works = []
+        slot = self.packed[b][self.rank * self.pairs_per:(self.rank + 1) * self.pairs_per]
+        self.pack(mine_raw, slot)
+        gather = dist.all_gather_into_tensor(self.packed[b], slot, group=self.group, async_op=True)
+        if gloo:  # (tests: see FrameBroadcaster.post)
+            gather.wait()
+            for w in works:
+                w.wait()
+            works = []
+        else:
+            works.append(gather)
+        self._work[b] = works
+
+    def wait(self, k: int) -> torch.Tensor:
+        works = self._work[k % 2]
+        if works:
+            for w in works:
+                w.wait()
+        self._work[k % 2] = None
+        return self.packed[k % 2]
+
+
 class LocalCopyExchange:
     """Stand-in for FrameBroadcaster on ONE device (bench.py's projected_scaling): the same post/wait protocol and
     the same stream ordering as an asynchronous collective -- the transfer waits for what the caller's stream has
@@ -176,9 +243,15 @@ class LocalCopyExchange:
 
     mode = "local_copy"
 
-    def __init__(self, buffers: Tuple[torch.Tensor, torch.Tensor], arrival: torch.Tensor, priority: int = 0):
+    def __init__(self, buffers: Tuple[torch.Tensor, torch.Tensor], arrival: torch.Tensor, priority: int = 0, raw_scatter=None):
+        # raw_scatter = (raw receive buffer, raw source of the same shape, pack(raw, slot), rank, world): stand in for
+        # RawScatterExchange instead -- the rank's raw slice "arrives" by a local copy, the rank packs it into its slot, the
+        # other ranks' slots "arrive" from `arrival`
         if arrival.shape != buffers[0].shape:
             raise ValueError("arrival must have the shape of a batch buffer")
+        self.raw_scatter = raw_scatter
+        if raw_scatter is not None:
+            self.mode = "local_copy of raw_scatter"
         self.buffers = buffers
         self.arrival = arrival
         self.cuda = buffers[0].is_cuda
@@ -194,7 +267,17 @@ class LocalCopyExchange:
             self.posted[b].record(torch.cuda.current_stream(self.buffers[b].device))
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.posted[b])
-                self.buffers[b].copy_(self.arrival, non_blocking=True)
+                if self.raw_scatter is None:
+                    self.buffers[b].copy_(self.arrival, non_blocking=True)
+                else:
+                    raw, raw_src, pack, rank, world = self.raw_scatter
+                    per = self.buffers[b].shape[0] // world
+                    raw.copy_(raw_src, non_blocking=True)
+                    pack(raw, self.buffers[b][rank * per:(rank + 1) * per])
+                    if rank > 0:
+                        self.buffers[b][:rank * per].copy_(self.arrival[:rank * per], non_blocking=True)
+                    if rank + 1 < world:
+                        self.buffers[b][(rank + 1) * per:].copy_(self.arrival[(rank + 1) * per:], non_blocking=True)
                 self.landed[b].record(self.side)
         else:
             self.buffers[b].copy_(self.arrival)

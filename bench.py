@@ -362,15 +362,35 @@ class RankJob:
             self.bufs = (self.d_full, self.d_full)
             self.exchange_mb = 0.0
         self.d_power = torch.zeros((B, self.shard.pixel_count), dtype=torch.float32, device=dev)
+        # "raw_scatter" (sharding.RawScatterExchange): the root's pack pass spread over the ranks -- every rank but the root
+        # receives batch / world raw snapshots per step and packs them itself
+        self.raw = None
+        self.raw_ok = self.exchange == "packed" and world > 1 and (B // 2) % world == 0
+        if self.raw_ok and (rank != 0 or stub == "raw_scatter"):
+            self.raw = tuple(torch.empty((B // world, spec.n_mics, pkg.binding.HIST), dtype=torch.float32, device=dev) for _ in range(2))
         if stub:
             # stands for the bytes the collective would deliver (the real frames, so that the sweep sees real samples)
             self.arrival = torch.empty_like(self.bufs[0])
             torch.cuda.synchronize()
             self.fill(self.arrival, torch.cuda.current_stream(dev))
-            self.bcast = sharding.LocalCopyExchange(self.bufs, self.arrival, priority=prio[1])
+            raw_stub = None
+            if stub == "raw_scatter":  # this rank's slice arrives raw and is packed here; the other slots arrive packed
+                raw_stub = (self.raw[0], self.d_full[:B // world], self.pack_slice, 0, world)
+            self.bcast = sharding.LocalCopyExchange(self.bufs, self.arrival, priority=prio[1], raw_scatter=raw_stub)
         else:
-            self.bcast = sharding.FrameBroadcaster(self.bufs, src=0, mode=os.environ.get("BENCH_BCAST", "broadcast"))
+            self.bcast = self.make_exchange(os.environ.get("BENCH_BCAST", "broadcast"))
         torch.cuda.synchronize()
+
+    def pack_slice(self, raw, slot):
+        """awpu_hip_pack_frames for a slice of the batch, on the calling stream: raw snapshots [n, mics, 1024] -> their n / 2 packed pairs"""
+        self.eng.pack_frames(raw.data_ptr(), raw.shape[0], slot.data_ptr(), self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def make_exchange(self, mode):
+        if mode == "raw_scatter":
+            if not self.raw_ok:
+                raise ValueError("raw_scatter needs the packed exchange format and whole frame pairs per rank")
+            return self.sharding.RawScatterExchange(self.bufs, self.raw, self.d_full if self.rank == 0 else None, self.pack_slice, src=0)
+        return self.sharding.FrameBroadcaster(self.bufs, src=0, mode=mode)
 
     def make_engine(self, math_id, max_batch, off_, frac_, begin, count, grid_columns=None, window=None, hist=None):
         spec = self.spec
@@ -401,7 +421,7 @@ class RankJob:
             return
         if k >= 2:
             self.aux.wait_event(self.swept[k % 2])
-        if self.rank == 0 and self.root_work:
+        if self.rank == 0 and self.root_work and "raw_scatter" not in self.bcast.mode:
             self.fill(self.bufs[k % 2], self.aux)
         with self.torch.cuda.stream(self.aux):  # (a collective is ordered after the work of the stream it is called on)
             self.bcast.post(k)
@@ -521,13 +541,18 @@ def main():
     # an all-gather (every xGMI link carries 1/N instead of the root's ring neighbour carrying all of it).  Which is
     # faster depends on the collective library's schedule for this topology, so both are timed over a few warm-up
     # steps and the faster one (the same on every rank: decided on the maximum over ranks) runs the timed region.
-    # BENCH_BCAST=broadcast|scatter_allgather pins it.
+    # A third schedule, raw_scatter (sharding.RawScatterExchange), spreads the root's pack pass over the ranks at the price of
+    # raw snapshots on the wire.  BENCH_BCAST=broadcast|scatter_allgather|raw_scatter pins one.
     bcast_choice = {"mode": job.bcast.mode, "why": "BENCH_BCAST" if "BENCH_BCAST" in os.environ else "single mode"}
     trial_ranks = 2 if rehearsal else 4  # (two ranks have one link either way: nothing to choose)
     if world >= trial_ranks and "BENCH_BCAST" not in os.environ and B % world == 0:
         trial = {}
-        for mode in ("broadcast", "scatter_allgather"):
-            job.bcast = sharding.FrameBroadcaster(bufs, src=0, mode=mode)
+        for mode in ("broadcast", "scatter_allgather") + (("raw_scatter",) if job.raw_ok else ()):
+            try:
+                job.bcast = job.make_exchange(mode)
+            except Exception as exc:  # noqa: BLE001 -- (the same on every rank: a property of the configuration)
+                print(f"[bench] {mode} not available on rank {rank} ({exc})", file=sys.stderr)
+                continue
             mine_s = float("inf")
             try:
                 run_steps(1)
@@ -544,7 +569,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             trial[mode] = float(tt.item()) / max(2, W)
         best = min(trial, key=trial.get) if min(trial.values()) != float("inf") else "broadcast"
-        job.bcast = sharding.FrameBroadcaster(bufs, src=0, mode=best)
+        job.bcast = job.make_exchange(best)
         bcast_choice = {"mode": best, "why": "faster over the warm-up steps",
                         "ms_per_step": {m: (round(v * 1e3, 4) if v != float("inf") else None) for m, v in trial.items()}}
         run_steps(1)
@@ -901,6 +926,23 @@ def projected_scaling(pkg, sharding, torch, dist, args, spec, dev, local_rank, d
                 f"are not in it).  NOT a scaling measurement",
     }
     job.close()
+    del job
+    # the same share under the raw_scatter schedule (sharding.RawScatterExchange): no pack pass of the whole batch on the
+    # ingest rank -- every rank receives its eighth of the raw snapshots and packs that; ingest rank and peers then do the same
+    try:
+        job2 = RankJob(pkg, sharding, torch, dist, sub, spec, ranks, 0, dev, local_rank, B, stub="raw_scatter", frames_src=frames)
+        if job2.raw_ok:
+            e2, k2, _ = job2.timed(K, 2)
+            out["raw_scatter"] = {
+                "step_wall_ms": e2 / K * 1e3, "slab_kernel_ms": k2, "ceiling_x": (B / (e2 / K)) / fps_one_gpu,
+                "raw_mb_per_rank_per_step": (B // ranks) * spec.n_mics * pkg.binding.HIST * 4 / 1e6,
+                "note": "every rank (the ingest rank too) under the raw_scatter schedule: its eighth of the raw snapshots arrives by a "
+                        "local copy, it packs them into its slot, the other slots arrive packed; bench.py --gpus N times this schedule "
+                        "against the other two on the node and keeps the fastest",
+            }
+        job2.close()
+    except Exception as exc:  # noqa: BLE001 -- an optional leg
+        out["raw_scatter"] = {"error": str(exc)}
     return out
 
 

@@ -1510,3 +1510,39 @@ def test_fir8_vertical_quads_share_samples_bit_for_bit(pkg, oracle, arrays, res,
         check_full_grid(oracle, out[res][0][b], X[b], off, frac, f"fir8 shared {res}x{res} frame {b}", index=index, fir_table=table)
     scaled = X * gains[None, :, None]
     check_full_grid(oracle, out[res][1][0], scaled[0], off, frac, f"fir8 shared {res}x{res} with gains", index=index, fir_table=table)
+
+
+def test_pack_frames_in_slices_equals_one_pass(pkg, oracle):
+    """What sharding.RawScatterExchange relies on: awpu_hip_pack_frames on a slice of the batch, written to that slice's
+    slot of the packed buffer, gives the bytes one pass over the whole batch writes there -- and the sweep on the buffer
+    assembled from slices gives the same powers."""
+    import torch
+
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c2"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    B, parts = 16, 4
+    frames = S.make_frames(xyz, B, seed=5)
+    dev = torch.device("cuda", 0)
+    d_frames = torch.from_numpy(frames).to(dev)
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=B, grid_columns=spec.res) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        n = eng.packed_bytes(B) // 4
+        whole = torch.zeros((B // 2, n // (B // 2)), dtype=torch.float32, device=dev)
+        pieces = torch.zeros_like(whole)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        eng.pack_frames(d_frames.data_ptr(), B, whole.data_ptr(), stream.cuda_stream)
+        per = B // parts
+        for r in (2, 0, 3, 1):  # any order
+            eng.pack_frames(d_frames[r * per:(r + 1) * per].data_ptr(), per, pieces[r * per // 2:(r + 1) * per // 2].data_ptr(), stream.cuda_stream)
+        p_whole = torch.zeros((B, spec.n_pixels), dtype=torch.float32, device=dev)
+        p_pieces = torch.zeros_like(p_whole)
+        eng.process_packed(whole.data_ptr(), B, p_whole.data_ptr(), stream.cuda_stream)
+        eng.process_packed(pieces.data_ptr(), B, p_pieces.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+    assert torch.equal(whole, pieces)
+    assert torch.equal(p_whole, p_pieces)
+    check_full_grid(oracle, p_pieces[B - 1].cpu().numpy(), frames[B - 1], off, frac, "c2, packed in four slices, last frame")

@@ -104,6 +104,51 @@ def test_rccl_exchange_schedule_over_gloo(tmp_path, world, res, batch):
     assert np.load(tmp_path / "ok.npy")[0]
 
 
+def _raw_scatter_worker(rank, world, port, steps, out_dir):
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = importlib.import_module("beamforming-lk_amd.sharding")
+    batch, mics, hist, wp = 4 * world, 3, 16, 5
+    per = batch // world
+    rng = np.random.default_rng(5)
+    all_frames = [rng.standard_normal((batch, mics, hist)).astype(np.float32) for _ in range(steps)]
+
+    def pack(raw, slot):  # a stand-in for awpu_hip_pack_frames: two frames interleaved, a window of wp samples from sample 2
+        slot.copy_(torch.stack([raw[0::2, :, 2:2 + wp], raw[1::2, :, 2:2 + wp]], dim=-1).reshape(slot.shape))
+
+    packed = tuple(torch.zeros((batch // 2, mics * wp * 2)) for _ in range(2))
+    raw = tuple(torch.zeros((per, mics, hist)) for _ in range(2)) if rank != 0 else None
+    full = [torch.from_numpy(f) for f in all_frames]
+    ex = sh.RawScatterExchange(packed, raw, (lambda k: full[k]) if rank == 0 else None, pack, src=0)
+    ok = True
+    ex.post(0)
+    for k in range(steps):
+        got = ex.wait(k)
+        if k + 1 < steps:
+            ex.post(k + 1)
+        want = np.stack([all_frames[k][0::2, :, 2:2 + wp], all_frames[k][1::2, :, 2:2 + wp]], axis=-1).reshape(batch // 2, -1)
+        ok &= np.array_equal(got.numpy(), want)
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "ok.npy"), flag.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_raw_scatter_exchange(tmp_path, world):
+    """RawScatterExchange: raw slices to every rank, every rank packs its own, in-place all-gather of the packed batch --
+    every rank ends up with the whole packed batch, three steps through the double buffer."""
+    port = free_port()
+    mp.spawn(_raw_scatter_worker, args=(world, port, 3, str(tmp_path)), nprocs=world, join=True)
+    assert np.load(tmp_path / "ok.npy")[0]
+
+
 def _scatter_worker(rank, world, port, steps, out_dir):
     import sys
     from pathlib import Path
