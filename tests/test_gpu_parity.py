@@ -1363,8 +1363,11 @@ def test_bench_two_ranks_on_one_gpu_assemble_the_oracle_heatmap():
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AWPU_NO_BUILD")}  # (not under a profiler here)
     env.update(BENCH_REHEARSAL="1", BENCH_GATHER_CHECK="1")
-    for exchange in ("packed", "window"):
+    for exchange, schedule in (("packed", None), ("window", None), ("packed", "raw_scatter")):
         env["BENCH_EXCHANGE"] = exchange
+        env.pop("BENCH_BCAST", None)
+        if schedule:  # the schedule that spreads rank 0's pack pass over the ranks, pinned (over gloo it is slow, not wrong)
+            env["BENCH_BCAST"] = schedule
         proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "2", "--warmup", "1",
                                "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=600)
         assert proc.returncode == 0, proc.stderr[-3000:]
@@ -1375,6 +1378,8 @@ def test_bench_two_ranks_on_one_gpu_assemble_the_oracle_heatmap():
         assert rec["parity"]["ok"] and rec["parity"]["pixels"] == 2048  # rank 0's share: 32 of the 64 rows
         assert ("packed frame pairs" in rec["config"]["sharding"]) == (exchange == "packed")
         assert "gather check: ok" in proc.stderr, proc.stderr[-3000:]
+        if schedule:
+            assert rec["config"]["frame_exchange"]["mode"] == schedule
 
 
 def test_dc_offset_frames_batched_sweep_is_closer_to_exact_than_the_reference(pkg, oracle):
