@@ -30,7 +30,8 @@ At N = 1 the line also carries, next to the batched `value`:
   "bf16"              the bf16-accumulator mode on the same frames: its ERROR against the fp32 sweep
   "reference_default" the shape the reference ships (64 mics, 100x100, one frame per call) with its CPU time and the
                       5.24 ms real-time budget of a block beside it
-  "workloads"         c2, c3 and the c5 slab, a few steps each: kernel ms, VALU fraction, full-grid parity
+  "workloads"         c2, c3 (lerp and the 8-tap FIR variant) and the c5 slab, a few steps each: kernel ms, VALU fraction,
+                      full-grid parity
   "projected_scaling" rank 0's slab of an 8-rank run through the N > 1 step loop, the collective replaced by a local
                       copy of the same bytes: what one GPU can say about the 8-GPU step (NOT a scaling measurement)
   "cpu_baseline"      the reference's own compiled delay() on the host
@@ -850,19 +851,23 @@ def other_workloads(pkg, sharding, torch, dist, args, dev, local_rank):
     out = []
     # (steps, warm-up): the short launches get more of both -- three c2 steps after one warm-up step ran 17 % below the
     # rate of a 20-step run of the same workload (profiles/r03_bench_c2.json: the clocks and the caches had not settled)
-    for name, batch, K, W in (("c2", 128, 12, 6), ("c3", 128, 4, 2), ("c5", 1024, 3, 1)):
+    for name, batch, K, W in (("c2", 128, 12, 6), ("c3", 128, 4, 2), ("c3 fir8", 128, 3, 1), ("c5", 1024, 3, 1)):
         c5 = name == "c5"
-        spec = S.WORKLOADS["c4" if c5 else name]
+        fir = name.endswith("fir8")  # BASELINE configs[2] read as the 8-tap fractional-delay variant of delay() (delay.cpp:31-40)
+        spec = S.WORKLOADS["c4" if c5 else name.split()[0]]
         t0 = time.perf_counter()
         sub = argparse.Namespace(**vars(args))
+        sub.interp = "fir8" if fir else "lerp"
         job = RankJob(pkg, sharding, torch, dist, sub, spec, 1, 0, dev, local_rank, batch, c5=c5)
         elapsed, kernel_ms, _ = job.timed(K, W)
         st = job.eng.stats()
-        par = full_grid_parity(job.d_power[0].cpu().numpy(), job.host_first[0], job.off, job.frac)
+        par = full_grid_parity(job.d_power[0].cpu().numpy(), job.host_first[0], job.off, job.frac, interp=sub.interp)
         flops = int(st.alg_flops_frame) * batch
+        if fir:  # 16 flop per (pixel, mic, sample) instead of 4
+            flops = (16 * job.shard.pixel_count * st.usable * 256 + 6 * job.shard.pixel_count * 254) * batch
         out.append({
             "workload": (f"c5: one rank's slab of 8 of 512 mics x 256x256 ({job.shard.pixel_count} pixels), {batch} frames in flight"
-                         if c5 else spec.name),
+                         if c5 else spec.name + (", 8-tap FIR variant of delay() (--interp fir8)" if fir else "")),
             "frames_per_step": batch, "steps": K, "warmup": W, "value": batch * K / elapsed, "unit": "frames/s",
             "kernel_ms": kernel_ms, "valu_frac": flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
             "hbm_frac": int(st.alg_bytes_frame) * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
