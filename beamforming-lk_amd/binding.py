@@ -87,6 +87,7 @@ _SIGNATURES = {
     "awpu_hip_process_async": (C.c_int, [C.c_void_p, _f32p, C.c_int32, _f32p]),
     "awpu_hip_wait": (C.c_int, [C.c_void_p]),
     "awpu_hip_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "awpu_hip_process_device_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "awpu_hip_synchronize": (C.c_int, [C.c_void_p]),
     "awpu_hip_packed_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "awpu_hip_pack_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -394,6 +395,13 @@ class Engine:
         _check(self._lib.awpu_hip_process_device(self._h, C.c_void_p(d_frames_ptr), batch,
                                                  C.c_void_p(d_power_ptr), C.c_void_p(stream)),
                "awpu_hip_process_device")
+
+    def process_device_sums(self, d_frames_ptr: int, batch: int, d_power_ptr: int, d_sums_ptr: int, stream: int = 0) -> None:
+        """process_device plus every pixel's out[0..255] before the epilogue into d_sums [batch, pixels, 256]
+        (awpu_hip_process_device_sums: MATH_F32_EXACT + INTERP_LERP only; bit-identical to the reference's out[])."""
+        _check(self._lib.awpu_hip_process_device_sums(self._h, C.c_void_p(d_frames_ptr), batch, C.c_void_p(d_power_ptr),
+                                                      C.c_void_p(d_sums_ptr), C.c_void_p(stream)),
+               "awpu_hip_process_device_sums")
 
     def packed_bytes(self, batch: int) -> int:
         """Bytes of the packed frame-pair buffer for `batch` frames (awpu_hip_packed_bytes); raises AwpuError with

@@ -80,6 +80,10 @@ struct awpu_hip {
         awpu::FastEntry *d = nullptr;
     };
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
+    awpu::FastEntry *d_exact_pair_lut = nullptr;  // reference-order sweep on the frame-pair layout (das_exact_pair_kernel)
+    awpu::FastPlan exact_plan{};
+    bool exact_pairs_ok = false;  // AWPU_MATH_F32_EXACT + LERP and the window fits the pair image
+    float *sums_out = nullptr;    // awpu_hip_process_device_sums: where the launch in progress exports out[] (else null)
     awpu::QuadEntry *d_quad_lut = nullptr;  // quad-major table of the quad shape (das_quad_kernel)
     awpu::QuadEntry *d_quad1_lut = nullptr; // the same with the single-frame layout's LDS addresses (das_quad1_kernel)
     awpu::QuadEntry *d_quadh_lut = nullptr; // the same with the halves layout's LDS addresses (das_quadh_kernel)
@@ -199,6 +203,7 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
     int wgs = 0;                   // AWPU_FAST_WGS: persistent workgroups of the quad shape (0 = one workgroup per item)
     int live_graph = 1;            // AWPU_LIVE_GRAPH=0: awpu_hip_live_block always enqueues its steps one by one
     int halves = -1;               // AWPU_FAST_HALVES=0/1: never / always (where the quad table is built) sweep single frames on the halves layout
+    int exact_pairs = 1;           // AWPU_EXACT_PAIRS=0: AWPU_MATH_F32_EXACT on the round-1 verification kernel (das_exact_kernel; A/B runs and tests)
     int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0]; 2: and through pinned host memory, the path of a node without peer access (tests)
     EnvKnobs() {
         if (const char *v = std::getenv("AWPU_FAST_QUADS")) quads = std::atoi(v);
@@ -206,6 +211,7 @@ struct EnvKnobs {  // tuning / test knobs, read once per process
         if (const char *v = std::getenv("AWPU_QUAD_VARIANT")) quad_variant = std::atoi(v);
         if (const char *v = std::getenv("AWPU_GROUP_FORCE_COPY")) group_copy = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_HALVES")) halves = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_EXACT_PAIRS")) exact_pairs = std::atoi(v);
         if (const char *v = std::getenv("AWPU_LIVE_GRAPH")) live_graph = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_WGS")) wgs = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FIR8_PLANES")) fir_planes = std::atoi(v);
@@ -250,6 +256,7 @@ void release_device(awpu_hip *h) {
     dev_free(h->d_lut);
     for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
+    dev_free(h->d_exact_pair_lut);
     dev_free(h->d_quad_lut);
     dev_free(h->d_quad1_lut);
     dev_free(h->d_quadh_lut);
@@ -319,6 +326,7 @@ int prepare(awpu_hip *h) {
     dev_free(h->d_index);
     for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
+    dev_free(h->d_exact_pair_lut);
     dev_free(h->d_quad_lut);
     dev_free(h->d_quad1_lut);
     dev_free(h->d_quadh_lut);
@@ -364,6 +372,7 @@ int prepare(awpu_hip *h) {
         }
     }
 
+    h->exact_pairs_ok = c.math == AWPU_MATH_F32_EXACT && c.interp == AWPU_INTERP_LERP && awpu::pair_plan(h->window, U, &h->exact_plan);
     if (c.math != AWPU_MATH_F32_FAST || c.interp == AWPU_INTERP_FIR8) {
         int chunk = 0;
         if (awpu::das_exact_lds_bytes(h->window, U, &chunk) == 0)
@@ -643,6 +652,59 @@ int dump_diag(awpu_hip *h, size_t n_waves, int wg_waves, const char *tag, hipStr
         std::fprintf(stderr, " %d:%.0f/%.0f", k, sw[k] * wg_waves / n_waves / 1e3, ba[k] * wg_waves / n_waves / 1e3);
     std::fprintf(stderr, "\n");
     return AWPU_OK;
+}
+
+// The reference-order sweep on the frame-pair layout (das_exact_pair_kernel): the table is the pair shape's with the
+// UNSCALED fraction in .f (gains go on the samples, as in das_exact_kernel) and padding entries -- mics usable ..
+// usable_pad-1, and whole rows past the grid -- that read a row of zeros with fraction 0 (they add +0).
+int build_exact_pair_lut(awpu_hip *h) {
+    if (h->d_exact_pair_lut) return AWPU_OK;
+    const auto &c = h->cfg;
+    const awpu::FastPlan &plan = h->exact_plan;
+    const int U = h->usable(), P = c.pixel_count;
+    const int P_pad = (P + h->pair_cols + 127) / 128 * 128;  // whole tiles; with vertical pairs the partner of a last-row pixel lies one grid row past the table
+    const size_t n = (size_t) P_pad * plan.usable_pad + 16;  // + one spare group: the block prefetches one past a row's end
+    std::vector<awpu::FastEntry> packed(n);
+    for (size_t i = 0; i < n; i++)  // null entry of slot s: the zero row of its own slot in the last chunk, or any row with fraction 0 ...
+        packed[i] = awpu::FastEntry{0.0f, (uint32_t) ((int) (i % plan.usable_pad) % plan.chunk * plan.row_bytes), 0.0f, 0u};
+    for (int p = 0; p < P; p++) {
+        const int32_t *orow = &h->off[(size_t) p * c.lut_stride];
+        const float *frow = &h->frac[(size_t) p * c.lut_stride];
+        awpu::FastEntry *dst = &packed[(size_t) p * plan.usable_pad];
+        for (int s = 0; s < U; s++) {
+            const int id = h->index[s];
+            dst[s].f = frow[id];  // the reference's `fraction`, mimo.cpp:126
+            dst[s].addr = (uint32_t) ((s % plan.chunk) * plan.row_bytes + (orow[id] - h->wstart) * 8);
+        }
+    }
+    AWPU_HIP_TRY(hipMalloc(&h->d_exact_pair_lut, n * sizeof(awpu::FastEntry)));
+    AWPU_HIP_TRY(hipMemcpy(h->d_exact_pair_lut, packed.data(), n * sizeof(awpu::FastEntry), hipMemcpyHostToDevice));
+    return AWPU_OK;
+}
+
+int launch_exact_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
+    int rc = build_exact_pair_lut(h);
+    if (rc != AWPU_OK) return rc;
+    const awpu::FastPlan &pp = h->exact_plan;
+    const size_t need = (size_t) ((std::max(h->cfg.max_batch, batch) + 1) / 2) * pp.usable_pad * pp.wr * 2;
+    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
+    awpu::ExactPairArgs a{};
+    a.packed = h->d_pack;
+    a.lut = h->d_exact_pair_lut;
+    a.power = d_power;
+    a.sums = h->sums_out;
+    a.usable = h->usable();
+    a.usable_pad = pp.usable_pad;
+    a.pixel_count = h->cfg.pixel_count;
+    a.wp = pp.wr;
+    a.chunk = pp.chunk;
+    a.batch = batch;
+    a.cols = h->pair_cols;
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad,
+                                         h->d_gain, pp.wr, batch, h->d_pack, false, s));  // raw samples: no stencil in front of the reference's order
+    AWPU_HIP_TRY(awpu::launch_das_exact_pairs(a, s));
+    return finish_launch(h, batch, s);
 }
 
 int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
@@ -952,6 +1014,8 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         if (awpu::pair_plan(h->window, h->usable(), &h->fir_plan))
             return launch_fir8_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
     }
+    if (h->exact_pairs_ok && env().exact_pairs != 0) return launch_exact_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+    if (h->sums_out) return fail(AWPU_ERR_STATE, "the pre-epilogue sums are exported by the frame-pair reference-order kernel only");
     if (h->cfg.math != AWPU_MATH_F32_FAST || h->cfg.interp == AWPU_INTERP_FIR8)
         return launch_exact(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
 
@@ -1811,6 +1875,22 @@ int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch,
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     TimingOff untimed(h);  // asynchronous path: the caller times its own stream
     return launch(h, d_frames, batch, d_power, s);
+}
+
+int awpu_hip_process_device_sums(awpu_hip_t *h, const float *d_frames, int32_t batch, float *d_power, float *d_sums, void *stream) {
+    AWPU_CTX(h);
+    if (!h) return invalid("null handle");
+    if (!d_frames || !d_power || !d_sums) return invalid("null argument");
+    if (!h->parts.empty()) return invalid("the pre-epilogue sums are exported by single-device handles only");
+    const int rc = check_ready(h, batch);
+    if (rc != AWPU_OK) return rc;
+    if (!h->exact_pairs_ok) return fail(AWPU_ERR_STATE, "the pre-epilogue sums need AWPU_MATH_F32_EXACT with AWPU_INTERP_LERP");
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    TimingOff untimed(h);
+    h->sums_out = d_sums;
+    const int lrc = launch(h, d_frames, batch, d_power, s);
+    h->sums_out = nullptr;
+    return lrc;
 }
 
 namespace {

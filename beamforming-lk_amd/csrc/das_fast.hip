@@ -953,6 +953,135 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
 }
 
 // ---------------------------------------------------------------------------------------
+// Reference-order sweep on the frame-pair layout (AWPU_MATH_F32_EXACT, round 4): das_pair_kernel's staging -- rows of
+// RAW samples (pack_pairs_kernel<false>: the gain, if any, applied to the samples as das_exact_kernel applies it), one
+// linear LDS-DMA stream per chunk, two images, one barrier per chunk -- around the block sweep_duo_exact, which performs
+// delay.cpp:19-25's three operations per sample in the reference's order with the mics in antenna.index[] order
+// (mimo.cpp:124-130).  out[i] of a pixel lives in acc[k] of lane l (i = l + 64 k), both frames of the pair side by side,
+// and never leaves its register between the first mic and the epilogue: the pre-epilogue sums are bit-identical to the
+// reference's (and to das_exact_kernel's; a.sums exports them for the tests).  The epilogue is mimo.cpp:131-137 with
+// whole-wave rotations for the neighbours.  Padding mics (usable rounded up to 4) read rows of zeros with fraction 0:
+// t = fma(0, 0 - 0, 0) = +0 and out + 0 = out bit for bit (out starts at +0 and can never become -0).
+// Workgroup = 16 waves, a wave 4 pixels (two vertical pairs when the row length is known); grid = (pairs, tiles).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ f2 finish_pixel_pair_exact(const f2 (&o)[4], int lane) {
+    f2 sum = f2{0.0f, 0.0f};
+    f2 dn = wave_rotate<kDppWaveRol1>(o[0]);         // out[l+1 + 64k]; lane 63: out[64k]
+    f2 up_before = wave_rotate<kDppWaveRor1>(o[0]);  // (k = 0, lane 0: sample 0 is not summed)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const f2 dn_after = k < 3 ? wave_rotate<kDppWaveRol1>(o[k < 3 ? k + 1 : 3]) : dn;  // (k = 3, lane 63: sample 255 is not summed)
+        const f2 up = wave_rotate<kDppWaveRor1>(o[k]);  // out[l-1 + 64k]; lane 0: out[63 + 64k]
+        const f2 next = lane == 63 ? dn_after : dn;
+        const f2 prev = lane == 0 ? up_before : up;
+        const int i = lane + 64 * k;
+        const f2 ma = o[k] * 0.5f - 0.25f * (next + prev);  // mimo.cpp:132-134
+        if (i >= 1 && i <= kSamples - 2) sum += ma * ma;
+        dn = dn_after;
+        up_before = up;
+    }
+    sum.x = wave_sum(sum.x);
+    sum.y = wave_sum(sum.y);
+    return sum;
+}
+
+__global__ __launch_bounds__(1024, 4) void das_exact_pair_kernel(ExactPairArgs a) {
+    constexpr int PPW = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
+    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int pair = blockIdx.x, tile = blockIdx.y;
+    int pix[PPW];    // pixel of slot q (slots 2j, 2j+1 are the two pixels of one block)
+    bool live[PPW];  // false: outside the grid, swept on another pixel's (or a null) row and not stored
+    int pair_rows;   // table rows between the two pixels of a block
+    if (a.cols > 0) {  // 2 rows x 32 columns per workgroup, a wave two vertical pixel pairs (see das_pair_kernel)
+        const int tiles_per_rowpair = (a.cols + 2 * NW - 1) / (2 * NW);
+        const int row2 = tile / tiles_per_rowpair, col0 = (tile - row2 * tiles_per_rowpair) * 2 * NW + 2 * wave;
+        const int rows = a.pixel_count / a.cols;
+#pragma unroll
+        for (int q = 0; q < PPW; q++) {
+            const int row = 2 * row2 + (q & 1), col = col0 + (q >> 1);
+            live[q] = row < rows && col < a.cols;
+            pix[q] = min(2 * row2 * a.cols + col, a.pixel_count - 1) + (q & 1) * a.cols;
+        }
+        pair_rows = a.cols;
+    } else {
+#pragma unroll
+        for (int q = 0; q < PPW; q++) {
+            pix[q] = (tile * NW + wave) * PPW + q;
+            live[q] = pix[q] < a.pixel_count;
+        }
+        pair_rows = 1;
+    }
+    const size_t row_floats = (size_t) a.wp * 2;
+    const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;  // usable_pad rows per pair, the extra ones zero
+
+    f2 acc[PPW][4];
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[pp][k] = f2{0.0f, 0.0f};  // float out[N_SAMPLES] = {0.0}, mimo.cpp:122
+
+    auto dma_chunk = [&](int m0, int mc, int buf) {  // rows m0 .. m0+mc of this pair: contiguous in HBM and in the image
+        const float *src = pair_base + (size_t) m0 * row_floats;
+        const int n_pieces = (int) ((size_t) mc * row_floats / 4);
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            const int piece = threadIdx.x + k * kThreads;
+            if (piece < n_pieces) {
+                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + (size_t) piece * 4),
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+            }
+        }
+    };
+
+    const int n_chunks = (a.usable_pad + a.chunk - 1) / a.chunk;
+    dma_chunk(0, min(a.chunk, a.usable_pad), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int stride = pair_rows * a.usable_pad * (int) sizeof(FastEntry);  // from pixel A's row to pixel B's
+    const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
+    for (int c = 0; c < n_chunks; c++) {
+        const int m0 = c * a.chunk;
+        const int mc = min(a.chunk, a.usable_pad - m0);  // a multiple of 4: chunk and usable_pad both are
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable_pad - m0 - a.chunk), buf ^ 1);
+        const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
+#pragma unroll
+        for (int q = 0; q < PPW; q += 2) {
+            const void *row = uniform_ptr(a.lut + (size_t) pix[q] * a.usable_pad + m0);
+            const int ng = __builtin_amdgcn_readfirstlane(mc >> 2);
+            sweep_duo_exact(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const float norm = (float) (kSamples * a.usable);
+#pragma unroll
+    for (int pp = 0; pp < PPW; pp++) {
+        const int p = pix[pp];
+        if (a.sums && live[pp]) {  // the pre-epilogue sums, for the tests: [batch][pixel_count][256]
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                a.sums[((size_t) (2 * pair) * a.pixel_count + p) * kSamples + lane + 64 * k] = acc[pp][k].x;
+                if (2 * pair + 1 < a.batch) a.sums[((size_t) (2 * pair + 1) * a.pixel_count + p) * kSamples + lane + 64 * k] = acc[pp][k].y;
+            }
+        }
+        const f2 sum = finish_pixel_pair_exact(acc[pp], lane);
+        if (lane == 0 && live[pp]) {
+            a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
+            if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // FIR8 on the frame-pair layout (AWPU_INTERP_FIR8 with AWPU_MATH_F32_FAST, batches): the 8-tap table variant of
 // delay(), src/dsp/delay.cpp:31-40,
 //     k = (int)(frac * 100 + 0.5);  out[n] += sum_{t<8} C[k][t] * X[off + n + t],
@@ -2029,6 +2158,17 @@ hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, cons
 #endif
     (void) variant;
     return launch_fir8_plane_variant<0>(a, d_entries, d_coeffs, stream);
+}
+
+hipError_t launch_das_exact_pairs(const ExactPairArgs &a, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (hipError_t e = allow_lds((const void *) das_exact_pair_kernel, lds_bytes, attr_set); e != hipSuccess) return e;
+    if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || (size_t) a.chunk * a.wp * 8 > (size_t) kFastLdsBytes) return hipErrorInvalidValue;
+    dim3 grid((a.batch + 1) / 2, pair_tiles(a.pixel_count, a.cols));
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(das_exact_pair_kernel, grid, dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {

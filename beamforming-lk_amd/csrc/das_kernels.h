@@ -103,6 +103,18 @@ hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int
                              int usable, int rows_out, const float *d_gain, int wp, int batch, float *d_packed,
                              bool filter, hipStream_t stream);
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream);
+// ---- reference-order sweep on the frame-pair layout (das_exact_pair_kernel, AWPU_MATH_F32_EXACT): raw samples
+// (launch_pack_pairs with filter = false and rows_out = usable_pad: gains on the samples, padding rows zero), the pair
+// shape's table with the UNSCALED fraction in .f and padding entries that point at their own (zero) row
+struct ExactPairArgs {
+    const float *packed;   // [pairs][usable_pad][wp][2]
+    const FastEntry *lut;  // [P_pad][usable_pad]; f = the reference's fraction, addr = slot * wp * 8 + (off - wstart) * 8
+    float *power;          // [batch][pixel_count]
+    float *sums;           // optional [batch][pixel_count][256]: out[] of every pixel before the epilogue (tests), or null
+    int32_t usable, usable_pad, pixel_count, wp, chunk, batch;
+    int32_t cols;          // > 0: the grid's row length; a wave then sweeps vertical pixel pairs (pixel_count % cols == 0)
+};
+hipError_t launch_das_exact_pairs(const ExactPairArgs &a, hipStream_t stream);
 // FIR8 on the frame-pair layout (batches): d_entries [pixel_count][usable_pad] x {u32 LDS address, i32 coefficient row},
 // addresses as in the pair shape's plan (pair_plan on a window that reaches off + 262); d_coeffs [101][8]
 hipError_t launch_das_fir8_pairs(const PairArgs &a, const void *d_entries, const float *d_coeffs, hipStream_t stream);

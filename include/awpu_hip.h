@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define AWPU_HIP_ABI_VERSION 3
+#define AWPU_HIP_ABI_VERSION 4
 
 /* compile-time constants of the reference */
 #define AWPU_N_SAMPLES 256 /* src/fpga/streams.hpp:28  N_SAMPLES */
@@ -215,6 +215,14 @@ int awpu_hip_wait(awpu_hip_t *h);
  * [batch][n_streams][hist], d_power [batch][pixel_count]. */
 int awpu_hip_process_device(awpu_hip_t *h, const float *d_frames, int32_t batch, float *d_power,
                             void *stream);
+
+/* Verification export (no reference counterpart; the reference's `float out[N_SAMPLES]` of src/dsp/mimo.cpp:122 is a local):
+ * the same sweep with every pixel's out[0..255] AFTER the last mic's delay() and BEFORE the moving average of
+ * mimo.cpp:131-137 also written to d_sums [batch][pixel_count][256].  AWPU_MATH_F32_EXACT + AWPU_INTERP_LERP on a
+ * single-device handle only (AWPU_ERR_STATE otherwise): those sums are bit-identical to what the reference's delay()
+ * leaves in out[] (tests/test_gpu_parity.py checks them against the goldens its compiled object code produced). */
+int awpu_hip_process_device_sums(awpu_hip_t *h, const float *d_frames, int32_t batch, float *d_power, float *d_sums,
+                                 void *stream);
 
 /* ---- the sweep split at its pack pass (multi-GPU: the exchange format between ranks) --------------------------
  * The batched sweep first interleaves the touched window of two consecutive frames sample by sample ("packed frame

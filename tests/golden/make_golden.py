@@ -116,6 +116,34 @@ def sweep_case(name, arrays_x, arrays_y, res, pixels, seed, index=None, hist=102
     print(f"{name}.npz", off.shape, "power range", power.min(), power.max())
 
 
+DC_OFFSETS = np.array([1e-4, 1e-3, 1e-2, 0.25], np.float32)
+
+
+def sweep_case_dc(name, arrays_x, arrays_y, res, pixels, seed, hist=1024, fov=180.0):
+    """The same sweep on DC-BIASED frames: X = hash_frames(seed) + offset (one fp32 add per sample), for every offset in
+    DC_OFFSETS -- an ADC bias, which src/fpga/pipeline.cpp:290 does not remove and the reference's moving average
+    (mimo.cpp:131-134) exists to cancel.  The reference sums the bias 256-fold into out[] before its stencil removes it,
+    so its fp32 result carries rounding noise that grows with the offset; an implementation is "within 1e-5 of the
+    reference" on such input only if it keeps the reference's operation order (AWPU_MATH_F32_EXACT).  Stored: powers and
+    the first / last pixel's out[] from the reference's compiled delay(), per offset."""
+    xyz = O.create_tiled_antenna(arrays_x, arrays_y)
+    off, frac = O.compute_delay_lut(xyz, res, res, fov)
+    off, frac = off[pixels], frac[pixels]
+    n = xyz.shape[1]
+    X0 = util.hash_frames(n, hist, seed=seed)[0]
+    power = np.empty((DC_OFFSETS.size, len(pixels)), np.float32)
+    out_first = np.empty((DC_OFFSETS.size, 4, 256), np.float32)
+    out_last = np.empty((DC_OFFSETS.size, 1, 256), np.float32)
+    for k, dc in enumerate(DC_OFFSETS):
+        X = (X0 + dc).astype(np.float32)
+        power[k], out = O.das_f32(X, off, frac, None, want_out=True, impl="ref")
+        out_first[k], out_last[k] = out[:4], out[-1:]
+    np.savez_compressed(HERE / f"{name}.npz", arrays=np.array([arrays_x, arrays_y]), res=res, fov=fov, pixels=pixels,
+                        seed=seed, hist=hist, off=off, frac=frac, index=np.arange(n, dtype=np.int32), offsets=DC_OFFSETS,
+                        power=power, out_first=out_first, out_last=out_last)
+    print(f"{name}.npz", off.shape, "power range per offset", power.min(axis=1), power.max(axis=1))
+
+
 def steer_split(xyz, theta, phi):
     """Particle::steer, src/dsp/particle.cpp:37-49, on the restated steering vector."""
     off = np.empty((len(theta), xyz.shape[1]), np.int32)
@@ -165,6 +193,11 @@ def main():
     # 512 mics (4x2 arrays), 128x128 grid, shortest legal history
     pix = np.unique(np.concatenate([[0, 16383], rng.choice(16384, 22, replace=False)]))
     sweep_case("sweep_c3", 4, 2, 128, pix, seed=105, hist=520)
+    # ---- DC-biased frames (round 4): the same geometries with an offset on every sample
+    dc_rng = np.random.Generator(np.random.PCG64(2025))  # (its own stream: the draws above and below stay what they were)
+    sweep_case_dc("sweep_c1_dc", 1, 1, 32, np.arange(0, 1024, 7), seed=121)
+    pix = np.unique(np.concatenate([[0, 127, 16256, 16383], dc_rng.choice(16384, 44, replace=False)]))
+    sweep_case_dc("sweep_headline_dc", 4, 1, 128, pix, seed=124, hist=640)
     # ---- the 8-tap variant of delay() (the reference built without -mavx2)
     delay_kat_fir8()
     sweep_case_fir8("sweep_c1_fir8", 1, 1, 32, np.arange(1, 1024, 9), seed=111)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/awpu_hip.h but not exported"
     assert sorted(pkg.binding.EXPORTED_SYMBOLS) == names
-    assert lib.awpu_hip_abi_version() == 3
+    assert lib.awpu_hip_abi_version() == 4
 
 
 def test_shipping_build_has_no_wrong_result_switches(pkg):
@@ -171,6 +171,7 @@ def test_null_arguments_are_refused_not_dereferenced(pkg):
     call("awpu_hip_set_mic_gains", None, fp)
     call("awpu_hip_process", None, fp, 1, fp)
     call("awpu_hip_process_device", None, None, 1, None, None)
+    call("awpu_hip_process_device_sums", None, None, 1, None, None, None)
     call("awpu_hip_process_async", None, fp, 1, fp)
     call("awpu_hip_wait", None)
     call("awpu_hip_synchronize", None)

@@ -34,16 +34,17 @@ def run_engine(pkg, X, off, frac, index=None, math="fast", max_batch=None, **kw)
 
 def check_full_grid(oracle, got, frame, off, frac, what, index=None, fir_table=None):
     """The parity claim in the north star's wording, on EVERY pixel handed in: per-pixel power within 1e-5 relative of
-    the reference's arithmetic (oracle.das_f32 / das_fir8_f32), no floor.  Where the reference's own fp32 sums are
-    further than 3.3e-6 from the exact (fp64) ones at some pixel -- deep beam nulls of large arrays -- the bound is
-    3 x that distance (util.parity_report).  Oracle cost: 2-8 s per full 128x128 frame."""
+    the reference's arithmetic (oracle.das_f32 / das_fir8_f32), no floor, no allowance: `ok` of util.parity_report is
+    max_rel_unfloored <= 1e-5 and pixels_over_1e5 == 0 (round 4: the 3 x reference-noise allowance of round 3 is gone
+    from here; it survives only as the named field `ok_within_reference_noise`, used by the one DC-bias test of the
+    re-ordered fast sweep).  Oracle cost: 2-8 s per full 128x128 frame."""
     if fir_table is None:
         r32, r64 = oracle.das_f32(frame, off, frac, index), oracle.das_f64(frame, off, frac, index)
     else:
         r32, r64 = oracle.das_fir8_f32(frame, off, frac, fir_table, index), oracle.das_fir8_f64(frame, off, frac, fir_table, index)
     rep = util.parity_report(got, r32, r64)
     print(f"parity {what}: {rep}")
-    assert rep["ok"], (what, rep)
+    assert rep["ok"] and rep["max_rel_unfloored"] <= util.POWER_RTOL and rep["pixels_over_1e5"] == 0, (what, rep)
     return rep
 
 
@@ -1385,10 +1386,12 @@ def test_bench_two_ranks_on_one_gpu_assemble_the_oracle_heatmap():
 def test_dc_offset_frames_batched_sweep_is_closer_to_exact_than_the_reference(pkg, oracle):
     """Samples with a DC offset (an ADC bias the wire format does not remove): the reference sums 256 mics' worth of
     the offset into every out[i] and lets its moving-average stencil cancel it again -- in fp32 that cancellation costs
-    it several digits (its distance to exact fp64 sums grows a hundredfold).  The batched sweep applies the stencil to
-    the samples first, so the offset never enters a sum: its result stays at fp32 precision of the
-    exact one.  Parity against the reference's arithmetic then holds within the reference's own error, which is what
-    util.parity_report's bound (3 x ref_f32_vs_f64) says; and the GPU is the closer of the two to exact."""
+    it several digits (its distance to exact fp64 sums grows a hundredfold).  The batched FAST sweep applies the stencil
+    to the samples first, so the offset never enters a sum: its result stays at fp32 precision of the
+    exact one -- and is therefore NOT within 1e-5 of the reference's own fp32 result on such input: the strict `ok` is
+    False here, and this is the one test that uses the named allowance `ok_within_reference_noise` (3 x the reference's
+    own distance to exact).  AWPU_MATH_F32_EXACT is the mode that stays within 1e-5 of the reference on biased input
+    (test_exact_mode_is_within_1e5_of_the_reference_on_dc_biased_full_grids)."""
     S = pkg.synthetic
     spec = S.WORKLOADS["c2"]
     xyz = S.geometry(spec)
@@ -1398,10 +1401,116 @@ def test_dc_offset_frames_batched_sweep_is_closer_to_exact_than_the_reference(pk
     for b in (0, 9):
         r32, r64 = oracle.das_f32(frames[b], off, frac), oracle.das_f64(frames[b], off, frac)
         rep = util.parity_report(power[b], r32, r64)
-        print(f"parity DC-offset frame {b}: {rep}")
-        assert rep["ok"], rep
+        print(f"parity DC-offset frame {b}, fast mode: {rep}")
+        assert rep["ok_within_reference_noise"], rep
+        assert not rep["ok"]  # 150 x the north star's tolerance away from the REFERENCE: said, not hidden
         assert rep["ref_f32_vs_f64_unfloored"] > 1e-5  # the reference's own cancellation noise ...
         assert rep["gpu_vs_f64_unfloored"] < 0.2 * rep["ref_f32_vs_f64_unfloored"]  # ... which the pre-filtered sweep does not have
+
+
+DC_SWEEPS = ["sweep_c1_dc", "sweep_headline_dc"]
+
+
+@pytest.mark.parametrize("name", DC_SWEEPS)
+def test_dc_biased_goldens_exact_mode_flat_1e5_fast_mode_recorded(pkg, name):
+    """tests/golden/sweep_*_dc.npz: powers the reference's compiled delay() produced on hash frames + {1e-4, 1e-3, 1e-2,
+    0.25}.  AWPU_MATH_F32_EXACT keeps delay.cpp:19-25's operation order and mimo.cpp:124-130's mic order and must be
+    within 1e-5 of those powers, flat, on every pixel and offset -- one frame per call and as a batch of all four.  The
+    re-ordered AWPU_MATH_F32_FAST sweep is run on the same input and its error per offset PRINTED (the curve bench.py
+    reports as `parity_dc`); it is asserted only where it holds 1e-5 today (offsets up to 1e-3 of full scale)."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    ax, ay = g["arrays"]
+    X0 = util.hash_frames(64 * int(ax) * int(ay), int(g["hist"]), seed=int(g["seed"]))[0]
+    frames = np.stack([(X0 + np.float32(dc)).astype(np.float32) for dc in g["offsets"]])
+    exact_batch, _ = run_engine(pkg, frames, g["off"], g["frac"], g["index"], math="exact")
+    fast_batch, _ = run_engine(pkg, frames, g["off"], g["frac"], g["index"], math="fast")
+    curve = {}
+    for k, dc in enumerate(g["offsets"]):
+        exact_single, _ = run_engine(pkg, frames[k], g["off"], g["frac"], g["index"], math="exact")
+        assert np.array_equal(exact_single, exact_batch[k])  # same order of the same operations whatever the batch
+        e_exact = util.power_rel_err_unfloored(exact_batch[k], g["power"][k])
+        e_fast = util.power_rel_err_unfloored(fast_batch[k], g["power"][k])
+        curve[float(dc)] = (e_exact, e_fast)
+        assert e_exact <= util.POWER_RTOL, (name, float(dc), e_exact)
+        if dc <= 1e-3:
+            assert e_fast <= util.POWER_RTOL, (name, float(dc), e_fast)
+    print(f"parity_dc {name}: offset -> (exact, fast) max unfloored error vs the reference build: {curve}")
+
+
+def _sums_through_the_abi(pkg, frames, off, frac, index=None, **kw):
+    """(power [B, P], out [B, P, 256]) of AWPU_MATH_F32_EXACT through awpu_hip_process_device_sums."""
+    import torch
+
+    frames = np.ascontiguousarray(frames, np.float32)
+    B, P = frames.shape[0], off.shape[0]
+    with pkg.Engine(n_pixels=P, n_streams=frames.shape[1], lut_stride=off.shape[1], hist=frames.shape[2],
+                    math=pkg.MATH_F32_EXACT, max_batch=B, **kw) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(index)
+        d_X = torch.from_numpy(frames).cuda()
+        d_P = torch.empty((B, P), dtype=torch.float32, device="cuda")
+        d_S = torch.full((B, P, 256), float("nan"), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        eng.process_device_sums(d_X.data_ptr(), B, d_P.data_ptr(), d_S.data_ptr())
+        eng.synchronize()
+        return d_P.cpu().numpy(), d_S.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["sweep_c1", "sweep_c1_ragged", "sweep_c1_onemic", "sweep_headline", "sweep_c3"] + DC_SWEEPS)
+def test_exact_mode_pre_epilogue_sums_are_the_reference_bits(pkg, name):
+    """out[0..255] of a pixel after the last mic and before the moving average, exported by the frame-pair
+    reference-order kernel (awpu_hip_process_device_sums), against what the reference's compiled delay() left in out[]
+    (golden out_first / out_last): BIT-identical -- the three operations of delay.cpp:19-25 in its order, mics in
+    antenna.index[] order."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    ax, ay = g["arrays"]
+    X0 = util.hash_frames(64 * int(ax) * int(ay), int(g["hist"]), seed=int(g["seed"]))[0]
+    if "offsets" in g.files:
+        frames = np.stack([(X0 + np.float32(dc)).astype(np.float32) for dc in g["offsets"]])
+        first, last = g["out_first"], g["out_last"]
+    else:
+        frames, first, last = X0[None], g["out_first"][None], g["out_last"][None]
+    power, out = _sums_through_the_abi(pkg, frames, g["off"], g["frac"], g["index"])
+    for b in range(frames.shape[0]):
+        assert np.array_equal(out[b, :4], first[b]), (name, b)
+        assert np.array_equal(out[b, -1:], last[b]), (name, b)
+    assert not np.isnan(out).any()
+
+
+@pytest.mark.parametrize("cols", [0, 32])
+def test_exact_mode_sums_equal_the_oracle_on_every_pixel(pkg, oracle, cols):
+    """The same export against oracle_das_f32's out_dbg on EVERY pixel of c1 (plane wave + noise, three frames: an odd
+    batch), consecutive pixel pairs (no row length) and vertical ones (row length given): bit-identical sums, powers
+    within the sum-order noise of the 254-term epilogue."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c1"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 3, seed=91)
+    power, out = _sums_through_the_abi(pkg, frames, off, frac, grid_columns=cols)
+    for b in range(3):
+        want_p, want_out = oracle.das_f32(frames[b], off, frac, want_out=True)
+        assert np.array_equal(out[b], want_out), (b, np.argwhere(out[b] != want_out)[:4])
+        assert util.power_rel_err_unfloored(power[b], want_p) < 3e-6
+
+
+@pytest.mark.parametrize("wl,offset", [("c2", 0.25), ("c2", 1e-2), ("headline", 0.25)])
+def test_exact_mode_is_within_1e5_of_the_reference_on_dc_biased_full_grids(pkg, oracle, wl, offset):
+    """DC-biased plane-wave frames on FULL grids (beam nulls included), AWPU_MATH_F32_EXACT against the reference's
+    arithmetic (oracle.das_f32: bit-identical pre-epilogue sums to the reference's object code): 1e-5 flat on every
+    pixel, although the reference itself is ~1e-3 from exact sums here.  Batch of three (odd: the last pair is a frame
+    with itself), row length given."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS[wl]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 3, seed=72) + np.float32(offset)
+    power, _ = run_engine(pkg, frames, off, frac, math="exact", grid_columns=spec.res)
+    for b in (0, 2):
+        r32, r64 = oracle.das_f32(frames[b], off, frac), oracle.das_f64(frames[b], off, frac)
+        rep = util.parity_report(power[b], r32, r64)
+        print(f"parity DC-offset {offset} {wl} frame {b}, exact mode: {rep}")
+        assert rep["ok"] and rep["max_rel_unfloored"] <= util.POWER_RTOL, rep
 
 
 def test_packed_entry_points_refuse_what_they_cannot_sweep(pkg, oracle):

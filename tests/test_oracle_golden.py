@@ -40,6 +40,26 @@ def test_sweep_golden(oracle, name):
     assert util.power_rel_err(power, g["power"]) < 2e-6
 
 
+@pytest.mark.parametrize("name", ["sweep_c1_dc", "sweep_headline_dc"])
+def test_sweep_golden_dc_biased(oracle, name):
+    """The same on DC-BIASED frames (hash frames + {1e-4 .. 0.25}; round 4): the restatement's pre-epilogue sums are the
+    reference object code's bit for bit at every offset; powers agree to the sum-order noise of the -Ofast epilogue
+    (2e-6, as without the bias: measured 7e-7 at every offset).  Also records how far
+    the reference's own fp32 result is from exact (fp64) sums on this input -- the noise an implementation that
+    re-orders the arithmetic cannot reproduce."""
+    g = np.load(GOLDEN / f"{name}.npz")
+    ax, ay = g["arrays"]
+    X0 = util.hash_frames(64 * int(ax) * int(ay), int(g["hist"]), seed=int(g["seed"]))[0]
+    for k, dc in enumerate(g["offsets"]):
+        X = (X0 + np.float32(dc)).astype(np.float32)
+        power, out = oracle.das_f32(X, g["off"], g["frac"], g["index"], want_out=True)
+        assert np.array_equal(out[:4], g["out_first"][k]) and np.array_equal(out[-1:], g["out_last"][k])
+        assert util.power_rel_err_unfloored(power, g["power"][k]) < 2e-6
+        p64 = oracle.das_f64(X, g["off"], g["frac"], g["index"])
+        print(f"{name} offset {dc}: oracle vs reference build {util.power_rel_err_unfloored(power, g['power'][k]):.2e}, "
+              f"reference build vs exact {util.power_rel_err_unfloored(g['power'][k], p64):.2e}")
+
+
 @pytest.mark.parametrize("name", ["beams_c1", "beams_c1_ragged"])
 def test_particle_beams_golden(oracle, pkg, name):
     """Particle::beam / Particle::das, src/dsp/particle.cpp:51-103 (SURVEY 8f N3): the beams the reference's
@@ -299,9 +319,11 @@ def test_parity_report_is_unfloored():
     rep = util.parity_report(bad, ref, ref * (1 + 1e-6))
     assert not rep["ok"] and rep["pixels_over_1e5"] == 1 and abs(rep["max_rel_unfloored"] - 2e-5) < 1e-9
     assert util.power_rel_err(bad, ref) < 1e-5  # ... which the floored metric would have let through
-    # where the reference's own fp32 is far from exact sums, the bound follows it: 3 x its distance
+    # where the reference's own fp32 is far from exact sums, `ok` stays strict (1e-5 flat against the reference's fp32
+    # result); only the separately NAMED allowance follows the reference's distance to exact: 3 x that distance
     rep = util.parity_report(bad, ref, ref * (1 + 8e-6))
-    assert abs(rep["bound"] - 2.4e-5) < 1e-9 and rep["ok"]
+    assert rep["bound"] == 1e-5 and not rep["ok"]
+    assert abs(rep["noise_bound"] - 2.4e-5) < 1e-9 and rep["ok_within_reference_noise"]
     assert util.power_rel_err_unfloored(np.array([0.0, 1.0]), np.array([0.0, 1.0])) == 0.0
     assert util.power_rel_err_unfloored(np.array([1e-30, 1.0]), np.array([0.0, 1.0])) == np.inf
 

@@ -47,10 +47,15 @@ def parity_report(got: np.ndarray, ref32: np.ndarray, ref64: np.ndarray | None =
     """Everything the parity claim rests on for one frame, on EVERY pixel handed in:
       max_rel_unfloored / max_rel_floored  GPU vs the fp32 oracle (= the reference's operations)
       pixels_below_floor                   how many pixels the floored metric treats as absolute
+      pixels_over_1e5                      pixels whose unfloored error exceeds 1e-5
+      bound                                POWER_RTOL = 1e-5, flat: the north star's number
+      ok                                   max_rel_unfloored <= 1e-5 -- STRICT, against the reference's own fp32 result
       ref_f32_vs_f64_unfloored             the reference arithmetic's own distance to exact (fp64) sums
       gpu_vs_f64_unfloored                 the GPU's distance to the same
-      bound                                max(POWER_RTOL, 3 x ref_f32_vs_f64_unfloored): what `ok` asserts
-      pixels_over_1e5                      pixels whose unfloored error exceeds 1e-5 (0 wherever `ok` without slack)."""
+      noise_bound                          max(1e-5, 3 x ref_f32_vs_f64_unfloored)
+      ok_within_reference_noise            max_rel_unfloored <= noise_bound: a NAMED exception, for input on which the
+                                           reference's own fp32 order is further than 3.3e-6 from exact (DC-biased frames
+                                           through the re-ordered AWPU_MATH_F32_FAST sweep); never what `ok` means."""
     got = np.asarray(got, np.float64)
     ref32 = np.asarray(ref32, np.float64)
     floor = NULL_FLOOR * np.abs(ref32).max()
@@ -62,15 +67,15 @@ def parity_report(got: np.ndarray, ref32: np.ndarray, ref64: np.ndarray | None =
         "max_rel_floored": power_rel_err(got, ref32),
         "pixels_below_floor": int((np.abs(ref32) < floor).sum()),
         "pixels_over_1e5": int((rel > POWER_RTOL).sum()),
+        "bound": POWER_RTOL,
     }
-    bound = POWER_RTOL
+    rep["ok"] = bool(rep["max_rel_unfloored"] <= POWER_RTOL and rep["pixels_over_1e5"] == 0)
     if ref64 is not None:
         ref64 = np.asarray(ref64, np.float64)
         rep["ref_f32_vs_f64_unfloored"] = power_rel_err_unfloored(ref32, ref64)
         rep["gpu_vs_f64_unfloored"] = power_rel_err_unfloored(got, ref64)
-        bound = max(POWER_RTOL, 3.0 * rep["ref_f32_vs_f64_unfloored"])
-    rep["bound"] = bound
-    rep["ok"] = bool(rep["max_rel_unfloored"] <= bound)
+        rep["noise_bound"] = max(POWER_RTOL, 3.0 * rep["ref_f32_vs_f64_unfloored"])
+        rep["ok_within_reference_noise"] = bool(rep["max_rel_unfloored"] <= rep["noise_bound"])
     return rep
 
 

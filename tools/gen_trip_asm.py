@@ -390,6 +390,121 @@ __device__ __forceinline__ void {name}(f2 (&P0)[8], f2 (&P1)[8], const void *row
 '''
 
 
+def block_exact_shared(name, vbase):
+    """Reference-order sweep (AWPU_MATH_F32_EXACT) of TWO pixels on the frame-pair layout, RAW samples.
+
+    Per pixel, mic and sample the operations are delay.cpp:19-25's, in its order, on both frames of the pair at once:
+        d = cur - next            v_pk_add_f32 with the second operand negated (IEEE: a - b == a + (-b), bit for bit)
+        t = fma(frac, d, next)    v_pk_fma_f32, frac a scalar operand (the reference's `fraction`)
+        out = out + t             v_pk_add_f32
+    and mics are visited in table order (= antenna.index[] order, mimo.cpp:124-130): the pre-epilogue sums equal the
+    reference's bit for bit.  The block is block_shared's schedule: mic-major over pixel A then pixel B, trips of 4 mics,
+    entry sets of 16 SGPRs per pixel ping-ponging, B's entry compared with A's -- when the two carry the same LDS address
+    (same integer delay: most mics of vertical neighbours) B takes A's `next` and `d = cur - next` registers (d does not
+    depend on the fraction) and issues no address add, no LDS read and no subtraction: 8 packed VALU instructions instead
+    of 13.  Lane l owns samples l + 64 k; an item reads cur_k (offset 512 k) and next_k (512 k + 8): 8 ds_read_b64.
+    VGPR slots of 16 registers (cur0..3 then next0..3): two for A (this mic / next mic), one for B; 4 register pairs for t.
+    In flight at most 8 (A, next mic) + 8 (B, next mic) LDS reads + 2 scalar loads: beyond lgkmcnt's 4 bits the issue
+    simply stalls; every wait names only the reads YOUNGER than the data it proves (8: A's next mic), so it cannot pass early."""
+    setA, setB = (36, 68), (52, 84)
+    accA = tuple(f"%[P0{k}]" for k in range(4))
+    accB = tuple(f"%[P1{k}]" for k in range(4))
+    slotA = (vbase, vbase + 16)
+    slotB = vbase + 32
+    tmp = vbase + 48
+    addr_t = vbase + 56
+
+    def reads(slot, addr_sgpr):
+        L = [f"v_add_u32 v{addr_t}, s{addr_sgpr}, %[lane]"]
+        for k in range(4):
+            off = f" offset:{512 * k}" if k else ""
+            L.append(f"ds_read_b64 v[{slot + 2 * k}:{slot + 2 * k + 1}], v{addr_t}{off}")
+            L.append(f"ds_read_b64 v[{slot + 8 + 2 * k}:{slot + 9 + 2 * k}], v{addr_t} offset:{512 * k + 8}")
+        return L
+
+    def diffs(slot):  # d_k = cur_k - next_k, in place of cur_k
+        return [f"v_pk_add_f32 v[{slot + 2 * k}:{slot + 2 * k + 1}], v[{slot + 2 * k}:{slot + 2 * k + 1}], "
+                f"v[{slot + 8 + 2 * k}:{slot + 9 + 2 * k}] neg_lo:[0,1] neg_hi:[0,1]" for k in range(4)]
+
+    def terms(acc, base, i, slot):  # t_k = fma(frac, d_k, next_k); out_k += t_k
+        L = []
+        for k in range(4):
+            L.append(f"v_pk_fma_f32 v[{tmp + 2 * k}:{tmp + 2 * k + 1}], s[{base + 4 * i}:{base + 4 * i + 1}], "
+                     f"v[{slot + 2 * k}:{slot + 2 * k + 1}], v[{slot + 8 + 2 * k}:{slot + 9 + 2 * k}] op_sel_hi:[0,1,1]")
+        for k in range(4):
+            L.append(f"v_pk_add_f32 {acc[k]}, {acc[k]}, v[{tmp + 2 * k}:{tmp + 2 * k + 1}]")
+        return L
+
+    def uid():
+        COUNTER[0] += 1
+        return f"%=_{COUNTER[0]}"
+
+    cold = []
+
+    def issue_b(sA, sB, i):
+        u = uid()
+        cold.extend([f".Lread{u}:"] + reads(slotB, sB + 4 * i + 1) + [f"s_branch .Lreadback{u}"])
+        return [f"s_cmp_lg_u32 s{sA + 4 * i + 1}, s{sB + 4 * i + 1}", f"s_cbranch_scc1 .Lread{u}", f".Lreadback{u}:"]
+
+    def trip_s(par):
+        sA, sB = setA[par], setB[par]
+        nA, nB = setA[1 - par], setB[1 - par]
+        L = trip_prio("X" if par == 0 else "Y") if PRIO >= 3 else []
+        L += reads(slotA[0], sA + 1)
+        L += issue_b(sA, sB, 0)
+        L += [f"s_load_dwordx16 s[{nA}:{nA + 15}], %[ptr], s{S_PF}",
+              f"s_add_u32 s{S_OFF}, s{S_PF}, %[stride]",
+              f"s_load_dwordx16 s[{nB}:{nB + 15}], %[ptr], s{S_OFF}",
+              f"s_add_u32 s{S_PF}, s{S_PF}, 64"]
+        for st in range(4):
+            if st < 3:
+                L += reads(slotA[(st + 1) % 2], sA + 4 * (st + 1) + 1)
+            L.append(f"s_waitcnt lgkmcnt({8 if st < 3 else 0})")
+            L += diffs(slotA[st % 2])
+            L += terms(accA, sA, st, slotA[st % 2])
+            u = uid()
+            cold.extend([f".Lown{u}:"] + diffs(slotB) + terms(accB, sB, st, slotB) + [f"s_branch .Ltermsdone{u}"])
+            L += [f"s_cmp_lg_u32 s{sA + 4 * st + 1}, s{sB + 4 * st + 1}", f"s_cbranch_scc1 .Lown{u}"]
+            L += terms(accB, sB, st, slotA[st % 2]) + [f".Ltermsdone{u}:"]
+            if st < 3:
+                L += issue_b(sA, sB, st + 1)
+        return L
+
+    L = []
+    if PRIO >= 3:
+        L += [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    L += [f"s_load_dwordx16 s[{setA[0]}:{setA[0] + 15}], %[ptr], 0x0",
+          f"s_load_dwordx16 s[{setB[0]}:{setB[0] + 15}], %[ptr], %[stride]",
+          f"s_mov_b32 s{S_LEFT}, %[ng]",
+          f"s_movk_i32 s{S_PF}, 0x40",
+          "s_waitcnt lgkmcnt(0)"]
+    L += [".LT0_%=:"] + trip_s(0)
+    L += [f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_cmp_eq_u32 s{S_LEFT}, 0", "s_cbranch_scc1 .Ldone_%="]
+    L += trip_s(1)
+    L += [f"s_sub_u32 s{S_LEFT}, s{S_LEFT}, 1", f"s_cmp_lg_u32 s{S_LEFT}, 0", "s_cbranch_scc1 .LT0_%="]
+    L += ["s_branch .Ldone_%="] + cold + [".Ldone_%=:"]
+    if PRIO:
+        L += [f"s_setprio {BLOCK_END_PRIO}"]
+    body = "\n".join(f'        "{l}\\n\\t"' for l in L)
+    vregs = list(range(vbase, vbase + 57))
+    sregs = sorted({S_RANK, S_PRIO, S_LEFT, S_PF, S_OFF}) + list(range(36, 100))
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
+    acc_ops = ", ".join(f'[P{j}{k}] "+v"(P{j}[{k}])' for j in range(2) for k in range(4))
+    return f'''// Reference-order sweep of two pixels of the staged chunk (raw frame-pair samples) in mic-major order, ng groups of four
+// mics each (ng >= 1); pixel A's entries start at `row`, pixel B's at `row` + stride bytes; P[k] = out[l + 64 k] of both
+// frames.  delay.cpp:19-25's operations in its order; the reads and cur - next are shared whenever the two entries of a
+// mic carry the same LDS address.  Reads the table up to one group past each row's end.
+// temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}
+__device__ __forceinline__ void {name}(f2 (&P0)[4], f2 (&P1)[4], const void *row, int stride, int ng, unsigned lane_addr, int rank) {{
+    asm volatile(
+{body}
+        : {acc_ops}
+        : [ptr] "s"(row), [stride] "s"(stride), [ng] "s"(ng), [lane] "v"(lane_addr), [rank] "s"(rank)
+        : {clobbers});
+}}
+'''
+
+
 # ---------------------------------------------------------------------------------------------------
 # Quad block with a shared integer-delay sum (das_quad_kernel).
 #
@@ -1438,6 +1553,7 @@ def main():
     out.append(block("sweep_duo_pairs_stamped", 2, 128 - (8 * (pd + 1) + 1) - 3, stamp=True, pair_depth=pd))
     out.append(block_shared("sweep_duo_shared", 128 - 25 - 3))
     out.append(block_shared("sweep_duo_shared_stamped", 128 - 25 - 3, stamp=True))
+    out.append(block_exact_shared("sweep_duo_exact", 128 - 57 - 3))  # das_exact_pair_kernel (AWPU_MATH_F32_EXACT)
     out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))
     out.append(block_quad("sweep_quad_item", dma=True, chain=CHAIN, item=True))  # the production batch kernel: one block per item
