@@ -1180,7 +1180,6 @@ int create_group(awpu_hip_t **out, const awpu_hip_cfg &c) {
             for (int b = 0; b < 2 && e == hipSuccess; b++) {
                 e = hipEventCreateWithFlags(&part->ev_copied[b], hipEventDisableTiming);
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_swept[b], hipEventDisableTiming);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_tile_free[b], hipEventDisableTiming);
             }
             if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_done, hipEventDisableTiming);
             if (e != hipSuccess) rc = hip_fail(e, "group stream/event creation");
@@ -1226,6 +1225,10 @@ int create_group(awpu_hip_t **out, const awpu_hip_cfg &c) {
     AWPU_HIP_TRY(hipSetDevice(c.devices[0]));
     hipError_t e = hipEventCreateWithFlags(&g->ev_fan, hipEventDisableTiming);
     for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipEventCreateWithFlags(&g->ev_staged[b], hipEventDisableTiming);
+    // a staged part's ev_tile_free[] is recorded on the CALLER's stream (devices[0]) and only waited for on the part's own:
+    // an event must be recorded on a stream of the device it was created on, so these belong to devices[0], not the part's
+    for (awpu_hip *part : g->parts)
+        for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipEventCreateWithFlags(&part->ev_tile_free[b], hipEventDisableTiming);
     if (e != hipSuccess) {
         awpu_hip_destroy(g);
         return hip_fail(e, "group event creation");

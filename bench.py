@@ -28,10 +28,11 @@ At N = 1 the line also carries, next to the batched `value`:
   "single_frame"      one frame per call, the regime the reference's live display runs in
   "pcie_inclusive"    awpu_hip_process on pageable host buffers, upload and read-back inside the clock; never `value`
   "bf16"              the bf16-accumulator mode on the same frames: its ERROR against the fp32 sweep
+  "parity_dc"         both math modes on the reference-generated DC-biased goldens: error per offset (exact <= 1e-5 flat)
   "reference_default" the shape the reference ships (64 mics, 100x100, one frame per call) with its CPU time and the
                       5.24 ms real-time budget of a block beside it
-  "workloads"         c2, c3 (lerp and the 8-tap FIR variant) and the c5 slab, a few steps each: kernel ms, VALU fraction,
-                      full-grid parity
+  "workloads"         the headline shape in AWPU_MATH_F32_EXACT (the reference's operation order), c2, c3 (lerp and the 8-tap
+                      FIR variant) and the c5 slab, a few steps each: kernel ms, VALU fraction, full-grid parity
   "projected_scaling" rank 0's slab of an 8-rank run through the N > 1 step loop, the collective replaced by a local
                       copy of the same bytes: what one GPU can say about the 8-GPU step (NOT a scaling measurement)
   "cpu_baseline"      the reference's own compiled delay() on the host
@@ -99,8 +100,8 @@ def under_profiler(env=None) -> str:
     profiler's preloaded library has initialised the GPU before main() runs, and a process in that state must not
     start another program (this pool forbids it; the box can go down)."""
     env = os.environ if env is None else env
-    if env.get("AWPU_NO_BUILD") == "1":
-        return "AWPU_NO_BUILD=1 (set by tools/pmc.sh, pmc_hbm.sh, gpu_profile.sh: a profiler is in the picture)"
+    if env.get("AWPU_UNDER_PROFILER") == "1":  # (NOT AWPU_NO_BUILD: that one only stops rebuilds and says nothing about a profiler)
+        return "AWPU_UNDER_PROFILER=1 (set by tools/pmc.sh, pmc_hbm.sh, gpu_profile.sh: a profiler is in the picture)"
     if "rocprof" in env.get("LD_PRELOAD", "").lower():
         return "LD_PRELOAD carries the rocprofiler tool library"
     for key in env:
@@ -585,7 +586,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(*events)]))  # this rank's sweep launch
+    step_kernel_ms = [a.elapsed_time(b) for a, b in zip(*events)]  # this rank's sweep launch, every timed step
+    kernel_ms = float(np.mean(step_kernel_ms))
 
     # ---- parity of what was just computed: frame 0, EVERY pixel of this rank's slab, unfloored
     st = eng.stats()
@@ -593,7 +595,7 @@ def main():
     if rank == 0:
         parity = full_grid_parity(d_power[0].cpu().numpy(), host_first[0], job.off_abs, frac, args.math, args.interp)
         parity["what"] = (f"frame 0 of the timed batch, all {shard.pixel_count} pixels of rank 0's slab, GPU vs oracle.das_f32 "
-                          f"(the reference's operations) and vs exact fp64 sums; bound = max(1e-5, 3 x ref_f32_vs_f64_unfloored)")
+                          f"(the reference's operations) and vs exact fp64 sums; `ok` = max_rel_unfloored <= 1e-5, flat")
 
     # ---- N > 1, second measurement: the frame-sharded decomposition (whole frames per rank, full grid;
     # each frame crosses xGMI once).  Reported beside the headline number, not instead of it.
@@ -669,7 +671,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "das sweep", "kernel_ms": kernel_ms, "launch_bytes": launch_bytes,
+                "kernel": "das sweep", "kernel_ms": kernel_ms, "kernel_ms_min": float(np.min(step_kernel_ms)),
+                "kernel_ms_median": float(np.median(step_kernel_ms)), "launch_bytes": launch_bytes,
                 "note": "HBM is the bound the metric names; the sweep itself is fp32-VALU bound (126 flop/B >> the "
                         "chip's ridge), its fraction of that peak is in \"valu\"",
             },
@@ -758,6 +761,7 @@ def main():
         }
         eng16.close()
 
+        out["parity_dc"] = parity_dc(pkg)
         out["reference_default"] = reference_default(pkg, torch, args, dev, local_rank)
         out["workloads"] = other_workloads(pkg, sharding, torch, dist, args, dev, local_rank)
         out["projected_scaling"] = projected_scaling(pkg, sharding, torch, dist, args, spec, dev, local_rank, d_full, B,
@@ -772,7 +776,7 @@ def main():
 
     # ---- N > 1, opt-in: the assembled heatmap of frame 0 must equal what the shards computed (a collective
     # after the result line, so that a rank that fails here cannot cost the run its line)
-    if world > 1 and os.environ.get("BENCH_GATHER_CHECK") == "1":
+    if world > 1 and os.environ.get("BENCH_GATHER_CHECK", "1") == "1":  # (on by default: the RCCL schedules have only ever run over gloo)
         full = sharding.gather_power(d_power[:1].contiguous(), job.shards, dst=0)
         if rank == 0:
             cols = spec.res
@@ -790,6 +794,36 @@ def main():
         run_guard.__exit__(None, None, None)
     if world > 1:
         dist.destroy_process_group()
+
+
+def parity_dc(pkg):
+    """DC-biased input (an ADC bias: src/fpga/pipeline.cpp:290 removes none): both math modes on the committed goldens
+    tests/golden/sweep_{c1,headline}_dc.npz -- hash frames + {1e-4, 1e-3, 1e-2, 0.25} through the reference's compiled
+    delay() (oracle/_ref, tests/golden/make_golden.py) -- max unfloored per-pixel error against those powers, per offset.
+    AWPU_MATH_F32_EXACT keeps the reference's order and stays within 1e-5 at every offset; the re-ordered
+    AWPU_MATH_F32_FAST (stencil on the samples) leaves the REFERENCE's own cancellation noise behind and
+    is therefore further than 1e-5 from it once the bias dwarfs the signal."""
+    import util
+
+    out = {"what": "max unfloored per-pixel error vs the powers the reference's compiled delay() produced (tests/golden/*_dc.npz), "
+                   "hash frames (amplitude 2^-6) + offset; exact = AWPU_MATH_F32_EXACT, fast = AWPU_MATH_F32_FAST (the default)",
+           "cases": []}
+    for name in ("sweep_c1_dc", "sweep_headline_dc"):
+        g = np.load(REPO / "tests" / "golden" / f"{name}.npz")
+        ax, ay = (int(v) for v in g["arrays"])
+        X0 = util.hash_frames(64 * ax * ay, int(g["hist"]), seed=int(g["seed"]))[0]
+        frames = np.stack([(X0 + np.float32(dc)).astype(np.float32) for dc in g["offsets"]])
+        rec = {"golden": name, "mics": 64 * ax * ay, "pixels": int(g["off"].shape[0]), "offsets": [float(v) for v in g["offsets"]]}
+        for label, math_id in (("exact", pkg.MATH_F32_EXACT), ("fast", pkg.MATH_F32_FAST)):
+            with pkg.Engine(n_pixels=g["off"].shape[0], n_streams=frames.shape[1], lut_stride=g["off"].shape[1], hist=frames.shape[2],
+                            math=math_id, max_batch=frames.shape[0]) as eng:
+                eng.set_delay_table(g["off"], g["frac"])
+                eng.set_active_mics(g["index"])
+                power = eng.process(frames)
+            rec[label] = [util.power_rel_err_unfloored(power[k], g["power"][k]) for k in range(frames.shape[0])]
+        rec["exact_ok_1e5"] = bool(max(rec["exact"]) <= 1e-5)
+        out["cases"].append(rec)
+    return out
 
 
 def reference_default(pkg, torch, args, dev, local_rank):
@@ -851,23 +885,26 @@ def other_workloads(pkg, sharding, torch, dist, args, dev, local_rank):
     out = []
     # (steps, warm-up): the short launches get more of both -- three c2 steps after one warm-up step ran 17 % below the
     # rate of a 20-step run of the same workload (profiles/r03_bench_c2.json: the clocks and the caches had not settled)
-    for name, batch, K, W in (("c2", 128, 12, 6), ("c3", 128, 4, 2), ("c3 fir8", 128, 3, 1), ("c5", 1024, 3, 1)):
+    for name, batch, K, W in (("headline exact", 128, 4, 2), ("c2", 128, 12, 6), ("c3", 128, 4, 2), ("c3 fir8", 128, 3, 1), ("c5", 1024, 3, 1)):
         c5 = name == "c5"
         fir = name.endswith("fir8")  # BASELINE configs[2] read as the 8-tap fractional-delay variant of delay() (delay.cpp:31-40)
+        exact = name.endswith("exact")  # AWPU_MATH_F32_EXACT: delay.cpp:19-25's operation order, mimo.cpp:124-130's mic order
         spec = S.WORKLOADS["c4" if c5 else name.split()[0]]
         t0 = time.perf_counter()
         sub = argparse.Namespace(**vars(args))
         sub.interp = "fir8" if fir else "lerp"
+        sub.math = "exact" if exact else "fast"
         job = RankJob(pkg, sharding, torch, dist, sub, spec, 1, 0, dev, local_rank, batch, c5=c5)
         elapsed, kernel_ms, _ = job.timed(K, W)
         st = job.eng.stats()
-        par = full_grid_parity(job.d_power[0].cpu().numpy(), job.host_first[0], job.off, job.frac, interp=sub.interp)
+        par = full_grid_parity(job.d_power[0].cpu().numpy(), job.host_first[0], job.off, job.frac, math=sub.math, interp=sub.interp)
         flops = int(st.alg_flops_frame) * batch
         if fir:  # 16 flop per (pixel, mic, sample) instead of 4
             flops = (16 * job.shard.pixel_count * st.usable * 256 + 6 * job.shard.pixel_count * 254) * batch
         out.append({
             "workload": (f"c5: one rank's slab of 8 of 512 mics x 256x256 ({job.shard.pixel_count} pixels), {batch} frames in flight"
-                         if c5 else spec.name + (", 8-tap FIR variant of delay() (--interp fir8)" if fir else "")),
+                         if c5 else spec.name + (", 8-tap FIR variant of delay() (--interp fir8)" if fir else "") +
+                         (", AWPU_MATH_F32_EXACT: the reference's operation and mic order (--math exact; das_exact_pair_kernel)" if exact else "")),
             "frames_per_step": batch, "steps": K, "warmup": W, "value": batch * K / elapsed, "unit": "frames/s",
             "kernel_ms": kernel_ms, "valu_frac": flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
             "hbm_frac": int(st.alg_bytes_frame) * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -61,23 +61,26 @@ def test_batch_grows_with_the_ranks():
 
 
 def test_no_child_ranks_under_a_profiler():
-    """Under rocprofv3 (or the repo's profiling scripts, which set AWPU_NO_BUILD=1) the GPU is initialised before
+    """Under rocprofv3 (or the repo's profiling scripts, which set AWPU_UNDER_PROFILER=1) the GPU is initialised before
     main() runs; starting torch.distributed.run from there is the exec this pool forbids.  --gpus N must refuse."""
     bench = load_bench()
     assert bench.under_profiler({}) == ""
-    assert bench.under_profiler({"AWPU_NO_BUILD": "1"})
+    assert bench.under_profiler({"AWPU_UNDER_PROFILER": "1"})
+    assert bench.under_profiler({"AWPU_NO_BUILD": "1"}) == ""  # only stops rebuilds (tools/gpu_ab_libs.sh sets it with no profiler about)
     assert bench.under_profiler({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})
     assert bench.under_profiler({"ROCPROF_OUTPUT_PATH": "/tmp/x"}) and bench.under_profiler({"ROCP_TOOL_LIB": "x"})
     import os
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env["AWPU_NO_BUILD"] = "1"
+    env["AWPU_UNDER_PROFILER"] = "1"
     proc = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--selftest-launcher", "ok"], env=env,
                           capture_output=True, text=True, timeout=120)
     assert proc.returncode == 2 and "refusing to start child ranks" in proc.stderr
     assert not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     for script in ("pmc.sh", "pmc_hbm.sh", "gpu_profile.sh"):
-        assert "--gpus" in (REPO / "tools" / script).read_text(), f"tools/{script} must reject --gpus"
+        text = (REPO / "tools" / script).read_text()
+        assert "--gpus" in text, f"tools/{script} must reject --gpus"
+        assert "export AWPU_UNDER_PROFILER=1" in text, f"tools/{script} must mark its processes as profiled"
 
 
 def test_watchdog_exits_non_zero():

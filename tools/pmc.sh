@@ -16,6 +16,7 @@ if [ "${AWPU_NO_BUILD:-}" != "1" ]; then  # (a caller that has built already say
   python3 -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1
 fi
 export AWPU_NO_BUILD=1
+export AWPU_UNDER_PROFILER=1  # bench.py refuses to start child ranks when it sees this (not AWPU_NO_BUILD, which only stops rebuilds)
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT" \
            "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SMEM SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_WAVES SQ_INSTS_VMEM SQ_ACTIVE_INST_MISC"; do

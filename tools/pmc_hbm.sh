@@ -17,6 +17,7 @@ if [ "${AWPU_NO_BUILD:-}" != "1" ]; then  # (a caller that has built already say
   python3 -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1
 fi
 export AWPU_NO_BUILD=1
+export AWPU_UNDER_PROFILER=1  # bench.py refuses to start child ranks when it sees this (not AWPU_NO_BUILD, which only stops rebuilds)
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_REQ_sum TCC_READ_sum"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --pmc $grp --output-format csv -d $out/$tag -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 "$@" > $out/$tag.log 2>&1 || { echo "rocprofv3 pass $tag failed, see $out/$tag.log" >&2; exit 1; }
