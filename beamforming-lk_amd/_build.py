@@ -17,7 +17,11 @@ CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libawpu_hip.so"
 
 SOURCES = [CSRC / "das_kernels.hip", CSRC / "das_fast.hip", CSRC / "awpu_hip.cpp", CSRC / "geometry_host.cpp"]
-HEADERS = [CSRC / "das_kernels.h", CSRC / "das_fast_trip.inc", REPO / "include" / "awpu_hip.h"]
+# das_fast_trip.inc -- the hand-scheduled inner loops of das_fast.hip -- is GENERATED at build time by tools/gen_trip_asm.py
+# (not tracked: ~19 000 lines of asm text whose source is the generator)
+GENERATOR = REPO / "tools" / "gen_trip_asm.py"
+TRIP_INC = CSRC / "das_fast_trip.inc"
+HEADERS = [CSRC / "das_kernels.h", GENERATOR, REPO / "include" / "awpu_hip.h"]
 
 
 def hipcc_path() -> str:
@@ -46,10 +50,25 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not stale():
             return LIB_PATH
-        return _compile(verbose)
+        return _compile(verbose, force)
 
 
-def _compile(verbose: bool) -> Path:
+def generate_blocks(force: bool = False) -> Path:
+    """Write csrc/das_fast_trip.inc with the generator's defaults (its tuning variables are for tuning builds, by hand)."""
+    if not force and TRIP_INC.exists() and TRIP_INC.stat().st_mtime >= GENERATOR.stat().st_mtime:
+        return TRIP_INC
+    import sys
+
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith(("QUAD", "TRIP_", "PAIR_DEPTH", "FIR_PRIO", "BLOCK_END_PRIO"))}  # a shipping build: the defaults
+    proc = subprocess.run([sys.executable, str(GENERATOR)], capture_output=True, text=True, env=env)
+    if proc.returncode != 0 or not TRIP_INC.exists():
+        raise RuntimeError(f"tools/gen_trip_asm.py failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")
+    return TRIP_INC
+
+
+def _compile(verbose: bool, force: bool = False) -> Path:
+    generate_blocks(force)
     tmp = LIB_PATH.with_suffix(f".so.tmp{os.getpid()}")
     cmd = [
         hipcc_path(),

@@ -85,15 +85,11 @@ struct awpu_hip {
     bool exact_pairs_ok = false;  // AWPU_MATH_F32_EXACT + LERP and the window fits the pair image
     float *sums_out = nullptr;    // awpu_hip_process_device_sums: where the launch in progress exports out[] (else null)
     awpu::QuadEntry *d_quad_lut = nullptr;  // quad-major table of the quad shape (das_quad_kernel)
-    awpu::QuadEntry *d_quad1_lut = nullptr; // the same with the single-frame layout's LDS addresses (das_quad1_kernel)
     awpu::QuadEntry *d_quadh_lut = nullptr; // the same with the halves layout's LDS addresses (das_quadh_kernel)
-    awpu::LutEntry *d_fir_pair_lut = nullptr;  // FIR8 on the frame-pair layout: {LDS address, coefficient row} per (pixel, mic)
-    awpu::FastPlan fir_plan{};
     void *d_fir_plane_lut = nullptr;           // FIR8 on the four-plane layout: one dword per (pixel, mic): address, plane, coefficient row
     awpu::FastPlan fir_plane_plan{};
     std::vector<float> fir;                    // host copy of the [101][8] coefficient table (baked into the plane entries)
-    awpu::FastPlan quad_plan{}, quad1_plan{}, quadh_plan{};
-    bool quad1_fits = false;
+    awpu::FastPlan quad_plan{}, quadh_plan{};
     bool quadh_fits = false;      // single frames on the halves layout (das_quadh_kernel)
     bool quad_ok = false;         // the table's statistics favour the quad shape (decided in prepare)
     double quad_cost = 0.0;       // its expected packed VALU instructions per quad and mic (32 = no sharing at all)
@@ -190,40 +186,72 @@ int ensure_diag(awpu_hip *h, size_t words) {
     return AWPU_OK;
 }
 
-struct EnvKnobs {  // tuning / test knobs, read once per process
-    int fpi = 0, ppw = 0, nw = 0;  // AWPU_FAST_VARIANT
-    int pairs = -1;                // AWPU_FAST_PAIRS
-    int debug = 0;                 // AWPU_FAST_DEBUG
-    int fpw = 0;                   // AWPU_FAST_FPW
-    int quads = -1;                // AWPU_FAST_QUADS
-    int pair_group = 0;            // AWPU_FAST_PAIRGROUP: frame pairs an XCD works on at a time (quad shape)
-    int quad_variant = 0;          // AWPU_QUAD_VARIANT (tuning builds)
-    int stationary = -1;           // AWPU_FAST_STATIONARY=0/1: never / always (where it fits) the stationary pair shape
-    int fir_planes = 1;            // AWPU_FIR8_PLANES=0: FIR8 batches on the older lane-strided pair kernel (A/B measurements); 2: the plane kernel for every batch >= 2, however small the grid (tests)
-    int wgs = 0;                   // AWPU_FAST_WGS: persistent workgroups of the quad shape (0 = one workgroup per item)
-    int live_graph = 1;            // AWPU_LIVE_GRAPH=0: awpu_hip_live_block always enqueues its steps one by one
-    int halves = -1;               // AWPU_FAST_HALVES=0/1: never / always (where the quad table is built) sweep single frames on the halves layout
-    int exact_pairs = 1;           // AWPU_EXACT_PAIRS=0: AWPU_MATH_F32_EXACT on the round-1 verification kernel (das_exact_kernel; A/B runs and tests)
-    int group_copy = 0;            // AWPU_GROUP_FORCE_COPY=1: a device group copies the window even to a part on devices[0]; 2: and through pinned host memory, the path of a node without peer access (tests)
+// What the process environment can change.  The SHIPPING library reads three variables, none of them needed in production:
+//   AWPU_SHAPE             force one of the production sweep shapes wherever it can serve the call (tests sweep every shape
+//                          through the oracle this way; the default rule -- launch() below -- picks by table statistics and launch size):
+//                          pair | pair_vertical | pair_horizontal | quad | noquad | stationary | quadh | single_db | single_small |
+//                          fir8_planes | exact_verify
+//   AWPU_LIVE_GRAPH=0      awpu_hip_live_block always enqueues its steps one by one (no HIP-graph replay)
+//   AWPU_GROUP_FORCE_COPY  device groups: 1 = a part on devices[0] takes the window-copy path too, 2 = through pinned host
+//                          memory (how one GPU exercises the paths a part on another GPU takes)
+// Everything else -- chunk geometry, XCD pair groups, persistent workgroups, priority variants, cycle stamps -- exists only in
+// builds with -DAWPU_TUNING_BUILD (AWPU_EXTRA_HIPCC_FLAGS; -DAWPU_TIMING_BUILD implies it), which read the round-1..3 variables
+// (AWPU_FAST_*, AWPU_FIR8_*, AWPU_QUAD_VARIANT, AWPU_EXACT_PAIRS) as before.  Read once per process.
+struct EnvKnobs {
+    int fpi = 0, ppw = 0, nw = 0;  // single-frame shape forced: frames per item (always 1 here), pixels per wave, 8 / 32
+    int pairs = -1;                // 0 / 1: never / always a frame-pair sweep (quad, stationary or pair shape) for batches >= 2
+    int debug = 0;                 // AWPU_FAST_DEBUG bits (tuning builds)
+    int fpw = 0;                   // tuning: consecutive frames per workgroup of the double-buffered single-frame shape
+    int quads = -1;                // 0 / 1: never / always (where the row length is known) the quad shapes
+    int pair_group = 0;            // tuning: frame pairs an XCD works on at a time (quad shape)
+    int quad_variant = 0;          // tuning: block variant (AWPU_QUAD_VARIANT)
+    int stationary = -1;           // 0 / 1: never / always (where the window fits the LDS) the stationary pair shape
+    int fir_planes = 1;            // 2: the four-plane FIR8 kernel for every batch >= 2 however small the grid
+    int fir_share = 1;             // tuning: 0 = the FIR8 plane kernel sweeps four consecutive pixels even where the row length is known
+    int wgs = 0;                   // tuning: persistent workgroups of the quad shape (0 = default rule, -1 = one workgroup per item)
+    int live_graph = 1;            // AWPU_LIVE_GRAPH
+    int halves = -1;               // 1: single frames on the halves layout for every call (where the quad table is built)
+    int exact_pairs = 1;           // 0: AWPU_MATH_F32_EXACT on the round-1 verification kernel (das_exact_kernel)
+    int pair_cols = -1;            // 0 / 1: the pair shape pairs consecutive / vertically adjacent pixels (default: whichever coincides more)
+    int group_copy = 0;            // AWPU_GROUP_FORCE_COPY
     EnvKnobs() {
+        if (const char *v = std::getenv("AWPU_GROUP_FORCE_COPY")) group_copy = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_LIVE_GRAPH")) live_graph = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_SHAPE")) {
+            const std::string shape(v);
+            if (shape == "pair" || shape == "pair_vertical" || shape == "pair_horizontal") {
+                pairs = 1, quads = 0, stationary = 0;
+                if (shape != "pair") pair_cols = shape == "pair_vertical";
+            } else if (shape == "quad") quads = 1;
+            else if (shape == "noquad") quads = 0;
+            else if (shape == "stationary") pairs = 1, quads = 0, stationary = 1;
+            else if (shape == "quadh") quads = 1, pairs = 0, halves = 1;
+            else if (shape == "single_db") pairs = 0, quads = 0, fpi = 1, ppw = 8, nw = 32;
+            else if (shape == "single_small") pairs = 0, quads = 0, fpi = 1, ppw = 2, nw = 8;
+            else if (shape == "fir8_planes") fir_planes = 2;
+            else if (shape == "exact_verify") exact_pairs = 0;
+            else std::fprintf(stderr, "libawpu_hip: AWPU_SHAPE=%s is not a shape of this build; ignored\n", v);
+        }
+#ifdef AWPU_TUNING_BUILD
         if (const char *v = std::getenv("AWPU_FAST_QUADS")) quads = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_PAIRGROUP")) pair_group = std::atoi(v);
         if (const char *v = std::getenv("AWPU_QUAD_VARIANT")) quad_variant = std::atoi(v);
-        if (const char *v = std::getenv("AWPU_GROUP_FORCE_COPY")) group_copy = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_HALVES")) halves = std::atoi(v);
         if (const char *v = std::getenv("AWPU_EXACT_PAIRS")) exact_pairs = std::atoi(v);
-        if (const char *v = std::getenv("AWPU_LIVE_GRAPH")) live_graph = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_WGS")) wgs = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FIR8_PLANES")) fir_planes = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FIR8_SHARE")) fir_share = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_STATIONARY")) stationary = std::atoi(v);
+        if (const char *v = std::getenv("AWPU_FAST_PAIRCOLS")) pair_cols = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_VARIANT"))
             if (std::sscanf(v, "%d,%d,%d", &fpi, &ppw, &nw) < 2) fpi = ppw = nw = 0;
         if (const char *v = std::getenv("AWPU_FAST_PAIRS")) pairs = std::atoi(v);
         if (const char *v = std::getenv("AWPU_FAST_DEBUG")) debug = std::atoi(v);
 #ifndef AWPU_TIMING_BUILD
-        debug &= awpu::kDebugSafeBits;  // the wrong-result timing switches do not exist in this build (das_kernels.h)
+        debug &= awpu::kDebugSafeBits;  // the wrong-result timing switches exist only with -DAWPU_TIMING_BUILD (das_kernels.h)
 #endif
         if (const char *v = std::getenv("AWPU_FAST_FPW")) fpw = std::atoi(v);
+#endif
     }
 };
 const EnvKnobs &env() {
@@ -258,9 +286,7 @@ void release_device(awpu_hip *h) {
     h->fast_luts.clear();
     dev_free(h->d_exact_pair_lut);
     dev_free(h->d_quad_lut);
-    dev_free(h->d_quad1_lut);
     dev_free(h->d_quadh_lut);
-    dev_free(h->d_fir_pair_lut);
     dev_free(h->d_fir_plane_lut);
     dev_free(h->d_index);
     dev_free(h->d_gain);
@@ -328,9 +354,7 @@ int prepare(awpu_hip *h) {
     h->fast_luts.clear();
     dev_free(h->d_exact_pair_lut);
     dev_free(h->d_quad_lut);
-    dev_free(h->d_quad1_lut);
     dev_free(h->d_quadh_lut);
-    dev_free(h->d_fir_pair_lut);
     dev_free(h->d_fir_plane_lut);
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
@@ -424,7 +448,7 @@ int prepare(awpu_hip *h) {
                 }
             }
             if (seen > 0 && same_v > same_h) h->pair_cols = cols;
-            if (const char *e = std::getenv("AWPU_FAST_PAIRCOLS")) h->pair_cols = std::atoi(e) ? cols : 0;  // tests force either
+            if (env().pair_cols >= 0) h->pair_cols = env().pair_cols ? cols : 0;  // AWPU_SHAPE=pair_vertical / pair_horizontal: tests force either
         }
     }
 
@@ -458,9 +482,6 @@ int prepare(awpu_hip *h) {
             h->quad_cost = seen ? 20.0 + (8.0 * (double) differ - 4.0 * (double) together) / (double) seen : 32.0;
             h->quad_ok = h->quad_cost < 31.0 && awpu::pair_plan(h->window, U, &h->quad_plan);
             if (env().quads >= 0) h->quad_ok = env().quads != 0 && awpu::pair_plan(h->window, U, &h->quad_plan);
-            h->quad1_fits = h->quad_ok && h->gain.empty() &&  // (gains ride on the weights of the other single-frame tables)
-                            awpu::fast_plan(h->window, U, 1, awpu::kFastLdsBytes - awpu::kQuad1ZeroBytes, &h->quad1_plan) &&
-                            awpu::fast_db_fits(h->quad1_plan);
             // the halves layout: a row holds the window less 128 samples, as (sample, sample + 128) pairs (its pack pass applies the gains)
             h->quadh_fits = h->quad_ok && awpu::pair_plan(h->window - 128, U, &h->quadh_plan);
         }
@@ -534,13 +555,12 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
 // address), quads = groups of four grid rows x columns padded to whole 16-column tiles.  Pixels past the grid
 // carry weight 0 and the address of the nearest pixel inside it (they then follow the shared path and add
 // nothing); padding mics (usable rounded up to 4) carry weight 0 and the address of their own, zero, row.
-enum QuadLayout { kQuadPairs = 0, kQuadSingle = 1, kQuadHalves = 2 };
+enum QuadLayout { kQuadPairs = 0, kQuadHalves = 2 };
 int build_quad_lut(awpu_hip *h, int layout) {
-    const bool single = layout == kQuadSingle;
-    awpu::QuadEntry *&d_lut = single ? h->d_quad1_lut : (layout == kQuadHalves ? h->d_quadh_lut : h->d_quad_lut);
+    awpu::QuadEntry *&d_lut = layout == kQuadHalves ? h->d_quadh_lut : h->d_quad_lut;
     if (d_lut) return AWPU_OK;
     const auto &c = h->cfg;
-    const awpu::FastPlan &plan = single ? h->quad1_plan : (layout == kQuadHalves ? h->quadh_plan : h->quad_plan);
+    const awpu::FastPlan &plan = layout == kQuadHalves ? h->quadh_plan : h->quad_plan;
     const int U = h->usable(), cols = c.grid_columns, rows = c.pixel_count / cols;
     const int groups = plan.usable_pad / 4;
     const int cols_pad = (cols + 15) / 16 * 16, rows4 = (rows + 3) / 4;
@@ -562,15 +582,10 @@ int build_quad_lut(awpu_hip *h, int layout) {
                         const int id = h->index[s];
                         const int off_rel = orow[id] - h->wstart;
                         e.f = inside ? frow[id] - 0.5f : 0.0f;  // centred weight (das_fast.hip, das_quad_kernel)
-                        if (single) {  // copy (off & 1) of the window starts 8-byte aligned
-                            const int par = off_rel & 1;
-                            e.addr = (uint32_t) ((j * 2 + par) * plan.row_bytes + (off_rel - par) * 4);
-                        } else {
-                            e.addr = (uint32_t) (j * plan.row_bytes + off_rel * 8);
-                        }
-                    } else {  // padding mic: silence (the pair layout packs zero rows; the single-frame images end in one)
+                        e.addr = (uint32_t) (j * plan.row_bytes + off_rel * 8);
+                    } else {  // padding mic: silence (the pack passes write zero rows)
                         e.f = 0.0f;
-                        e.addr = single ? (uint32_t) (awpu::kFastLdsBytes - awpu::kQuad1ZeroBytes) : (uint32_t) (j * plan.row_bytes);
+                        e.addr = (uint32_t) (j * plan.row_bytes);
                     }
                 }
             }
@@ -730,45 +745,6 @@ int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     return finish_launch(h, batch, s);
 }
 
-// FIR8 on the frame-pair layout (das_fir8_pair_kernel): batches of the 8-tap variant with AWPU_MATH_F32_FAST
-int launch_fir8_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
-    const awpu::FastPlan &pp = h->fir_plan;
-    const int U = h->usable(), P = h->cfg.pixel_count;
-    if (!h->d_fir_pair_lut) {
-        std::vector<awpu::LutEntry> packed((size_t) P * pp.usable_pad, awpu::LutEntry{0, 0});
-        for (int p = 0; p < P; p++) {
-            const int32_t *orow = &h->off[(size_t) p * h->cfg.lut_stride];
-            const float *frow = &h->frac[(size_t) p * h->cfg.lut_stride];
-            for (int m = 0; m < U; m++) {
-                const int id = h->index[m];
-                const float get_filter = frow[id] * 100.0f + 0.5f;  // delay.cpp:32-33: the coefficient row
-                packed[(size_t) p * pp.usable_pad + m] =
-                    awpu::LutEntry{(int32_t) ((m % pp.chunk) * pp.row_bytes + (orow[id] - h->wstart) * 8), (float) 0};
-                const int32_t k = (int32_t) get_filter;
-                std::memcpy(&packed[(size_t) p * pp.usable_pad + m].frac, &k, sizeof(k));
-            }
-        }
-        AWPU_HIP_TRY(hipMalloc(&h->d_fir_pair_lut, packed.size() * sizeof(awpu::LutEntry)));
-        AWPU_HIP_TRY(hipMemcpy(h->d_fir_pair_lut, packed.data(), packed.size() * sizeof(awpu::LutEntry), hipMemcpyHostToDevice));
-    }
-    const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * U * pp.wr * 2;
-    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
-    awpu::PairArgs pa{};
-    pa.packed = h->d_pack;
-    pa.power = d_power;
-    pa.usable = U;
-    pa.usable_pad = pp.usable_pad;
-    pa.pixel_count = P;
-    pa.wp = pp.wr;
-    pa.chunk = pp.chunk;
-    pa.batch = batch;
-    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, U, U, h->d_gain,
-                                         pp.wr, batch, h->d_pack, false, s));
-    AWPU_HIP_TRY(awpu::launch_das_fir8_pairs(pa, h->d_fir_pair_lut, h->d_fir, s));
-    return finish_launch(h, batch, s);
-}
-
 // FIR8 on the four-plane frame-pair layout (das_fir8_plane_kernel): a lane owns four consecutive outputs
 int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
     const awpu::FastPlan &pp = h->fir_plane_plan;
@@ -807,7 +783,7 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
     // vertical pixel quads (samples shared between pixels of one column with the same integer delay) where the grid's row
     // length is known and the rows are staged at the pitch that block is generated for; AWPU_FIR8_SHARE=0: consecutive pixels
     {
-        static const bool allow = !(std::getenv("AWPU_FIR8_SHARE") && std::atoi(std::getenv("AWPU_FIR8_SHARE")) == 0);
+        const bool allow = env().fir_share != 0;
         const int cols = h->cfg.grid_columns;
         if (allow && cols > 0 && P % cols == 0 && h->cfg.pixel_begin % cols == 0 && (uint32_t) pp.wr * 2u == awpu::kFirStaticPlaneBytesHost)
             pa.cols = cols;
@@ -925,43 +901,6 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     return dump_diag(h, n_waves, 16, "quads", s);
 }
 
-// quad shape for single frames (das_quad1_kernel): frames read in place, qpw quads per wave
-int launch_quads1(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff,
-                  const int32_t *d_row_off, int qpw) {
-    int rc = build_quad_lut(h, kQuadSingle);
-    if (rc != AWPU_OK) return rc;
-    const awpu::FastPlan &pp = h->quad1_plan;
-    awpu::Quad1Args qa{};
-    qa.frames = d_frames;
-    qa.lut = h->d_quad1_lut;
-    qa.row_off = d_row_off;
-    qa.power = d_power;
-    qa.n_streams = h->cfg.n_streams;
-    qa.hist = hist_eff;
-    qa.usable = h->usable();
-    qa.usable_pad = pp.usable_pad;
-    qa.pixel_count = h->cfg.pixel_count;
-    qa.wr = pp.wr;
-    qa.chunk = pp.chunk;
-    qa.batch = batch;
-    qa.cols = h->cfg.grid_columns;
-    qa.rows = h->cfg.pixel_count / qa.cols;
-    qa.debug = env().debug;
-    qa.debug_out = nullptr;
-    size_t n_waves = 0;
-    if (qa.debug & 16) {
-        n_waves = (size_t) 16 * batch * awpu::quad1_tiles(qa.rows, qa.cols, qpw);
-        rc = ensure_diag(h, n_waves * 12);
-        if (rc != AWPU_OK) return rc;
-        qa.debug_out = h->d_diag;
-    }
-    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    AWPU_HIP_TRY(awpu::launch_das_quads1(qa, qpw, s));
-    rc = finish_launch(h, batch, s);
-    if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
-    return dump_diag(h, n_waves, 16, "quads1", s);
-}
-
 // quad shape for single frames on the halves layout (das_quadh_kernel): a pack + filter pre-pass, then the sweep
 int launch_quadsh(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int pitch, int hist_eff, int wstart_eff,
                   int qpw) {
@@ -1011,8 +950,6 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         (fir_wgs >= (batch >= 2 ? 256 : 192) || (env().fir_planes == 2 && batch >= 2))) {
         if (env().fir_planes && awpu::fir8_plane_plan(h->window, h->usable(), &h->fir_plane_plan))
             return launch_fir8_planes(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
-        if (awpu::pair_plan(h->window, h->usable(), &h->fir_plan))
-            return launch_fir8_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
     }
     if (h->exact_pairs_ok && env().exact_pairs != 0) return launch_exact_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
     if (h->sums_out) return fail(AWPU_ERR_STATE, "the pre-epilogue sums are exported by the frame-pair reference-order kernel only");
@@ -1049,8 +986,8 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         // else (an allocation or copy that failed) is the caller's to know about
         if (rc != AWPU_ERR_INVALID) return rc;
     }
-    // ---- single frames on a grid whose table favours the quad shape (AWPU_FAST_VARIANT set: the older shapes): the
-    // halves layout behind a pack + filter pre-pass (AWPU_FAST_HALVES=0: the in-place layout of round 2)
+    // ---- single frames on a grid whose table favours the quad shape (a forced single-frame shape goes past): the halves
+    // layout behind a pack + filter pre-pass
     if (h->quadh_fits && env().fpi == 0 && env().halves != 0) {
         const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
         const int qpw = (long) awpu::quad1_tiles(rows, cols, 2) * batch >= 256 ? 2 : 1;
@@ -1059,13 +996,6 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
             const int pitch = hist_eff;
             return launch_quadsh(h, d_frames, batch, d_power, s, pitch, layout == kRing ? AWPU_HIST : hist_eff, wstart_eff, qpw);
         }
-    }
-    if (h->quad1_fits && env().fpi == 0 && wstart_eff + 1 + h->quad1_plan.wr <= hist_eff) {
-        const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
-        const int qpw = (long) awpu::quad1_tiles(rows, cols, 2) * batch >= 256 ? 2 : 1;
-        if ((long) awpu::quad1_tiles(rows, cols, qpw) * batch >= 192 || env().quads == 1)
-            return launch_quads1(h, d_frames, batch, d_power, s, hist_eff,
-                                 compact ? h->d_row_off_compact : (layout == kRing ? h->d_row_off_ring : h->d_row_off), qpw);
     }
     int fpi = 1, ppw = 8, nw = 8;
     choose_fast_variant(h, batch, &fpi, &ppw, &nw);

@@ -1082,127 +1082,6 @@ __global__ __launch_bounds__(1024, 4) void das_exact_pair_kernel(ExactPairArgs a
 }
 
 // ---------------------------------------------------------------------------------------
-// FIR8 on the frame-pair layout (AWPU_INTERP_FIR8 with AWPU_MATH_F32_FAST, batches): the 8-tap table variant of
-// delay(), src/dsp/delay.cpp:31-40,
-//     k = (int)(frac * 100 + 0.5);  out[n] += sum_{t<8} C[k][t] * X[off + n + t],
-// swept like das_pair_kernel sweeps the linear one: the window (here off .. off + 262) of a chunk of mics in LDS as
-// (frame a, frame b) sample pairs, two images filled by LDS-DMA, lane l owns samples l + 64 j, the two packed lanes
-// are the two frames.  An item is 32 ds_read_b64 (4 sample groups x 8 taps, the taps 8 bytes apart: immediate
-// offsets off one address) and 32 v_pk_fma_f32 with the 8 coefficients of its table row as scalar operands -- no
-// skewed accumulators, no 257th-sample pass: out[n] is complete in its lane.  Taps accumulate in the reference's
-// order t = 0..7, mics in order.  Compiler-scheduled (the FMA-to-read ratio is 1:1 and every read is independent).
-// ---------------------------------------------------------------------------------------
-struct FirEntry {
-    uint32_t addr;  // LDS byte offset of the element X[off] in the chunk's image
-    int32_t k;      // coefficient row (delay.cpp:32-33)
-};
-
-template <int PPW>
-__global__ __launch_bounds__(1024, 4) void das_fir8_pair_kernel(PairArgs a, const FirEntry *lut, const float *coeffs) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
-    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = blockIdx.x, tile = blockIdx.y;
-    const int pix0 = (tile * NW + wave) * PPW;
-    const size_t row_floats = (size_t) a.wp * 2;
-    const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
-    const unsigned lane_bytes = threadIdx.x * 16;
-    auto dma_chunk = [&](int m0, int mc, int buf) {
-        const unsigned n_bytes = (unsigned) ((size_t) mc * row_floats * 4);
-        const char *src = (const char *) (pair_base + (size_t) m0 * row_floats);
-#pragma unroll
-        for (int k = 0; k < kPieces; k++) {
-            if (lane_bytes + k * kThreads * 16 < n_bytes) {
-                const char *base = (const char *) uniform_ptr(src + k * kThreads * 16);
-                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (base + lane_bytes),
-                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
-            }
-        }
-    };
-    f2 acc[PPW][4];
-#pragma unroll
-    for (int pp = 0; pp < PPW; pp++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[pp][j] = f2{0.0f, 0.0f};
-
-    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
-    dma_chunk(0, min(a.chunk, a.usable), 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int c = 0; c < n_chunks; c++) {
-        const int m0 = c * a.chunk;
-        const int mc = min(a.chunk, a.usable - m0);
-        const int buf = c & 1;
-        if (c + 1 < n_chunks) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
-        const char *img = (const char *) (lds + buf * (BUF / 4)) + lane * 8;
-#pragma unroll
-        for (int pp = 0; pp < PPW; pp++) {
-            const int p = min(pix0 + pp, a.pixel_count - 1);  // pixels past the grid repeat the last one (not stored)
-            const AWPU_AS4 FirEntry *row = (const AWPU_AS4 FirEntry *) (unsigned long long) (lut + (size_t) p * a.usable_pad + m0);
-            // An item's address and its eight coefficients are wave-uniform: scalar loads.  They are requested for
-            // the NEXT mic after this mic's last FMA and waited for at the head of the next iteration, so that no
-            // scalar load is in flight while LDS reads are (hipcc waits lgkmcnt(0) for an LDS result whenever a
-            // scalar load is pending: the two share the counter and scalar loads return out of order).
-            unsigned addr_n = row[0].addr;
-            const AWPU_AS4 float *cf_n = (const AWPU_AS4 float *) (unsigned long long) (coeffs + 8 * row[0].k);
-            float ct_n[8];
-#pragma unroll
-            for (int t = 0; t < 8; t++) ct_n[t] = cf_n[t];
-            for (int m = 0; m < mc; m++) {
-                const char *x = img + addr_n;
-                float ct[8];
-#pragma unroll
-                for (int t = 0; t < 8; t++) ct[t] = ct_n[t];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < 4; j += 2) {  // two sample groups' reads in flight (16), then their FMAs
-                    f2 v[2][8];
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-#pragma unroll
-                        for (int t = 0; t < 8; t++) {
-                            v[u][t] = *(const f2 *) (x + 512 * (j + u) + 8 * t);
-                            no_fuse();
-                        }
-#pragma unroll
-                    for (int u = 0; u < 2; u++)
-#pragma unroll
-                        for (int t = 0; t < 8; t++)
-                            acc[pp][j + u] = __builtin_elementwise_fma(f2{ct[t], ct[t]}, v[u][t], acc[pp][j + u]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const int mn = min(m + 1, mc - 1);
-                addr_n = row[mn].addr;
-                const AWPU_AS4 float *cf = (const AWPU_AS4 float *) (unsigned long long) (coeffs + 8 * row[mn].k);
-#pragma unroll
-                for (int t = 0; t < 8; t++) ct_n[t] = cf[t];
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    const float norm = (float) (kSamples * a.usable);
-#pragma unroll
-    for (int pp = 0; pp < PPW; pp++) {
-        f2 P[8];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            P[j] = acc[pp][j];
-            P[4 + j] = f2{0.0f, 0.0f};  // no skewed terms: out[n] is complete in its lane
-        }
-        const f2 sum = finish_pixel_pair(P, f2{0.0f, 0.0f}, lane);
-        const int p = pix0 + pp;
-        if (lane == 0 && p < a.pixel_count) {
-            a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
-            if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
 // FIR8, four-plane frame-pair layout (the default for FIR8 batches): das_fir8_pair_kernel reads 32 LDS elements for
 // 32 FMAs, and the LDS array -- one per CU, 2 cycles per ds_read_b64, shared by four SIMDs that each want a
 // v_pk_fma_f32 every 4 cycles -- then holds the sweep at half the VALU rate.  Here a lane owns four CONSECUTIVE
@@ -1597,187 +1476,6 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Quad shape for single frames (calls of one frame, frames read in place from the ingest ring): the staging of
-// das_fast_db_kernel -- one 16-wave workgroup per CU, two LDS images of [mic][copy q][wr] floats filled by LDS-DMA,
-// copy q = the window shifted by q samples so that any integer delay starts 8-byte aligned -- under the quad
-// arithmetic of das_quad_kernel: a wave sweeps QPW quads of four vertically adjacent pixels; lane l owns samples
-// {2l, 2l+1} and {128+2l, 129+2l}, so a quad's accumulators are 32 registers (A_p, T, V_p: two register pairs
-// each).  Per mic and quad 10 packed VALU instructions and 2 LDS reads where the four integer delays coincide
-// (+4 and +2 per pixel that differs), against 16 and 8 in das_fast_db_kernel.  Same 8-byte quad-major table
-// layout as das_quad_kernel, with this layout's LDS addresses; grid = (frames, tiles of 4 rows x 16 QPW columns).
-// ---------------------------------------------------------------------------------------
-template <int QPW, bool DIAG>
-__global__ __launch_bounds__(1024, 4) void das_quad1_kernel(Quad1Args a) {
-    static_assert(QPW == 1 || QPW == 2, "one or two quads per wave");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
-    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
-    const int frame = blockIdx.x;
-    const int tile = blockIdx.y;
-    const int wr = a.wr, wr4 = wr >> 2;
-
-    const int tile_cols = NW * QPW;
-    const int tiles_per_row4 = (a.cols + tile_cols - 1) / tile_cols;
-    const int cols_pad = (a.cols + 15) / 16 * 16;  // the table's quads: columns padded to 16 (quad_count)
-    const int row4 = tile / tiles_per_row4;
-    const int col0 = (tile - row4 * tiles_per_row4) * tile_cols + wave * QPW;
-    const int groups_total = a.usable_pad >> 2;
-
-    int *row_off_lds = (int *) (lds + 2 * (BUF / 4));
-    for (int i = threadIdx.x; i < 2 * a.usable_pad; i += kThreads) row_off_lds[i] = a.row_off[i];
-    int piece_rc[kPieces];  // row << 16 | column of this thread's 16-byte pieces of the flat image
-#pragma unroll
-    for (int k = 0; k < kPieces; k++) {
-        const int piece = threadIdx.x + k * kThreads;
-        const int row = piece / wr4;
-        piece_rc[k] = (row << 16) | ((piece - row * wr4) * 4);
-    }
-    __syncthreads();
-
-    f4 A0a = {0, 0, 0, 0}, A1a = A0a, A2a = A0a, A3a = A0a, Ta = A0a, V0a = A0a, V2a = A0a, V3a = A0a;
-    f4 A0b = A0a, A1b = A0a, A2b = A0a, A3b = A0a, Tb = A0a, V0b = A0a, V2b = A0a, V3b = A0a;
-    float tail = 0.0f;
-    // tail pass: lane LPP pp + k takes pixel slot pp (quad pp / 4, pixel pp % 4) and the mics k (mod LPP); every lane
-    // has a pixel: 16 lanes each for one quad per wave, 8 for two; a round covers 32 mics in 32 / LPP entries per lane
-    constexpr int LPP = QPW == 1 ? 16 : 8, NU = 32 / LPP;
-    const int tail_pp = lane / LPP;
-    const int tail_col = min(col0 + (tail_pp >> 2), cols_pad - 1);
-    const bool tail_lane = tail_pp < 4 * QPW && col0 + (tail_pp >> 2) < a.cols && 4 * row4 + (tail_pp & 3) < a.rows;
-    const QuadEntry *tail_lut = a.lut + ((size_t) row4 * cols_pad + tail_col) * groups_total * 16;
-
-    const float *frame_base = a.frames + (size_t) frame * a.n_streams * a.hist;
-    auto dma_chunk = [&](int m0, int mc, int buf) {
-        const int rows = 2 * mc;
-        int src_off[kPieces];  // all row offsets first (one LDS round trip), then the transfers back to back
-#pragma unroll
-        for (int k = 0; k < kPieces; k++)
-            src_off[k] = row_off_lds[2 * m0 + min(piece_rc[k] >> 16, rows - 1)] + (piece_rc[k] & 0xffff);
-#pragma unroll
-        for (int k = 0; k < kPieces; k++) {
-            if ((piece_rc[k] >> 16) < rows) {
-                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (frame_base + src_off[k]),
-                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
-            }
-        }
-    };
-    // Padding mics (usable rounded up to 4) carry weight 0 and the address of the zero row that closes either
-    // image (kQuad1ZeroBytes, never touched by the DMA): they add nothing to T either.
-    for (int i = threadIdx.x; i < 2 * (kQuad1ZeroBytes / 4); i += kThreads)
-        lds[(i / (kQuad1ZeroBytes / 4)) * (BUF / 4) + (BUF - kQuad1ZeroBytes) / 4 + i % (kQuad1ZeroBytes / 4)] = 0.0f;
-
-    unsigned t_wait = 0, t_all = 0;
-    const long long t_begin = __builtin_readcyclecounter();
-    const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
-    dma_chunk(0, min(a.chunk, a.usable), 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    unsigned t_ph[5] = {0, 0, 0, 0, 0};
-    auto stamp = [&](int k, long long &t) {
-        if (DIAG) {
-            const long long n = __builtin_readcyclecounter();
-            t_ph[k] += (unsigned) (n - t);
-            t = n;
-        }
-    };
-    const int rank = wave >> 2;
-    for (int c = 0; c < n_chunks; c++) {
-        const int m0 = c * a.chunk;
-        const int mc = min(a.chunk, a.usable - m0);
-        const int mc4 = (mc + 3) & ~3;
-        const int buf = c & 1;
-        long long t = DIAG ? __builtin_readcyclecounter() : 0;
-        // table entries of the tail pass below (the 257th sample): requested now, consumed after the sweep
-        QuadEntry te[NU];
-#pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int m = m0 + min(LPP * u + ((lane - m0) & (LPP - 1)), mc4 - 1);
-            te[u] = tail_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
-        }
-        if (c + 1 < n_chunks && !AWPU_DBG(a, 1)) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable - m0 - a.chunk), buf ^ 1);
-        stamp(0, t);
-        const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
-        const int ng = __builtin_amdgcn_readfirstlane(mc4 >> 2);
-        {
-            const void *row = uniform_ptr(a.lut + (((size_t) row4 * cols_pad + min(col0, cols_pad - 1)) * groups_total + (m0 >> 2)) * 16);
-            if constexpr (DIAG) {
-                unsigned dw = 0, da = 0;
-                sweep_quad1_sum_a_stamped(A0a, A1a, A2a, A3a, Ta, V0a, V2a, V3a, row, ng, lane_addr, rank, dw, da);
-                t_wait += dw;
-                t_all += da;
-            } else {
-                sweep_quad1_sum_a(A0a, A1a, A2a, A3a, Ta, V0a, V2a, V3a, row, ng, lane_addr, rank);
-            }
-        }
-        if constexpr (QPW == 2) {
-            const void *row = uniform_ptr(a.lut + (((size_t) row4 * cols_pad + min(col0 + 1, cols_pad - 1)) * groups_total + (m0 >> 2)) * 16);
-            sweep_quad1_sum_b(A0b, A1b, A2b, A3b, Tb, V0b, V2b, V3b, row, ng, lane_addr, rank);
-        }
-        stamp(1, t);
-        // the 257th sample of every window (X[off+256], weight 1 - f, goes to out[255])
-        const float *buf_f = lds + buf * (BUF / 4);
-        if (!AWPU_DBG(a, 4))
-#pragma unroll
-            for (int u = 0; u < NU; u++) {  // mics 0..31 of the chunk (prefetched above)
-                const bool on = tail_lane && LPP * u + ((lane - m0) & (LPP - 1)) < mc;
-                tail = __builtin_fmaf(on ? 0.5f - te[u].f : 0.0f, buf_f[(te[u].addr + 1024u) >> 2], tail);  // 1 - f
-            }
-        for (int j0 = 32; j0 < (AWPU_DBG(a, 4) ? 0 : mc4); j0 += 32) {  // chunks of more than 32 mics (narrow windows)
-            QuadEntry e[NU];
-            bool on[NU];
-#pragma unroll
-            for (int u = 0; u < NU; u++) {
-                const int j = j0 + LPP * u + ((lane - m0) & (LPP - 1));
-                const int m = m0 + min(j, mc4 - 1);
-                e[u] = tail_lut[((m >> 2) * 4 + (tail_pp & 3)) * 4 + (m & 3)];
-                on[u] = tail_lane && j < mc;  // padding mics (j >= mc) add nothing
-            }
-#pragma unroll
-            for (int u = 0; u < NU; u++)
-                tail = __builtin_fmaf(on[u] ? 0.5f - e[u].f : 0.0f, buf_f[(e[u].addr + 1024u) >> 2], tail);  // 1 - f
-        }
-        if (DIAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stamp(2, t);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(3, t);
-        if (!AWPU_DBG(a, 8)) __syncthreads();
-        stamp(4, t);
-    }
-
-    if (DIAG && a.debug_out && lane == 0) {
-        unsigned long long *o = a.debug_out + 12 * ((size_t) (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
-        o[0] = t_wait;
-        o[1] = t_all;
-        o[2] = (unsigned long long) (__builtin_readcyclecounter() - t_begin);
-        o[3] = (unsigned long long) n_chunks;
-        for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
-    }
-    tail = LPP == 16 ? sum16(tail) : sum8(tail);
-    const float norm = (float) (kSamples * a.usable);
-    auto finish = [&](const f4 &A, const f4 &S, int slot) {
-        const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
-        const f2 Ax = f2{A[0], A[1]}, Ay = f2{A[2], A[3]};  // accumulated with f - 1/2 (see QuadEntry)
-        const f2 Hx = 0.5f * f2{S[0], S[1]}, Hy = 0.5f * f2{S[2], S[3]};
-        const float tl = lane_value(tail, slot * LPP);
-        const float sum = finish_pixel(Hx + Ax, Hx - Ax, Hy + Ay, Hy - Ay, tl, lane);  // sum f X, sum (1 - f) X
-        if (lane == 0 && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = sum / norm;
-    };
-    finish(A0a, Ta + V0a, 0);
-    finish(A1a, Ta, 1);
-    finish(A2a, Ta + V2a, 2);
-    finish(A3a, Ta + V3a, 3);
-    if constexpr (QPW == 2) {
-        finish(A0b, Tb + V0b, 4);
-        finish(A1b, Tb, 5);
-        finish(A2b, Tb + V2b, 6);
-        finish(A3b, Tb + V3b, 7);
-    }
-}
-// ---------------------------------------------------------------------------------------
 // Quad shape for single frames on the HALVES layout (round 3; the default for calls of one frame where the quad table
 // pays): a pre-pass (pack_halves_kernel) writes, per active mic, the touched window as 8-byte elements
 //     element t = (Y[wstart + t], Y[wstart + t + 128]),      Y = the pre-filtered samples of pack_one_row<true>,
@@ -2076,25 +1774,19 @@ bool pair_plan_stationary(int window, int usable, FastPlan *plan) {
 
 hipError_t launch_das_pairs_stationary(const PairArgs &a, int tiles_per_wg, hipStream_t stream) {
     static LdsFlags attr_set[2] = {};
-    const bool share = (a.debug & 4096) == 0;
     constexpr int lds_bytes = 2 * kFastLdsBytes;
-    const void *fn = share ? (const void *) das_pair_stationary_kernel<true> : (const void *) das_pair_stationary_kernel<false>;
-    if (hipError_t e = allow_lds(fn, lds_bytes, attr_set[share]); e != hipSuccess) return e;
     const int n_tiles = pair_tiles(a.pixel_count, a.cols);
     dim3 grid((a.batch + 1) / 2, (n_tiles + tiles_per_wg - 1) / tiles_per_wg);
     if (grid.y > 65535) return hipErrorInvalidValue;
-    if (share) hipLaunchKernelGGL(das_pair_stationary_kernel<true>, grid, dim3(1024), lds_bytes, stream, a, n_tiles, tiles_per_wg);
-    else hipLaunchKernelGGL(das_pair_stationary_kernel<false>, grid, dim3(1024), lds_bytes, stream, a, n_tiles, tiles_per_wg);
-    return hipGetLastError();
-}
-
-hipError_t launch_das_fir8_pairs(const PairArgs &a, const void *d_entries, const float *d_coeffs, hipStream_t stream) {
-    static LdsFlags attr_set = {};
-    constexpr int lds_bytes = 2 * kFastLdsBytes;
-    if (hipError_t e = allow_lds((const void *) das_fir8_pair_kernel<4>, lds_bytes, attr_set); e != hipSuccess) return e;
-    dim3 grid((a.batch + 1) / 2, (a.pixel_count + 63) / 64);
-    if (grid.y > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(das_fir8_pair_kernel<4>, grid, dim3(1024), lds_bytes, stream, a, (const FirEntry *) d_entries, d_coeffs);
+#ifdef AWPU_TUNING_BUILD  // debug bit 4096: the pixel-major block without read sharing (the same bits)
+    if (a.debug & 4096) {
+        if (hipError_t e = allow_lds((const void *) das_pair_stationary_kernel<false>, lds_bytes, attr_set[0]); e != hipSuccess) return e;
+        hipLaunchKernelGGL(das_pair_stationary_kernel<false>, grid, dim3(1024), lds_bytes, stream, a, n_tiles, tiles_per_wg);
+        return hipGetLastError();
+    }
+#endif
+    if (hipError_t e = allow_lds((const void *) das_pair_stationary_kernel<true>, lds_bytes, attr_set[1]); e != hipSuccess) return e;
+    hipLaunchKernelGGL(das_pair_stationary_kernel<true>, grid, dim3(1024), lds_bytes, stream, a, n_tiles, tiles_per_wg);
     return hipGetLastError();
 }
 
@@ -2103,7 +1795,11 @@ bool fir8_plane_plan(int window, int usable, FastPlan *plan) {
     // windows of 321..384 samples (every BASELINE shape but the single 8x8 array) are staged at the plane pitch the
     // one-address block is generated for (sweep_fir8_planes_static: 33 instead of 36 VALU instructions per item);
     // AWPU_FIR8_STATIC=0 keeps the natural pitch for A/B runs
+#ifdef AWPU_TUNING_BUILD
     static const bool allow_static = !(std::getenv("AWPU_FIR8_STATIC") && std::atoi(std::getenv("AWPU_FIR8_STATIC")) == 0);
+#else
+    constexpr bool allow_static = true;
+#endif
     const int wp_static = (int) (kFirStaticPlaneBytes / 2);
     if (allow_static && wp > wp_static - 64 && wp <= wp_static) wp = wp_static;
     const size_t row_bytes = (size_t) wp * 8;
@@ -2172,9 +1868,12 @@ hipError_t launch_das_exact_pairs(const ExactPairArgs &a, hipStream_t stream) {
 }
 
 hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {
-    const bool share = (a.debug & 4096) == 0;  // bit 4096: the pixel-major block without read sharing
+#ifdef AWPU_TUNING_BUILD  // stamped builds (bit 16) and the pixel-major block without read sharing (bit 4096: the same bits)
+    const bool share = (a.debug & 4096) == 0;
     if (a.debug & 16) return share ? launch_pair_variant<4, true, true>(a, stream) : launch_pair_variant<4, true, false>(a, stream);
-    return share ? launch_pair_variant<4, false, true>(a, stream) : launch_pair_variant<4, false, false>(a, stream);
+    if (!share) return launch_pair_variant<4, false, false>(a, stream);
+#endif
+    return launch_pair_variant<4, false, true>(a, stream);
 }
 
 template <bool DIAG, int VAR>
@@ -2196,29 +1895,15 @@ static hipError_t launch_quad_variant(const QuadArgs &a, hipStream_t stream) {
 }
 
 hipError_t launch_das_quads(const QuadArgs &a, hipStream_t stream) {
+#ifdef AWPU_TUNING_BUILD
     if (a.debug & 16) return launch_quad_variant<true, 0>(a, stream);
+#endif
 #ifdef AWPU_QUAD_VARIANTS
     if (a.variant == 1) return launch_quad_variant<false, 1>(a, stream);
     if (a.variant == 2) return launch_quad_variant<false, 2>(a, stream);
     if (a.variant == 3) return launch_quad_variant<false, 3>(a, stream);
 #endif
     return launch_quad_variant<false, 0>(a, stream);
-}
-
-template <int QPW, bool DIAG>
-static hipError_t launch_quad1_variant(const Quad1Args &a, hipStream_t stream) {
-    static LdsFlags attr_set = {};
-    constexpr int lds_bytes = 2 * kFastLdsBytes + kFastSideBytes;
-    if (hipError_t e = allow_lds((const void *) das_quad1_kernel<QPW, DIAG>, lds_bytes, attr_set); e != hipSuccess) return e;
-    dim3 grid(a.batch, quad1_tiles(a.rows, a.cols, QPW));
-    if (grid.y > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((das_quad1_kernel<QPW, DIAG>), grid, dim3(1024), lds_bytes, stream, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_das_quads1(const Quad1Args &a, int qpw, hipStream_t stream) {
-    if (a.debug & 16) return qpw == 2 ? launch_quad1_variant<2, true>(a, stream) : launch_quad1_variant<1, true>(a, stream);
-    return qpw == 2 ? launch_quad1_variant<2, false>(a, stream) : launch_quad1_variant<1, false>(a, stream);
 }
 
 int fast_image_bytes(int nw) { return nw == 24 ? kFastLdsBytesSmall : kFastLdsBytes; }
@@ -2239,7 +1924,9 @@ static hipError_t launch_quadh_variant(const QuadhArgs &a, hipStream_t stream) {
 }
 
 hipError_t launch_das_quadh(const QuadhArgs &a, int qpw, hipStream_t stream) {
+#ifdef AWPU_TUNING_BUILD
     if (a.debug & 16) return qpw == 2 ? launch_quadh_variant<2, true>(a, stream) : launch_quadh_variant<1, true>(a, stream);
+#endif
     return qpw == 2 ? launch_quadh_variant<2, false>(a, stream) : launch_quadh_variant<1, false>(a, stream);
 }
 
@@ -2255,11 +1942,14 @@ hipError_t launch_pack_halves(const float *d_frames, int n_streams, int pitch, i
 
 hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream) {
     if (nw == 32) {  // double-buffered, one 16-wave workgroup per CU
+#ifdef AWPU_TUNING_BUILD
         if (a.debug & 16) return ppw == 4 ? launch_db<16, 4, kFastLdsBytes, 4, true>(a, stream)
                                           : launch_db<16, 8, kFastLdsBytes, 4, true>(a, stream);
+#endif
         if (ppw == 4) return launch_db<16, 4, kFastLdsBytes, 4, false>(a, stream);
         return launch_db<16, 8, kFastLdsBytes, 4, false>(a, stream);
     }
+#ifdef AWPU_TUNING_BUILD  // shapes only AWPU_FAST_VARIANT reaches (measured and not taken: DESIGN.md 8)
     if (nw == 24) {  // double-buffered, two 12-wave workgroups per CU, 6 waves per SIMD
         if (a.debug & 16) return launch_db<12, 4, kFastLdsBytesSmall, 6, true>(a, stream);
         return launch_db<12, 4, kFastLdsBytesSmall, 6, false>(a, stream);
@@ -2268,9 +1958,11 @@ hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStrea
         if (ppw == 2) return launch_variant<8, 2, 2, 4>(a, stream);
         return launch_variant<8, 4, 2, 4>(a, stream);
     }
+    if (ppw == 8) return launch_variant<8, 8, 1, 4>(a, stream);
+#endif
+    if (fpi != 1 || nw != 8 || (ppw != 2 && ppw != 4)) return hipErrorInvalidValue;
     if (ppw == 2) return launch_variant<8, 2, 1, 4>(a, stream);
-    if (ppw == 4) return launch_variant<8, 4, 1, 4>(a, stream);
-    return launch_variant<8, 8, 1, 4>(a, stream);
+    return launch_variant<8, 4, 1, 4>(a, stream);
 }
 
 }  // namespace awpu

@@ -15,6 +15,9 @@ constexpr int kSamples = 256;  // N_SAMPLES, src/fpga/streams.hpp:28
 // variable cannot reach them (awpu_hip.cpp masks it to kDebugSafeBits).
 constexpr int kDebugNoRefill = 1, kDebugNoSweep = 2, kDebugNoTail = 4, kDebugNoBarrier = 8, kDebugRegStaging = 64;
 constexpr int kDebugSafeBits = 16 | 256 | 512 | 4096;  // stamps, dispatch order, refill by rank, unshared block: same results
+#if defined(AWPU_TIMING_BUILD) && !defined(AWPU_TUNING_BUILD)
+#define AWPU_TUNING_BUILD 1  // the timing experiments need the tuning knobs and the stamped kernels
+#endif
 #ifdef AWPU_TIMING_BUILD
 #define AWPU_DBG(a, bit) ((a).debug & (bit))
 #else
@@ -115,10 +118,7 @@ struct ExactPairArgs {
     int32_t cols;          // > 0: the grid's row length; a wave then sweeps vertical pixel pairs (pixel_count % cols == 0)
 };
 hipError_t launch_das_exact_pairs(const ExactPairArgs &a, hipStream_t stream);
-// FIR8 on the frame-pair layout (batches): d_entries [pixel_count][usable_pad] x {u32 LDS address, i32 coefficient row},
-// addresses as in the pair shape's plan (pair_plan on a window that reaches off + 262); d_coeffs [101][8]
-hipError_t launch_das_fir8_pairs(const PairArgs &a, const void *d_entries, const float *d_coeffs, hipStream_t stream);
-// The same on the four-plane layout (a lane owns four consecutive outputs: 11 LDS reads per 32 FMAs).  Rows packed by
+// FIR8 on the four-plane frame-pair layout (a lane owns four consecutive outputs: 11 LDS reads per 32 FMAs).  Rows packed by
 // launch_pack_planes, `wr` a multiple of 4 (fir8_plane_plan); d_entries [pixel_count][usable_pad] + 4 spare dwords,
 // one per (pixel, mic): fir8_plane_word(LDS byte offset of X[off] in its chunk's image, its plane, coefficient row);
 // the entries that pad a row to usable_pad carry coefficient row kFir8ZeroRow and row 0's address.  d_coeffs: the
@@ -160,21 +160,8 @@ inline int quad_tiles(int rows, int cols) { return ((rows + 3) / 4) * ((cols + 1
 inline int quad_count(int rows, int cols) { return ((rows + 3) / 4) * ((cols + 15) / 16) * 16; }  // table quads incl. padding columns
 hipError_t launch_das_quads(const QuadArgs &a, hipStream_t stream);
 
-// the same arithmetic for single frames (das_quad1_kernel): the staging of the single-frame shapes (parity copies,
-// rows fetched in place from the frame), each image closed by a zero row that padding mics point at
-constexpr int kQuad1ZeroBytes = 1152;  // >= 64 lanes x 8 B + 512 + 8 (the widest read of a row), whole 128-byte lines
-struct Quad1Args {
-    const float *frames;      // [batch][n_streams][hist]
-    const QuadEntry *lut;     // [quads][usable_pad / 4][4 pixels][4 mics], this layout's LDS addresses
-    const int32_t *row_off;   // [2 * usable_pad + spare] float offset of staged row 2 s + q in a frame
-    float *power;             // [batch][pixel_count]
-    int32_t n_streams, hist, usable, usable_pad, pixel_count, wr, chunk, batch;
-    int32_t cols, rows;
-    unsigned long long *debug_out;
-    int32_t debug;
-};
+// tiles of the single-frame quad kernel (das_quadh_kernel): 4 rows x 16 qpw columns
 inline int quad1_tiles(int rows, int cols, int qpw) { return ((rows + 3) / 4) * ((cols + 16 * qpw - 1) / (16 * qpw)); }
-hipError_t launch_das_quads1(const Quad1Args &a, int qpw, hipStream_t stream);
 
 // ---- single frames on the halves layout (das_quadh_kernel): the two halves of the 256-sample block in the two packed
 // lanes, pre-filtered; rows packed by launch_pack_halves, table = the quad-major table with this layout's addresses

@@ -838,7 +838,7 @@ xyz = S.geometry(spec)
 off, frac = S.delay_table(spec, xyz)
 frames = S.make_frames(xyz, 6, seed=21)
 import os
-EXACT = os.environ.get("AWPU_FAST_QUADS") == "0"
+EXACT = os.environ.get("AWPU_SHAPE") == "noquad"
 def run(devices, batch, **kw):
     with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=8, grid_columns=spec.res, devices=devices, **kw) as eng:
         eng.set_delay_table(off, frac); eng.set_active_mics(None)
@@ -866,7 +866,7 @@ for batch in (1, 6):
         grp = run(devices, batch)
         for name, a, b in zip(("host", "device", "ring", "snapshot"), one[:4], grp[:4]):
             # the same bits where the slabs run the kernel shapes the whole grid runs (the shapes of round 1 do not
-            # depend on the slab: AWPU_FAST_QUADS=0); a small slab may pick another shape than the whole grid, and
+            # depend on the slab: AWPU_SHAPE=noquad); a small slab may pick another shape than the whole grid, and
             # the quad shapes differ from the others by rounding
             if EXACT or name == "snapshot":
                 assert np.array_equal(a, b), (name, devices, batch)
@@ -894,12 +894,12 @@ print("GROUP OK")
 """
 
 
-@pytest.mark.parametrize("force_copy,quads", [("0", "0"), ("1", "0"), ("2", "0"), ("0", ""), ("1", ""), ("2", "")])
+@pytest.mark.parametrize("force_copy,quads", [("0", "noquad"), ("1", "noquad"), ("2", "noquad"), ("0", ""), ("1", ""), ("2", "")])
 def test_device_group_equals_one_device(force_copy, quads):
     """awpu_hip_cfg.n_devices > 1 (the multi-GPU split under the C ABI): a handle that spreads the grid's rows over
     two / three engines -- here all on the one GPU of the box, the same code path with devices[k] equal -- gives
     the bits of the single-device handle through the host entry, the device-pointer entry (three calls back to
-    back) and the ingest ring, for one frame and for a batch (quads="0": with the kernel shapes that do not depend
+    back) and the ingest ring, for one frame and for a batch (quads="noquad": with the kernel shapes that do not depend
     on the slab; otherwise to rounding, a small slab may run another shape than the whole grid).  force_copy=1 makes
     every part take the copy path of the fan-out (2-D window copies, two buffers per part, events between the copy
     and the sweep streams) that a part on another GPU takes; force_copy=2 the path of a node WITHOUT peer access: the
@@ -908,7 +908,7 @@ def test_device_group_equals_one_device(force_copy, quads):
     import os, subprocess, sys
     env = dict(os.environ, AWPU_GROUP_FORCE_COPY=force_copy)
     if quads:
-        env["AWPU_FAST_QUADS"] = quads
+        env["AWPU_SHAPE"] = quads
     out = subprocess.run([sys.executable, "-c", GROUP_CHILD, str(Path(__file__).resolve().parent.parent)],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "GROUP OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

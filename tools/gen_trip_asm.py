@@ -1558,8 +1558,9 @@ def main():
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))
     out.append(block_quad("sweep_quad_item", dma=True, chain=CHAIN, item=True))  # the production batch kernel: one block per item
     out.append(block_quad("sweep_quad_sum_stamped", stamp=True, chain=CHAIN))
-    for q, base in enumerate(QUAD1_ACC):  # single-frame layout, first / second quad of a wave
-        out.append(block_quad_ar(f"sweep_quad1_sum_{'ab'[q]}", nk=2, acc=base, tmp=QUAD1_TMP))
+    # single frames on the halves layout (das_quadh_kernel): the first quad of a wave through the block that also issues the
+    # refill (sweep_quad1_sum_a_dma, below), the second quad through this one
+    out.append(block_quad_ar("sweep_quad1_sum_b", nk=2, acc=QUAD1_ACC[1], tmp=QUAD1_TMP))
     out.append(block_quad_ar("sweep_quad1_sum_a_stamped", stamp=True, nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP))
     out.append(block_quad_ar("sweep_quad1_sum_a_dma", nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP, dma=True))  # das_quadh_kernel
     if os.environ.get("QUAD1_EARLY_X"):  # tuning builds: conditional reads at the head of the stage (measured: 79 vs 71 us)
@@ -1578,8 +1579,10 @@ def main():
     lo = 80 - (4 * (DEPTH + 1) + 1) - 3  # shapes with an 80-VGPR budget (6 waves per SIMD)
     out.append(block("sweep_quad_lo", 4, lo))
     out.append(block("sweep_quad_lo_stamped", 4, lo, stamp=True))
-    path = Path(__file__).resolve().parent.parent / "beamforming-lk_amd" / "csrc" / "das_fast_trip.inc"
-    path.write_text("\n".join(out))
+    path = Path(os.environ.get("TRIP_INC_OUT") or Path(__file__).resolve().parent.parent / "beamforming-lk_amd" / "csrc" / "das_fast_trip.inc")
+    tmp = path.with_suffix(f".inc.tmp{os.getpid()}")
+    tmp.write_text("\n".join(out))
+    os.replace(tmp, path)  # (several ranks may build at once: never a half-written include)
     print("wrote", path, sum(1 for _ in path.read_text().splitlines()), "lines")
 
 

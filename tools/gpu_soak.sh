@@ -14,20 +14,24 @@ run() {  # run <label> <seed> <cases> ENV=VAL...
   fi
 }
 for seed in ${SEEDS:-11 12 13}; do
-  run pairs $seed 20 AWPU_FAST_PAIRS=1
-  run quads_random $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1
-  run quads_coincide $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
-  run stationary $seed 20 AWPU_FAST_STATIONARY=1 AWPU_FAST_PAIRS=1
-  run stationary_grid $seed 20 AWPU_FAST_STATIONARY=1 AWPU_FAST_PAIRS=1 AWPU_TEST_GRID=1 AWPU_FAST_QUADS=0 AWPU_TEST_COINCIDE=1
-  run quadh_every_call $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1 AWPU_FAST_PAIRS=0
-  run quad1_in_place $seed 20 AWPU_FAST_QUADS=1 AWPU_TEST_GRID=1 AWPU_FAST_PAIRS=0 AWPU_FAST_HALVES=0 AWPU_TEST_COINCIDE=1
-  run fir8_planes $seed 20 AWPU_TEST_INTERP=fir8 AWPU_FIR8_PLANES=2
-  run fir8_planes_grid $seed 20 AWPU_TEST_INTERP=fir8 AWPU_FIR8_PLANES=2 AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
+  run pairs $seed 20 AWPU_SHAPE=pair
+  run pairs_grid $seed 20 AWPU_SHAPE=pair_vertical AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
+  run quads_random $seed 20 AWPU_SHAPE=quad AWPU_TEST_GRID=1
+  run quads_coincide $seed 20 AWPU_SHAPE=quad AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
+  run stationary $seed 20 AWPU_SHAPE=stationary
+  run stationary_grid $seed 20 AWPU_SHAPE=stationary AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
+  run quadh_every_call $seed 20 AWPU_SHAPE=quadh AWPU_TEST_GRID=1
+  run single_db $seed 12 AWPU_SHAPE=single_db
+  run single_small $seed 12 AWPU_SHAPE=single_small
+  run fir8_planes $seed 20 AWPU_TEST_INTERP=fir8 AWPU_SHAPE=fir8_planes
+  run fir8_planes_grid $seed 20 AWPU_TEST_INTERP=fir8 AWPU_SHAPE=fir8_planes AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
   run fir8 $seed 12 AWPU_TEST_INTERP=fir8
   run default_grid $seed 20 AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
   run default $seed 20 X=1
   run device $seed 12 AWPU_TEST_PATH=device
   run reuse $seed 10 AWPU_TEST_REUSE=1
-  run exact $seed 10 AWPU_TEST_MATH=exact
+  run exact $seed 20 AWPU_TEST_MATH=exact
+  run exact_grid $seed 20 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
+  run exact_verify $seed 8 AWPU_TEST_MATH=exact AWPU_SHAPE=exact_verify
 done
 exit $fail
