@@ -1005,7 +1005,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     // the double-buffered shapes read whole 16-byte pieces of every staged row
     if (nw != 8 && (rc != AWPU_OK || !awpu::fast_db_fits(lut->plan) || wstart_eff + 1 + lut->plan.wr > hist_eff)) {
         nw = 8;
-        if (ppw > 4 && fpi == 2) ppw = 4;
+        if (ppw > 4) ppw = 4;  // (the 8-wave shape is built for 2 and 4 pixels per wave)
         rc = build_fast_lut(h, fpi, awpu::fast_image_bytes(nw), &lut);
     }
     if (rc != AWPU_OK) return rc;
