@@ -69,6 +69,9 @@ class AwpuError(RuntimeError):
 
 
 PEER_SAME_DEVICE, PEER_DIRECT, PEER_HOST_STAGED = 0, 1, 2
+# awpu_kernel_id (include/awpu_hip.h): Stats.kernel_variant after a launch
+KERNEL_NAMES = ("none", "quad", "pair", "pair_stationary", "quadh", "quadh_stationary", "single_db", "single_small", "fir8_planes",
+                "fir8", "exact_pair", "exact_verify", "tuning")
 
 _lib: Optional[C.CDLL] = None
 

@@ -86,11 +86,13 @@ struct awpu_hip {
     float *sums_out = nullptr;    // awpu_hip_process_device_sums: where the launch in progress exports out[] (else null)
     awpu::QuadEntry *d_quad_lut = nullptr;  // quad-major table of the quad shape (das_quad_kernel)
     awpu::QuadEntry *d_quadh_lut = nullptr; // the same with the halves layout's LDS addresses (das_quadh_kernel)
+    awpu::QuadEntry *d_quadhs_lut = nullptr; // the same with slot = mic (das_quadh_stationary_kernel: every mic's row resident)
     void *d_fir_plane_lut = nullptr;           // FIR8 on the four-plane layout: one dword per (pixel, mic): address, plane, coefficient row
     awpu::FastPlan fir_plane_plan{};
     std::vector<float> fir;                    // host copy of the [101][8] coefficient table (baked into the plane entries)
-    awpu::FastPlan quad_plan{}, quadh_plan{};
+    awpu::FastPlan quad_plan{}, quadh_plan{}, quadhs_plan{};
     bool quadh_fits = false;      // single frames on the halves layout (das_quadh_kernel)
+    bool quadhs_fits = false;     // ... with every active mic's row in LDS at once (das_quadh_stationary_kernel: one 8x8 array does)
     bool quad_ok = false;         // the table's statistics favour the quad shape (decided in prepare)
     double quad_cost = 0.0;       // its expected packed VALU instructions per quad and mic (32 = no sharing at all)
     int32_t *d_index = nullptr;
@@ -189,7 +191,7 @@ int ensure_diag(awpu_hip *h, size_t words) {
 // What the process environment can change.  The SHIPPING library reads three variables, none of them needed in production:
 //   AWPU_SHAPE             force one of the production sweep shapes wherever it can serve the call (tests sweep every shape
 //                          through the oracle this way; the default rule -- launch() below -- picks by table statistics and launch size):
-//                          pair | pair_vertical | pair_horizontal | quad | noquad | stationary | quadh | single_db | single_small |
+//                          pair | pair_vertical | pair_horizontal | quad | noquad | stationary | quadh | quadh_chunked | single_db | single_small |
 //                          fir8_planes | exact_verify
 //   AWPU_LIVE_GRAPH=0      awpu_hip_live_block always enqueues its steps one by one (no HIP-graph replay)
 //   AWPU_GROUP_FORCE_COPY  device groups: 1 = a part on devices[0] takes the window-copy path too, 2 = through pinned host
@@ -226,6 +228,7 @@ struct EnvKnobs {
             else if (shape == "noquad") quads = 0;
             else if (shape == "stationary") pairs = 1, quads = 0, stationary = 1;
             else if (shape == "quadh") quads = 1, pairs = 0, halves = 1;
+            else if (shape == "quadh_chunked") quads = 1, pairs = 0, halves = 1, stationary = 0;  // never the resident-window variant
             else if (shape == "single_db") pairs = 0, quads = 0, fpi = 1, ppw = 8, nw = 32;
             else if (shape == "single_small") pairs = 0, quads = 0, fpi = 1, ppw = 2, nw = 8;
             else if (shape == "fir8_planes") fir_planes = 2;
@@ -287,6 +290,7 @@ void release_device(awpu_hip *h) {
     dev_free(h->d_exact_pair_lut);
     dev_free(h->d_quad_lut);
     dev_free(h->d_quadh_lut);
+    dev_free(h->d_quadhs_lut);
     dev_free(h->d_fir_plane_lut);
     dev_free(h->d_index);
     dev_free(h->d_gain);
@@ -355,6 +359,7 @@ int prepare(awpu_hip *h) {
     dev_free(h->d_exact_pair_lut);
     dev_free(h->d_quad_lut);
     dev_free(h->d_quadh_lut);
+    dev_free(h->d_quadhs_lut);
     dev_free(h->d_fir_plane_lut);
     AWPU_HIP_TRY(hipMalloc(&h->d_index, (size_t) U * sizeof(int32_t)));
     AWPU_HIP_TRY(hipMemcpy(h->d_index, h->index.data(), (size_t) U * sizeof(int32_t),
@@ -459,6 +464,7 @@ int prepare(awpu_hip *h) {
     // 4 % faster than the pair shape, 29.4 -- c3 -- 8 %, 25.3 -- the headline -- 20 %; AWPU_FAST_QUADS=0/1 forces either).
     h->quad_ok = false;
     h->quadh_fits = false;
+    h->quadhs_fits = false;
     h->quad_cost = 0.0;
     {
         const int cols = c.grid_columns;
@@ -484,6 +490,7 @@ int prepare(awpu_hip *h) {
             if (env().quads >= 0) h->quad_ok = env().quads != 0 && awpu::pair_plan(h->window, U, &h->quad_plan);
             // the halves layout: a row holds the window less 128 samples, as (sample, sample + 128) pairs (its pack pass applies the gains)
             h->quadh_fits = h->quad_ok && awpu::pair_plan(h->window - 128, U, &h->quadh_plan);
+            h->quadhs_fits = h->quadh_fits && awpu::quadh_stationary_plan(h->window, U, &h->quadhs_plan);
         }
     }
 
@@ -493,7 +500,7 @@ int prepare(awpu_hip *h) {
     st.usable = U;
     st.alg_bytes_frame = 4ull * U * h->window + 8ull * P * U + 4ull * P;
     st.alg_flops_frame = 4ull * P * U * awpu::kSamples + 6ull * P * (awpu::kSamples - 2);
-    st.kernel_variant = c.math;
+    st.kernel_variant = AWPU_KERNEL_NONE;
     h->prepared = true;
     h->table_gen++;  // graphs of awpu_hip_live_block captured against the old tables are stale
     retire_live_graphs(h);
@@ -555,12 +562,12 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
 // address), quads = groups of four grid rows x columns padded to whole 16-column tiles.  Pixels past the grid
 // carry weight 0 and the address of the nearest pixel inside it (they then follow the shared path and add
 // nothing); padding mics (usable rounded up to 4) carry weight 0 and the address of their own, zero, row.
-enum QuadLayout { kQuadPairs = 0, kQuadHalves = 2 };
+enum QuadLayout { kQuadPairs = 0, kQuadHalves = 2, kQuadHalvesStationary = 3 };
 int build_quad_lut(awpu_hip *h, int layout) {
-    awpu::QuadEntry *&d_lut = layout == kQuadHalves ? h->d_quadh_lut : h->d_quad_lut;
+    awpu::QuadEntry *&d_lut = layout == kQuadHalves ? h->d_quadh_lut : (layout == kQuadHalvesStationary ? h->d_quadhs_lut : h->d_quad_lut);
     if (d_lut) return AWPU_OK;
     const auto &c = h->cfg;
-    const awpu::FastPlan &plan = layout == kQuadHalves ? h->quadh_plan : h->quad_plan;
+    const awpu::FastPlan &plan = layout == kQuadHalves ? h->quadh_plan : (layout == kQuadHalvesStationary ? h->quadhs_plan : h->quad_plan);
     const int U = h->usable(), cols = c.grid_columns, rows = c.pixel_count / cols;
     const int groups = plan.usable_pad / 4;
     const int cols_pad = (cols + 15) / 16 * 16, rows4 = (rows + 3) / 4;
@@ -636,7 +643,8 @@ enum FrameLayout { kFull = 0, kCompact = 1, kRing = 2 };
 enum PeerPath { kPeerSame = 0, kPeerDirect = 1, kPeerStaged = 2 };
 
 // a launch is over: close the timing bracket and count it (also on the diagnostic paths)
-int finish_launch(awpu_hip *h, int batch, hipStream_t s) {
+int finish_launch(awpu_hip *h, int batch, hipStream_t s, int kernel_id) {
+    h->stats.kernel_variant = kernel_id;
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_end, s));
     h->stats.launches += 1;
     h->stats.frames += (uint64_t) batch;
@@ -719,7 +727,7 @@ int launch_exact_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_p
     AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad,
                                          h->d_gain, pp.wr, batch, h->d_pack, false, s));  // raw samples: no stencil in front of the reference's order
     AWPU_HIP_TRY(awpu::launch_das_exact_pairs(a, s));
-    return finish_launch(h, batch, s);
+    return finish_launch(h, batch, s, AWPU_KERNEL_EXACT_PAIR);
 }
 
 int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
@@ -742,7 +750,7 @@ int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     } else {
         AWPU_HIP_TRY(awpu::launch_das_exact(a, h->cfg.math == AWPU_MATH_BF16_ACC, s));
     }
-    return finish_launch(h, batch, s);
+    return finish_launch(h, batch, s, h->cfg.interp == AWPU_INTERP_FIR8 ? AWPU_KERNEL_FIR8 : AWPU_KERNEL_EXACT_VERIFY);
 }
 
 // FIR8 on the four-plane frame-pair layout (das_fir8_plane_kernel): a lane owns four consecutive outputs
@@ -792,7 +800,7 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
     AWPU_HIP_TRY(awpu::launch_pack_planes(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, U, h->d_gain, pp.wr,
                                           batch, h->d_pack, s));
     AWPU_HIP_TRY(awpu::launch_das_fir8_planes(pa, h->d_fir_plane_lut, h->d_fir, env().quad_variant, s));
-    return finish_launch(h, batch, s);
+    return finish_launch(h, batch, s, AWPU_KERNEL_FIR8_PLANES);
 }
 
 // frame-pair shape: two frames per item, for batches on grids that fill the chip
@@ -832,7 +840,7 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
     } else {
         AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
     }
-    const int rc = finish_launch(h, batch, s);
+    const int rc = finish_launch(h, batch, s, stationary_tiles > 0 ? AWPU_KERNEL_PAIR_STATIONARY : AWPU_KERNEL_PAIR);
     if (rc != AWPU_OK || !(pa.debug & 16)) return rc;
     return dump_diag(h, n_waves, 16, "pairs", s);
 }
@@ -896,7 +904,7 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
         AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
                                              pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, true, s));
     AWPU_HIP_TRY(awpu::launch_das_quads(qa, s));
-    rc = finish_launch(h, batch, s);
+    rc = finish_launch(h, batch, s, AWPU_KERNEL_QUAD);
     if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
     return dump_diag(h, n_waves, 16, "quads", s);
 }
@@ -934,9 +942,43 @@ int launch_quadsh(awpu_hip *h, const float *d_frames, int batch, float *d_power,
     AWPU_HIP_TRY(awpu::launch_pack_halves(d_frames, h->cfg.n_streams, pitch, hist_eff, wstart_eff, h->d_index, h->usable(),
                                           pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, s));
     AWPU_HIP_TRY(awpu::launch_das_quadh(qa, qpw, s));
-    rc = finish_launch(h, batch, s);
+    rc = finish_launch(h, batch, s, AWPU_KERNEL_QUADH);
     if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
     return dump_diag(h, n_waves, 16, "quadsh", s);
+}
+
+// single frames of small arrays: every mic's halves row resident, the workgroup stages the window itself (das_quadh_stationary_kernel)
+int launch_quadsh_stationary(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int pitch, int hist_eff,
+                             int wstart_eff, int qpw) {
+    int rc = build_quad_lut(h, kQuadHalvesStationary);
+    if (rc != AWPU_OK) return rc;
+    const awpu::FastPlan &pp = h->quadhs_plan;
+    awpu::QuadhStationaryArgs qa{};
+    qa.frames = d_frames;
+    qa.lut = h->d_quadhs_lut;
+    qa.index = h->d_index;
+    qa.gain = h->d_gain;
+    qa.power = d_power;
+    qa.n_streams = h->cfg.n_streams;
+    qa.pitch = pitch;
+    qa.hist = hist_eff;
+    qa.wstart = wstart_eff;
+    qa.usable = h->usable();
+    qa.usable_pad = pp.usable_pad;
+    qa.pixel_count = h->cfg.pixel_count;
+    qa.wp = pp.wr;
+    qa.batch = batch;
+    qa.cols = h->cfg.grid_columns;
+    qa.rows = h->cfg.pixel_count / qa.cols;
+    qa.waves = 16;
+    qa.identity = 1;
+    for (int k = 0; k < qa.usable && qa.identity; k++) qa.identity = h->index[k] == k;
+    qa.row_limit = pitch;  // (the ring's rows are 2048 floats of which any 1024 + window are valid: double-written)
+    if (!awpu::quadh_stationary_raw(pp, qa.usable, wstart_eff, qa.row_limit, &qa.raw_begin, &qa.raw_wr, &qa.image_offset))
+        return invalid("the raw window does not fit the LDS beside the halves image");  // (launch() asks before it comes here)
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_das_quadh_stationary(qa, qpw, s));
+    return finish_launch(h, batch, s, AWPU_KERNEL_QUADH_STATIONARY);
 }
 
 int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int layout = kFull) {
@@ -988,6 +1030,16 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     }
     // ---- single frames on a grid whose table favours the quad shape (a forced single-frame shape goes past): the halves
     // layout behind a pack + filter pre-pass
+    if (h->quadhs_fits && env().fpi == 0 && env().halves != 0 && env().stationary != 0) {
+        // one 8x8 array (every mic's halves row fits the LDS): one launch, no pack pre-pass, no chunks.  A call this small is
+        // latency, not throughput: taken from 48 workgroups on (below that the 8-wave shapes spread a tiny grid over more CUs)
+        const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
+        const int qpw = (long) awpu::quad1_tiles(rows, cols, 2) * batch >= 256 ? 2 : 1;
+        int rb = 0, rw = 0, io = 0;
+        if (((long) awpu::quad1_tiles(rows, cols, qpw) * batch >= 48 || env().quads == 1 || env().halves == 1 || env().stationary == 1) &&
+            awpu::quadh_stationary_raw(h->quadhs_plan, h->usable(), wstart_eff, hist_eff, &rb, &rw, &io))
+            return launch_quadsh_stationary(h, d_frames, batch, d_power, s, hist_eff, layout == kRing ? AWPU_HIST : hist_eff, wstart_eff, qpw);
+    }
     if (h->quadh_fits && env().fpi == 0 && env().halves != 0) {
         const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
         const int qpw = (long) awpu::quad1_tiles(rows, cols, 2) * batch >= 256 ? 2 : 1;
@@ -1040,7 +1092,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, s));
-    rc = finish_launch(h, batch, s);
+    rc = finish_launch(h, batch, s, nw == 32 ? AWPU_KERNEL_SINGLE_DB : (nw == 8 && fpi == 1 && ppw <= 4 ? AWPU_KERNEL_SINGLE_SMALL : AWPU_KERNEL_TUNING));
     if (rc != AWPU_OK || !a.debug_out) return rc;
     return dump_diag(h, n_waves, wg_waves, "single", s);
 }

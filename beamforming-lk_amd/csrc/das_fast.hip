@@ -1492,6 +1492,40 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
 // The block (always-read schedule), the quad-major table and the tile geometry are das_quad1_kernel's; the table
 // carries this layout's LDS addresses (slot x row bytes + (off - wstart) x 8).  grid = (frames, tiles).
 // ---------------------------------------------------------------------------------------
+// Epilogue of the halves-layout kernels: the un-skewed sums ARE the moving average (pre-filtered samples): MA[i] = P[i] +
+// G[i+1], i = 1..254, with P = sum f Y = S/2 + A, G = sum (1 - f) Y = S/2 - A (A was accumulated with f - 1/2).  Sample
+// order of a lane's four values: pair 0 low (l), pair 1 low (64 + l), pair 0 high (128 + l), pair 1 high (192 + l).
+// Returns sum MA^2 over the wave (every lane).
+__device__ __forceinline__ float quadh_pixel_power(const f4 &A, const f4 &S, int lane) {
+    const float Av[4] = {A[0], A[2], A[1], A[3]}, Sv[4] = {S[0], S[2], S[1], S[3]};  // in sample order
+    float P[4], G[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        P[r] = __builtin_fmaf(0.5f, Sv[r], Av[r]);
+        G[r] = __builtin_fmaf(0.5f, Sv[r], -Av[r]);
+    }
+    float sum = 0.0f;
+    float rq = wave_rotate1<kDppWaveRol1>(G[0]);  // G_r one lane down; lane 63 holds G_r[0]
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float rq_next = r < 3 ? wave_rotate1<kDppWaveRol1>(G[r < 3 ? r + 1 : 3]) : rq;
+        const float ma = P[r] + (lane == 63 ? rq_next : rq);  // MA[l + 64 r]
+        const int i = lane + 64 * r;
+        if (i >= 1 && i <= kSamples - 2) sum = __builtin_fmaf(ma, ma, sum);
+        rq = rq_next;
+    }
+    return wave_sum(sum);
+}
+
+// The filtered sample pack_halves_kernel and das_quadh_stationary_kernel stage: Y[i] = X[i]/2 - (X[i+1] + X[i-1])/4 with the
+// gain on every sample first; neighbours outside the history count as 0 (values that would need them are never used:
+// pack_one_row).  One expression for both, so that the two paths stage the same bits.
+__device__ __forceinline__ float filtered_sample(const float *x, int i, int hist, float gm) {
+    if (i < 0 || i >= hist) return 0.0f;
+    const float lo = i > 0 ? x[i - 1] * gm : 0.0f, hi = i + 1 < hist ? x[i + 1] * gm : 0.0f;
+    return __builtin_fmaf(-0.25f, lo + hi, 0.5f * (x[i] * gm));
+}
+
 __global__ void pack_halves_kernel(const float *frames, int n_streams, int pitch, int hist, int wstart, const int32_t *index,
                                    int usable, const float *gain, int wp, float *packed) {
     const int frame = blockIdx.y, s = blockIdx.x, rows_out = gridDim.x;
@@ -1502,12 +1536,8 @@ __global__ void pack_halves_kernel(const float *frames, int n_streams, int pitch
     }
     const float *x = frames + ((size_t) frame * n_streams + index[s]) * pitch;
     const float gm = gain ? gain[s] : 1.0f;
-    auto y = [&](int i) -> float {  // the filtered sample at history index i; neighbours outside the history count as 0
-        if (i < 0 || i >= hist) return 0.0f;  // (values that would need them are never used: pack_one_row)
-        const float lo = i > 0 ? x[i - 1] * gm : 0.0f, hi = i + 1 < hist ? x[i + 1] * gm : 0.0f;
-        return __builtin_fmaf(-0.25f, lo + hi, 0.5f * (x[i] * gm));
-    };
-    for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = f2{y(wstart + t), y(wstart + t + 128)};
+    for (int t = threadIdx.x; t < wp; t += blockDim.x)
+        dst[t] = f2{filtered_sample(x, wstart + t, hist, gm), filtered_sample(x, wstart + t + 128, hist, gm)};
 }
 
 template <int QPW, bool DIAG>
@@ -1610,30 +1640,113 @@ __global__ __launch_bounds__(1024, 4) void das_quadh_kernel(QuadhArgs a) {
         o[3] = (unsigned long long) n_chunks;
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
     }
-    // epilogue: the un-skewed sums ARE the moving average (pre-filtered samples): MA[i] = P[i] + G[i+1], i = 1..254, with
-    // P = sum f Y = S/2 + A, G = sum (1 - f) Y = S/2 - A (A was accumulated with f - 1/2).  Sample order of a lane's four
-    // values: pair 0 low (l), pair 1 low (64 + l), pair 0 high (128 + l), pair 1 high (192 + l).
     const float norm = (float) (kSamples * a.usable);
     auto finish = [&](const f4 &A, const f4 &S, int slot) {
         const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
-        const float Av[4] = {A[0], A[2], A[1], A[3]}, Sv[4] = {S[0], S[2], S[1], S[3]};  // in sample order
-        float P[4], G[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            P[r] = __builtin_fmaf(0.5f, Sv[r], Av[r]);
-            G[r] = __builtin_fmaf(0.5f, Sv[r], -Av[r]);
+        const float sum = quadh_pixel_power(A, S, lane);
+        if (lane == 0 && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = sum / norm;
+    };
+    finish(A0a, Ta + V0a, 0);
+    finish(A1a, Ta, 1);
+    finish(A2a, Ta + V2a, 2);
+    finish(A3a, Ta + V3a, 3);
+    if constexpr (QPW == 2) {
+        finish(A0b, Tb + V0b, 4);
+        finish(A1b, Tb, 5);
+        finish(A2b, Tb + V2b, 6);
+        finish(A3b, Tb + V3b, 7);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Single frames of SMALL arrays (round 4): when the halves rows of EVERY active mic fit the CU's LDS at once -- the
+// reference's own configuration does: one 8x8 array, 64 mics x 158 elements x 8 bytes = 79 KiB of the 156 KiB the two
+// images span -- there is nothing to chunk, and a call of one frame (MIMOWorker::update, once per 5.24 ms block,
+// src/dsp/worker.h:212-224) is all latency: das_quadh_kernel behind pack_halves_kernel is two launches, a DMA wait and two
+// chunks with a barrier each for 6 us of arithmetic.  Here a workgroup stages the window ITSELF -- the raw samples of every mic
+// by LDS-DMA straight from the caller's frame (or the ingest ring: `pitch`), then filtered from LDS into the halves image with
+// pack_halves_kernel's expression, so the image holds the same bits -- and sweeps all mics in one block per quad: one launch,
+// no refill.  LDS: [usable][raw_wr] floats raw + [usable_pad][wp] elements + a 4 KiB row table <= 156 KiB.
+// Table: the quad-major table with slot = mic (build_quad_lut, kQuadHalvesStationary).  grid = (frames, tiles).
+// ---------------------------------------------------------------------------------------
+constexpr int kQuadhsRowTableOffset = (2 * kFastLdsBytes - 4096) / 4;  // floats: the last 4 KiB hold the streams' row offsets
+template <int QPW>
+__global__ __launch_bounds__(1024, 4) void das_quadh_stationary_kernel(QuadhStationaryArgs a) {
+    static_assert(QPW == 1 || QPW == 2, "one or two quads per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // waves per workgroup = columns per tile: the host launches 16.  (Measured on the reference's 100 x 100 grid, us per frame:
+    // 16 waves / 175 workgroups 19.7, 14 / 200 20.4, 12 / 225 20.1, 10 / 250 -- every CU busy, 2.5 waves per SIMD -- 21.1,
+    // 8 / 325 -- two rounds -- 39.0: a workgroup's time hardly depends on its wave count, the call is a chain of latencies --
+    // launch, DMA, three barriers, 64 dependent mic stages -- so what counts is the staging work per wave.)
+    const int NW = (int) (blockDim.x >> 6), kThreads = (int) blockDim.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int frame = blockIdx.x, tile = blockIdx.y;
+    const int tile_cols = NW * QPW;
+    const int tiles_per_row4 = (a.cols + tile_cols - 1) / tile_cols;
+    const int cols_pad = (a.cols + 15) / 16 * 16;
+    const int row4 = tile / tiles_per_row4;
+    const int col0 = (tile - row4 * tiles_per_row4) * tile_cols + wave * QPW;
+    const int groups_total = a.usable_pad >> 2;
+
+    // ---- stage, phase A: the raw window of every active mic, [usable][raw_wr] floats from history sample raw_begin on, by
+    // LDS-DMA: one wave instruction moves 64 pieces of 16 bytes from 64 addresses into 1 KiB of LDS, nothing passes through
+    // registers and all of a wave's instructions are in flight together (a register-staged loop was latency, row after row)
+    const float *frame_base = a.frames + (size_t) frame * a.n_streams * a.pitch;
+    float *raw = lds;
+    f2 *image = (f2 *) (lds + a.image_offset);              // [usable_pad][wp] elements (Y[wstart + t], Y[wstart + t + 128])
+    int32_t *row_of = (int32_t *) (lds + kQuadhsRowTableOffset);  // float offset of stream index[s] in the frame
+    if (!a.identity) {  // (the default mic list 0..usable-1 needs no table: one global round trip and one barrier less)
+        for (int s = threadIdx.x; s < a.usable; s += kThreads) row_of[s] = a.index[s] * a.pitch;
+        __syncthreads();
+    }
+    const int ppr = a.raw_wr >> 2;  // 16-byte pieces per row
+    const int n_pieces = a.usable * ppr;
+    for (int p0 = __builtin_amdgcn_readfirstlane(wave * 64); p0 < n_pieces; p0 += kThreads) {  // (p0 stays wave-uniform)
+        const int p = p0 + lane;
+        if (p < n_pieces) {
+            const int s = p / ppr, col = a.raw_begin + 4 * (p - s * ppr);
+            if (col + 4 <= a.row_limit)  // (never past the stream's row: the last stream of the last frame ends the allocation)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (frame_base + (a.identity ? s * a.pitch : row_of[s]) + col),
+                                                 (__attribute__((address_space(3))) void *) (raw + (size_t) p0 * 4), 16, 0, 0);
         }
-        float sum = 0.0f;
-        float rq = wave_rotate1<kDppWaveRol1>(G[0]);  // G_r one lane down; lane 63 holds G_r[0]
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float rq_next = r < 3 ? wave_rotate1<kDppWaveRol1>(G[r < 3 ? r + 1 : 3]) : rq;
-            const float ma = P[r] + (lane == 63 ? rq_next : rq);  // MA[l + 64 r]
-            const int i = lane + 64 * r;
-            if (i >= 1 && i <= kSamples - 2) sum = __builtin_fmaf(ma, ma, sum);
-            rq = rq_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- phase B: filter on the way from the raw rows to the halves image: pack_halves_kernel's expression (the same bits);
+    // samples outside the history count as 0 (the values that would need them are never used)
+    for (int s = wave; s < a.usable_pad; s += NW) {
+        f2 *dst = image + (size_t) s * a.wp;
+        if (s < a.usable) {
+            const float *x = raw + (size_t) s * a.raw_wr - a.raw_begin;  // x[i] = history sample i of this mic
+            const float gm = a.gain ? a.gain[s] : 1.0f;
+            for (int t = lane; t < a.wp; t += 64)
+                dst[t] = f2{filtered_sample(x, a.wstart + t, a.hist, gm), filtered_sample(x, a.wstart + t + 128, a.hist, gm)};
+        } else {
+            for (int t = lane; t < a.wp; t += 64) dst[t] = f2{0.0f, 0.0f};  // padding mics: silence
         }
-        sum = wave_sum(sum);
+    }
+    __syncthreads();
+
+    f4 A0a = {0, 0, 0, 0}, A1a = A0a, A2a = A0a, A3a = A0a, Ta = A0a, V0a = A0a, V2a = A0a, V3a = A0a;
+    f4 A0b = A0a, A1b = A0a, A2b = A0a, A3b = A0a, Tb = A0a, V0b = A0a, V2b = A0a, V3b = A0a;
+    const int rank = wave >> 2;
+    const unsigned lane_addr = lds_base + a.image_offset * 4 + lane * 8;
+    const int ng = __builtin_amdgcn_readfirstlane(groups_total);
+    {
+        const void *row = uniform_ptr(a.lut + ((size_t) row4 * cols_pad + min(col0, cols_pad - 1)) * groups_total * 16);
+        sweep_quad1_sum_a(A0a, A1a, A2a, A3a, Ta, V0a, V2a, V3a, row, ng, lane_addr, rank);
+    }
+    if constexpr (QPW == 2) {
+        const void *row = uniform_ptr(a.lut + ((size_t) row4 * cols_pad + min(col0 + 1, cols_pad - 1)) * groups_total * 16);
+        sweep_quad1_sum_b(A0b, A1b, A2b, A3b, Tb, V0b, V2b, V3b, row, ng, lane_addr, rank);
+    }
+
+    const float norm = (float) (kSamples * a.usable);
+    auto finish = [&](const f4 &A, const f4 &S, int slot) {
+        const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
+        const float sum = quadh_pixel_power(A, S, lane);
         if (lane == 0 && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = sum / norm;
     };
     finish(A0a, Ta + V0a, 0);
@@ -1928,6 +2041,59 @@ hipError_t launch_das_quadh(const QuadhArgs &a, int qpw, hipStream_t stream) {
     if (a.debug & 16) return qpw == 2 ? launch_quadh_variant<2, true>(a, stream) : launch_quadh_variant<1, true>(a, stream);
 #endif
     return qpw == 2 ? launch_quadh_variant<2, false>(a, stream) : launch_quadh_variant<1, false>(a, stream);
+}
+
+bool quadh_stationary_plan(int window, int usable, FastPlan *plan) {
+    const int wp = (window - 128 + 1) & ~1;  // elements (sample t, sample t + 128) per row
+    if (wp < 130) return false;
+    const size_t row_bytes = (size_t) wp * 8;
+    const int usable_pad = (usable + 3) & ~3;
+    // the halves image + the raw rows it is filtered from (at most wp + 136 floats each) + the row table
+    if ((size_t) usable_pad * row_bytes + (size_t) usable * (wp + 130) * 4 > (size_t) kQuadhsRowTableOffset * 4) return false;
+    plan->fpi = 1;
+    plan->wr = wp;
+    plan->chunk = usable_pad;  // every mic has its own slot
+    plan->usable_pad = usable_pad;
+    plan->row_bytes = (int) row_bytes;
+    plan->image_bytes = -3;
+    return true;
+}
+
+// the raw rows a launch stages: history samples [raw_begin, raw_begin + raw_wr) of every active stream, whole 16-byte pieces;
+// false if they do not fit beside the image (the caller then takes das_quadh_kernel)
+bool quadh_stationary_raw(const FastPlan &plan, int usable, int wstart, int row_limit, int *raw_begin, int *raw_wr, int *image_offset) {
+    const int begin = std::max(0, wstart - 1) & ~3;
+    const int end = std::min(row_limit, (wstart + plan.wr + 128 + 1 + 3) & ~3);
+    if (end <= begin || ((end - begin) & 3)) return false;
+    const size_t raw_floats = (size_t) usable * (end - begin);
+    const size_t image_off = (raw_floats + 3) & ~(size_t) 3;
+    if (image_off * 4 + (size_t) plan.usable_pad * plan.row_bytes > (size_t) kQuadhsRowTableOffset * 4) return false;
+    if (usable > 1024) return false;  // (the row table)
+    *raw_begin = begin;
+    *raw_wr = end - begin;
+    *image_offset = (int) image_off;
+    return true;
+}
+
+template <int QPW>
+static hipError_t launch_quadh_stationary_variant(const QuadhStationaryArgs &a, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (hipError_t e = allow_lds((const void *) das_quadh_stationary_kernel<QPW>, lds_bytes, attr_set); e != hipSuccess) return e;
+    if ((size_t) a.image_offset * 4 + (size_t) a.usable_pad * a.wp * 8 > (size_t) kQuadhsRowTableOffset * 4 || (a.usable_pad & 3) ||
+        (a.raw_wr & 3) || (a.image_offset & 3) || (size_t) a.usable * a.raw_wr > (size_t) a.image_offset || a.usable > 1024 ||
+        a.raw_begin + a.raw_wr > a.row_limit)
+        return hipErrorInvalidValue;
+    if (a.waves < 4 || a.waves > 16) return hipErrorInvalidValue;
+    const int tile_cols = a.waves * QPW;
+    dim3 grid(a.batch, ((a.rows + 3) / 4) * ((a.cols + tile_cols - 1) / tile_cols));
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((das_quadh_stationary_kernel<QPW>), grid, dim3(a.waves * 64), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_das_quadh_stationary(const QuadhStationaryArgs &a, int qpw, hipStream_t stream) {
+    return qpw == 2 ? launch_quadh_stationary_variant<2>(a, stream) : launch_quadh_stationary_variant<1>(a, stream);
 }
 
 hipError_t launch_pack_halves(const float *d_frames, int n_streams, int pitch, int hist, int wstart, const int32_t *d_index, int usable,

@@ -176,6 +176,26 @@ struct QuadhArgs {
     int32_t debug;
 };
 hipError_t launch_das_quadh(const QuadhArgs &a, int qpw, hipStream_t stream);
+// the same for arrays small enough that every active mic's halves row fits the LDS at once (das_quadh_stationary_kernel): the
+// workgroup stages (and filters) the window itself from the caller's frame -- no pack pre-pass, no chunks
+struct QuadhStationaryArgs {
+    const float *frames;      // [batch][n_streams][pitch] (pitch = hist, or 2048 for a frame read in place from the ingest ring)
+    const QuadEntry *lut;     // quad-major table, slot = mic: address = s * wp * 8 + (off - wstart) * 8
+    const int32_t *index;     // [usable]
+    const float *gain;        // [usable] or null
+    float *power;             // [batch][pixel_count]
+    int32_t n_streams, pitch, hist, wstart;
+    int32_t usable, usable_pad, pixel_count, wp, batch;
+    int32_t cols, rows;
+    int32_t raw_begin, raw_wr;  // the raw rows staged by LDS-DMA: history samples [raw_begin, raw_begin + raw_wr), whole 16-byte pieces
+    int32_t row_limit;          // floats of a stream's row that may be read (never past the frame's allocation)
+    int32_t image_offset;       // floats from the start of the LDS to the halves image (after the raw rows)
+    int32_t waves;              // waves per workgroup = columns (x qpw) per tile: 16
+    int32_t identity;           // the active-mic list is 0 .. usable-1 (awpu_hip_set_active_mics(NULL)): rows need no look-up
+};
+bool quadh_stationary_plan(int window, int usable, FastPlan *plan);
+bool quadh_stationary_raw(const FastPlan &plan, int usable, int wstart, int row_limit, int *raw_begin, int *raw_wr, int *image_offset);
+hipError_t launch_das_quadh_stationary(const QuadhStationaryArgs &a, int qpw, hipStream_t stream);
 // `pitch` = floats between two streams of a frame (hist, or 2048 in the ingest ring), `hist` = samples of a stream's
 // history (neighbours of the filter outside it count as 0), wstart = first history sample of the window
 hipError_t launch_pack_halves(const float *d_frames, int n_streams, int pitch, int hist, int wstart, const int32_t *d_index, int usable,

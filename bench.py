@@ -671,7 +671,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "das sweep", "kernel_ms": kernel_ms, "kernel_ms_min": float(np.min(step_kernel_ms)),
+                "kernel": "das sweep: " + pkg.binding.KERNEL_NAMES[st.kernel_variant], "kernel_ms": kernel_ms, "kernel_ms_min": float(np.min(step_kernel_ms)),
                 "kernel_ms_median": float(np.median(step_kernel_ms)), "launch_bytes": launch_bytes,
                 "note": "HBM is the bound the metric names; the sweep itself is fp32-VALU bound (126 flop/B >> the "
                         "chip's ridge), its fraction of that peak is in \"valu\"",
@@ -715,6 +715,7 @@ def main():
         parity1 = full_grid_parity(d_p1[0].cpu().numpy(), host_first[0], off, frac)
         out["single_frame"] = {
             "value": n1 / wall1, "unit": "frames/s", "calls": n1, "ms_per_frame_device": ms1,
+            "kernel": pkg.binding.KERNEL_NAMES[eng1.stats().kernel_variant],
             "valu_frac": int(st.alg_flops_frame) / (ms1 * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
             "hbm_frac": int(st.alg_bytes_frame) / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "parity_max_rel_err": parity1["max_rel_unfloored"], "parity": parity1,
@@ -859,12 +860,13 @@ def reference_default(pkg, torch, args, dev, local_rank):
         for _ in range(20):
             eng.process(frames[:1])
         host_call_ms = (time.perf_counter() - t0) / 20 * 1e3
+        kernel_name = pkg.binding.KERNEL_NAMES[eng.stats().kernel_variant]
     ms = ev[0].elapsed_time(ev[1]) / n
     par = full_grid_parity(d_p[0].cpu().numpy(), frames[0], off, frac)
     block_ms = 256 / 48828.0 * 1e3
     out = {
         "workload": spec.name + ", one frame per call (src/main.cpp:38-41,53-56; aw_processing_unit.cpp:74)",
-        "ms_per_frame_device": ms, "value": 1e3 / ms, "unit": "frames/s",
+        "ms_per_frame_device": ms, "value": 1e3 / ms, "unit": "frames/s", "kernel": kernel_name,
         "ms_per_host_call": host_call_ms,
         "realtime_block_ms": block_ms, "fraction_of_realtime_budget": host_call_ms / block_ms,
         "parity_max_rel_unfloored": par["max_rel_unfloored"], "parity_ok": par["ok"], "pixels_checked": par["pixels"],
@@ -906,6 +908,7 @@ def other_workloads(pkg, sharding, torch, dist, args, dev, local_rank):
                          if c5 else spec.name + (", 8-tap FIR variant of delay() (--interp fir8)" if fir else "") +
                          (", AWPU_MATH_F32_EXACT: the reference's operation and mic order (--math exact; das_exact_pair_kernel)" if exact else "")),
             "frames_per_step": batch, "steps": K, "warmup": W, "value": batch * K / elapsed, "unit": "frames/s",
+            "kernel": pkg.binding.KERNEL_NAMES[st.kernel_variant],
             "kernel_ms": kernel_ms, "valu_frac": flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
             "hbm_frac": int(st.alg_bytes_frame) * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "parity_max_rel_unfloored": par["max_rel_unfloored"], "parity_bound": par["bound"], "parity_ok": par["ok"],

@@ -72,6 +72,24 @@ typedef enum {
     AWPU_MATH_BF16_ACC = 2
 } awpu_math;
 
+/* which sweep kernel a launch ran (awpu_hip_stats.kernel_variant): the dispatcher picks by math mode, batch, grid and
+ * table statistics */
+typedef enum {
+    AWPU_KERNEL_NONE = 0,
+    AWPU_KERNEL_QUAD = 1,             /* das_quad_kernel: batches, four vertically adjacent pixels share their integer-delay sum */
+    AWPU_KERNEL_PAIR = 2,             /* das_pair_kernel: batches, pixel pairs share sample reads */
+    AWPU_KERNEL_PAIR_STATIONARY = 3,  /* das_pair_stationary_kernel: batches of small arrays, every mic's window resident */
+    AWPU_KERNEL_QUADH = 4,            /* das_quadh_kernel behind pack_halves_kernel: single frames */
+    AWPU_KERNEL_QUADH_STATIONARY = 5, /* das_quadh_stationary_kernel: single frames of small arrays (the reference's own shape) */
+    AWPU_KERNEL_SINGLE_DB = 6,        /* das_fast_db_kernel: single frames without a row length */
+    AWPU_KERNEL_SINGLE_SMALL = 7,     /* das_fast_kernel: small grids */
+    AWPU_KERNEL_FIR8_PLANES = 8,      /* das_fir8_plane_kernel */
+    AWPU_KERNEL_FIR8 = 9,             /* das_fir8_kernel: FIR8 on small launches, or in the reference's tap order (exact math) */
+    AWPU_KERNEL_EXACT_PAIR = 10,      /* das_exact_pair_kernel: the reference's operation order on the frame-pair layout */
+    AWPU_KERNEL_EXACT_VERIFY = 11,    /* das_exact_kernel: round-1 verification structure (bf16 accumulator mode, fallback) */
+    AWPU_KERNEL_TUNING = 12           /* a shape only -DAWPU_TUNING_BUILD builds dispatch to */
+} awpu_kernel_id;
+
 typedef struct awpu_hip awpu_hip_t;
 
 typedef struct {
@@ -124,7 +142,7 @@ typedef struct {
     int32_t tau_max;          /* largest integer delay in the table = 256 - min(off) */
     int32_t window;           /* W */
     int32_t usable;           /* U */
-    int32_t kernel_variant;   /* which sweep kernel the handle dispatches to */
+    int32_t kernel_variant;   /* awpu_kernel_id of the sweep kernel the LAST launch ran (AWPU_KERNEL_NONE before the first) */
 } awpu_hip_stats;
 
 /* fills cfg with the reference defaults (64 streams, hist 1024, LERP, F32_FAST, batch 1) */

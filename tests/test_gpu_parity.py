@@ -666,6 +666,53 @@ def test_single_frames_on_the_headline_grid(pkg, oracle):
     check_full_grid(oracle, batched[0], ring, off, frac, "headline pair of frames (quad shape)")
 
 
+def test_reference_default_single_frames_run_the_resident_window_kernel(pkg, oracle):
+    """The configuration the reference ships and runs live -- ONE 8x8 array, --mimo-res 100, one frame per
+    MIMOWorker::update (src/main.cpp:38-41, worker.h:212-224): every mic's halves row fits the LDS at once, so the
+    call runs das_quadh_stationary_kernel (the workgroup stages and filters the window itself: one launch, no pack
+    pre-pass, no chunks).  Every pixel against the oracle, unfloored, for: a host frame, the same frame from the
+    ingest ring (same kernel, other pitch: the same bits), a ragged mic list (51 of 64: padding mics), per-mic gains,
+    a grid whose rows are no multiple of four and columns no multiple of 16 (90 x 70), and a call of two frames."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["ref_default"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    names = pkg.binding.KERNEL_NAMES
+    rng = np.random.default_rng(4)
+    ring = np.zeros((64, 1024), np.float32)
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=64, max_batch=2, grid_columns=spec.res) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        for b in range(5):  # five blocks of 24-bit noise: the ring wraps once
+            stream = rng.integers(-(1 << 21), 1 << 21, size=(256, 256), dtype=np.int32)
+            eng.ingest_block(make_datagrams(stream, counter0=256 * b, n_arrays=1))
+            ring = np.concatenate([ring[:, 256:], oracle.unpack_exposure(stream, 64)], axis=1)
+        from_ring = eng.process_ring()
+        assert names[eng.stats().kernel_variant] == "quadh_stationary"
+        from_host = eng.process(ring)
+        assert names[eng.stats().kernel_variant] == "quadh_stationary"
+        assert np.array_equal(from_ring, from_host)
+        check_full_grid(oracle, from_host, ring, off, frac, "reference default, one frame (resident-window kernel)")
+        two = eng.process(np.stack([ring, 0.5 * ring]))
+        check_full_grid(oracle, two[0], ring, off, frac, "reference default, first of two frames")
+        assert util.power_rel_err_unfloored(two[1], 0.25 * two[0]) < 1e-6
+        keep = np.sort(rng.choice(64, size=51, replace=False)).astype(np.int32)
+        gains = rng.uniform(0.5, 2.0, 64).astype(np.float32)
+        eng.set_active_mics(keep)
+        eng.set_mic_gains(gains)
+        ragged = eng.process(ring)
+        assert names[eng.stats().kernel_variant] == "quadh_stationary"
+        check_full_grid(oracle, ragged, ring * gains[:, None], off, frac, "reference default, 51 mics with gains", index=keep)
+    X = S.make_frames(xyz, 1, seed=14)[0]
+    off2, frac2 = pkg.build_delay_table(xyz, 90, 70, 120.0)
+    with pkg.Engine(n_pixels=90 * 70, n_streams=64, grid_columns=70) as eng:
+        eng.set_delay_table(off2, frac2)
+        eng.set_active_mics(None)
+        odd = eng.process(X)
+        assert names[eng.stats().kernel_variant] == "quadh_stationary"
+    check_full_grid(oracle, odd, X, off2, frac2, "one array, 90 x 70 grid, fov 120")
+
+
 def test_two_handles_from_two_threads(pkg, oracle):
     """Several AWPUs in one process (the reference runs one per --port): two handles of different shapes used from two
     threads at the same time (ctypes drops the GIL during a call), first launches included -- the one-time kernel

@@ -30,8 +30,10 @@ pytestmark = pytest.mark.gpu
     {"AWPU_SHAPE": "stationary", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},
     {"AWPU_SHAPE": "quadh", "AWPU_TEST_GRID": "1"},                              # single-frame quad shape on the halves layout for every call
     {"AWPU_SHAPE": "quadh", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},
+    {"AWPU_SHAPE": "quadh_chunked", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},  # ... never its resident-window variant
 ], ids=["pairs", "db", "small", "exact", "exact_grid", "exact_verify", "device", "fir8", "fir8_planes", "reuse", "pairs_vertical",
-        "quads_random", "quads_coincide", "pairs_coincide", "stationary", "stationary_grid", "quadh_every_call", "quadh_coincide"])
+        "quads_random", "quads_coincide", "pairs_coincide", "stationary", "stationary_grid", "quadh_every_call", "quadh_coincide",
+        "quadh_chunked"])
 def test_random_tables(env):
     out = subprocess.run([sys.executable, str(REPO / "tests" / "gpu_random_check.py"), "2024", "14"],
                          env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)

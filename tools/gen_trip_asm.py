@@ -1560,6 +1560,7 @@ def main():
     out.append(block_quad("sweep_quad_sum_stamped", stamp=True, chain=CHAIN))
     # single frames on the halves layout (das_quadh_kernel): the first quad of a wave through the block that also issues the
     # refill (sweep_quad1_sum_a_dma, below), the second quad through this one
+    out.append(block_quad_ar("sweep_quad1_sum_a", nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP))  # das_quadh_stationary_kernel: no refill
     out.append(block_quad_ar("sweep_quad1_sum_b", nk=2, acc=QUAD1_ACC[1], tmp=QUAD1_TMP))
     out.append(block_quad_ar("sweep_quad1_sum_a_stamped", stamp=True, nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP))
     out.append(block_quad_ar("sweep_quad1_sum_a_dma", nk=2, acc=QUAD1_ACC[0], tmp=QUAD1_TMP, dma=True))  # das_quadh_kernel
