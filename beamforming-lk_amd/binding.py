@@ -59,6 +59,8 @@ class Stats(C.Structure):
         ("window", C.c_int32),
         ("usable", C.c_int32),
         ("kernel_variant", C.c_int32),
+        ("group_exchange", C.c_int32),
+        ("group_ranges", C.c_int32),
     ]
 
 
@@ -69,6 +71,7 @@ class AwpuError(RuntimeError):
 
 
 PEER_SAME_DEVICE, PEER_DIRECT, PEER_HOST_STAGED = 0, 1, 2
+EXCHANGE_NONE, EXCHANGE_WINDOWS, EXCHANGE_PACKED_PAIRS = 0, 1, 2  # Stats.group_exchange
 # awpu_kernel_id (include/awpu_hip.h): Stats.kernel_variant after a launch
 KERNEL_NAMES = ("none", "quad", "pair", "pair_stationary", "quadh", "quadh_stationary", "single_db", "single_small", "fir8_planes",
                 "fir8", "exact_pair", "exact_verify", "tuning")

@@ -140,6 +140,11 @@ struct awpu_hip {
 
     // device group (cfg.n_devices > 1): this handle owns no sweep state of its own, only one part per device
     std::vector<awpu_hip *> parts;
+    // a part's pixels inside the group's range: (first pixel relative to the group's pixel_begin, count), ascending; the part's
+    // own table and power rows hold them back to back.  One range = a contiguous slab; several = row groups of four dealt
+    // round-robin over the devices (edge rows of the sine-space grid cost the quad shapes more than centre rows: DESIGN.md 6)
+    std::vector<std::pair<int, int>> ranges;
+    bool union_window_done = false;  // group: every part stages the union of the parts' windows (packed frames need one layout)
     hipEvent_t ev_fan = nullptr;            // group: recorded on the caller's stream, awaited by every part
     // a part's share of the fan-out (awpu_hip_process_device on a group): two window buffers, so that the copy of
     // call k+1 (on copy_stream) runs beside the sweep of call k (on stream)
@@ -159,6 +164,8 @@ struct awpu_hip {
     float *h_tile[2] = {nullptr, nullptr};   // part (staged): pinned staging of its power tile on the way back
     size_t tile_cap = 0;
     hipEvent_t ev_tile_free[2] = {nullptr, nullptr};  // part (staged): the caller's stream has read h_tile[b]
+    hipEvent_t ev_staged_read[2] = {nullptr, nullptr};  // part (staged): its upload out of the group's h_stage[b] is done
+    bool stage_used[2] = {false, false};
     bool tile_used[2] = {false, false}, fan_used[2] = {false, false};
     bool in_flight = false;                 // awpu_hip_process_async without its awpu_hip_wait yet
 
@@ -1146,22 +1153,34 @@ int create_group(awpu_hip_t **out, const awpu_hip_cfg &c) {
     if (!g) return AWPU_ERR_NOMEM;
     g->cfg = c;
     g->cfg.device = c.devices[0];
+    // Row groups of four dealt round-robin (device k owns groups k, k + G, ...) where every device gets at least two of them:
+    // the sweep's cost per row grows from the centre of the sine-space grid outwards (fewer shared integer delays), and a
+    // group's call takes as long as its slowest device; contiguous slabs otherwise.  Either way a quad is four adjacent grid rows.
+    const bool interleave = by_rows && unit == 4 * c.grid_columns && units >= 2 * G;
     int begin = 0;
     for (int k = 0; k < G; k++) {
         awpu_hip_cfg pc = c;
         pc.n_devices = 1;
         pc.device = c.devices[k];
         const int n = units / G + (k < units % G ? 1 : 0);  // the first units % G devices take one more
-        pc.pixel_begin = c.pixel_begin + begin * unit;
+        std::vector<std::pair<int, int>> ranges;
+        if (interleave) {
+            for (int u = k; u < units; u += G) ranges.emplace_back(u * unit, unit);
+        } else {
+            ranges.emplace_back(begin * unit, n * unit);
+        }
+        pc.pixel_begin = c.pixel_begin + (interleave ? 0 : begin * unit);  // (a part's pixels are what `ranges` says; this only has to be a row start)
         pc.pixel_count = n * unit;
         begin += n;
         awpu_hip *part = nullptr;
         int rc = awpu_hip_create(&part, &pc);
+        if (rc == AWPU_OK) part->ranges = ranges;
         if (rc == AWPU_OK) {  // what the fan-out needs on top of an ordinary engine
             hipError_t e = hipStreamCreateWithFlags(&part->copy_stream, hipStreamNonBlocking);
             for (int b = 0; b < 2 && e == hipSuccess; b++) {
                 e = hipEventCreateWithFlags(&part->ev_copied[b], hipEventDisableTiming);
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_swept[b], hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_staged_read[b], hipEventDisableTiming);
             }
             if (e == hipSuccess) e = hipEventCreateWithFlags(&part->ev_done, hipEventDisableTiming);
             if (e != hipSuccess) rc = hip_fail(e, "group stream/event creation");
@@ -1243,7 +1262,6 @@ struct TimingOff {
     ~TimingOff() { h->timing = keep; }
 };
 
-int slab_offset(const awpu_hip *g, const awpu_hip *part) { return part->cfg.pixel_begin - g->cfg.pixel_begin; }
 
 // upload of host frames + the sweep into h->d_power, all on h->stream, nothing waited for
 int enqueue_host_process(awpu_hip *h, const float *frames, int batch) {
@@ -1296,13 +1314,23 @@ int enqueue_host_process(awpu_hip *h, const float *frames, int batch) {
     return AWPU_OK;
 }
 
-// h->d_power [batch][pixel_count] -> host rows `pitch` floats apart (a slab of a wider image), on h->stream
+// h->d_power [batch][pixel_count] -> host image `power` [batch][pitch] (pitch = this handle's pixels, or the whole group's: a
+// part's pixel ranges then land where they belong in the wider image), on h->stream
 int enqueue_power_to_host(awpu_hip *h, int batch, float *power, size_t pitch) {
     const size_t row = (size_t) h->cfg.pixel_count * sizeof(float);
-    if (pitch == (size_t) h->cfg.pixel_count) {
-        AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_power, row * batch, hipMemcpyDeviceToHost, h->stream));
-    } else {
-        AWPU_HIP_TRY(hipMemcpy2DAsync(power, pitch * sizeof(float), h->d_power, row, row, (size_t) batch, hipMemcpyDeviceToHost, h->stream));
+    if (h->ranges.empty()) {
+        if (pitch == (size_t) h->cfg.pixel_count) {
+            AWPU_HIP_TRY(hipMemcpyAsync(power, h->d_power, row * batch, hipMemcpyDeviceToHost, h->stream));
+        } else {
+            AWPU_HIP_TRY(hipMemcpy2DAsync(power, pitch * sizeof(float), h->d_power, row, row, (size_t) batch, hipMemcpyDeviceToHost, h->stream));
+        }
+        return AWPU_OK;
+    }
+    size_t done = 0;  // pixels of the part's own rows already sent
+    for (const auto &r : h->ranges) {
+        AWPU_HIP_TRY(hipMemcpy2DAsync(power + r.first, pitch * sizeof(float), h->d_power + done, row, (size_t) r.second * sizeof(float),
+                                      (size_t) batch, hipMemcpyDeviceToHost, h->stream));
+        done += (size_t) r.second;
     }
     return AWPU_OK;
 }
@@ -1325,18 +1353,82 @@ int group_process(awpu_hip *g, const float *frames, int batch, float *power) {
     int rc = for_each_part(g, [&](awpu_hip *part) {
         AWPU_CTX(part);
         const int r = enqueue_host_process(part, frames, batch);
-        return r != AWPU_OK ? r : enqueue_power_to_host(part, batch, power + slab_offset(g, part), pitch);
+        return r != AWPU_OK ? r : enqueue_power_to_host(part, batch, power, pitch);
     });
     if (rc != AWPU_OK) return rc;
     return for_each_part(g, [&](awpu_hip *part) { return wait_and_time(part); });
 }
 
-// Frames and power in the memory of devices[0], on the caller's stream there.  The window of every stream that the
-// tables touch travels to each other device by one (2-D) peer copy on that device's copy stream; the slabs are
-// swept concurrently; the tiles return by peer copies on the caller's stream, which thereby waits for all of it.
-// Parts without peer access to devices[0] (kPeerStaged) get the same window through pinned host memory: ONE copy
-// down on the caller's stream for all of them, one copy up per part on its copy stream; their tiles return the
-// same way.  Two buffers everywhere, so that call k+1's copies run beside call k's sweeps.
+// Would launch() sweep this batch with one of the frame-pair shapes that read the packed layout (quad or pair)?  The rule of
+// awpu_hip_process_packed, asked before anything is packed.
+bool takes_packed_pairs(awpu_hip *h, int batch, awpu::FastPlan *plan) {
+    if (batch < 2 || h->cfg.math != AWPU_MATH_F32_FAST || h->cfg.interp != AWPU_INTERP_LERP) return false;
+    if (h->usable() % 4 != 0 || !h->gain.empty() || env().pairs == 0) return false;
+    if (!awpu::pair_plan(h->window, h->usable(), plan)) return false;
+    const long pairs = (batch + 1) / 2;
+    const bool quad_fills = h->quad_ok && h->quad_plan.wr == plan->wr && h->quad_plan.usable_pad == h->usable() &&
+                            ((long) awpu::quad_tiles(h->cfg.pixel_count / h->cfg.grid_columns, h->cfg.grid_columns) * pairs >= 256 || env().quads == 1);
+    const bool pair_fills = (long) awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols) * pairs >= 256 || env().pairs == 1;
+    return quad_fills || pair_fills;
+}
+
+// the sweep of packed frame pairs (what awpu_hip_process_packed does once its arguments are checked)
+int sweep_packed(awpu_hip *h, const awpu::FastPlan &plan, const float *d_packed, int batch, float *d_power, hipStream_t s) {
+    const bool quad_fills = h->quad_ok && ((long) awpu::quad_tiles(h->cfg.pixel_count / h->cfg.grid_columns, h->cfg.grid_columns) *
+                                               ((batch + 1) / 2) >= 256 || env().quads == 1);
+    if (quad_fills && env().pairs != 0 && h->quad_plan.wr == plan.wr && h->quad_plan.usable_pad == h->usable())
+        return launch_quads(h, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, d_packed);
+    const awpu_hip::FastLut *plut = nullptr;
+    const int rc = build_fast_lut(h, 2, -1, &plut);
+    if (rc != AWPU_OK) return rc;
+    return launch_pairs(h, plut, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, 0, d_packed);
+}
+
+// Every part of a group stages the same window -- the union of what the parts' own rows touch -- so that ONE packed buffer
+// serves them all (the layout's row length and first sample follow the window).  Results do not depend on the window.
+int group_union_window(awpu_hip *g, int batch) {
+    if (g->union_window_done) return AWPU_OK;
+    int lo = g->cfg.hist, hi = 0;
+    for (awpu_hip *part : g->parts) {
+        lo = std::min(lo, part->wstart);
+        hi = std::max(hi, part->wstart + part->window);
+    }
+    for (awpu_hip *part : g->parts) {
+        if (part->wstart == lo && part->wstart + part->window == hi) continue;
+        AWPU_CTX(part);
+        part->cfg.window_begin = lo;
+        part->cfg.window_end = hi;
+        part->prepared = false;
+        const int rc = check_ready(part, batch);
+        if (rc != AWPU_OK) return part_failed(g, part, rc);
+    }
+    g->union_window_done = true;
+    return AWPU_OK;
+}
+
+// a part's tile [batch][its pixels, back to back] -> the group's image [batch][pitch floats]: one 2-D copy per pixel range
+int tile_to_image(awpu_hip *part, const float *tile, float *image, size_t pitch_floats, int batch, hipMemcpyKind kind, hipStream_t s) {
+    const size_t row = (size_t) part->cfg.pixel_count * sizeof(float);
+    size_t done = 0;
+    for (const auto &r : part->ranges) {
+        AWPU_HIP_TRY(hipMemcpy2DAsync(image + r.first, pitch_floats * sizeof(float), tile + done, row, (size_t) r.second * sizeof(float),
+                                      (size_t) batch, kind, s));
+        done += (size_t) r.second;
+    }
+    return AWPU_OK;
+}
+
+// Frames and power in the memory of devices[0], on the caller's stream there.  What travels to the other devices:
+//   * batches that the parts sweep with a frame-pair shape (takes_packed_pairs): devices[0] runs the sweep's pack pass ONCE
+//     (two frames interleaved, filtered: the packed frame pairs of awpu_hip_pack_frames, the exchange format of the
+//     one-process-per-GPU path too) and every other device gets that buffer by ONE linear peer copy on its copy stream and
+//     sweeps it as it arrives -- no window cut on devices[0], no pack pass anywhere else;
+//   * everything else (single frames, FIR8, exact math, gains): the window of every stream that the tables touch, by one 2-D
+//     peer copy per device, and every device runs its whole sweep.
+// The parts' pixel ranges are swept concurrently; the tiles return by peer copies on the caller's stream, which thereby waits
+// for all of it.  Parts without peer access to devices[0] (kPeerStaged) get the same bytes through pinned host memory: ONE
+// copy down on the caller's stream for all of them, one copy up per part on its copy stream; their tiles return the same
+// way.  Two buffers everywhere, so that call k+1's copies run beside call k's sweeps.
 int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d_power, hipStream_t stream) {
     const int dev0 = g->cfg.devices[0];
     AWPU_HIP_TRY(hipSetDevice(dev0));
@@ -1346,23 +1438,75 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
         return check_ready(part, batch);  // (tables packed: every part's window is known)
     });
     if (rc != AWPU_OK) return rc;
-    AWPU_HIP_TRY(hipSetDevice(dev0));
-    AWPU_HIP_TRY(hipEventRecord(g->ev_fan, s));  // the frames are in place once the caller's stream gets here
+    rc = group_union_window(g, batch);
+    if (rc != AWPU_OK) return rc;
+    g->stats.group_exchange = AWPU_EXCHANGE_WINDOWS;
+    auto in_place = [&](const awpu_hip *part) { return part->cfg.device == dev0 && !env().group_copy; };
 
-    // ---- staged parts: the union of their windows goes down to pinned memory once
+    // ---- packed frame pairs, where every part sweeps them
+    awpu::FastPlan pplan{};
+    bool packed = true;
+    for (awpu_hip *part : g->parts) {
+        awpu::FastPlan one{};
+        packed = packed && takes_packed_pairs(part, batch, &one);
+        if (packed && pplan.wr && (one.wr != pplan.wr || one.usable_pad != pplan.usable_pad)) packed = false;
+        pplan = one;
+    }
+    const size_t packed_floats = packed ? (size_t) ((batch + 1) / 2) * g->parts[0]->usable() * pplan.wr * 2 : 0;
+    int pb = 0;  // which of the group's two packed buffers this call fills
+    AWPU_HIP_TRY(hipSetDevice(dev0));
+    if (packed) {
+        g->stats.group_exchange = AWPU_EXCHANGE_PACKED_PAIRS;
+        const size_t cap = (size_t) ((g->cfg.max_batch + 1) / 2) * g->parts[0]->usable() * pplan.wr * 2;
+        if (g->fan_cap < cap) {  // (nobody may still be reading the old buffers)
+            for (awpu_hip *part : g->parts) {
+                AWPU_HIP_TRY(hipSetDevice(part->cfg.device));
+                AWPU_HIP_TRY(hipStreamSynchronize(part->copy_stream));
+                AWPU_HIP_TRY(hipStreamSynchronize(part->stream));
+            }
+            AWPU_HIP_TRY(hipSetDevice(dev0));
+            AWPU_HIP_TRY(hipStreamSynchronize(s));
+            dev_free(g->d_fan[0]);
+            dev_free(g->d_fan[1]);
+            g->fan_cap = 0;
+            AWPU_HIP_TRY(hipMalloc(&g->d_fan[0], cap * sizeof(float)));
+            AWPU_HIP_TRY(hipMalloc(&g->d_fan[1], cap * sizeof(float)));
+            g->fan_cap = cap;
+            g->fan_used[0] = g->fan_used[1] = false;
+        }
+        pb = (int) (g->fan_turn++ & 1);
+        if (g->fan_used[pb])  // buffer pb was read two calls ago: by the peers' copies and by the in-place parts' sweeps
+            for (awpu_hip *part : g->parts) AWPU_HIP_TRY(hipStreamWaitEvent(s, in_place(part) ? part->ev_swept[pb] : part->ev_copied[pb], 0));
+        awpu_hip *p0 = g->parts[0];
+        AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, p0->cfg.n_streams, p0->cfg.hist, p0->wstart, p0->d_index, p0->usable(), p0->usable(),
+                                             nullptr, pplan.wr, batch, g->d_fan[pb], true, s));
+        g->fan_used[pb] = true;
+    }
+    AWPU_HIP_TRY(hipEventRecord(g->ev_fan, s));  // the frames (or their packed pairs) are in place once the caller's stream gets here
+
+    // ---- staged parts: what they need goes down to pinned memory once -- the packed buffer, or the union of their windows
     int gb = 0;
     bool any_staged = false;
-    for (awpu_hip *part : g->parts) any_staged |= part->peer == kPeerStaged && !(part->cfg.device == dev0 && !env().group_copy);
+    for (awpu_hip *part : g->parts) any_staged |= part->peer == kPeerStaged && !in_place(part);
     if (any_staged) {
-        int lo = g->cfg.hist, hi = 0;
-        for (awpu_hip *part : g->parts) {
-            if (part->peer != kPeerStaged) continue;
-            const bool compact = part->compact_hist > 0;
-            lo = std::min(lo, compact ? part->wstart : 0);
-            hi = std::max(hi, compact ? part->wstart + part->compact_hist : part->cfg.hist);
+        int lo = 0, w = 0;
+        size_t need = 0;
+        if (packed) {
+            need = (size_t) ((g->cfg.max_batch + 1) / 2) * g->parts[0]->usable() * pplan.wr * 2;
+            lo = -1;  // (marks the packed payload: a change of payload re-sizes the staging like a change of window)
+            w = (int) pplan.wr;
+        } else {
+            lo = g->cfg.hist;
+            int hi = 0;
+            for (awpu_hip *part : g->parts) {
+                if (part->peer != kPeerStaged) continue;
+                const bool compact = part->compact_hist > 0;
+                lo = std::min(lo, compact ? part->wstart : 0);
+                hi = std::max(hi, compact ? part->wstart + part->compact_hist : part->cfg.hist);
+            }
+            w = hi - lo;
+            need = (size_t) g->cfg.n_streams * w * g->cfg.max_batch;
         }
-        const int w = hi - lo;
-        const size_t need = (size_t) g->cfg.n_streams * w * g->cfg.max_batch;
         if (g->stage_cap < need || g->stage_lo != lo || g->stage_w != w) {
             for (awpu_hip *part : g->parts) {  // nobody may still be reading the old staging buffers
                 AWPU_HIP_TRY(hipSetDevice(part->cfg.device));
@@ -1382,13 +1526,17 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
             g->stage_lo = lo;
             g->stage_w = w;
             g->stage_turn = 0;
+            for (awpu_hip *part : g->parts) part->stage_used[0] = part->stage_used[1] = false;
         }
         gb = g->stage_turn++ & 1;
-        if (g->stage_turn > 2)  // h_stage[gb] was read by the staged parts' uploads two calls ago
-            for (awpu_hip *part : g->parts)
-                if (part->peer == kPeerStaged && part->fan_used[gb]) AWPU_HIP_TRY(hipStreamWaitEvent(s, part->ev_copied[gb], 0));
-        AWPU_HIP_TRY(hipMemcpy2DAsync(g->h_stage[gb], (size_t) w * sizeof(float), d_frames + lo, (size_t) g->cfg.hist * sizeof(float),
-                                      (size_t) w * sizeof(float), (size_t) batch * g->cfg.n_streams, hipMemcpyDeviceToHost, s));
+        for (awpu_hip *part : g->parts)  // h_stage[gb] was read by the staged parts' uploads two calls ago
+            if (part->peer == kPeerStaged && !in_place(part) && part->stage_used[gb]) AWPU_HIP_TRY(hipStreamWaitEvent(s, part->ev_staged_read[gb], 0));
+        if (packed) {
+            AWPU_HIP_TRY(hipMemcpyAsync(g->h_stage[gb], g->d_fan[pb], packed_floats * sizeof(float), hipMemcpyDeviceToHost, s));
+        } else {
+            AWPU_HIP_TRY(hipMemcpy2DAsync(g->h_stage[gb], (size_t) w * sizeof(float), d_frames + lo, (size_t) g->cfg.hist * sizeof(float),
+                                          (size_t) w * sizeof(float), (size_t) batch * g->cfg.n_streams, hipMemcpyDeviceToHost, s));
+        }
         AWPU_HIP_TRY(hipEventRecord(g->ev_staged[gb], s));
     }
 
@@ -1398,13 +1546,21 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
         int r = ensure_power(part, (size_t) part->cfg.pixel_count * batch);
         if (r != AWPU_OK) return r;
         TimingOff untimed(part);  // asynchronous path: the caller times its own stream
-        if (part->cfg.device == dev0 && !env().group_copy) {  // same GPU: sweep the caller's buffer in place
+        const bool staged = part->peer == kPeerStaged && !in_place(part);
+        if (in_place(part)) {  // same GPU: sweep the caller's frames (or the group's packed buffer) in place
             AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, g->ev_fan, 0));
-            r = launch(part, d_frames, batch, part->d_power, part->stream, kFull);
+            if (packed) {
+                r = sweep_packed(part, pplan, g->d_fan[pb], batch, part->d_power, part->stream);
+                if (r == AWPU_OK) AWPU_HIP_TRY(hipEventRecord(part->ev_swept[pb], part->stream));
+            } else {
+                r = launch(part, d_frames, batch, part->d_power, part->stream, kFull);
+            }
         } else {
             const bool compact = part->compact_hist > 0;
             const int dev_hist = compact ? part->compact_hist : part->cfg.hist;
-            const size_t need = (size_t) part->cfg.n_streams * dev_hist * part->cfg.max_batch;
+            const size_t need_window = (size_t) part->cfg.n_streams * dev_hist * part->cfg.max_batch;
+            const size_t need_packed = (size_t) ((part->cfg.max_batch + 1) / 2) * part->usable() * (packed ? pplan.wr : 0) * 2;
+            const size_t need = std::max(need_window, need_packed);
             if (part->fan_cap < need) {
                 AWPU_HIP_TRY(hipStreamSynchronize(part->stream));
                 AWPU_HIP_TRY(hipStreamSynchronize(part->copy_stream));
@@ -1416,25 +1572,37 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
                 part->fan_cap = need;
                 part->fan_used[0] = part->fan_used[1] = false;
             }
-            const bool staged = part->peer == kPeerStaged;
-            const int b = staged ? gb : (int) (part->fan_turn++ & 1);  // (a staged part follows the staging buffer's turn)
+            // the part's own receive buffer follows the buffer it reads from: the group's packed buffer (pb) or, for a staged
+            // part, the staging buffer (gb); a window copy out of the caller's frames takes its own turns
+            const int b = staged ? gb : (packed ? pb : (int) (part->fan_turn++ & 1));
             if (part->fan_used[b]) AWPU_HIP_TRY(hipStreamWaitEvent(part->copy_stream, part->ev_swept[b], 0));  // buffer b is free again
             const size_t row = (size_t) dev_hist * sizeof(float);
             if (staged) {
                 AWPU_HIP_TRY(hipStreamWaitEvent(part->copy_stream, g->ev_staged[gb], 0));
-                AWPU_HIP_TRY(hipMemcpy2DAsync(part->d_fan[b], row, g->h_stage[gb] + ((compact ? part->wstart : 0) - g->stage_lo),
-                                              (size_t) g->stage_w * sizeof(float), row, (size_t) batch * part->cfg.n_streams,
-                                              hipMemcpyHostToDevice, part->copy_stream));
+                if (packed) {
+                    AWPU_HIP_TRY(hipMemcpyAsync(part->d_fan[b], g->h_stage[gb], packed_floats * sizeof(float), hipMemcpyHostToDevice, part->copy_stream));
+                } else {
+                    AWPU_HIP_TRY(hipMemcpy2DAsync(part->d_fan[b], row, g->h_stage[gb] + ((compact ? part->wstart : 0) - g->stage_lo),
+                                                  (size_t) g->stage_w * sizeof(float), row, (size_t) batch * part->cfg.n_streams,
+                                                  hipMemcpyHostToDevice, part->copy_stream));
+                }
+                AWPU_HIP_TRY(hipEventRecord(part->ev_staged_read[gb], part->copy_stream));
+                part->stage_used[gb] = true;
             } else {
                 AWPU_HIP_TRY(hipStreamWaitEvent(part->copy_stream, g->ev_fan, 0));
-                AWPU_HIP_TRY(hipMemcpy2DAsync(part->d_fan[b], row, d_frames + (compact ? part->wstart : 0),
-                                              (size_t) part->cfg.hist * sizeof(float), row, (size_t) batch * part->cfg.n_streams,
-                                              hipMemcpyDeviceToDevice, part->copy_stream));
+                if (packed) {  // ONE linear copy: the packed pairs of the whole batch
+                    AWPU_HIP_TRY(hipMemcpyAsync(part->d_fan[b], g->d_fan[pb], packed_floats * sizeof(float), hipMemcpyDeviceToDevice, part->copy_stream));
+                } else {
+                    AWPU_HIP_TRY(hipMemcpy2DAsync(part->d_fan[b], row, d_frames + (compact ? part->wstart : 0),
+                                                  (size_t) part->cfg.hist * sizeof(float), row, (size_t) batch * part->cfg.n_streams,
+                                                  hipMemcpyDeviceToDevice, part->copy_stream));
+                }
             }
             part->fan_used[b] = true;
             AWPU_HIP_TRY(hipEventRecord(part->ev_copied[b], part->copy_stream));
             AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, part->ev_copied[b], 0));
-            r = launch(part, part->d_fan[b], batch, part->d_power, part->stream, compact ? kCompact : kFull);
+            r = packed ? sweep_packed(part, pplan, part->d_fan[b], batch, part->d_power, part->stream)
+                       : launch(part, part->d_fan[b], batch, part->d_power, part->stream, compact ? kCompact : kFull);
             if (r == AWPU_OK) AWPU_HIP_TRY(hipEventRecord(part->ev_swept[b], part->stream));
             if (r == AWPU_OK && staged) {  // the tile's way back starts on the part's own stream: device -> pinned
                 const size_t tile = (size_t) part->cfg.pixel_count * part->cfg.max_batch;
@@ -1449,10 +1617,10 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
                     part->tile_cap = tile;
                     part->tile_used[0] = part->tile_used[1] = false;
                 }
-                if (part->tile_used[b]) AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, part->ev_tile_free[b], 0));
-                AWPU_HIP_TRY(hipMemcpyAsync(part->h_tile[b], part->d_power, (size_t) part->cfg.pixel_count * batch * sizeof(float),
+                if (part->tile_used[gb]) AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, part->ev_tile_free[gb], 0));
+                AWPU_HIP_TRY(hipMemcpyAsync(part->h_tile[gb], part->d_power, (size_t) part->cfg.pixel_count * batch * sizeof(float),
                                             hipMemcpyDeviceToHost, part->stream));
-                part->tile_used[b] = true;
+                part->tile_used[gb] = true;
             }
         }
         if (r == AWPU_OK) AWPU_HIP_TRY(hipEventRecord(part->ev_done, part->stream));
@@ -1460,18 +1628,17 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
     });
     if (rc != AWPU_OK) return rc;
     AWPU_HIP_TRY(hipSetDevice(dev0));
-    const size_t pitch = (size_t) g->cfg.pixel_count * sizeof(float);
-    for (awpu_hip *part : g->parts) {  // tiles back into the caller's [batch][pixel_count] image
+    const size_t pitch = (size_t) g->cfg.pixel_count;
+    for (awpu_hip *part : g->parts) {  // tiles back into the caller's [batch][pixel_count] image, range by range
         AWPU_HIP_TRY(hipStreamWaitEvent(s, part->ev_done, 0));
-        const size_t row = (size_t) part->cfg.pixel_count * sizeof(float);
-        const bool staged = part->peer == kPeerStaged && !(part->cfg.device == dev0 && !env().group_copy);
+        const bool staged = part->peer == kPeerStaged && !in_place(part);
         if (staged) {
-            AWPU_HIP_TRY(hipMemcpy2DAsync(d_power + slab_offset(g, part), pitch, part->h_tile[gb], row, row, (size_t) batch,
-                                          hipMemcpyHostToDevice, s));
+            rc = tile_to_image(part, part->h_tile[gb], d_power, pitch, batch, hipMemcpyHostToDevice, s);
+            if (rc != AWPU_OK) return rc;
             AWPU_HIP_TRY(hipEventRecord(part->ev_tile_free[gb], s));
         } else {
-            AWPU_HIP_TRY(hipMemcpy2DAsync(d_power + slab_offset(g, part), pitch, part->d_power, row, row, (size_t) batch,
-                                          hipMemcpyDeviceToDevice, s));
+            rc = tile_to_image(part, part->d_power, d_power, pitch, batch, hipMemcpyDeviceToDevice, s);
+            if (rc != AWPU_OK) return rc;
         }
     }
     return AWPU_OK;
@@ -1479,6 +1646,8 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
 
 int group_stats(awpu_hip *g, awpu_hip_stats *out) {
     awpu_hip_stats st = g->parts[0]->stats;
+    st.group_exchange = g->stats.group_exchange;
+    st.group_ranges = (int32_t) g->parts[0]->ranges.size();
     for (size_t k = 1; k < g->parts.size(); k++) {
         const awpu_hip_stats &p = g->parts[k]->stats;
         st.launches += p.launches;
@@ -1576,7 +1745,7 @@ int awpu_hip_destroy(awpu_hip_t *h) {
     if (h->copy_stream) (void) hipStreamSynchronize(h->copy_stream);
     release_device(h);
     for (hipEvent_t ev : {h->ev_begin, h->ev_end, h->ev_fan, h->ev_copied[0], h->ev_copied[1], h->ev_swept[0], h->ev_swept[1], h->ev_done,
-                          h->ev_staged[0], h->ev_staged[1], h->ev_tile_free[0], h->ev_tile_free[1]})
+                          h->ev_staged[0], h->ev_staged[1], h->ev_tile_free[0], h->ev_tile_free[1], h->ev_staged_read[0], h->ev_staged_read[1]})
         if (ev) (void) hipEventDestroy(ev);
     if (h->stream) (void) hipStreamDestroy(h->stream);
     if (h->copy_stream) (void) hipStreamDestroy(h->copy_stream);
@@ -1587,11 +1756,25 @@ int awpu_hip_destroy(awpu_hip_t *h) {
 int awpu_hip_set_delay_table(awpu_hip_t *h, const int32_t *off, const float *frac) {
     AWPU_CTX(h);
     if (!h || !off || !frac) return invalid("null argument");
-    if (!h->parts.empty())  // every device gets the rows of its slab
+    if (!h->parts.empty()) {  // every device gets the rows of its pixel ranges, back to back
+        h->union_window_done = false;
         return for_each_part(h, [&](awpu_hip *part) {
-            const size_t first = (size_t) slab_offset(h, part) * h->cfg.lut_stride;
-            return awpu_hip_set_delay_table(part, off + first, frac + first);
+            const size_t stride = (size_t) h->cfg.lut_stride;
+            if (part->ranges.size() == 1) {
+                const size_t first = (size_t) part->ranges[0].first * stride;
+                return awpu_hip_set_delay_table(part, off + first, frac + first);
+            }
+            std::vector<int32_t> o((size_t) part->cfg.pixel_count * stride);
+            std::vector<float> f(o.size());
+            size_t done = 0;
+            for (const auto &r : part->ranges) {
+                std::memcpy(&o[done * stride], off + (size_t) r.first * stride, (size_t) r.second * stride * sizeof(int32_t));
+                std::memcpy(&f[done * stride], frac + (size_t) r.first * stride, (size_t) r.second * stride * sizeof(float));
+                done += (size_t) r.second;
+            }
+            return awpu_hip_set_delay_table(part, o.data(), f.data());
         });
+    }
     const size_t n = (size_t) h->cfg.pixel_count * h->cfg.lut_stride;
     for (size_t i = 0; i < n; i++) {
         if (!(frac[i] >= 0.0f && frac[i] <= 1.0f)) return invalid("fraction outside [0, 1]");
@@ -1606,7 +1789,10 @@ int awpu_hip_set_delay_table(awpu_hip_t *h, const int32_t *off, const float *fra
 int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable) {
     AWPU_CTX(h);
     if (!h) return invalid("null handle");
-    if (!h->parts.empty()) return for_each_part(h, [&](awpu_hip *part) { return awpu_hip_set_active_mics(part, index, usable); });
+    if (!h->parts.empty()) {
+        h->union_window_done = false;
+        return for_each_part(h, [&](awpu_hip *part) { return awpu_hip_set_active_mics(part, index, usable); });
+    }
     const int limit = std::min(h->cfg.n_streams, h->cfg.lut_stride);
     if (usable < 1 || usable > limit) return invalid("usable outside [1, min(n_streams, lut_stride)]");
     std::vector<int32_t> idx(usable);
@@ -1820,7 +2006,7 @@ int awpu_hip_process_async(awpu_hip_t *h, const float *frames, int32_t batch, fl
         rc = for_each_part(h, [&](awpu_hip *part) {
             AWPU_CTX(part);
             const int r = enqueue_host_process(part, frames, batch);
-            return r != AWPU_OK ? r : enqueue_power_to_host(part, batch, power + slab_offset(h, part), pitch);
+            return r != AWPU_OK ? r : enqueue_power_to_host(part, batch, power, pitch);
         });
         if (rc != AWPU_OK) {  // parts before the failing one hold copies from `frames` and into `power` in flight, and
             const std::string why = h->last_error;  // the caller is about to hear "failed": finish them before it does
@@ -2072,7 +2258,7 @@ int awpu_hip_process_ring(awpu_hip_t *h, float *power) {
             if (!part->d_ring) return fail(AWPU_ERR_STATE, "no block ingested yet");
             r = ensure_power(part, (size_t) part->cfg.pixel_count);
             if (r == AWPU_OK) r = launch(part, part->d_ring + part->ring_pos, 1, part->d_power, part->stream, kRing);
-            return r != AWPU_OK ? r : enqueue_power_to_host(part, 1, power + slab_offset(h, part), (size_t) h->cfg.pixel_count);
+            return r != AWPU_OK ? r : enqueue_power_to_host(part, 1, power, (size_t) h->cfg.pixel_count);
         });
         if (grc != AWPU_OK) return grc;
         return for_each_part(h, [&](awpu_hip *part) { return wait_and_time(part); });
@@ -2225,14 +2411,7 @@ int awpu_hip_process_packed(awpu_hip_t *h, const float *d_packed, int32_t batch,
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     TimingOff untimed(h);  // asynchronous path: the caller times its own stream
     // the shape awpu_hip_process_device takes for this batch (same rule: same bits), as long as that is a frame-pair shape
-    const bool quad_fills = h->quad_ok && ((long) awpu::quad_tiles(h->cfg.pixel_count / h->cfg.grid_columns, h->cfg.grid_columns) *
-                                               ((batch + 1) / 2) >= 256 || env().quads == 1);
-    if (quad_fills && env().pairs != 0 && h->quad_plan.wr == plan.wr && h->quad_plan.usable_pad == h->usable())
-        return launch_quads(h, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, d_packed);
-    const awpu_hip::FastLut *plut = nullptr;
-    rc = build_fast_lut(h, 2, -1, &plut);
-    if (rc != AWPU_OK) return rc;
-    return launch_pairs(h, plut, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, 0, d_packed);
+    return sweep_packed(h, plan, d_packed, batch, d_power, s);
 }
 
 int awpu_hip_synchronize(awpu_hip_t *h) {

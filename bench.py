@@ -35,6 +35,7 @@ At N = 1 the line also carries, next to the batched `value`:
                       FIR variant) and the c5 slab, a few steps each: kernel ms, VALU fraction, full-grid parity
   "projected_scaling" rank 0's slab of an 8-rank run through the N > 1 step loop, the collective replaced by a local
                       copy of the same bytes: what one GPU can say about the 8-GPU step (NOT a scaling measurement)
+  "projected_scaling_strong"  the same for configs[3]: 512 mics x 256x256 at a FIXED batch, an eighth of the grid per GPU
   "cpu_baseline"      the reference's own compiled delay() on the host
 BENCH_ALT=1 (N > 1) adds a second, separately timed pass with whole frames per rank.
 """
@@ -767,6 +768,10 @@ def main():
         out["workloads"] = other_workloads(pkg, sharding, torch, dist, args, dev, local_rank)
         out["projected_scaling"] = projected_scaling(pkg, sharding, torch, dist, args, spec, dev, local_rank, d_full, B,
                                                      fps_one_gpu=out["value"], ms_one_gpu=out["ms_per_step"])
+        try:
+            out["projected_scaling_strong"] = projected_scaling_strong(pkg, sharding, torch, dist, args, dev, local_rank)
+        except Exception as exc:  # noqa: BLE001 -- an optional leg
+            out["projected_scaling_strong"] = {"error": str(exc)}
 
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(spec, off, frac, host_first[0], args.cpu_seconds, args.interp)
@@ -988,6 +993,43 @@ def projected_scaling(pkg, sharding, torch, dist, args, spec, dev, local_rank, d
         job2.close()
     except Exception as exc:  # noqa: BLE001 -- an optional leg
         out["raw_scatter"] = {"error": str(exc)}
+    return out
+
+
+def projected_scaling_strong(pkg, sharding, torch, dist, args, dev, local_rank, ranks=8, batch=128):
+    """BASELINE configs[3] -- 512 mics, ONE 256x256 frame stream sharded over 8 GPUs -- is the STRONG-scaling case: the batch a
+    display wants per step is fixed (`batch` frames) and every GPU sweeps an eighth of the grid for all of them.  What one
+    GPU can say about it: the whole c4 grid at that batch on this GPU (the N = 1 step), then rank 0's share of an 8-rank run
+    through the exact N > 1 loop with the collective replaced by a local copy of the same bytes (as projected_scaling).
+    ceiling_x = one-GPU step / rank-0 step: everything but the wire.  NOT a scaling measurement."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c4"]
+    sub = argparse.Namespace(**vars(args))
+    sub.batch = batch  # (a fixed batch: "scaling": "strong")
+    one = RankJob(pkg, sharding, torch, dist, sub, spec, 1, 0, dev, local_rank, batch)
+    e1, k1, _ = one.timed(3, 1)
+    frames = one.d_full
+    one_ms = e1 / 3 * 1e3
+    one.eng.close()
+    job = RankJob(pkg, sharding, torch, dist, sub, spec, ranks, 0, dev, local_rank, batch, stub=True, frames_src=frames)
+    K = 8
+    e8, k8, _ = job.timed(K, 2)
+    step_ms = e8 / K * 1e3
+    job.root_work = False
+    ep, kp, _ = job.timed(K, 1)
+    out = {
+        "workload": f"configs[3]: {spec.name}, {batch} frames per step whatever the number of GPUs (strong scaling)",
+        "ranks": ranks, "frames_per_step": batch, "slab_rows": job.shard.row_count, "exchange": job.exchange,
+        "one_gpu_ms_per_step": one_ms, "one_gpu_kernel_ms": k1, "one_gpu_value": batch / (one_ms * 1e-3),
+        "step_wall_ms": step_ms, "slab_kernel_ms": k8, "peer_step_wall_ms": ep / K * 1e3,
+        "exchange_mb_per_step": job.exchange_mb, "exchange_gbs_needed": job.exchange_mb / 1e3 / (step_ms * 1e-3),
+        "projected_value": batch / (step_ms * 1e-3), "unit": "frames/s", "ceiling_x": one_ms / step_ms,
+        "note": f"rank 0's eighth of the 256x256 grid on ONE GPU, the frame exchange replaced by a local device copy of the same "
+                f"{job.exchange_mb:.0f} MB: an upper bound on the {ranks}-GPU value from everything but the wire.  NOT a scaling measurement",
+    }
+    job.close()
+    del job, one, frames
+    torch.cuda.empty_cache()
     return out
 
 

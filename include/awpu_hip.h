@@ -115,12 +115,14 @@ typedef struct {
      * pixel_begin and pixel_count are whole rows. */
     int32_t grid_columns;
     /* Device group: with n_devices > 1 the handle spreads its pixels over devices[0 .. n_devices-1]
-     * (HIP ordinals; `device` is then ignored) in contiguous slabs -- whole grid rows when grid_columns is set --
+     * (HIP ordinals; `device` is then ignored) -- row groups of four dealt round-robin when grid_columns is set and every
+     * device gets at least two of them (edge rows cost more than centre rows), contiguous slabs otherwise --
      * one internal engine, stream and table slab per device; all in this one process, no collective library.
      * Entry points keep their meaning: host frames are uploaded by every device over its own PCIe link; device
      * frames (awpu_hip_process_device, pointers on devices[0]) fan out by direct peer copies over xGMI, one per
-     * destination on that destination's stream; the slabs are swept concurrently; power tiles come back to the
-     * caller's buffer.  awpu_hip_ingest_block feeds every device's ring.  0 or 1 = one device, as before. */
+     * destination on that destination's stream -- as PACKED frame pairs (devices[0] runs the sweep's pack pass once, the
+     * others sweep the pairs as they arrive) wherever the batch is swept by a frame-pair shape, as raw windows otherwise;
+     * the slabs are swept concurrently; power tiles come back to the caller's buffer.  awpu_hip_ingest_block feeds every device's ring.  0 or 1 = one device, as before. */
     int32_t n_devices;
     int32_t devices[AWPU_MAX_DEVICES];
     /* Optional: history samples [window_begin, window_end) that the handle stages per stream even where its own table
@@ -143,7 +145,12 @@ typedef struct {
     int32_t window;           /* W */
     int32_t usable;           /* U */
     int32_t kernel_variant;   /* awpu_kernel_id of the sweep kernel the LAST launch ran (AWPU_KERNEL_NONE before the first) */
+    int32_t group_exchange;   /* device groups: what the last awpu_hip_process_device sent to the other devices (AWPU_EXCHANGE_*) */
+    int32_t group_ranges;     /* device groups: pixel ranges per device (1 = contiguous slabs, more = row groups of four dealt round-robin) */
 } awpu_hip_stats;
+#define AWPU_EXCHANGE_NONE 0
+#define AWPU_EXCHANGE_WINDOWS 1      /* the touched window of every stream, one 2-D copy per device; every device runs its whole sweep */
+#define AWPU_EXCHANGE_PACKED_PAIRS 2 /* devices[0] packs once, one linear copy per device, every device sweeps the packed pairs */
 
 /* fills cfg with the reference defaults (64 streams, hist 1024, LERP, F32_FAST, batch 1) */
 void awpu_hip_default_cfg(awpu_hip_cfg *cfg);

@@ -961,6 +961,66 @@ def test_device_group_equals_one_device(force_copy, quads):
     assert out.returncode == 0 and "GROUP OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+GROUP_PACKED_CHILD = r"""
+import importlib, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import util
+pkg = importlib.import_module("beamforming-lk_amd")
+B = pkg.binding
+S = pkg.synthetic
+spec = S.WORKLOADS["headline"]
+xyz = S.geometry(spec)
+off, frac = S.delay_table(spec, xyz)
+frames = util.hash_frames(spec.n_mics, 1024, seed=31, batch=10)
+def run(devices, batch, index=None):
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=10, grid_columns=spec.res, devices=devices) as eng:
+        eng.set_delay_table(off, frac); eng.set_active_mics(index)
+        d_X = torch.from_numpy(frames[:batch]).cuda(); d_P = torch.zeros((batch, spec.n_pixels), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        st = torch.cuda.Stream()
+        for _ in range(4):  # four calls back to back: both packed buffers, both receive buffers and their events get reused
+            eng.process_device(d_X.data_ptr(), batch, d_P.data_ptr(), st.cuda_stream)
+        st.synchronize(); eng.synchronize()
+        stats = eng.stats()
+        host = eng.process(frames[:batch])
+    return d_P.cpu().numpy(), host, stats
+one = run(None, 10)
+assert B.KERNEL_NAMES[one[2].kernel_variant] == "quad"
+for devices in ([0, 0], [0, 0, 0, 0]):
+    grp = run(devices, 10)
+    assert grp[2].group_exchange == B.EXCHANGE_PACKED_PAIRS, grp[2].group_exchange
+    assert grp[2].group_ranges == 32 // len(devices)  # 32 groups of four rows dealt round-robin
+    assert np.array_equal(grp[0], one[0]), devices     # the same quads of the same packed samples through the same kernel: the same bits
+    assert np.array_equal(grp[1], one[1]), devices     # (host entry: every part uploads the union window and sweeps on its own)
+# a single frame, and a ragged mic list (usable % 4 != 0): raw windows travel, every part runs its whole sweep
+grp1 = run([0, 0], 1)
+assert grp1[2].group_exchange == B.EXCHANGE_WINDOWS
+assert util.power_rel_err(grp1[0], run(None, 1)[0]) < 5e-6
+keep = np.array([m for m in range(spec.n_mics) if m % 9 != 2], np.int32)
+grp2 = run([0, 0, 0], 10, keep)
+assert grp2[2].group_exchange == B.EXCHANGE_WINDOWS and grp2[2].group_ranges == 32 // 3 + 1
+assert util.power_rel_err(grp2[0], run(None, 10, keep)[0]) < 5e-6
+print("GROUP PACKED OK")
+"""
+
+
+@pytest.mark.parametrize("force_copy", ["0", "1", "2"])
+def test_device_group_exchanges_packed_frame_pairs(force_copy):
+    """Round 4: the in-process device group on the exchange format of the one-process-per-GPU path.  A batch that the parts
+    sweep with a frame-pair shape travels as PACKED frame pairs -- devices[0] runs the pack pass once, every other part gets
+    one linear copy (force_copy=1: the peer-copy path; 2: through pinned host memory; 0: parts on devices[0] sweep the
+    group's packed buffer in place) -- and the grid's rows are dealt to the parts in groups of four, round-robin.  The
+    assembled heatmaps equal the single-device handle's BIT FOR BIT (the same quads of the same packed samples through the
+    same kernel); single frames and mic lists that are no multiple of four fall back to raw windows, to rounding."""
+    import os, subprocess, sys
+    env = dict(os.environ, AWPU_GROUP_FORCE_COPY=force_copy)
+    out = subprocess.run([sys.executable, "-c", GROUP_PACKED_CHILD, str(Path(__file__).resolve().parent.parent)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "GROUP PACKED OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 GROUP_TWO_DEVICES_CHILD = r"""
 import importlib, sys
 import numpy as np
