@@ -81,6 +81,7 @@ struct awpu_hip {
     };
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     awpu::FastEntry *d_exact_pair_lut = nullptr;  // reference-order sweep on the frame-pair layout (das_exact_pair_kernel)
+    awpu::QuadEntry *d_exact_quad_lut = nullptr;  // ... four vertically adjacent pixels per wave (das_exact_quad_kernel): quad-major, raw fractions
     awpu::FastPlan exact_plan{};
     bool exact_pairs_ok = false;  // AWPU_MATH_F32_EXACT + LERP and the window fits the pair image
     float *sums_out = nullptr;    // awpu_hip_process_device_sums: where the launch in progress exports out[] (else null)
@@ -199,7 +200,7 @@ int ensure_diag(awpu_hip *h, size_t words) {
 //   AWPU_SHAPE             force one of the production sweep shapes wherever it can serve the call (tests sweep every shape
 //                          through the oracle this way; the default rule -- launch() below -- picks by table statistics and launch size):
 //                          pair | pair_vertical | pair_horizontal | quad | noquad | stationary | quadh | quadh_chunked | single_db | single_small |
-//                          fir8_planes | exact_verify
+//                          fir8_planes | exact_pair | exact_verify
 //   AWPU_LIVE_GRAPH=0      awpu_hip_live_block always enqueues its steps one by one (no HIP-graph replay)
 //   AWPU_GROUP_FORCE_COPY  device groups: 1 = a part on devices[0] takes the window-copy path too, 2 = through pinned host
 //                          memory (how one GPU exercises the paths a part on another GPU takes)
@@ -240,6 +241,7 @@ struct EnvKnobs {
             else if (shape == "single_small") pairs = 0, quads = 0, fpi = 1, ppw = 2, nw = 8;
             else if (shape == "fir8_planes") fir_planes = 2;
             else if (shape == "exact_verify") exact_pairs = 0;
+            else if (shape == "exact_pair") exact_pairs = 2;  // the two-pixel reference-order block even where quads would run
             else std::fprintf(stderr, "libawpu_hip: AWPU_SHAPE=%s is not a shape of this build; ignored\n", v);
         }
 #ifdef AWPU_TUNING_BUILD
@@ -295,6 +297,7 @@ void release_device(awpu_hip *h) {
     for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
     dev_free(h->d_exact_pair_lut);
+    dev_free(h->d_exact_quad_lut);
     dev_free(h->d_quad_lut);
     dev_free(h->d_quadh_lut);
     dev_free(h->d_quadhs_lut);
@@ -364,6 +367,7 @@ int prepare(awpu_hip *h) {
     for (auto &l : h->fast_luts) dev_free(l.d);
     h->fast_luts.clear();
     dev_free(h->d_exact_pair_lut);
+    dev_free(h->d_exact_quad_lut);
     dev_free(h->d_quad_lut);
     dev_free(h->d_quadh_lut);
     dev_free(h->d_quadhs_lut);
@@ -569,12 +573,19 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
 // address), quads = groups of four grid rows x columns padded to whole 16-column tiles.  Pixels past the grid
 // carry weight 0 and the address of the nearest pixel inside it (they then follow the shared path and add
 // nothing); padding mics (usable rounded up to 4) carry weight 0 and the address of their own, zero, row.
-enum QuadLayout { kQuadPairs = 0, kQuadHalves = 2, kQuadHalvesStationary = 3 };
+enum QuadLayout { kQuadPairs = 0, kQuadHalves = 2, kQuadHalvesStationary = 3, kQuadExact = 4 };
 int build_quad_lut(awpu_hip *h, int layout) {
-    awpu::QuadEntry *&d_lut = layout == kQuadHalves ? h->d_quadh_lut : (layout == kQuadHalvesStationary ? h->d_quadhs_lut : h->d_quad_lut);
+    awpu::QuadEntry *&d_lut = layout == kQuadHalves             ? h->d_quadh_lut
+                              : layout == kQuadHalvesStationary ? h->d_quadhs_lut
+                              : layout == kQuadExact            ? h->d_exact_quad_lut
+                                                                : h->d_quad_lut;
     if (d_lut) return AWPU_OK;
     const auto &c = h->cfg;
-    const awpu::FastPlan &plan = layout == kQuadHalves ? h->quadh_plan : (layout == kQuadHalvesStationary ? h->quadhs_plan : h->quad_plan);
+    const awpu::FastPlan &plan = layout == kQuadHalves             ? h->quadh_plan
+                                 : layout == kQuadHalvesStationary ? h->quadhs_plan
+                                 : layout == kQuadExact            ? h->exact_plan
+                                                                   : h->quad_plan;
+    const float centre = layout == kQuadExact ? 0.0f : 0.5f;  // the reference-order sweep takes the fraction as it is (mimo.cpp:126)
     const int U = h->usable(), cols = c.grid_columns, rows = c.pixel_count / cols;
     const int groups = plan.usable_pad / 4;
     const int cols_pad = (cols + 15) / 16 * 16, rows4 = (rows + 3) / 4;
@@ -595,7 +606,7 @@ int build_quad_lut(awpu_hip *h, int layout) {
                     if (s < U) {
                         const int id = h->index[s];
                         const int off_rel = orow[id] - h->wstart;
-                        e.f = inside ? frow[id] - 0.5f : 0.0f;  // centred weight (das_fast.hip, das_quad_kernel)
+                        e.f = inside ? frow[id] - centre : 0.0f;  // centred weight (das_fast.hip, das_quad_kernel); exact: as it is
                         e.addr = (uint32_t) (j * plan.row_bytes + off_rel * 8);
                     } else {  // padding mic: silence (the pack passes write zero rows)
                         e.f = 0.0f;
@@ -735,6 +746,33 @@ int launch_exact_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_p
                                          h->d_gain, pp.wr, batch, h->d_pack, false, s));  // raw samples: no stencil in front of the reference's order
     AWPU_HIP_TRY(awpu::launch_das_exact_pairs(a, s));
     return finish_launch(h, batch, s, AWPU_KERNEL_EXACT_PAIR);
+}
+
+// ... four vertically adjacent pixels per wave where the row length is known (das_exact_quad_kernel): same bits, fewer LDS reads
+int launch_exact_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
+    int rc = build_quad_lut(h, kQuadExact);
+    if (rc != AWPU_OK) return rc;
+    const awpu::FastPlan &pp = h->exact_plan;
+    const size_t need = (size_t) ((std::max(h->cfg.max_batch, batch) + 1) / 2) * pp.usable_pad * pp.wr * 2;
+    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
+    awpu::ExactQuadArgs a{};
+    a.packed = h->d_pack;
+    a.lut = h->d_exact_quad_lut;
+    a.power = d_power;
+    a.sums = h->sums_out;
+    a.usable = h->usable();
+    a.usable_pad = pp.usable_pad;
+    a.pixel_count = h->cfg.pixel_count;
+    a.wp = pp.wr;
+    a.chunk = pp.chunk;
+    a.batch = batch;
+    a.cols = h->cfg.grid_columns;
+    a.rows = h->cfg.pixel_count / a.cols;
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad,
+                                         h->d_gain, pp.wr, batch, h->d_pack, false, s));
+    AWPU_HIP_TRY(awpu::launch_das_exact_quads(a, s));
+    return finish_launch(h, batch, s, AWPU_KERNEL_EXACT_QUAD);
 }
 
 int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
@@ -1000,7 +1038,13 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         if (env().fir_planes && awpu::fir8_plane_plan(h->window, h->usable(), &h->fir_plane_plan))
             return launch_fir8_planes(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
     }
-    if (h->exact_pairs_ok && env().exact_pairs != 0) return launch_exact_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+    if (h->exact_pairs_ok && env().exact_pairs != 0) {
+        // vertical pixel quads where the row length is known and vertical neighbours coincide more often than horizontal ones
+        // (prepare() counted: pair_cols); AWPU_SHAPE=exact_pair keeps the two-pixel block everywhere
+        if (h->pair_cols > 0 && env().exact_pairs != 2 && h->cfg.pixel_count / h->cfg.grid_columns >= 4)
+            return launch_exact_quads(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+        return launch_exact_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+    }
     if (h->sums_out) return fail(AWPU_ERR_STATE, "the pre-epilogue sums are exported by the frame-pair reference-order kernel only");
     if (h->cfg.math != AWPU_MATH_F32_FAST || h->cfg.interp == AWPU_INTERP_FIR8)
         return launch_exact(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);

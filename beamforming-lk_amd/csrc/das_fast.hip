@@ -1082,6 +1082,91 @@ __global__ __launch_bounds__(1024, 4) void das_exact_pair_kernel(ExactPairArgs a
 }
 
 // ---------------------------------------------------------------------------------------
+// The same reference-order sweep with FOUR vertically adjacent pixels per wave (round 4; taken where the grid's row length is
+// known and vertical neighbours share their integer delays more often than horizontal ones): das_exact_pair_kernel's staging
+// around the block sweep_quad_exact, in which the reads of a mic's samples and the difference cur - next are shared by
+// every pixel of the column that carries the reference pixel's LDS address.  Per pixel the three operations and the mic
+// order are unchanged: the same bits as das_exact_pair_kernel and das_exact_kernel (a.sums exports them).
+// Tile = 4 rows x 16 columns (a wave one column), quad-major table as das_quad_kernel's with the RAW fraction; grid = (pairs, tiles).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024, 4) void das_exact_quad_kernel(ExactQuadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
+    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int pair = blockIdx.x, tile = blockIdx.y;
+    const int tiles_per_row4 = (a.cols + NW - 1) / NW;
+    const int row4 = tile / tiles_per_row4;
+    const int col = (tile - row4 * tiles_per_row4) * NW + wave;
+    const int quad = row4 * tiles_per_row4 * NW + col;  // the table's quads: columns padded to whole tiles
+    const int groups_total = a.usable_pad >> 2;
+    const QuadEntry *quad_lut = a.lut + (size_t) quad * groups_total * 16;
+    const size_t row_floats = (size_t) a.wp * 2;
+    const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
+
+    f8 O0 = {0, 0, 0, 0, 0, 0, 0, 0}, O1 = O0, O2 = O0, O3 = O0;  // float out[N_SAMPLES] = {0.0}, mimo.cpp:122
+
+    auto dma_chunk = [&](int m0, int mc, int buf) {
+        const float *src = pair_base + (size_t) m0 * row_floats;
+        const int n_pieces = (int) ((size_t) mc * row_floats / 4);
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            const int piece = threadIdx.x + k * kThreads;
+            if (piece < n_pieces) {
+                float *dst = lds + buf * (BUF / 4) + (wave * 64 + k * kThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + (size_t) piece * 4),
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+            }
+        }
+    };
+
+    const int n_chunks = (a.usable_pad + a.chunk - 1) / a.chunk;
+    dma_chunk(0, min(a.chunk, a.usable_pad), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int rank = wave >> 2;
+    for (int c = 0; c < n_chunks; c++) {
+        const int m0 = c * a.chunk;
+        const int mc = min(a.chunk, a.usable_pad - m0);
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) dma_chunk(m0 + a.chunk, min(a.chunk, a.usable_pad - m0 - a.chunk), buf ^ 1);
+        const unsigned lane_addr = lds_base + buf * BUF + lane * 8;
+        const void *row = uniform_ptr(quad_lut + (size_t) (m0 >> 2) * 16);
+        sweep_quad_exact(O0, O1, O2, O3, row, __builtin_amdgcn_readfirstlane(mc >> 2), lane_addr, rank);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    const float norm = (float) (kSamples * a.usable);
+    auto finish = [&](const f8 &O, int q) {
+        const int row = 4 * row4 + q;
+        const bool live = row < a.rows && col < a.cols;
+        const int p = min(row, a.rows - 1) * a.cols + min(col, a.cols - 1);
+        f2 o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o[k] = f2{O[2 * k], O[2 * k + 1]};
+        if (a.sums && live) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                a.sums[((size_t) (2 * pair) * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k].x;
+                if (2 * pair + 1 < a.batch) a.sums[((size_t) (2 * pair + 1) * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k].y;
+            }
+        }
+        const f2 sum = finish_pixel_pair_exact(o, lane);
+        if (lane == 0 && live) {
+            a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
+            if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
+        }
+    };
+    finish(O0, 0);
+    finish(O1, 1);
+    finish(O2, 2);
+    finish(O3, 3);
+}
+
+// ---------------------------------------------------------------------------------------
 // FIR8, four-plane frame-pair layout (the default for FIR8 batches): das_fir8_pair_kernel reads 32 LDS elements for
 // 32 FMAs, and the LDS array -- one per CU, 2 cycles per ds_read_b64, shared by four SIMDs that each want a
 // v_pk_fma_f32 every 4 cycles -- then holds the sweep at half the VALU rate.  Here a lane owns four CONSECUTIVE
@@ -1967,6 +2052,19 @@ hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, cons
 #endif
     (void) variant;
     return launch_fir8_plane_variant<0>(a, d_entries, d_coeffs, stream);
+}
+
+hipError_t launch_das_exact_quads(const ExactQuadArgs &a, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (hipError_t e = allow_lds((const void *) das_exact_quad_kernel, lds_bytes, attr_set); e != hipSuccess) return e;
+    if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || (size_t) a.chunk * a.wp * 8 > (size_t) kFastLdsBytes || a.cols < 1 ||
+        a.rows * a.cols != a.pixel_count)
+        return hipErrorInvalidValue;
+    dim3 grid((a.batch + 1) / 2, quad_tiles(a.rows, a.cols));
+    if (grid.y > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(das_exact_quad_kernel, grid, dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_das_exact_pairs(const ExactPairArgs &a, hipStream_t stream) {

@@ -118,6 +118,17 @@ struct ExactPairArgs {
     int32_t cols;          // > 0: the grid's row length; a wave then sweeps vertical pixel pairs (pixel_count % cols == 0)
 };
 hipError_t launch_das_exact_pairs(const ExactPairArgs &a, hipStream_t stream);
+// the same with four vertically adjacent pixels per wave (das_exact_quad_kernel): the quad-major table of the quad shapes
+// ([quad][group of 4 mics][pixel][mic] x QuadEntry) with the RAW fraction in .f; needs the grid's row length
+struct ExactQuadArgs {
+    const float *packed;   // [pairs][usable_pad][wp][2], padding rows zero
+    const struct QuadEntry *lut;
+    float *power;          // [batch][pixel_count]
+    float *sums;           // optional [batch][pixel_count][256], or null
+    int32_t usable, usable_pad, pixel_count, wp, chunk, batch;
+    int32_t cols, rows;
+};
+hipError_t launch_das_exact_quads(const ExactQuadArgs &a, hipStream_t stream);
 // FIR8 on the four-plane frame-pair layout (a lane owns four consecutive outputs: 11 LDS reads per 32 FMAs).  Rows packed by
 // launch_pack_planes, `wr` a multiple of 4 (fir8_plane_plan); d_entries [pixel_count][usable_pad] + 4 spare dwords,
 // one per (pixel, mic): fir8_plane_word(LDS byte offset of X[off] in its chunk's image, its plane, coefficient row);

@@ -1633,15 +1633,18 @@ def test_exact_mode_pre_epilogue_sums_are_the_reference_bits(pkg, name):
     assert not np.isnan(out).any()
 
 
-@pytest.mark.parametrize("cols", [0, 32])
-def test_exact_mode_sums_equal_the_oracle_on_every_pixel(pkg, oracle, cols):
-    """The same export against oracle_das_f32's out_dbg on EVERY pixel of c1 (plane wave + noise, three frames: an odd
-    batch), consecutive pixel pairs (no row length) and vertical ones (row length given): bit-identical sums, powers
-    within the sum-order noise of the 254-term epilogue."""
+@pytest.mark.parametrize("wl,cols,rows", [("c1", 0, 32), ("c1", 32, 32), ("c2", 64, 64), ("c2", 64, 30)])
+def test_exact_mode_sums_equal_the_oracle_on_every_pixel(pkg, oracle, wl, cols, rows):
+    """The same export against oracle_das_f32's out_dbg on EVERY pixel (plane wave + noise, three frames: an odd batch):
+    consecutive pixel pairs (no row length: das_exact_pair_kernel) and, with the row length given, whichever of the two
+    reference-order kernels the table's statistics pick (das_exact_quad_kernel where vertical neighbours coincide more; a
+    grid of 30 rows: a last quad of two live pixels) -- bit-identical sums, powers within the sum-order noise of the 254-term
+    epilogue."""
     S = pkg.synthetic
-    spec = S.WORKLOADS["c1"]
+    spec = S.WORKLOADS[wl]
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz)
+    off, frac = off[: rows * spec.res], frac[: rows * spec.res]
     frames = S.make_frames(xyz, 3, seed=91)
     power, out = _sums_through_the_abi(pkg, frames, off, frac, grid_columns=cols)
     for b in range(3):

@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
     {"AWPU_SHAPE": "single_small"},                             # 8-wave shape, 2 pixels per wave
     {"AWPU_TEST_MATH": "exact"},                                # the reference-order kernel on the frame-pair layout
     {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},  # ... vertical pixel pairs sharing reads and differences
+    {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1", "AWPU_SHAPE": "exact_pair"},  # ... two-pixel block on the same tables
     {"AWPU_TEST_MATH": "exact", "AWPU_SHAPE": "exact_verify"},  # the round-1 verification kernel (the bf16 mode's structure)
     {"AWPU_TEST_PATH": "device"},                               # device-resident frames + two pixel shards per case
     {"AWPU_TEST_INTERP": "fir8"},                               # the 8-tap variant of delay()
@@ -31,7 +32,7 @@ pytestmark = pytest.mark.gpu
     {"AWPU_SHAPE": "quadh", "AWPU_TEST_GRID": "1"},                              # single-frame quad shape on the halves layout for every call
     {"AWPU_SHAPE": "quadh", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},
     {"AWPU_SHAPE": "quadh_chunked", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},  # ... never its resident-window variant
-], ids=["pairs", "db", "small", "exact", "exact_grid", "exact_verify", "device", "fir8", "fir8_planes", "reuse", "pairs_vertical",
+], ids=["pairs", "db", "small", "exact", "exact_grid", "exact_grid_pairs", "exact_verify", "device", "fir8", "fir8_planes", "reuse", "pairs_vertical",
         "quads_random", "quads_coincide", "pairs_coincide", "stationary", "stationary_grid", "quadh_every_call", "quadh_coincide",
         "quadh_chunked"])
 def test_random_tables(env):

@@ -505,6 +505,155 @@ __device__ __forceinline__ void {name}(f2 (&P0)[4], f2 (&P1)[4], const void *row
 '''
 
 
+EXQ_ACC = 26   # block_exact_quad: out[] of the four pixels, 8 registers each, pinned at v26..v57
+EXQ_TMP = 58   # its temps: two slots for the reference pixel's samples, one for pixel 0's own, one that pixels 2 and 3 share, t, address
+
+
+def block_exact_quad(name):
+    """Reference-order sweep (AWPU_MATH_F32_EXACT) of FOUR vertically adjacent pixels on the frame-pair layout, raw samples.
+
+    Arithmetic per pixel, mic and sample exactly block_exact_shared's (delay.cpp:19-25 in its order, mics in table order):
+    d = cur - next; t = fma(frac, d, next); out += t -- so the pre-epilogue sums stay bit-identical to the reference's.  What the
+    four pixels of a column share is the SAMPLES and the difference d (neither depends on the fraction): the second pixel is
+    the reference, its reads (8 ds_read_b64: cur and next of the lane's four samples) and its d serve every pixel whose entry
+    carries the same LDS address -- 8 packed VALU instructions per pixel and mic, +4 (its own d) and 8 reads for a pixel whose
+    integer delay differs.  Schedule and table are block_quad's: quad-major entries [group][pixel][mic] x (fraction, address),
+    trips of 4 mics, two SGPR sets of 32 ping-ponging; per mic the reference's reads for the NEXT mic go out first, one
+    counted wait (8 younger reads) proves this mic's samples, then pixels 3, 2, 0 -- each followed by the conditional read
+    of its own samples for the next mic -- and the reference.  Pixels 2 and 3 share one slot (a delay is monotone down a
+    column: when both differ from the reference they almost always carry the same address; pixel 2 reads on the spot in the
+    rare other cases).  Slots are 16 registers: cur0..3 (d in their place once formed), next0..3."""
+    O = [EXQ_ACC + 8 * p for p in range(4)]
+    R = [EXQ_TMP, EXQ_TMP + 16]
+    X0, X23 = EXQ_TMP + 32, EXQ_TMP + 48
+    TT = EXQ_TMP + 64
+    addr_t = EXQ_TMP + 68
+    E = (36, 68)
+    S_TMP, S_PF_, S_LEFT_ = 22, 23, 24
+
+    def f_of(base, p, i):
+        return base + 8 * p + 2 * i
+
+    def a_of(base, p, i):
+        return base + 8 * p + 2 * i + 1
+
+    def pair(r, k):
+        return f"v[{r + 2 * k}:{r + 2 * k + 1}]"
+
+    def reads(slot, addr_sgpr):
+        L = [f"v_add_u32 v{addr_t}, s{addr_sgpr}, %[lane]"]
+        for k in range(4):
+            off = f" offset:{512 * k}" if k else ""
+            L.append(f"ds_read_b64 {pair(slot, k)}, v{addr_t}{off}")
+            L.append(f"ds_read_b64 {pair(slot + 8, k)}, v{addr_t} offset:{512 * k + 8}")
+        return L
+
+    def diffs(slot):  # d_k = cur_k - next_k, in place of cur_k
+        return [f"v_pk_add_f32 {pair(slot, k)}, {pair(slot, k)}, {pair(slot + 8, k)} neg_lo:[0,1] neg_hi:[0,1]" for k in range(4)]
+
+    def terms(p, base, i, slot):  # t_k = fma(frac, d_k, next_k); out_k += t_k   (two t registers, used alternately)
+        fs = f"s[{f_of(base, p, i)}:{f_of(base, p, i) + 1}]"
+        L = []
+        for k0 in (0, 2):
+            for k in (k0, k0 + 1):
+                L.append(f"v_pk_fma_f32 {pair(TT, k - k0)}, {fs}, {pair(slot, k)}, {pair(slot + 8, k)} op_sel_hi:[0,1,1]")
+            for k in (k0, k0 + 1):
+                L.append(f"v_pk_add_f32 {pair(O[p], k)}, {pair(O[p], k)}, {pair(TT, k - k0)}")
+        return L
+
+    def uid():
+        COUNTER[0] += 1
+        return f"%=_{COUNTER[0]}"
+
+    cold = []
+
+    def maybe_read(p, slot, base, i):
+        """pixel p's own reads for the mic whose entries sit at (base, i), unless it shares the reference's samples"""
+        u = uid()
+        cold.extend([f".Leread{u}:"] + reads(slot, a_of(base, p, i)) + [f"s_branch .Lereadback{u}"])
+        return [f"s_cmp_lg_u32 s{a_of(base, p, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Leread{u}", f".Lereadback{u}:"]
+
+    def pixel0(base, i, rslot):
+        u = uid()
+        cold.extend([f".Leown{u}:"] + diffs(X0) + terms(0, base, i, X0) + [f"s_branch .Ledone{u}"])
+        return ([f"s_cmp_lg_u32 s{a_of(base, 0, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Leown{u}"] + terms(0, base, i, rslot) +
+                [f".Ledone{u}:"])
+
+    def pixels_23(base, i, rslot):
+        """X23 holds pixel 3's samples whenever its address differs from the reference's (requested a mic ahead); pixel 2 takes
+        the reference's, or pixel 3's when it carries pixel 3's address, or reads into X23 on the spot once pixel 3 is done."""
+        u = uid()
+        a1, a2, a3 = a_of(base, REF, i), a_of(base, 2, i), a_of(base, 3, i)
+        spot = reads(X23, a2) + ["s_waitcnt lgkmcnt(0)"] + diffs(X23) + terms(2, base, i, X23)
+        cold.extend(
+            [f".Le3diff{u}:"] + diffs(X23) + terms(3, base, i, X23) +
+            [f"s_cmp_eq_u32 s{a2}, s{a3}", f"s_cbranch_scc1 .Letog{u}", f"s_cmp_lg_u32 s{a2}, s{a1}", f"s_cbranch_scc1 .Letwo{u}"] +
+            terms(2, base, i, rslot) + [f"s_branch .Le23done{u}"] +          # a-a-a-b
+            [f".Letog{u}:"] + terms(2, base, i, X23) + [f"s_branch .Le23done{u}"] +  # a-a-b-b: pixel 3's samples and d serve pixel 2
+            [f".Letwo{u}:"] + spot + [f"s_branch .Le23done{u}"] +                # a-a-b-c
+            [f".Le2odd{u}:"] + spot + [f"s_branch .Le23done{u}"])               # a-a-b-a (not monotone: rare)
+        return ([f"s_cmp_lg_u32 s{a3}, s{a1}", f"s_cbranch_scc1 .Le3diff{u}"] + terms(3, base, i, rslot) +
+                [f"s_cmp_lg_u32 s{a2}, s{a1}", f"s_cbranch_scc1 .Le2odd{u}"] + terms(2, base, i, rslot) + [f".Le23done{u}:"])
+
+    def load_set(base, off, literal=False):
+        if literal:
+            return [f"s_load_dwordx16 s[{base}:{base + 15}], %[ptr], {hex(off)}",
+                    f"s_load_dwordx16 s[{base + 16}:{base + 31}], %[ptr], {hex(off + 64)}"]
+        return [f"s_load_dwordx16 s[{base}:{base + 15}], %[ptr], s{off}",
+                f"s_add_u32 s{S_TMP}, s{off}, 64",
+                f"s_load_dwordx16 s[{base + 16}:{base + 31}], %[ptr], s{S_TMP}"]
+
+    def trip_q(par):
+        cur, nxt = E[par], E[1 - par]
+        L = select_prio(S_PRIO, 1) if par == 0 else select_prio(S_RANK, 0)  # rotation / youngest first, trip by trip
+        L += load_set(nxt, S_PF_) + [f"s_add_u32 s{S_PF_}, s{S_PF_}, 128"]
+        for st in range(4):
+            rslot = R[st & 1]
+            if st < 3:
+                L += reads(R[(st + 1) & 1], a_of(cur, REF, st + 1))
+                L.append("s_waitcnt lgkmcnt(8)")  # all but the eight reads just issued: this mic's samples are in
+                nbase, ni = cur, st + 1
+            else:
+                L.append("s_waitcnt lgkmcnt(0)")  # this mic's samples, and the next trip's entries
+                L += reads(R[0], a_of(nxt, REF, 0))
+                nbase, ni = nxt, 0
+            L += diffs(rslot)
+            L += pixels_23(cur, st, rslot) + maybe_read(3, X23, nbase, ni)
+            L += pixel0(cur, st, rslot) + maybe_read(0, X0, nbase, ni)
+            L += terms(REF, cur, st, rslot)
+        return L
+
+    L = [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    L += load_set(E[0], 0, literal=True)
+    L += [f"s_mov_b32 s{S_LEFT_}, %[ng]", f"s_movk_i32 s{S_PF_}, 0x80", "s_waitcnt lgkmcnt(0)"]
+    L += reads(R[0], a_of(E[0], REF, 0))
+    L += maybe_read(3, X23, E[0], 0) + maybe_read(0, X0, E[0], 0)
+    L += [".LE0_%=:"] + trip_q(0)
+    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_eq_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LEdone_%="]
+    L += trip_q(1)
+    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LE0_%="]
+    L += ["s_branch .LEdone_%="] + cold + [".LEdone_%=:", "s_waitcnt lgkmcnt(0)"]  # (the reads issued for a trip that does not come)
+    L += [f"s_setprio {BLOCK_END_PRIO}"]
+    body = "\n".join(f'        "{l}\\n\\t"' for l in L)
+    vregs = list(range(EXQ_TMP, addr_t + 1))
+    sregs = sorted({S_TMP, S_PF_, S_LEFT_, S_RANK, S_PRIO}) + list(range(36, 100))
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"'])
+    acc_params = ", ".join(f"f8 &O{p}" for p in range(4))
+    acc_ops = ", ".join(f'"+{{v[{O[p]}:{O[p] + 7}]}}"(O{p})' for p in range(4))
+    return f"""// Reference-order sweep of four vertically adjacent pixels of the staged chunk (raw frame-pair samples), ng groups of four
+// mics each (ng >= 1): see tools/gen_trip_asm.py, block_exact_quad.  `row` = the quad's entries of the chunk's first group in
+// the quad-major table ([group][pixel][mic] x (fraction, address)); reads one group past the last.  O_p = out[l + 64 k] of
+// pixel p, both frames, pinned at v[{O[0]}+8p ..]; temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}.
+__device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, unsigned lane_addr, int rank) {{
+    asm volatile(
+{body}
+        : {acc_ops}
+        : [ptr] "s"(row), [ng] "s"(ng), [lane] "v"(lane_addr), [rank] "s"(rank)
+        : {clobbers});
+}}
+"""
+
+
 # ---------------------------------------------------------------------------------------------------
 # Quad block with a shared integer-delay sum (das_quad_kernel).
 #
@@ -1554,6 +1703,7 @@ def main():
     out.append(block_shared("sweep_duo_shared", 128 - 25 - 3))
     out.append(block_shared("sweep_duo_shared_stamped", 128 - 25 - 3, stamp=True))
     out.append(block_exact_shared("sweep_duo_exact", 128 - 57 - 3))  # das_exact_pair_kernel (AWPU_MATH_F32_EXACT)
+    out.append(block_exact_quad("sweep_quad_exact"))  # das_exact_quad_kernel (AWPU_MATH_F32_EXACT, row length known)
     out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))
     out.append(block_quad("sweep_quad_item", dma=True, chain=CHAIN, item=True))  # the production batch kernel: one block per item
