@@ -768,6 +768,15 @@ int launch_exact_quads(awpu_hip *h, const float *d_frames, int batch, float *d_p
     a.batch = batch;
     a.cols = h->cfg.grid_columns;
     a.rows = h->cfg.pixel_count / a.cols;
+    a.tiles = awpu::quad_tiles(a.rows, a.cols);
+    a.n_pairs = (batch + 1) / 2;
+    {   // frame pairs an XCD works on at a time: as many as keep their samples in its 4 MiB L2 beside the table stream (launch_quads)
+        const size_t pair_bytes = (size_t) pp.usable_pad * pp.wr * 8;
+        int g = (int) std::max<size_t>(1, (3u << 20) / pair_bytes);
+        g = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;
+        while (g > 1 && g > a.n_pairs) g >>= 1;
+        a.pair_group = g;
+    }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad,
                                          h->d_gain, pp.wr, batch, h->d_pack, false, s));

@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(1024, 4) void das_exact_pair_kernel(ExactPairArgs a
 // around the block sweep_quad_exact, in which the reads of a mic's samples and the difference cur - next are shared by
 // every pixel of the column that carries the reference pixel's LDS address.  Per pixel the three operations and the mic
 // order are unchanged: the same bits as das_exact_pair_kernel and das_exact_kernel (a.sums exports them).
-// Tile = 4 rows x 16 columns (a wave one column), quad-major table as das_quad_kernel's with the RAW fraction; grid = (pairs, tiles).
+// Tile = 4 rows x 16 columns (a wave one column), quad-major table as das_quad_kernel's with the RAW fraction; 1-D grid of items.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024, 4) void das_exact_quad_kernel(ExactQuadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1096,7 +1096,23 @@ __global__ __launch_bounds__(1024, 4) void das_exact_quad_kernel(ExactQuadArgs a
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
-    const int pair = blockIdx.x, tile = blockIdx.y;
+    // Dispatch as das_quad_kernel's: the items (frame pair, tile), ordered (pair group, tile, pair), are cut into 8 contiguous
+    // runs, one per XCD (blockIdx & 7: round-robin placement, assumed for speed only), so that at any moment an XCD's
+    // workgroups sweep `pair_group` frame pairs x a few tiles: the pairs' samples stay in that XCD's 4 MiB L2 while it walks the
+    // table once per pair group (a (pairs, tiles) grid streamed 3.2 GB per headline launch from beyond the L2: PMC).
+    const int total = a.n_pairs * a.tiles;
+    const int per_xcd = (total + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= min(total, ((int) (blockIdx.x & 7) + 1) * per_xcd)) return;  // (uniform for the workgroup)
+    int pair, tile;
+    {
+        const int full_items = (a.n_pairs / a.pair_group) * a.pair_group * a.tiles;  // items of whole pair groups
+        const int ga = item < full_items ? a.pair_group : a.n_pairs % a.pair_group;   // the last group may be smaller
+        const int rem = item < full_items ? item : item - full_items;
+        const int grp = rem / (a.tiles * ga), in = rem - grp * a.tiles * ga;
+        tile = in / ga;
+        pair = (item < full_items ? grp * a.pair_group : a.n_pairs - ga) + (in - tile * ga);
+    }
     const int tiles_per_row4 = (a.cols + NW - 1) / NW;
     const int row4 = tile / tiles_per_row4;
     const int col = (tile - row4 * tiles_per_row4) * NW + wave;
@@ -2061,8 +2077,9 @@ hipError_t launch_das_exact_quads(const ExactQuadArgs &a, hipStream_t stream) {
     if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || (size_t) a.chunk * a.wp * 8 > (size_t) kFastLdsBytes || a.cols < 1 ||
         a.rows * a.cols != a.pixel_count)
         return hipErrorInvalidValue;
-    dim3 grid((a.batch + 1) / 2, quad_tiles(a.rows, a.cols));
-    if (grid.y > 65535) return hipErrorInvalidValue;
+    if (a.n_pairs != (a.batch + 1) / 2 || a.tiles != quad_tiles(a.rows, a.cols) || a.pair_group < 1) return hipErrorInvalidValue;
+    const long total = (long) a.n_pairs * a.tiles;
+    dim3 grid((unsigned) (8 * ((total + 7) / 8)));
     hipLaunchKernelGGL(das_exact_quad_kernel, grid, dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }

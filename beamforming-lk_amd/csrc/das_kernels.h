@@ -127,6 +127,7 @@ struct ExactQuadArgs {
     float *sums;           // optional [batch][pixel_count][256], or null
     int32_t usable, usable_pad, pixel_count, wp, chunk, batch;
     int32_t cols, rows;
+    int32_t tiles, n_pairs, pair_group;  // workgroup tiles of 4 rows x 16 columns; frame pairs, and how many an XCD works on at a time
 };
 hipError_t launch_das_exact_quads(const ExactQuadArgs &a, hipStream_t stream);
 // FIR8 on the four-plane frame-pair layout (a lane owns four consecutive outputs: 11 LDS reads per 32 FMAs).  Rows packed by

@@ -1,20 +1,23 @@
 #!/bin/bash
 # measurement pass of a round (run under gpurun): rocprofv3 evidence for the default bench (kernel stats incl. the warm-only
 # table, SQ counters, HBM-side counters in separate passes), the single-frame regime, the reference-order mode, then every
-# BASELINE workload through bench.py.  usage: tools/gpu_round.sh <tag>   (WITH_WORKLOADS=0 skips the last part)
+# BASELINE workload through bench.py.  usage: tools/gpu_round.sh <tag> [profiles|workloads|all]   (two gpurun calls fit the 20-minute limit)
 set -euo pipefail
 tag=${1:-r04}
+part=${2:-all}
 out=gpurun_out/${tag}_round
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 -c "import __graft_entry__ as g; g.build()" > $out/build.log 2>&1
+if [ "$part" != "workloads" ]; then
 bash tools/gpu_profile.sh ${tag}_headline_b128 > $out/profile_b128.log 2>&1
 echo "profile b128 done"
 bash tools/gpu_profile.sh ${tag}_headline_b1 --batch 1 --steps 200 --warmup 20 > $out/profile_b1.log 2>&1
 echo "profile b1 done"
 bash tools/gpu_profile.sh ${tag}_headline_exact --math exact --steps 8 --warmup 3 > $out/profile_exact.log 2>&1
 echo "profile exact done"
-if [ "${WITH_WORKLOADS:-1}" = "1" ]; then
+fi
+if [ "$part" != "profiles" ]; then
 for wl in headline c1 c2 c3 c4 c5; do
   timeout -k 10 500 python bench.py --workload $wl > $out/bench_$wl.json 2> $out/bench_$wl.err
   echo "bench $wl done"
