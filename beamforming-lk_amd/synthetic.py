@@ -84,12 +84,17 @@ def make_frames(xyz: np.ndarray, batch: int, seed: int = 1234, theta: float = SO
     """
     n = xyz.shape[1]
     tau = binding.steering_delays(xyz, theta, phi).astype(np.float64)
-    rng = np.random.Generator(np.random.PCG64(seed))
+    # the noise: the raw 32-bit stream of std::mt19937(seed) -- numpy's legacy MT19937 seeding is init_genrand,
+    # the same generator (tests/test_host_mirror.py compares it with a g++-compiled std::mt19937) -- drawn frame by frame, mic by
+    # mic, sample by sample, each draw r mapped to NOISE * (2 r / 2^32 - 1): reproducible from C++ without libstdc++'s
+    # distribution classes
+    rng = np.random.RandomState(seed)
     t = np.arange(hist, dtype=np.float64)
     out = np.empty((batch, n, hist), np.float32)
     for b in range(batch):
         phase = 2.0 * np.pi * CARRIER * (t[None, :] + b * binding.N_SAMPLES + tau[:, None]) / SAMPLE_RATE
-        noise = rng.uniform(-NOISE, NOISE, size=(n, hist))
+        raw = rng.randint(0, 2 ** 32, size=(n, hist), dtype=np.uint32).astype(np.float64)
+        noise = NOISE * (raw * (2.0 / 4294967296.0) - 1.0)
         out[b] = (AMPLITUDE * np.sin(phase) + noise).astype(np.float32)
     return out
 

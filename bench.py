@@ -215,11 +215,11 @@ def cpu_baseline(spec, off, frac, frame, seconds, interp="lerp"):
     return out
 
 
-def measured_traffic(workload, batch, world):
+def measured_traffic(workload, batch, world, math="fast"):
     """HBM-side bytes per launch from the committed PMC run (profiles/r0N_hbm_traffic.json, collected with
     tools/pmc_hbm.sh as MI355X_MICROARCH.md prescribes; newest round first); (None, None) when it was not
-    measured for this exact workload and batch."""
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    measured for this exact workload, batch and math mode."""
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         path = REPO / "profiles" / name
         if world != 1 or not path.exists():
             continue
@@ -227,7 +227,7 @@ def measured_traffic(workload, batch, world):
         if rec.get("workload") != workload:
             continue
         for m in rec["measurements"]:  # not proportional to the batch (L2 residency changes): exact matches only
-            if m["frames_per_step"] == batch:
+            if m["frames_per_step"] == batch and m.get("math", "fast") == math:
                 return int(m["traffic_bytes_per_launch"]), f"profiles/{name} (PMC, tools/pmc_hbm.sh; not re-measured in this run)"
     return None, None
 
@@ -648,7 +648,7 @@ def main():
         if args.interp == "fir8":  # 16 flop per (pixel, mic, sample) instead of 4
             launch_flops = (16 * shard.pixel_count * st.usable * 256 + 6 * shard.pixel_count * 254) * B
         ach_gbs = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(spec.name, B, world)
+        traffic, traffic_src = measured_traffic(spec.name, B, world, args.math) if args.interp == "lerp" else (None, None)
         out = {
             "metric": "heatmap frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,

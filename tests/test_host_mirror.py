@@ -87,3 +87,32 @@ def test_c_example_finds_the_source(pkg):
     er, ec = S.source_pixel(S.WORKLOADS["c1"])
     r, c = (int(v) for v in out.stdout.split("(")[1].split(")")[0].split(","))
     assert abs(r - er) <= 1 and abs(c - ec) <= 1 and "image value there 255" in out.stdout, out.stdout
+
+
+def test_synthetic_noise_is_the_std_mt19937_stream(pkg, tmp_path):
+    """SURVEY.md 8d seeds the synthetic inputs with std::mt19937(1234).  beamforming-lk_amd/synthetic.py draws its noise from
+    numpy's legacy MT19937 seeding, which is the same generator: the first draws equal a g++-compiled std::mt19937's, and a
+    frame's noise is NOISE * (2 r / 2^32 - 1) of consecutive draws (mic-major, sample-minor)."""
+    src = tmp_path / "mt.cpp"
+    src.write_text('#include <random>\n#include <cstdio>\nint main() { std::mt19937 g(1234); for (int i = 0; i < 6; i++) '
+                   'std::printf("%u\\n", (unsigned) g()); }\n')
+    subprocess.run(["g++", "-O1", "-o", str(tmp_path / "mt"), str(src)], check=True, capture_output=True)
+    want = [int(v) for v in subprocess.run([str(tmp_path / "mt")], capture_output=True, text=True, check=True).stdout.split()]
+    import numpy as np
+
+    got = np.random.RandomState(1234).randint(0, 2 ** 32, size=6, dtype=np.uint32)
+    assert [int(v) for v in got] == want
+    S = pkg.synthetic
+    xyz = S.geometry(S.WORKLOADS["c1"])
+    frame = S.make_frames(xyz, 1, seed=1234)[0]
+    clean = S.make_frames(xyz, 1, seed=1234)[0] - 0  # (deterministic)
+    assert np.array_equal(frame, clean)
+    # the noise of mic 0, samples 0..5, recovered by removing the plane wave generated with NOISE = 0
+    noise = np.float64(S.NOISE) * (np.array(want, np.float64) * (2.0 / 4294967296.0) - 1.0)
+    keep = S.NOISE
+    try:
+        S.NOISE = 0.0
+        wave = S.make_frames(xyz, 1, seed=1234)[0]
+    finally:
+        S.NOISE = keep
+    assert np.allclose(frame[0, :6].astype(np.float64) - wave[0, :6], noise, atol=2e-9)
