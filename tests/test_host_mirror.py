@@ -116,3 +116,64 @@ def test_synthetic_noise_is_the_std_mt19937_stream(pkg, tmp_path):
     finally:
         S.NOISE = keep
     assert np.allclose(frame[0, :6].astype(np.float64) - wave[0, :6], noise, atol=2e-9)
+
+
+def test_host_code_under_address_and_ub_sanitizers(pkg, oracle, tmp_path):
+    """the reference has no sanitizer coverage; the host side here gets one on the CPU (GPU sanitizers are not
+    available on the pool).  (a) csrc/geometry_host.cpp -- create_antenna, steer, computeDelayLUT -- compiled with
+    -fsanitize=address,undefined beside a small driver; its table equals the oracle's.  (b) the C++ mirror classes
+    (MIMOWorkerHip, AWProcessingUnitHip, PipelineHip) and tests/host/test_mimo_worker.cpp under the same flags, run on the
+    no-device path (construction, the refused start, destruction order)."""
+    import os
+
+    import numpy as np
+
+    pkg.binding.load()
+    oracle.oracle()
+    pkgdir = REPO / "beamforming-lk_amd"
+    san = ["-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall", "-pthread"]
+    main = tmp_path / "geometry_main.cpp"
+    main.write_text(r'''
+#include "awpu_hip.h"
+#include <cstdio>
+#include <vector>
+int main() {
+    std::vector<float> xyz(3 * 256);
+    if (awpu_hip_create_tiled_antenna(4, 1, 0.02f, xyz.data()) != 0) return 1;
+    const int res = 20;
+    std::vector<int32_t> off((size_t) res * res * 256);
+    std::vector<float> frac(off.size());
+    if (awpu_hip_build_delay_table(xyz.data(), 256, res, res, 180.0f, 0, res, off.data(), frac.data()) != 0) return 2;
+    FILE *f = std::fopen("table.bin", "wb");
+    std::fwrite(off.data(), 4, off.size(), f);
+    std::fwrite(frac.data(), 4, frac.size(), f);
+    std::fclose(f);
+    int32_t o1[64]; float f1[64]; double th = 0.4, ph = -1.3;
+    std::vector<float> one(3 * 64);
+    if (awpu_hip_create_antenna(8, 8, 0.02f, one.data()) != 0 || awpu_hip_steer_table(one.data(), 64, &th, &ph, 1, o1, f1) != 0) return 3;
+    return awpu_hip_create_antenna(8, 8, 0.02f, nullptr) < 0 ? 0 : 4;  // (a null output is refused, not written through)
+}
+''')
+    exe = tmp_path / "geometry_san"
+    subprocess.run(["g++", *san, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{REPO / 'include'}", f"-I{pkgdir / 'csrc'}",
+                    str(main), str(pkgdir / "csrc" / "geometry_host.cpp"), "-o", str(exe)], check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    raw = np.fromfile(tmp_path / "table.bin", dtype=np.uint8)
+    n = 20 * 20 * 256
+    off_o, frac_o = oracle.compute_delay_lut(oracle.create_tiled_antenna(4, 1), 20, 20, 180.0)
+    assert np.array_equal(raw[: 4 * n].view(np.int32).reshape(400, 256), off_o)
+    assert np.array_equal(raw[4 * n:].view(np.float32).reshape(400, 256), frac_o)
+    import torch
+
+    if torch.cuda.is_available():
+        return  # (the no-device path below is for CPU-only boxes; GPU sanitizers are not available on the pool)
+    host = [str(pkgdir / "host" / f) for f in ("mimo_worker_hip.cpp", "aw_processing_unit_hip.cpp", "pipeline_hip.cpp", "aw_processing_unit.cpp")]
+    exe2 = tmp_path / "mimo_worker_san"
+    subprocess.run(["g++", *san, f"-I{REPO / 'include'}", f"-I{pkgdir / 'host'}", f"-I{REPO / 'oracle'}",
+                    str(REPO / "tests/host/test_mimo_worker.cpp"), *host, f"-L{pkgdir}", "-lawpu_hip", f"-L{REPO / 'oracle'}", "-loracle_das",
+                    "-lm", f"-Wl,-rpath,{pkgdir}", f"-Wl,-rpath,{REPO / 'oracle'}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe2)],
+                   check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe2), "--nogpu"], capture_output=True, text=True,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))  # (the HIP runtime's own start-up allocations are not ours to free)
+    assert out.returncode == 0 and "OK nogpu" in out.stdout, out.stdout + out.stderr
