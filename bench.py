@@ -346,7 +346,7 @@ class RankJob:
                 self.d_full[b0:b0 + n] = self.d_full[:n]
         # a real (non-null) stream: its handle goes to the C ABI, and the torch events that time the sweep are
         # recorded on the same stream; `aux` carries the root's pack / window cut and the collectives' enqueue point.
-        # Both at the default priority: measured through projected_scaling (tools/gpu_prio.sh, two alternating runs on one
+        # Both at the default priority: measured through projected_scaling (round 3, two alternating runs on one
         # box), step wall of the root / of a peer: sweep above aux 4.99-5.03 / 4.68-4.69 ms, aux above sweep 4.99-5.00 /
         # 4.55-4.59, equal 4.93-4.95 / 4.55-4.56 -- a starved side stream delivers the next batch late, a starved sweep
         # is simply slower.  BENCH_STREAM_PRIO="sweep,aux" overrides for tuning runs.

@@ -42,7 +42,7 @@ def test_generated_blocks_are_current(pkg, tmp_path):
 
 
 # the shapes launch() can pick without a tuning knob (awpu_hip.cpp); stamped (diagnostic) builds and the shapes only
-# AWPU_FAST_VARIANT reaches are not timed and may spill
+# tuning builds reach are not timed and may spill
 PRODUCTION = [r"das_quad_kernelILb0ELi0E", r"das_quadh_kernelILi[12]ELb0E", r"das_quadh_stationary_kernelILi[12]E", r"das_pair_kernelILi4ELb0ELb1E",
               r"das_pair_stationary_kernelILb1E", r"das_fast_db_kernelILi16ELi[48]ELi\d+ELi4ELb0E",
               r"das_fast_kernelILi8ELi[24]ELi1ELi4E", r"das_fir8_plane_kernelILi0E", r"das_exact_pair_kernel"]
