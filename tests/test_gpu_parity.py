@@ -713,6 +713,32 @@ def test_reference_default_single_frames_run_the_resident_window_kernel(pkg, ora
     check_full_grid(oracle, odd, X, off2, frac2, "one array, 90 x 70 grid, fov 120")
 
 
+def test_reference_order_mode_on_the_ingest_ring(pkg, oracle):
+    """AWPU_MATH_F32_EXACT on the live path: frames read in place from the device ring (rows 2048 floats apart) through
+    pack_pairs_kernel<false> and the reference-order kernels give the bits the host-buffer entry gives, and the oracle's powers;
+    c2 geometry with the row length (das_exact_quad_kernel) and without (das_exact_pair_kernel)."""
+    S = pkg.synthetic
+    spec = S.WORKLOADS["c2"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    rng = np.random.default_rng(6)
+    names = pkg.binding.KERNEL_NAMES
+    for cols, want in ((spec.res, "exact_quad"), (0, "exact_pair")):
+        ring = np.zeros((spec.n_mics, 1024), np.float32)
+        with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, math=pkg.MATH_F32_EXACT, grid_columns=cols) as eng:
+            eng.set_delay_table(off, frac)
+            eng.set_active_mics(None)
+            for b in range(5):
+                stream = rng.integers(-(1 << 21), 1 << 21, size=(256, 256), dtype=np.int32)
+                eng.ingest_block(make_datagrams(stream, counter0=256 * b, n_arrays=4))
+                ring = np.concatenate([ring[:, 256:], oracle.unpack_exposure(stream, spec.n_mics)], axis=1)
+            from_ring = eng.process_ring()
+            assert names[eng.stats().kernel_variant] == want
+            from_host = eng.process(ring)
+        assert np.array_equal(from_ring, from_host)
+        check_full_grid(oracle, from_ring, ring, off, frac, f"c2 off the ring, reference-order mode ({want})")
+
+
 def test_two_handles_from_two_threads(pkg, oracle):
     """Several AWPUs in one process (the reference runs one per --port): two handles of different shapes used from two
     threads at the same time (ctypes drops the GIL during a call), first launches included -- the one-time kernel
@@ -1002,6 +1028,18 @@ keep = np.array([m for m in range(spec.n_mics) if m % 9 != 2], np.int32)
 grp2 = run([0, 0, 0], 10, keep)
 assert grp2[2].group_exchange == B.EXCHANGE_WINDOWS and grp2[2].group_ranges == 32 // 3 + 1
 assert util.power_rel_err(grp2[0], run(None, 10, keep)[0]) < 5e-6
+# the reference-order mode through a group: raw windows travel, every part runs das_exact_quad_kernel on its row groups --
+# the same quads in the same order as one device: the same bits
+def run_exact(devices):
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=3, grid_columns=spec.res, devices=devices, math=pkg.MATH_F32_EXACT) as eng:
+        eng.set_delay_table(off, frac); eng.set_active_mics(None)
+        d_X = torch.from_numpy(frames[:3]).cuda(); d_P = torch.zeros((3, spec.n_pixels), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        eng.process_device(d_X.data_ptr(), 3, d_P.data_ptr()); eng.synchronize()
+        return d_P.cpu().numpy(), eng.stats()
+e1, eg = run_exact(None), run_exact([0, 0, 0])
+assert B.KERNEL_NAMES[e1[1].kernel_variant] == "exact_quad" and eg[1].group_exchange == B.EXCHANGE_WINDOWS
+assert np.array_equal(e1[0], eg[0])
 print("GROUP PACKED OK")
 """
 
