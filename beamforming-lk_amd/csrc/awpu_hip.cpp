@@ -1103,7 +1103,11 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     if (h->quadh_fits && env().fpi == 0 && env().halves != 0) {
         const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
         const int qpw = (long) awpu::quad1_tiles(rows, cols, 2) * batch >= 256 ? 2 : 1;
-        if ((long) awpu::quad1_tiles(rows, cols, qpw) * batch >= 192 || env().quads == 1 || env().halves == 1) {
+        // from 96 workgroups on.  (Measured, one frame per call, 256 mics: a 100 x 100 grid = 175 workgroups 54.5 us here against
+        // 98.9 us for the 8-wave shape; 64 x 64 = 64 workgroups 56.5 against 47.8 -- this kernel's time is its 256-stage
+        // dependent chain whatever the grid, the 8-wave shape's grows with the pixels: they cross near 80 workgroups.  The
+        // threshold of rounds 2-3 was 192 and sent the four-array, default-resolution case to the slower shape.)
+        if ((long) awpu::quad1_tiles(rows, cols, qpw) * batch >= 96 || env().quads == 1 || env().halves == 1) {
             // pitch between streams: the ring's rows are 2048 floats apart; the history a stream offers the filter is hist_eff
             const int pitch = hist_eff;
             return launch_quadsh(h, d_frames, batch, d_power, s, pitch, layout == kRing ? AWPU_HIST : hist_eff, wstart_eff, qpw);

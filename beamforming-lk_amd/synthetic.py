@@ -52,6 +52,8 @@ WORKLOADS = {
     "c4": WorkloadSpec("c4: 512 mics x 256x256 x 256", 4, 2, 256),
     # what the reference ships: one 8x8 array, --mimo-res 100, --fov 180 (src/main.cpp:38-41,53-56)
     "ref_default": WorkloadSpec("reference default: 64 mics x 100x100 x 256", 1, 1, 100),
+    # the FPGA's four arrays at the reference's default resolution (not a BASELINE config: the mid-size single-frame case)
+    "ref_4arrays": WorkloadSpec("four arrays at the reference's resolution: 256 mics x 100x100 x 256", 4, 1, 100),
 }
 
 

@@ -261,7 +261,7 @@ int awpu_hip_process_device_sums(awpu_hip_t *h, const float *d_frames, int32_t b
  * rank must have been created with the same n_streams, hist, active mics and cfg.window_begin/window_end.
  * awpu_hip_process_packed(pack_frames(x)) gives the bits awpu_hip_process_device(x) gives wherever that call sweeps
  * frame pairs itself (batches that fill the chip: >= 256 workgroups); for smaller batches, where process_device
- * prefers a single-frame shape, the two agree to fp32 rounding (2e-6).
+ * prefers a single-frame shape, the two agree to fp32 rounding (a few 1e-6).
  *   _packed_bytes: *bytes = size of the packed buffer for `batch` frames, AWPU_ERR_STATE when the handle's sweep does
  *                  not take packed frames (the caller then exchanges raw windows and calls awpu_hip_process_device)
  *   _pack_frames:  d_frames [batch][n_streams][hist] -> d_packed, enqueued on `stream` (NULL = the handle's)
