@@ -23,9 +23,12 @@ $(LIB): $(KERNEL_SRC) $(CSRC)/das_kernels.h $(CSRC)/das_fast_trip.inc include/aw
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-result -Werror=inline-asm -x hip \
 	    -Iinclude -I$(CSRC) $(KERNEL_SRC) -o $@
 
-# the hand-scheduled inner loops are generated (tools/gen_trip_asm.py documents the schedule and its knobs)
-trips:
+# the hand-scheduled inner loops are GENERATED at build time (tools/gen_trip_asm.py documents the schedule and its knobs;
+# the include is not tracked)
+$(CSRC)/das_fast_trip.inc: tools/gen_trip_asm.py
 	python3 tools/gen_trip_asm.py
+
+trips: $(CSRC)/das_fast_trip.inc
 
 oracle:
 	$(MAKE) -C oracle
