@@ -723,6 +723,15 @@ int build_exact_pair_lut(awpu_hip *h) {
     return AWPU_OK;
 }
 
+// frame pairs an XCD works on at a time: as many as keep their samples in its 4 MiB L2 beside the table stream (launch_quads)
+int xcd_pair_group(const awpu::FastPlan &pp, int rows_per_pair, int n_pairs) {
+    const size_t pair_bytes = (size_t) rows_per_pair * pp.wr * 8;
+    int g = (int) std::max<size_t>(1, (3u << 20) / pair_bytes);
+    g = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;
+    while (g > 1 && g > n_pairs) g >>= 1;
+    return g;
+}
+
 int launch_exact_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
     int rc = build_exact_pair_lut(h);
     if (rc != AWPU_OK) return rc;
@@ -741,6 +750,9 @@ int launch_exact_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_p
     a.chunk = pp.chunk;
     a.batch = batch;
     a.cols = h->pair_cols;
+    a.tiles = awpu::pair_tiles(a.pixel_count, a.cols);
+    a.n_pairs = (batch + 1) / 2;
+    a.pair_group = xcd_pair_group(pp, pp.usable_pad, a.n_pairs);
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad,
                                          h->d_gain, pp.wr, batch, h->d_pack, false, s));  // raw samples: no stencil in front of the reference's order
@@ -770,13 +782,7 @@ int launch_exact_quads(awpu_hip *h, const float *d_frames, int batch, float *d_p
     a.rows = h->cfg.pixel_count / a.cols;
     a.tiles = awpu::quad_tiles(a.rows, a.cols);
     a.n_pairs = (batch + 1) / 2;
-    {   // frame pairs an XCD works on at a time: as many as keep their samples in its 4 MiB L2 beside the table stream (launch_quads)
-        const size_t pair_bytes = (size_t) pp.usable_pad * pp.wr * 8;
-        int g = (int) std::max<size_t>(1, (3u << 20) / pair_bytes);
-        g = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;
-        while (g > 1 && g > a.n_pairs) g >>= 1;
-        a.pair_group = g;
-    }
+    a.pair_group = xcd_pair_group(pp, pp.usable_pad, a.n_pairs);
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad,
                                          h->d_gain, pp.wr, batch, h->d_pack, false, s));

@@ -962,7 +962,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
 // reference's (and to das_exact_kernel's; a.sums exports them for the tests).  The epilogue is mimo.cpp:131-137 with
 // whole-wave rotations for the neighbours.  Padding mics (usable rounded up to 4) read rows of zeros with fraction 0:
 // t = fma(0, 0 - 0, 0) = +0 and out + 0 = out bit for bit (out starts at +0 and can never become -0).
-// Workgroup = 16 waves, a wave 4 pixels (two vertical pairs when the row length is known); grid = (pairs, tiles).
+// Workgroup = 16 waves, a wave 4 pixels (two vertical pairs when the row length is known); 1-D grid of items, XCD-aware order.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ f2 finish_pixel_pair_exact(const f2 (&o)[4], int lane) {
     f2 sum = f2{0.0f, 0.0f};
@@ -993,7 +993,21 @@ __global__ __launch_bounds__(1024, 4) void das_exact_pair_kernel(ExactPairArgs a
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
-    const int pair = blockIdx.x, tile = blockIdx.y;
+    // items (frame pair, tile) in das_quad_kernel's order -- (pair group, tile, pair), one contiguous run per XCD -- so that an
+    // XCD's workgroups share a few pairs' samples in its L2 while they walk the table (see das_exact_quad_kernel)
+    const int total = a.n_pairs * a.tiles;
+    const int per_xcd = (total + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= min(total, ((int) (blockIdx.x & 7) + 1) * per_xcd)) return;  // (uniform for the workgroup)
+    int pair, tile;
+    {
+        const int full_items = (a.n_pairs / a.pair_group) * a.pair_group * a.tiles;
+        const int ga = item < full_items ? a.pair_group : a.n_pairs % a.pair_group;
+        const int rem = item < full_items ? item : item - full_items;
+        const int grp = rem / (a.tiles * ga), in = rem - grp * a.tiles * ga;
+        tile = in / ga;
+        pair = (item < full_items ? grp * a.pair_group : a.n_pairs - ga) + (in - tile * ga);
+    }
     int pix[PPW];    // pixel of slot q (slots 2j, 2j+1 are the two pixels of one block)
     bool live[PPW];  // false: outside the grid, swept on another pixel's (or a null) row and not stored
     int pair_rows;   // table rows between the two pixels of a block
@@ -2089,8 +2103,9 @@ hipError_t launch_das_exact_pairs(const ExactPairArgs &a, hipStream_t stream) {
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_exact_pair_kernel, lds_bytes, attr_set); e != hipSuccess) return e;
     if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || (size_t) a.chunk * a.wp * 8 > (size_t) kFastLdsBytes) return hipErrorInvalidValue;
-    dim3 grid((a.batch + 1) / 2, pair_tiles(a.pixel_count, a.cols));
-    if (grid.y > 65535) return hipErrorInvalidValue;
+    if (a.n_pairs != (a.batch + 1) / 2 || a.tiles != pair_tiles(a.pixel_count, a.cols) || a.pair_group < 1) return hipErrorInvalidValue;
+    const long total = (long) a.n_pairs * a.tiles;
+    dim3 grid((unsigned) (8 * ((total + 7) / 8)));
     hipLaunchKernelGGL(das_exact_pair_kernel, grid, dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }

@@ -116,6 +116,7 @@ struct ExactPairArgs {
     float *sums;           // optional [batch][pixel_count][256]: out[] of every pixel before the epilogue (tests), or null
     int32_t usable, usable_pad, pixel_count, wp, chunk, batch;
     int32_t cols;          // > 0: the grid's row length; a wave then sweeps vertical pixel pairs (pixel_count % cols == 0)
+    int32_t tiles, n_pairs, pair_group;  // 64-pixel tiles (pair_tiles); frame pairs, and how many an XCD works on at a time
 };
 hipError_t launch_das_exact_pairs(const ExactPairArgs &a, hipStream_t stream);
 // the same with four vertically adjacent pixels per wave (das_exact_quad_kernel): the quad-major table of the quad shapes
