@@ -881,6 +881,9 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
     pa.chunk = pp.chunk;
     pa.batch = batch;
     pa.cols = h->pair_cols;
+    pa.tiles = awpu::pair_tiles(h->cfg.pixel_count, h->pair_cols);
+    pa.n_pairs = (batch + 1) / 2;
+    pa.pair_group = xcd_pair_group(pp, h->usable(), pa.n_pairs);
     pa.debug = env().debug;
     pa.debug_out = nullptr;
     size_t n_waves = 0;

@@ -739,10 +739,22 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
-    // dispatch order: the pairs of a tile are consecutive (they share the tile's table rows in L2);
-    // debug bit 256 swaps the roles (tiles of a pair consecutive: they share the pair's samples)
-    const int pair = (a.debug & 256) ? blockIdx.y : blockIdx.x;
-    const int tile = (a.debug & 256) ? blockIdx.x : blockIdx.y;
+    // dispatch order (round 4: das_quad_kernel's): the items (frame pair, tile), ordered (pair group, tile, pair), are cut into 8
+    // contiguous runs, one per XCD (blockIdx & 7: round-robin placement, assumed for speed only): an XCD's workgroups sweep
+    // `pair_group` frame pairs x a few tiles at a time, the pairs' samples stay in its L2 while it walks the table
+    const int total = a.n_pairs * a.tiles;
+    const int per_xcd = (total + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= min(total, ((int) (blockIdx.x & 7) + 1) * per_xcd)) return;  // (uniform for the workgroup)
+    int pair, tile;
+    {
+        const int full_items = (a.n_pairs / a.pair_group) * a.pair_group * a.tiles;
+        const int ga = item < full_items ? a.pair_group : a.n_pairs % a.pair_group;
+        const int rem = item < full_items ? item : item - full_items;
+        const int grp = rem / (a.tiles * ga), in = rem - grp * a.tiles * ga;
+        tile = in / ga;
+        pair = (item < full_items ? grp * a.pair_group : a.n_pairs - ga) + (in - tile * ga);
+    }
     // Which pixels this wave sweeps.  Neighbouring pixels in a grid column usually differ less in delay than
     // neighbours in a row (arrays are wider than tall), and the shared-read block profits from pixels whose
     // integer delays coincide, so when the grid's row length is known (a.cols > 0) a workgroup takes 32
@@ -846,7 +858,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
     }
 
     if (DIAG && a.debug_out && lane == 0) {
-        unsigned long long *o = a.debug_out + 12 * ((size_t) (blockIdx.y * gridDim.x + blockIdx.x) * NW + wave);
+        unsigned long long *o = a.debug_out + 12 * ((size_t) item * NW + wave);
         o[0] = t_wait;
         o[1] = t_all;
         o[2] = (unsigned long long) (__builtin_readcyclecounter() - t_begin);
@@ -1979,9 +1991,9 @@ static hipError_t launch_pair_variant(const PairArgs &a, hipStream_t stream) {
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_pair_kernel<PPW, DIAG, SHARE>, lds_bytes, attr_set); e != hipSuccess) return e;
     static_assert(16 * PPW == 64, "pair_tiles() counts 64-pixel tiles");
-    dim3 grid((a.batch + 1) / 2, pair_tiles(a.pixel_count, a.cols));
-    if (a.debug & 256) grid = dim3(grid.y, grid.x);
-    if (grid.y > 65535) return hipErrorInvalidValue;
+    if (a.n_pairs != (a.batch + 1) / 2 || a.tiles != pair_tiles(a.pixel_count, a.cols) || a.pair_group < 1) return hipErrorInvalidValue;
+    const long total = (long) a.n_pairs * a.tiles;
+    dim3 grid((unsigned) (8 * ((total + 7) / 8)));
     hipLaunchKernelGGL((das_pair_kernel<PPW, DIAG, SHARE>), grid, dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }

@@ -90,6 +90,7 @@ struct PairArgs {
     float *power;          // [batch][pixel_count]
     int32_t usable, usable_pad, pixel_count, wp, chunk, batch;
     int32_t cols;  // > 0: the grid's row length; a wave then sweeps vertical pixel pairs (pixel_count % cols == 0)
+    int32_t tiles, n_pairs, pair_group;  // das_pair_kernel: 64-pixel tiles; frame pairs, and how many an XCD works on at a time
     unsigned long long *debug_out;
     int32_t debug;
 };
