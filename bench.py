@@ -783,17 +783,20 @@ def main():
     # ---- N > 1, opt-in: the assembled heatmap of frame 0 must equal what the shards computed (a collective
     # after the result line, so that a rank that fails here cannot cost the run its line)
     if world > 1 and os.environ.get("BENCH_GATHER_CHECK", "1") == "1":  # (on by default: the RCCL schedules have only ever run over gloo)
-        full = sharding.gather_power(d_power[:1].contiguous(), job.shards, dst=0)
-        if rank == 0:
-            cols = spec.res
-            mine = torch.cat([full[0, r * cols:(r + 1) * cols] for r in shard.rows()]) if not c5 else full[0, : shard.pixel_count]
-            ok = full.shape == (1, grid_pixels) and torch.equal(mine, d_power[0])
-            msg = "ok" if ok else "MISMATCH: the assembled heatmap differs from rank 0's tile"
-            if ok and not c5:  # the whole assembled heatmap against the oracle, every pixel, unfloored
-                off_all, frac_all = S.delay_table(spec, xyz, 0, spec.res)
-                rep = full_grid_parity(full[0].cpu().numpy(), host_first[0], off_all, frac_all, args.math, args.interp)
-                msg = f"{'ok' if rep['ok'] else 'PARITY FAILED'}: assembled {world}-rank heatmap vs oracle on {rep['pixels']} pixels: {rep}"
-            print("gather check:", msg, file=sys.stderr)
+        try:  # (a check AFTER the result line: whatever happens here must not cost the run its exit status)
+            full = sharding.gather_power(d_power[:1].contiguous(), job.shards, dst=0)
+            if rank == 0:
+                cols = spec.res
+                mine = torch.cat([full[0, r * cols:(r + 1) * cols] for r in shard.rows()]) if not c5 else full[0, : shard.pixel_count]
+                ok = full.shape == (1, grid_pixels) and torch.equal(mine, d_power[0])
+                msg = "ok" if ok else "MISMATCH: the assembled heatmap differs from rank 0's tile"
+                if ok and not c5:  # the whole assembled heatmap against the oracle, every pixel, unfloored
+                    off_all, frac_all = S.delay_table(spec, xyz, 0, spec.res)
+                    rep = full_grid_parity(full[0].cpu().numpy(), host_first[0], off_all, frac_all, args.math, args.interp)
+                    msg = f"{'ok' if rep['ok'] else 'PARITY FAILED'}: assembled {world}-rank heatmap vs oracle on {rep['pixels']} pixels: {rep}"
+                print("gather check:", msg, file=sys.stderr)
+        except Exception as exc:  # noqa: BLE001
+            print(f"gather check: raised on rank {rank}: {exc}", file=sys.stderr)
 
     job.close()
     if run_guard:
