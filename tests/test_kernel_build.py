@@ -57,3 +57,18 @@ def test_sweep_kernels_do_not_spill(kernel_metadata):
         assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (name, m)
         assert m["vgpr_count"] <= 128, (name, m)
     assert checked >= 12, sorted(kernel_metadata)
+
+
+def test_tuning_build_still_links(pkg, tmp_path):
+    """The kernels, stamped instances and environment knobs that round 4 moved out of the shipping library live on behind
+    -DAWPU_TUNING_BUILD / -DAWPU_TIMING_BUILD (AWPU_EXTRA_HIPCC_FLAGS): that build must keep compiling and linking, or the
+    measurements DESIGN.md cites could not be repeated.  It reads the round-1..3 variables; the shipping library does not."""
+    pkg._build.generate_blocks()
+    out = tmp_path / "libawpu_tuning.so"
+    srcs = [str(CSRC / f) for f in ("das_kernels.hip", "das_fast.hip", "awpu_hip.cpp", "geometry_host.cpp")]
+    subprocess.run([pkg._build.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
+                    "-Werror=inline-asm", "-x", "hip", "-DAWPU_TIMING_BUILD", f"-I{REPO / 'include'}", f"-I{CSRC}", *srcs, "-o", str(out)],
+                   check=True, capture_output=True)
+    names = {ln for ln in subprocess.run(["strings", "-a", str(out)], capture_output=True, text=True, check=True).stdout.splitlines()
+             if re.fullmatch(r"AWPU_[A-Z0-9_]+", ln)}
+    assert {"AWPU_SHAPE", "AWPU_FAST_DEBUG", "AWPU_FAST_QUADS", "AWPU_FAST_PAIRGROUP", "AWPU_FIR8_STATIC"} <= names
