@@ -1825,6 +1825,8 @@ int awpu_hip_set_delay_table(awpu_hip_t *h, const int32_t *off, const float *fra
     if (!h->parts.empty()) {  // every device gets the rows of its pixel ranges, back to back
         h->union_window_done = false;
         return for_each_part(h, [&](awpu_hip *part) {
+            part->cfg.window_begin = h->cfg.window_begin;  // (the union window of the OLD table is void: back to the caller's, if any)
+            part->cfg.window_end = h->cfg.window_end;
             const size_t stride = (size_t) h->cfg.lut_stride;
             if (part->ranges.size() == 1) {
                 const size_t first = (size_t) part->ranges[0].first * stride;
@@ -1857,7 +1859,11 @@ int awpu_hip_set_active_mics(awpu_hip_t *h, const int32_t *index, int32_t usable
     if (!h) return invalid("null handle");
     if (!h->parts.empty()) {
         h->union_window_done = false;
-        return for_each_part(h, [&](awpu_hip *part) { return awpu_hip_set_active_mics(part, index, usable); });
+        return for_each_part(h, [&](awpu_hip *part) {
+            part->cfg.window_begin = h->cfg.window_begin;  // (as in awpu_hip_set_delay_table: the union is taken anew)
+            part->cfg.window_end = h->cfg.window_end;
+            return awpu_hip_set_active_mics(part, index, usable);
+        });
     }
     const int limit = std::min(h->cfg.n_streams, h->cfg.lut_stride);
     if (usable < 1 || usable > limit) return invalid("usable outside [1, min(n_streams, lut_stride)]");

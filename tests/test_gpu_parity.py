@@ -1040,6 +1040,29 @@ def run_exact(devices):
 e1, eg = run_exact(None), run_exact([0, 0, 0])
 assert B.KERNEL_NAMES[e1[1].kernel_variant] == "exact_quad" and eg[1].group_exchange == B.EXCHANGE_WINDOWS
 assert np.array_equal(e1[0], eg[0])
+# one group handle re-targeted: the union window of the first table does not outlive it (a narrower second table gets its
+# own, narrower union -- and the same bits as a fresh single-device handle on that table)
+off_b = (off.max() + off.min() - off).astype(off.dtype); frac_b = np.ascontiguousarray(frac[::-1])
+off_n = np.clip(off, off.min(), off.min() + 8).astype(off.dtype)
+def sweep_tables(devices, tables):
+    res = []
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=10, grid_columns=spec.res, devices=devices) as eng:
+        eng.set_active_mics(None)
+        d_X = torch.from_numpy(frames).cuda(); d_P = torch.zeros((10, spec.n_pixels), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        for o, f in tables:
+            eng.set_delay_table(o, f)
+            eng.process_device(d_X.data_ptr(), 10, d_P.data_ptr()); eng.synchronize()
+            st = eng.stats()
+            res.append((d_P.cpu().numpy().copy(), st.window))
+    return res
+tables = [(off, frac), (off_b, frac_b), (off_n, frac), (off, frac)]
+grp = sweep_tables([0, 0], tables)
+for k, (o, f) in enumerate(tables):
+    fresh = sweep_tables(None, [(o, f)])[0]
+    assert np.array_equal(grp[k][0], fresh[0]), k
+    assert grp[k][1] == fresh[1], (k, grp[k][1], fresh[1])
+assert grp[2][1] < grp[0][1]   # the narrow table's window IS narrower
 print("GROUP PACKED OK")
 """
 
