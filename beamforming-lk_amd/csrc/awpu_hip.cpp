@@ -78,9 +78,12 @@ struct awpu_hip {
     struct FastLut {
         awpu::FastPlan plan;
         awpu::FastEntry *d = nullptr;
+        size_t entries = 0;  // allocated (the launchers check their kernel's reach against it: das_kernels.h, Extents)
     };
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     awpu::FastEntry *d_exact_pair_lut = nullptr;  // reference-order sweep on the frame-pair layout (das_exact_pair_kernel)
+    size_t exact_pair_lut_entries = 0, fir_plane_lut_entries = 0;  // allocated entries of the tables below and above ...
+    size_t quad_lut_entries[5] = {0, 0, 0, 0, 0};                  // ... and of the quad-major tables, by QuadLayout
     awpu::QuadEntry *d_exact_quad_lut = nullptr;  // ... four vertically adjacent pixels per wave (das_exact_quad_kernel): quad-major, raw fractions
     awpu::FastPlan exact_plan{};
     bool exact_pairs_ok = false;  // AWPU_MATH_F32_EXACT + LERP and the window fits the pair image
@@ -540,7 +543,7 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
     // grid get null rows) + spare groups: the kernels prefetch entries past the row they sweep
     // (with vertical pixel pairs the partner of a pixel in the last row lies one grid row past the table)
     const int P_pad = (P + (pairs ? h->pair_cols : 0) + 127) / 128 * 128;
-    const size_t n = (size_t) P_pad * plan.usable_pad + 16;
+    const size_t n = (size_t) P_pad * plan.usable_pad + 4 * awpu::kPairTablePrefetch;
     std::vector<awpu::FastEntry> packed(n, awpu::FastEntry{0.0f, 0u, 0.0f, 0u});
     for (int p = 0; p < P; p++) {
         const int32_t *orow = &h->off[(size_t) p * c.lut_stride];
@@ -563,6 +566,7 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
     }
     AWPU_HIP_TRY(hipMalloc(&lut.d, n * sizeof(awpu::FastEntry)));
     AWPU_HIP_TRY(hipMemcpy(lut.d, packed.data(), n * sizeof(awpu::FastEntry), hipMemcpyHostToDevice));
+    lut.entries = n;
     h->fast_luts.reserve(8);
     h->fast_luts.push_back(lut);
     *out = &h->fast_luts.back();
@@ -589,7 +593,7 @@ int build_quad_lut(awpu_hip *h, int layout) {
     const int U = h->usable(), cols = c.grid_columns, rows = c.pixel_count / cols;
     const int groups = plan.usable_pad / 4;
     const int cols_pad = (cols + 15) / 16 * 16, rows4 = (rows + 3) / 4;
-    const size_t n = (size_t) rows4 * cols_pad * groups * 16 + 32;  // + a spare group: the sweep prefetches one past the end
+    const size_t n = (size_t) rows4 * cols_pad * groups * 16 + 2 * awpu::kQuadTablePrefetch;  // spare groups: the sweep prefetches one past the end
     std::vector<awpu::QuadEntry> packed(n, awpu::QuadEntry{0.0f, 0u});
     for (int r4 = 0; r4 < rows4; r4++)
         for (int col = 0; col < cols_pad; col++) {
@@ -617,6 +621,7 @@ int build_quad_lut(awpu_hip *h, int layout) {
         }
     AWPU_HIP_TRY(hipMalloc(&d_lut, n * sizeof(awpu::QuadEntry)));
     AWPU_HIP_TRY(hipMemcpy(d_lut, packed.data(), n * sizeof(awpu::QuadEntry), hipMemcpyHostToDevice));
+    h->quad_lut_entries[layout] = n;
     return AWPU_OK;
 }
 
@@ -704,7 +709,7 @@ int build_exact_pair_lut(awpu_hip *h) {
     const awpu::FastPlan &plan = h->exact_plan;
     const int U = h->usable(), P = c.pixel_count;
     const int P_pad = (P + h->pair_cols + 127) / 128 * 128;  // whole tiles; with vertical pairs the partner of a last-row pixel lies one grid row past the table
-    const size_t n = (size_t) P_pad * plan.usable_pad + 16;  // + one spare group: the block prefetches one past a row's end
+    const size_t n = (size_t) P_pad * plan.usable_pad + 4 * awpu::kPairTablePrefetch;  // spare groups: the block prefetches one past a row's end
     std::vector<awpu::FastEntry> packed(n);
     for (size_t i = 0; i < n; i++)  // null entry of slot s: the zero row of its own slot in the last chunk, or any row with fraction 0 ...
         packed[i] = awpu::FastEntry{0.0f, (uint32_t) ((int) (i % plan.usable_pad) % plan.chunk * plan.row_bytes), 0.0f, 0u};
@@ -720,6 +725,7 @@ int build_exact_pair_lut(awpu_hip *h) {
     }
     AWPU_HIP_TRY(hipMalloc(&h->d_exact_pair_lut, n * sizeof(awpu::FastEntry)));
     AWPU_HIP_TRY(hipMemcpy(h->d_exact_pair_lut, packed.data(), n * sizeof(awpu::FastEntry), hipMemcpyHostToDevice));
+    h->exact_pair_lut_entries = n;
     return AWPU_OK;
 }
 
@@ -756,7 +762,7 @@ int launch_exact_pairs(awpu_hip *h, const float *d_frames, int batch, float *d_p
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad,
                                          h->d_gain, pp.wr, batch, h->d_pack, false, s));  // raw samples: no stencil in front of the reference's order
-    AWPU_HIP_TRY(awpu::launch_das_exact_pairs(a, s));
+    AWPU_HIP_TRY(awpu::launch_das_exact_pairs(a, {h->exact_pair_lut_entries, h->pack_cap}, s));
     return finish_launch(h, batch, s, AWPU_KERNEL_EXACT_PAIR);
 }
 
@@ -786,7 +792,7 @@ int launch_exact_quads(awpu_hip *h, const float *d_frames, int batch, float *d_p
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad,
                                          h->d_gain, pp.wr, batch, h->d_pack, false, s));
-    AWPU_HIP_TRY(awpu::launch_das_exact_quads(a, s));
+    AWPU_HIP_TRY(awpu::launch_das_exact_quads(a, {h->quad_lut_entries[kQuadExact], h->pack_cap}, s));
     return finish_launch(h, batch, s, AWPU_KERNEL_EXACT_QUAD);
 }
 
@@ -822,7 +828,7 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
         const uint32_t plane_bytes = (uint32_t) pp.row_bytes / 4;
         // one dword per (pixel, mic); four spare: the block requests entries four items ahead.  Null entries (the
         // padding of a row, the spares) read row 0 with the zero coefficient row.
-        std::vector<uint32_t> packed((size_t) P * row_entries + 4 + 64, awpu::fir8_plane_word(0, 0, awpu::kFir8ZeroRow));
+        std::vector<uint32_t> packed((size_t) P * row_entries + awpu::kFir8PlaneTablePrefetch, awpu::fir8_plane_word(0, 0, awpu::kFir8ZeroRow));
         for (int p = 0; p < P; p++) {
             const int32_t *orow = &h->off[(size_t) p * h->cfg.lut_stride];
             const float *frow = &h->frac[(size_t) p * h->cfg.lut_stride];
@@ -836,6 +842,7 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
         }
         AWPU_HIP_TRY(hipMalloc(&h->d_fir_plane_lut, packed.size() * sizeof(uint32_t)));
         AWPU_HIP_TRY(hipMemcpy(h->d_fir_plane_lut, packed.data(), packed.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        h->fir_plane_lut_entries = packed.size();
     }
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * U * pp.wr * 2;
     if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
@@ -859,13 +866,14 @@ int launch_fir8_planes(awpu_hip *h, const float *d_frames, int batch, float *d_p
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_planes(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, U, h->d_gain, pp.wr,
                                           batch, h->d_pack, s));
-    AWPU_HIP_TRY(awpu::launch_das_fir8_planes(pa, h->d_fir_plane_lut, h->d_fir, env().quad_variant, s));
+    AWPU_HIP_TRY(awpu::launch_das_fir8_planes(pa, h->d_fir_plane_lut, h->d_fir, env().quad_variant, {h->fir_plane_lut_entries, h->pack_cap}, s));
     return finish_launch(h, batch, s, AWPU_KERNEL_FIR8_PLANES);
 }
 
 // frame-pair shape: two frames per item, for batches on grids that fill the chip
 int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_frames, int batch, float *d_power,
-                 hipStream_t s, int hist_eff, int wstart_eff, int stationary_tiles = 0, const float *prepacked = nullptr) {
+                 hipStream_t s, int hist_eff, int wstart_eff, int stationary_tiles = 0, const float *prepacked = nullptr,
+                 size_t prepacked_floats = 0) {
     const awpu::FastPlan &pp = plut->plan;
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * h->usable() * pp.wr * 2;
     if (!prepacked)
@@ -898,10 +906,11 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
     if (!prepacked)
         AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
                                              h->usable(), nullptr, pp.wr, batch, h->d_pack, true, s));  // gains ride on the table weights here
+    const awpu::Extents have{plut->entries, prepacked ? prepacked_floats : h->pack_cap};
     if (stationary_tiles > 0) {
-        AWPU_HIP_TRY(awpu::launch_das_pairs_stationary(pa, stationary_tiles, s));
+        AWPU_HIP_TRY(awpu::launch_das_pairs_stationary(pa, stationary_tiles, have, s));
     } else {
-        AWPU_HIP_TRY(awpu::launch_das_pairs(pa, s));
+        AWPU_HIP_TRY(awpu::launch_das_pairs(pa, have, s));
     }
     const int rc = finish_launch(h, batch, s, stationary_tiles > 0 ? AWPU_KERNEL_PAIR_STATIONARY : AWPU_KERNEL_PAIR);
     if (rc != AWPU_OK || !(pa.debug & 16)) return rc;
@@ -910,7 +919,7 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
 
 // quad shape: the frame-pair layout swept four vertically adjacent pixels at a time (das_quad_kernel)
 int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff,
-                 const float *prepacked = nullptr) {
+                 const float *prepacked = nullptr, size_t prepacked_floats = 0) {
     int rc = build_quad_lut(h, kQuadPairs);
     if (rc != AWPU_OK) return rc;
     const awpu::FastPlan &pp = h->quad_plan;
@@ -966,7 +975,7 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
     if (!prepacked)
         AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
                                              pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, true, s));
-    AWPU_HIP_TRY(awpu::launch_das_quads(qa, s));
+    AWPU_HIP_TRY(awpu::launch_das_quads(qa, {h->quad_lut_entries[kQuadPairs], prepacked ? prepacked_floats : h->pack_cap}, s));
     rc = finish_launch(h, batch, s, AWPU_KERNEL_QUAD);
     if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
     return dump_diag(h, n_waves, 16, "quads", s);
@@ -1004,7 +1013,7 @@ int launch_quadsh(awpu_hip *h, const float *d_frames, int batch, float *d_power,
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_halves(d_frames, h->cfg.n_streams, pitch, hist_eff, wstart_eff, h->d_index, h->usable(),
                                           pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, s));
-    AWPU_HIP_TRY(awpu::launch_das_quadh(qa, qpw, s));
+    AWPU_HIP_TRY(awpu::launch_das_quadh(qa, qpw, {h->quad_lut_entries[kQuadHalves], h->pack_cap}, s));
     rc = finish_launch(h, batch, s, AWPU_KERNEL_QUADH);
     if (rc != AWPU_OK || !(qa.debug & 16)) return rc;
     return dump_diag(h, n_waves, 16, "quadsh", s);
@@ -1040,7 +1049,7 @@ int launch_quadsh_stationary(awpu_hip *h, const float *d_frames, int batch, floa
     if (!awpu::quadh_stationary_raw(pp, qa.usable, wstart_eff, qa.row_limit, &qa.raw_begin, &qa.raw_wr, &qa.image_offset))
         return invalid("the raw window does not fit the LDS beside the halves image");  // (launch() asks before it comes here)
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    AWPU_HIP_TRY(awpu::launch_das_quadh_stationary(qa, qpw, s));
+    AWPU_HIP_TRY(awpu::launch_das_quadh_stationary(qa, qpw, {h->quad_lut_entries[kQuadHalvesStationary], 0}, s));
     return finish_launch(h, batch, s, AWPU_KERNEL_QUADH_STATIONARY);
 }
 
@@ -1164,7 +1173,7 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         a.debug_out = h->d_diag;
     }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, s));
+    AWPU_HIP_TRY(awpu::launch_das_fast(a, fpi, ppw, nw, {lut->entries, 0}, s));
     rc = finish_launch(h, batch, s, nw == 32 ? AWPU_KERNEL_SINGLE_DB : (nw == 8 && fpi == 1 && ppw <= 4 ? AWPU_KERNEL_SINGLE_SMALL : AWPU_KERNEL_TUNING));
     if (rc != AWPU_OK || !a.debug_out) return rc;
     return dump_diag(h, n_waves, wg_waves, "single", s);
@@ -1439,15 +1448,16 @@ bool takes_packed_pairs(awpu_hip *h, int batch, awpu::FastPlan *plan) {
 }
 
 // the sweep of packed frame pairs (what awpu_hip_process_packed does once its arguments are checked)
-int sweep_packed(awpu_hip *h, const awpu::FastPlan &plan, const float *d_packed, int batch, float *d_power, hipStream_t s) {
+int sweep_packed(awpu_hip *h, const awpu::FastPlan &plan, const float *d_packed, size_t packed_floats, int batch, float *d_power,
+                 hipStream_t s) {
     const bool quad_fills = h->quad_ok && ((long) awpu::quad_tiles(h->cfg.pixel_count / h->cfg.grid_columns, h->cfg.grid_columns) *
                                                ((batch + 1) / 2) >= 256 || env().quads == 1);
     if (quad_fills && env().pairs != 0 && h->quad_plan.wr == plan.wr && h->quad_plan.usable_pad == h->usable())
-        return launch_quads(h, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, d_packed);
+        return launch_quads(h, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, d_packed, packed_floats);
     const awpu_hip::FastLut *plut = nullptr;
     const int rc = build_fast_lut(h, 2, -1, &plut);
     if (rc != AWPU_OK) return rc;
-    return launch_pairs(h, plut, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, 0, d_packed);
+    return launch_pairs(h, plut, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, 0, d_packed, packed_floats);
 }
 
 // Every part of a group stages the same window -- the union of what the parts' own rows touch -- so that ONE packed buffer
@@ -1616,7 +1626,7 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
         if (in_place(part)) {  // same GPU: sweep the caller's frames (or the group's packed buffer) in place
             AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, g->ev_fan, 0));
             if (packed) {
-                r = sweep_packed(part, pplan, g->d_fan[pb], batch, part->d_power, part->stream);
+                r = sweep_packed(part, pplan, g->d_fan[pb], g->fan_cap, batch, part->d_power, part->stream);
                 if (r == AWPU_OK) AWPU_HIP_TRY(hipEventRecord(part->ev_swept[pb], part->stream));
             } else {
                 r = launch(part, d_frames, batch, part->d_power, part->stream, kFull);
@@ -1667,7 +1677,7 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
             part->fan_used[b] = true;
             AWPU_HIP_TRY(hipEventRecord(part->ev_copied[b], part->copy_stream));
             AWPU_HIP_TRY(hipStreamWaitEvent(part->stream, part->ev_copied[b], 0));
-            r = packed ? sweep_packed(part, pplan, part->d_fan[b], batch, part->d_power, part->stream)
+            r = packed ? sweep_packed(part, pplan, part->d_fan[b], part->fan_cap, batch, part->d_power, part->stream)
                        : launch(part, part->d_fan[b], batch, part->d_power, part->stream, compact ? kCompact : kFull);
             if (r == AWPU_OK) AWPU_HIP_TRY(hipEventRecord(part->ev_swept[b], part->stream));
             if (r == AWPU_OK && staged) {  // the tile's way back starts on the part's own stream: device -> pinned
@@ -2483,7 +2493,8 @@ int awpu_hip_process_packed(awpu_hip_t *h, const float *d_packed, int32_t batch,
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
     TimingOff untimed(h);  // asynchronous path: the caller times its own stream
     // the shape awpu_hip_process_device takes for this batch (same rule: same bits), as long as that is a frame-pair shape
-    return sweep_packed(h, plan, d_packed, batch, d_power, s);
+    // (the buffer is the caller's: awpu_hip_packed_bytes(batch) of it are taken to be there, and the sweep reads no further)
+    return sweep_packed(h, plan, d_packed, (size_t) ((batch + 1) / 2) * h->usable() * plan.wr * 2, batch, d_power, s);
 }
 
 int awpu_hip_synchronize(awpu_hip_t *h) {

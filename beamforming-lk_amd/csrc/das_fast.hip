@@ -1928,6 +1928,20 @@ static hipError_t allow_lds(const void *kernel, int bytes, LdsFlags &done) {
     return hipSuccess;
 }
 
+// reach of the kernels (das_kernels.h, Extents): the furthest table entry / packed float a launch can load
+static bool within(const Extents &reach, const Extents &have) {
+    return reach.lut_entries <= have.lut_entries && reach.sample_floats <= have.sample_floats;
+}
+// pixel-major tables ([pixel][usable_pad] FastEntry / dword): rows a frame-pair launch can address -- with the grid's row
+// length known, the clamped pixel of slot A plus one grid row for its vertical partner; else whole 64-pixel tiles
+static size_t pair_table_rows(int pixel_count, int cols) {
+    return cols > 0 ? (size_t) pixel_count + cols : ((size_t) pixel_count + 63) / 64 * 64;
+}
+// quad-major tables ([quad][group][4 pixels][4 mics] QuadEntry): every quad of the padded grid, one group of prefetch
+static size_t quad_table_reach(int rows, int cols, int usable_pad) {
+    return (size_t) quad_count(rows, cols) * (usable_pad / 4) * 16 + kQuadTablePrefetch;
+}
+
 template <int NW, int PPW, int FPI, int WPS>
 static hipError_t launch_variant(const FastArgs &a, hipStream_t stream) {
     static LdsFlags attr_set = {};
@@ -1986,12 +2000,16 @@ hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int
 }
 
 template <int PPW, bool DIAG, bool SHARE>
-static hipError_t launch_pair_variant(const PairArgs &a, hipStream_t stream) {
+static hipError_t launch_pair_variant(const PairArgs &a, const Extents &have, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_pair_kernel<PPW, DIAG, SHARE>, lds_bytes, attr_set); e != hipSuccess) return e;
     static_assert(16 * PPW == 64, "pair_tiles() counts 64-pixel tiles");
     if (a.n_pairs != (a.batch + 1) / 2 || a.tiles != pair_tiles(a.pixel_count, a.cols) || a.pair_group < 1) return hipErrorInvalidValue;
+    // reach: the last pixel's row + one group of prefetch; `usable` rows of wp elements per frame pair, in whole 16-byte pieces
+    if ((a.wp & 1) || !within({pair_table_rows(a.pixel_count, a.cols) * a.usable_pad + kPairTablePrefetch,
+                               (size_t) a.n_pairs * a.usable * a.wp * 2}, have))
+        return hipErrorInvalidValue;
     const long total = (long) a.n_pairs * a.tiles;
     dim3 grid((unsigned) (8 * ((total + 7) / 8)));
     hipLaunchKernelGGL((das_pair_kernel<PPW, DIAG, SHARE>), grid, dim3(1024), lds_bytes, stream, a);
@@ -2012,10 +2030,14 @@ bool pair_plan_stationary(int window, int usable, FastPlan *plan) {
     return true;
 }
 
-hipError_t launch_das_pairs_stationary(const PairArgs &a, int tiles_per_wg, hipStream_t stream) {
+hipError_t launch_das_pairs_stationary(const PairArgs &a, int tiles_per_wg, const Extents &have, hipStream_t stream) {
     static LdsFlags attr_set[2] = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     const int n_tiles = pair_tiles(a.pixel_count, a.cols);
+    if (tiles_per_wg < 1 || (a.wp & 1) || (size_t) a.usable * a.wp * 8 > (size_t) lds_bytes ||
+        !within({pair_table_rows(a.pixel_count, a.cols) * a.usable_pad + kPairTablePrefetch,
+                 (size_t) ((a.batch + 1) / 2) * a.usable * a.wp * 2}, have))
+        return hipErrorInvalidValue;
     dim3 grid((a.batch + 1) / 2, (n_tiles + tiles_per_wg - 1) / tiles_per_wg);
     if (grid.y > 65535) return hipErrorInvalidValue;
 #ifdef AWPU_TUNING_BUILD  // debug bit 4096: the pixel-major block without read sharing (the same bits)
@@ -2067,13 +2089,17 @@ hipError_t launch_pack_planes(const float *d_frames, int n_streams, int hist, in
 }
 
 template <int VAR>
-static hipError_t launch_fir8_plane_variant(const PairArgs &a, const void *d_entries, const float *d_coeffs, hipStream_t stream) {
+static hipError_t launch_fir8_plane_variant(const PairArgs &a, const void *d_entries, const float *d_coeffs, const Extents &have,
+                                            hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_fir8_plane_kernel<VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
     const int n_pairs = (a.batch + 1) / 2;
     const int n_tiles = a.cols > 0 ? ((a.pixel_count / a.cols + 3) / 4) * ((a.cols + 15) / 16) : (a.pixel_count + 63) / 64;
     if (a.cols > 0 && (unsigned) a.wp * 2u != kFirStaticPlaneBytes) return hipErrorInvalidValue;  // (the shared block is generated for that pitch)
+    // reach: slots past the grid repeat a pixel inside it -- pixel_count rows of one dword per mic, and the block's prefetch
+    if ((a.wp & 3) || !within({(size_t) a.pixel_count * a.usable_pad + kFir8PlaneTablePrefetch, (size_t) n_pairs * a.usable * a.wp * 2}, have))
+        return hipErrorInvalidValue;
     // frame pairs an XCD works on at a time: as many as keep their packed samples in its 4 MiB L2 beside the table slices
     const size_t pair_bytes = (size_t) a.usable * a.wp * 8;
     int g = (int) std::max<size_t>(1, (3u << 20) / pair_bytes);
@@ -2086,17 +2112,18 @@ static hipError_t launch_fir8_plane_variant(const PairArgs &a, const void *d_ent
     return hipGetLastError();
 }
 
-hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, const float *d_coeffs, int variant, hipStream_t stream) {
+hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, const float *d_coeffs, int variant, const Extents &have,
+                                  hipStream_t stream) {
 #ifdef AWPU_QUAD_VARIANTS  // tuning builds (tools/gen_trip_asm.py with QUAD_VARIANTS=1): timing-only and alternative blocks
-    if (variant == 1) return launch_fir8_plane_variant<1>(a, d_entries, d_coeffs, stream);
-    if (variant == 2) return launch_fir8_plane_variant<2>(a, d_entries, d_coeffs, stream);
-    if (variant == 3) return launch_fir8_plane_variant<3>(a, d_entries, d_coeffs, stream);  // no table prefetch
+    if (variant == 1) return launch_fir8_plane_variant<1>(a, d_entries, d_coeffs, have, stream);
+    if (variant == 2) return launch_fir8_plane_variant<2>(a, d_entries, d_coeffs, have, stream);
+    if (variant == 3) return launch_fir8_plane_variant<3>(a, d_entries, d_coeffs, have, stream);  // no table prefetch
 #endif
     (void) variant;
-    return launch_fir8_plane_variant<0>(a, d_entries, d_coeffs, stream);
+    return launch_fir8_plane_variant<0>(a, d_entries, d_coeffs, have, stream);
 }
 
-hipError_t launch_das_exact_quads(const ExactQuadArgs &a, hipStream_t stream) {
+hipError_t launch_das_exact_quads(const ExactQuadArgs &a, const Extents &have, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_exact_quad_kernel, lds_bytes, attr_set); e != hipSuccess) return e;
@@ -2104,35 +2131,40 @@ hipError_t launch_das_exact_quads(const ExactQuadArgs &a, hipStream_t stream) {
         a.rows * a.cols != a.pixel_count)
         return hipErrorInvalidValue;
     if (a.n_pairs != (a.batch + 1) / 2 || a.tiles != quad_tiles(a.rows, a.cols) || a.pair_group < 1) return hipErrorInvalidValue;
+    if ((a.wp & 1) || !within({quad_table_reach(a.rows, a.cols, a.usable_pad), (size_t) a.n_pairs * a.usable_pad * a.wp * 2}, have))
+        return hipErrorInvalidValue;
     const long total = (long) a.n_pairs * a.tiles;
     dim3 grid((unsigned) (8 * ((total + 7) / 8)));
     hipLaunchKernelGGL(das_exact_quad_kernel, grid, dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_das_exact_pairs(const ExactPairArgs &a, hipStream_t stream) {
+hipError_t launch_das_exact_pairs(const ExactPairArgs &a, const Extents &have, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_exact_pair_kernel, lds_bytes, attr_set); e != hipSuccess) return e;
     if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || (size_t) a.chunk * a.wp * 8 > (size_t) kFastLdsBytes) return hipErrorInvalidValue;
     if (a.n_pairs != (a.batch + 1) / 2 || a.tiles != pair_tiles(a.pixel_count, a.cols) || a.pair_group < 1) return hipErrorInvalidValue;
+    if ((a.wp & 1) || !within({pair_table_rows(a.pixel_count, a.cols) * a.usable_pad + kPairTablePrefetch,
+                               (size_t) a.n_pairs * a.usable_pad * a.wp * 2}, have))
+        return hipErrorInvalidValue;
     const long total = (long) a.n_pairs * a.tiles;
     dim3 grid((unsigned) (8 * ((total + 7) / 8)));
     hipLaunchKernelGGL(das_exact_pair_kernel, grid, dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream) {
+hipError_t launch_das_pairs(const PairArgs &a, const Extents &have, hipStream_t stream) {
 #ifdef AWPU_TUNING_BUILD  // stamped builds (bit 16) and the pixel-major block without read sharing (bit 4096: the same bits)
     const bool share = (a.debug & 4096) == 0;
-    if (a.debug & 16) return share ? launch_pair_variant<4, true, true>(a, stream) : launch_pair_variant<4, true, false>(a, stream);
-    if (!share) return launch_pair_variant<4, false, false>(a, stream);
+    if (a.debug & 16) return share ? launch_pair_variant<4, true, true>(a, have, stream) : launch_pair_variant<4, true, false>(a, have, stream);
+    if (!share) return launch_pair_variant<4, false, false>(a, have, stream);
 #endif
-    return launch_pair_variant<4, false, true>(a, stream);
+    return launch_pair_variant<4, false, true>(a, have, stream);
 }
 
 template <bool DIAG, int VAR>
-static hipError_t launch_quad_variant(const QuadArgs &a, hipStream_t stream) {
+static hipError_t launch_quad_variant(const QuadArgs &a, const Extents &have, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_quad_kernel<DIAG, VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
@@ -2141,6 +2173,10 @@ static hipError_t launch_quad_variant(const QuadArgs &a, hipStream_t stream) {
     // many persistent workgroups instead, each walking several items with the next item's first chunk prefetched:
     // measured equal at the headline shape on an otherwise idle chip (5.41 vs 5.41 ms), and fragile when CUs are
     // shared (a static share of the items per workgroup).
+    if (a.rows * a.cols != a.pixel_count || a.n_pairs != (a.batch + 1) / 2 || a.tiles != quad_tiles(a.rows, a.cols) || a.pair_group < 1 ||
+        (a.wp & 1) || (a.usable_pad & 3) || (a.chunk & 3) || (size_t) a.chunk * a.wp * 8 > (size_t) kFastLdsBytes)
+        return hipErrorInvalidValue;
+    if (!within({quad_table_reach(a.rows, a.cols, a.usable_pad), (size_t) a.n_pairs * a.usable_pad * a.wp * 2}, have)) return hipErrorInvalidValue;
     const long items = (long) a.n_pairs * a.tiles;
     const long per_xcd = (items + 7) / 8;
     const long wgs_per_xcd = a.wgs > 0 ? std::min<long>(per_xcd, std::max(1, a.wgs / 8)) : per_xcd;
@@ -2149,16 +2185,16 @@ static hipError_t launch_quad_variant(const QuadArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_das_quads(const QuadArgs &a, hipStream_t stream) {
+hipError_t launch_das_quads(const QuadArgs &a, const Extents &have, hipStream_t stream) {
 #ifdef AWPU_TUNING_BUILD
-    if (a.debug & 16) return launch_quad_variant<true, 0>(a, stream);
+    if (a.debug & 16) return launch_quad_variant<true, 0>(a, have, stream);
 #endif
 #ifdef AWPU_QUAD_VARIANTS
-    if (a.variant == 1) return launch_quad_variant<false, 1>(a, stream);
-    if (a.variant == 2) return launch_quad_variant<false, 2>(a, stream);
-    if (a.variant == 3) return launch_quad_variant<false, 3>(a, stream);
+    if (a.variant == 1) return launch_quad_variant<false, 1>(a, have, stream);
+    if (a.variant == 2) return launch_quad_variant<false, 2>(a, have, stream);
+    if (a.variant == 3) return launch_quad_variant<false, 3>(a, have, stream);
 #endif
-    return launch_quad_variant<false, 0>(a, stream);
+    return launch_quad_variant<false, 0>(a, have, stream);
 }
 
 int fast_image_bytes(int nw) { return nw == 24 ? kFastLdsBytesSmall : kFastLdsBytes; }
@@ -2168,21 +2204,25 @@ bool fast_db_fits(const FastPlan &plan) {
 }
 
 template <int QPW, bool DIAG>
-static hipError_t launch_quadh_variant(const QuadhArgs &a, hipStream_t stream) {
+static hipError_t launch_quadh_variant(const QuadhArgs &a, const Extents &have, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_quadh_kernel<QPW, DIAG>, lds_bytes, attr_set); e != hipSuccess) return e;
+    if (a.rows * a.cols != a.pixel_count || (a.wp & 1) || (a.usable_pad & 3) || (a.chunk & 3) || a.chunk < 4 ||
+        (size_t) a.chunk * a.wp * 8 > (size_t) kFastLdsBytes ||
+        !within({quad_table_reach(a.rows, a.cols, a.usable_pad), (size_t) a.batch * a.usable_pad * a.wp * 2}, have))
+        return hipErrorInvalidValue;
     dim3 grid(a.batch, quad1_tiles(a.rows, a.cols, QPW));
     if (grid.y > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL((das_quadh_kernel<QPW, DIAG>), grid, dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
-hipError_t launch_das_quadh(const QuadhArgs &a, int qpw, hipStream_t stream) {
+hipError_t launch_das_quadh(const QuadhArgs &a, int qpw, const Extents &have, hipStream_t stream) {
 #ifdef AWPU_TUNING_BUILD
-    if (a.debug & 16) return qpw == 2 ? launch_quadh_variant<2, true>(a, stream) : launch_quadh_variant<1, true>(a, stream);
+    if (a.debug & 16) return qpw == 2 ? launch_quadh_variant<2, true>(a, have, stream) : launch_quadh_variant<1, true>(a, have, stream);
 #endif
-    return qpw == 2 ? launch_quadh_variant<2, false>(a, stream) : launch_quadh_variant<1, false>(a, stream);
+    return qpw == 2 ? launch_quadh_variant<2, false>(a, have, stream) : launch_quadh_variant<1, false>(a, have, stream);
 }
 
 bool quadh_stationary_plan(int window, int usable, FastPlan *plan) {
@@ -2218,7 +2258,7 @@ bool quadh_stationary_raw(const FastPlan &plan, int usable, int wstart, int row_
 }
 
 template <int QPW>
-static hipError_t launch_quadh_stationary_variant(const QuadhStationaryArgs &a, hipStream_t stream) {
+static hipError_t launch_quadh_stationary_variant(const QuadhStationaryArgs &a, const Extents &have, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     if (hipError_t e = allow_lds((const void *) das_quadh_stationary_kernel<QPW>, lds_bytes, attr_set); e != hipSuccess) return e;
@@ -2227,6 +2267,8 @@ static hipError_t launch_quadh_stationary_variant(const QuadhStationaryArgs &a, 
         a.raw_begin + a.raw_wr > a.row_limit)
         return hipErrorInvalidValue;
     if (a.waves < 4 || a.waves > 16) return hipErrorInvalidValue;
+    // (the samples are the caller's frames: rows [raw_begin, raw_begin + raw_wr) of a stream, inside row_limit -- checked above)
+    if (a.rows * a.cols != a.pixel_count || !within({quad_table_reach(a.rows, a.cols, a.usable_pad), 0}, have)) return hipErrorInvalidValue;
     const int tile_cols = a.waves * QPW;
     dim3 grid(a.batch, ((a.rows + 3) / 4) * ((a.cols + tile_cols - 1) / tile_cols));
     if (grid.y > 65535) return hipErrorInvalidValue;
@@ -2234,8 +2276,8 @@ static hipError_t launch_quadh_stationary_variant(const QuadhStationaryArgs &a, 
     return hipGetLastError();
 }
 
-hipError_t launch_das_quadh_stationary(const QuadhStationaryArgs &a, int qpw, hipStream_t stream) {
-    return qpw == 2 ? launch_quadh_stationary_variant<2>(a, stream) : launch_quadh_stationary_variant<1>(a, stream);
+hipError_t launch_das_quadh_stationary(const QuadhStationaryArgs &a, int qpw, const Extents &have, hipStream_t stream) {
+    return qpw == 2 ? launch_quadh_stationary_variant<2>(a, have, stream) : launch_quadh_stationary_variant<1>(a, have, stream);
 }
 
 hipError_t launch_pack_halves(const float *d_frames, int n_streams, int pitch, int hist, int wstart, const int32_t *d_index, int usable,
@@ -2248,7 +2290,13 @@ hipError_t launch_pack_halves(const float *d_frames, int n_streams, int pitch, i
     return hipGetLastError();
 }
 
-hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream) {
+hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, const Extents &have, hipStream_t stream) {
+    {   // reach: whole workgroup tiles of pixels (rows past the grid are null rows of the table) + one group of prefetch; the
+        // samples are the caller's frames, staged row by row through row_off[] with the valid length clamped to hist
+        const size_t tile = (size_t) (nw == 32 ? 16 : nw == 24 ? 12 : 8) * ppw;
+        if (ppw < 1 || !within({((size_t) a.pixel_count + tile - 1) / tile * tile * a.usable_pad + kPairTablePrefetch, 0}, have))
+            return hipErrorInvalidValue;
+    }
     if (nw == 32) {  // double-buffered, one 16-wave workgroup per CU
 #ifdef AWPU_TUNING_BUILD
         if (a.debug & 16) return ppw == 4 ? launch_db<16, 4, kFastLdsBytes, 4, true>(a, stream)

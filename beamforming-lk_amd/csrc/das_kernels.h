@@ -61,6 +61,19 @@ struct FastEntry {
     uint32_t pad;
 };
 
+// What lies behind the two pointers of a sweep launch.  The kernels read PAST the data they use, by design -- the table is
+// prefetched one group of mics ahead of the sweep (a load of entries the last trip never uses), slots outside the grid sweep
+// a clamped or a null table row, the samples arrive in whole 16-byte pieces -- so every launcher below states its kernel's
+// REACH (the furthest entry / float any wave can load, for the last frame pair, the last chunk and the last pixel) and
+// refuses, with hipErrorInvalidValue, a launch whose reach exceeds what the caller says it allocated.
+struct Extents {
+    size_t lut_entries;    // entries (of the table's element type) behind the table pointer
+    size_t sample_floats;  // floats behind `packed` (0: the samples are the caller's frames, bounded by hist / row_limit)
+};
+constexpr int kPairTablePrefetch = 4;        // FastEntry: one group of four mics past the end of a pixel's row
+constexpr int kQuadTablePrefetch = 16;       // QuadEntry: one group (4 pixels x 4 mics) past the end of a quad's groups
+constexpr int kFir8PlaneTablePrefetch = 68;  // dwords: entries four items ahead + 64 past a chunk (block_fir8)
+
 struct FastPlan {
     int fpi;         // frames per item (1 or 2)
     int wr;          // floats per staged row (even)
@@ -106,7 +119,7 @@ bool pair_plan(int window, int usable, FastPlan *plan);
 hipError_t launch_pack_pairs(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index,
                              int usable, int rows_out, const float *d_gain, int wp, int batch, float *d_packed,
                              bool filter, hipStream_t stream);
-hipError_t launch_das_pairs(const PairArgs &a, hipStream_t stream);
+hipError_t launch_das_pairs(const PairArgs &a, const Extents &have, hipStream_t stream);
 // ---- reference-order sweep on the frame-pair layout (das_exact_pair_kernel, AWPU_MATH_F32_EXACT): raw samples
 // (launch_pack_pairs with filter = false and rows_out = usable_pad: gains on the samples, padding rows zero), the pair
 // shape's table with the UNSCALED fraction in .f and padding entries that point at their own (zero) row
@@ -119,7 +132,7 @@ struct ExactPairArgs {
     int32_t cols;          // > 0: the grid's row length; a wave then sweeps vertical pixel pairs (pixel_count % cols == 0)
     int32_t tiles, n_pairs, pair_group;  // 64-pixel tiles (pair_tiles); frame pairs, and how many an XCD works on at a time
 };
-hipError_t launch_das_exact_pairs(const ExactPairArgs &a, hipStream_t stream);
+hipError_t launch_das_exact_pairs(const ExactPairArgs &a, const Extents &have, hipStream_t stream);
 // the same with four vertically adjacent pixels per wave (das_exact_quad_kernel): the quad-major table of the quad shapes
 // ([quad][group of 4 mics][pixel][mic] x QuadEntry) with the RAW fraction in .f; needs the grid's row length
 struct ExactQuadArgs {
@@ -131,7 +144,7 @@ struct ExactQuadArgs {
     int32_t cols, rows;
     int32_t tiles, n_pairs, pair_group;  // workgroup tiles of 4 rows x 16 columns; frame pairs, and how many an XCD works on at a time
 };
-hipError_t launch_das_exact_quads(const ExactQuadArgs &a, hipStream_t stream);
+hipError_t launch_das_exact_quads(const ExactQuadArgs &a, const Extents &have, hipStream_t stream);
 // FIR8 on the four-plane frame-pair layout (a lane owns four consecutive outputs: 11 LDS reads per 32 FMAs).  Rows packed by
 // launch_pack_planes, `wr` a multiple of 4 (fir8_plane_plan); d_entries [pixel_count][usable_pad] + 4 spare dwords,
 // one per (pixel, mic): fir8_plane_word(LDS byte offset of X[off] in its chunk's image, its plane, coefficient row);
@@ -145,11 +158,12 @@ bool fir8_plane_plan(int window, int usable, FastPlan *plan);
 hipError_t launch_pack_planes(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index, int usable,
                               const float *d_gain, int wp, int batch, float *d_packed, hipStream_t stream);
 constexpr uint32_t kFirStaticPlaneBytesHost = 768;  // = kFirStaticPlaneBytes of das_fast_trip.inc (static_assert in das_fast.hip)
-hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, const float *d_coeffs, int variant, hipStream_t stream);
+hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, const float *d_coeffs, int variant, const Extents &have,
+                                  hipStream_t stream);
 // stationary shape: every active mic's window of a frame pair in LDS at once (plan->chunk = usable_pad); a
 // workgroup stages the pair once and sweeps tiles_per_wg tiles from it
 bool pair_plan_stationary(int window, int usable, FastPlan *plan);
-hipError_t launch_das_pairs_stationary(const PairArgs &a, int tiles_per_wg, hipStream_t stream);
+hipError_t launch_das_pairs_stationary(const PairArgs &a, int tiles_per_wg, const Extents &have, hipStream_t stream);
 
 // ---- quad shape (das_quad_kernel): the frame-pair layout swept four vertically adjacent pixels at a time with
 // a shared integer-delay sum (das_fast.hip).  Needs the grid's row length.
@@ -172,7 +186,7 @@ struct QuadArgs {
 };
 inline int quad_tiles(int rows, int cols) { return ((rows + 3) / 4) * ((cols + 15) / 16); }
 inline int quad_count(int rows, int cols) { return ((rows + 3) / 4) * ((cols + 15) / 16) * 16; }  // table quads incl. padding columns
-hipError_t launch_das_quads(const QuadArgs &a, hipStream_t stream);
+hipError_t launch_das_quads(const QuadArgs &a, const Extents &have, hipStream_t stream);
 
 // tiles of the single-frame quad kernel (das_quadh_kernel): 4 rows x 16 qpw columns
 inline int quad1_tiles(int rows, int cols, int qpw) { return ((rows + 3) / 4) * ((cols + 16 * qpw - 1) / (16 * qpw)); }
@@ -189,7 +203,7 @@ struct QuadhArgs {
     unsigned long long *debug_out;
     int32_t debug;
 };
-hipError_t launch_das_quadh(const QuadhArgs &a, int qpw, hipStream_t stream);
+hipError_t launch_das_quadh(const QuadhArgs &a, int qpw, const Extents &have, hipStream_t stream);
 // the same for arrays small enough that every active mic's halves row fits the LDS at once (das_quadh_stationary_kernel): the
 // workgroup stages (and filters) the window itself from the caller's frame -- no pack pre-pass, no chunks
 struct QuadhStationaryArgs {
@@ -209,7 +223,7 @@ struct QuadhStationaryArgs {
 };
 bool quadh_stationary_plan(int window, int usable, FastPlan *plan);
 bool quadh_stationary_raw(const FastPlan &plan, int usable, int wstart, int row_limit, int *raw_begin, int *raw_wr, int *image_offset);
-hipError_t launch_das_quadh_stationary(const QuadhStationaryArgs &a, int qpw, hipStream_t stream);
+hipError_t launch_das_quadh_stationary(const QuadhStationaryArgs &a, int qpw, const Extents &have, hipStream_t stream);
 // `pitch` = floats between two streams of a frame (hist, or 2048 in the ingest ring), `hist` = samples of a stream's
 // history (neighbours of the filter outside it count as 0), wstart = first history sample of the window
 hipError_t launch_pack_halves(const float *d_frames, int n_streams, int pitch, int hist, int wstart, const int32_t *d_index, int usable,
@@ -221,7 +235,7 @@ int fast_image_bytes(int nw);
 // fpi in {1,2} frames per item; ppw in {2,4,8} pixels per wave (8 only with fpi 1)
 // nw: 8 = 8-wave workgroups (two per CU, single image); 32 = double-buffered 16-wave workgroup, one
 // per CU; 24 = double-buffered 12-wave workgroups, two per CU (fpi 1 only for 24 and 32)
-hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, hipStream_t stream);
+hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, const Extents &have, hipStream_t stream);
 bool fast_db_fits(const FastPlan &plan);
 
 // exact-order kernel (AWPU_MATH_F32_EXACT): sub, fma, add per sample, mics in order; with

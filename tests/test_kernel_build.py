@@ -72,3 +72,23 @@ def test_tuning_build_still_links(pkg, tmp_path):
     names = {ln for ln in subprocess.run(["strings", "-a", str(out)], capture_output=True, text=True, check=True).stdout.splitlines()
              if re.fullmatch(r"AWPU_[A-Z0-9_]+", ln)}
     assert {"AWPU_SHAPE", "AWPU_FAST_DEBUG", "AWPU_FAST_QUADS", "AWPU_FAST_PAIRGROUP", "AWPU_FIR8_STATIC"} <= names
+
+
+def test_every_sweep_launcher_checks_its_reach():
+    """Round-3 advisor: a launch whose kernel can read past a table or a packed buffer must be refused on the host.  Every sweep
+    launcher of das_kernels.h takes the caller's `Extents` (what was allocated) and compares its kernel's reach with it
+    (`within(...)` in das_fast.hip) before hipLaunchKernelGGL; the allocation sites use the same named prefetch constants."""
+    import re
+    hdr = (REPO / "beamforming-lk_amd" / "csrc" / "das_kernels.h").read_text()
+    src = (REPO / "beamforming-lk_amd" / "csrc" / "das_fast.hip").read_text()
+    host = (REPO / "beamforming-lk_amd" / "csrc" / "awpu_hip.cpp").read_text()
+    sweeps = ["launch_das_pairs", "launch_das_pairs_stationary", "launch_das_exact_pairs", "launch_das_exact_quads", "launch_das_fir8_planes",
+              "launch_das_quads", "launch_das_quadh", "launch_das_quadh_stationary", "launch_das_fast"]
+    for name in sweeps:
+        decl = re.search(r"hipError_t %s\(([^;]*)\);" % name, hdr)
+        assert decl and "const Extents &have" in decl.group(1), name
+        for call in re.findall(r"awpu::%s\(([^;]*)\);" % name, host):
+            assert "{" in call or "have" in call, (name, call)  # the host passes what it allocated
+    assert src.count("within({") >= len(sweeps)
+    for const in ("kPairTablePrefetch", "kQuadTablePrefetch", "kFir8PlaneTablePrefetch"):
+        assert const in hdr and const in src
