@@ -196,6 +196,46 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// EIGHT per-lane partial sums reduced together (round 4: the powers of a quad's four pixels x two frames).  gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange half-waves / alternate rows between two registers, so one swap and one add
+// fold two registers into one at each of the two upper levels; a row rotation by 8 and a select fold the third, three DPP adds
+// finish the 8-lane groups: 18 VALU instructions where eight wave_sum()s take 48 and eight v_readlane_b32 (and what follows --
+// division, address, store -- happens once, in vector form, instead of eight times on wave-uniform values).
+// Returns, in every lane of the 8-lane group g = lane >> 3, the wave sum of value kWaveSum8Value(g):
+//   row r = g >> 1, half h = g & 1:  value index = 4 h + {0, 2, 1, 3}[r]
+// (tools/microbench/permlane_swap_check.hip prints what the two swaps do, lane by lane).
+__device__ __forceinline__ float fold_halves(float a, float b) {  // lanes 0..31: a's two halves added, lanes 32..63: b's
+    // (inline asm, not __builtin_amdgcn_permlane32_swap: hipcc 7.2 folds `r[0] + r[1]` of the builtin's two results into
+    // `r[0] + r[0]` -- tools/microbench/permlane_swap_check.hip caught it; the nops cover the VALU-write -> swap-read hazard)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float fold_rows(float a, float b) {  // rows 0, 2: a's rows (0+1), (2+3); rows 1, 3: b's
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float wave_sum8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, int lane) {
+    const float x = fold_rows(fold_halves(v0, v1), fold_halves(v2, v3));  // rows: values 0, 2, 1, 3 (16 lanes each)
+    const float y = fold_rows(fold_halves(v4, v5), fold_halves(v6, v7));  // rows: values 4, 6, 5, 7
+    const float xs = x + dpp_take<0x128>(x), ys = y + dpp_take<0x128>(y);  // row_ror:8: lane l + lane l ^ 8 of its row
+    float z = (lane & 8) ? ys : xs;                                        // 8-lane groups: x's value | y's value of the row
+    z += dpp_take<0xB1>(z);   // quad_perm:[1,0,3,2]
+    z += dpp_take<0x4E>(z);   // quad_perm:[2,3,0,1]
+    z += dpp_take<0x141>(z);  // row_half_mirror: the other quad of the 8
+    return z;
+}
+__device__ __forceinline__ constexpr int kWaveSum8Value(int group) { return 4 * (group & 1) + (((group >> 1) & 1) << 1) + (group >> 2); }
+// The powers of a wave's four pixels x the two frames of its pair, from the lanes' partial sums s[pp] = (frame 2 pair, frame
+// 2 pair + 1): the eight wave sums together, then the first lane of each 8-lane group divides and stores its (pixel, frame).
+__device__ __forceinline__ void store_powers8(const f2 (&s)[4], const int (&pix)[4], const bool (&live)[4], int pair, int batch,
+                                              int pixel_count, float norm, float *power, int lane) {
+    const float total = wave_sum8(s[0].x, s[0].y, s[1].x, s[1].y, s[2].x, s[2].y, s[3].x, s[3].y, lane);
+    const int value = kWaveSum8Value(lane >> 3), pp = value >> 1, frame = 2 * pair + (value & 1);
+    const int p = pp == 0 ? pix[0] : pp == 1 ? pix[1] : pp == 2 ? pix[2] : pix[3];
+    const bool on = pp == 0 ? live[0] : pp == 1 ? live[1] : pp == 2 ? live[2] : live[3];
+    if ((lane & 7) == 0 && on && frame < batch) power[(size_t) frame * pixel_count + p] = total / norm;
+}
+
 // Sum over each group of 8 consecutive lanes, left in all 8 (the tail passes give 8 lanes to a pixel), and the value
 // of one lane as a wave-uniform scalar: DPP and v_readlane instead of ds_bpermute_b32.
 __device__ __forceinline__ float sum8(float v) {
@@ -703,7 +743,7 @@ __device__ __forceinline__ f2 finish_pixel_pair(const f2 (&P)[8], f2 tail, int l
 
 // The same for sweeps of PRE-FILTERED samples (pack_one_row<true>): the un-skewed sums ARE the moving average,
 // MA[i] = A[i] + Q[i+1], i = 1..254 -- no stencil, no 257th sample.  P as above.
-__device__ __forceinline__ f2 finish_pixel_pair_filtered(const f2 (&P)[8], int lane) {
+__device__ __forceinline__ f2 pixel_pair_partial_filtered(const f2 (&P)[8], int lane) {  // a lane's share of sum MA^2, both frames
     f2 sum = f2{0.0f, 0.0f};
     f2 rq = wave_rotate<kDppWaveRol1>(P[4]);  // Q_k one lane down; lane 63 holds Q_k[0]
 #pragma unroll
@@ -715,6 +755,10 @@ __device__ __forceinline__ f2 finish_pixel_pair_filtered(const f2 (&P)[8], int l
         if (i >= 1 && i <= kSamples - 2) sum = __builtin_elementwise_fma(ma, ma, sum);
         rq = rq_next;
     }
+    return sum;
+}
+__device__ __forceinline__ f2 finish_pixel_pair_filtered(const f2 (&P)[8], int lane) {
+    f2 sum = pixel_pair_partial_filtered(P, lane);
     sum.x = wave_sum(sum.x);
     sum.y = wave_sum(sum.y);
     return sum;
@@ -866,15 +910,13 @@ __global__ __launch_bounds__(1024, 4) void das_pair_kernel(PairArgs a) {
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
     }
     const float norm = (float) (kSamples * a.usable);
+    static_assert(PPW == 4, "store_powers8: four pixels x two frames per wave");
+    f2 part[PPW];
 #pragma unroll
     for (int pp = 0; pp < PPW; pp++) {
-        const int p = pix[pp];
-        const f2 sum = finish_pixel_pair_filtered(acc[pp], lane);
-        if (lane == 0 && live[pp]) {
-            a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
-            if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
-        }
+        part[pp] = pixel_pair_partial_filtered(acc[pp], lane);
     }
+    store_powers8(part, pix, live, pair, a.batch, a.pixel_count, norm, a.power, lane);
 }
 
 
@@ -953,14 +995,13 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
             if constexpr (SHARE) sweep_duo_shared(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
             else sweep_duo_pairs(acc[q], acc[q + 1], row, stride, ng, lane_addr, rank);
         }
+        static_assert(PPW == 4, "store_powers8: four pixels x two frames per wave");
+        f2 part[PPW];
 #pragma unroll
         for (int pp = 0; pp < PPW; pp++) {
-            const f2 sum = finish_pixel_pair_filtered(acc[pp], lane);
-            if (lane == 0 && live[pp]) {
-                a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
-                if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + pix[pp]] = sum.y / norm;
-            }
+            part[pp] = pixel_pair_partial_filtered(acc[pp], lane);
         }
+        store_powers8(part, pix, live, pair, a.batch, a.pixel_count, norm, a.power, lane);
     }
 }
 
@@ -976,7 +1017,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
 // t = fma(0, 0 - 0, 0) = +0 and out + 0 = out bit for bit (out starts at +0 and can never become -0).
 // Workgroup = 16 waves, a wave 4 pixels (two vertical pairs when the row length is known); 1-D grid of items, XCD-aware order.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ f2 finish_pixel_pair_exact(const f2 (&o)[4], int lane) {
+__device__ __forceinline__ f2 pixel_pair_partial_exact(const f2 (&o)[4], int lane) {  // a lane's share of sum MA^2, both frames
     f2 sum = f2{0.0f, 0.0f};
     f2 dn = wave_rotate<kDppWaveRol1>(o[0]);         // out[l+1 + 64k]; lane 63: out[64k]
     f2 up_before = wave_rotate<kDppWaveRor1>(o[0]);  // (k = 0, lane 0: sample 0 is not summed)
@@ -992,6 +1033,12 @@ __device__ __forceinline__ f2 finish_pixel_pair_exact(const f2 (&o)[4], int lane
         dn = dn_after;
         up_before = up;
     }
+    return sum;
+}
+// (the reference-order kernels and the FIR8 plane kernel keep one wave sum per pixel and frame: with their register budgets
+// the joint reduction of store_powers8 measured 0.2-0.5 % SLOWER -- gpurun_out/epi3ab, round 4)
+__device__ __forceinline__ f2 finish_pixel_pair_exact(const f2 (&o)[4], int lane) {
+    f2 sum = pixel_pair_partial_exact(o, lane);
     sum.x = wave_sum(sum.x);
     sum.y = wave_sum(sum.y);
     return sum;
@@ -1429,6 +1476,8 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
     const int n_chunks = (a.usable + a.chunk - 1) / a.chunk;
     const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
     const float norm = (float) (kSamples * a.usable);
+    // which (pixel of the quad, frame of the pair) this lane's 8-lane group holds after wave_sum8 of (s0.x, s0.y, s1.x, ... s3.y)
+    const int out_value = kWaveSum8Value(lane >> 3), out_pp = out_value >> 1, out_frame = out_value & 1;
     auto chunk_mics = [&](int m0) { return (min(a.chunk, a.usable - m0) + 3) & ~3; };
     // one chunk = mc4 rows of a pair (whole groups: the padding rows are zero), contiguous in HBM from `src` (a
     // wave-uniform pointer: the transfers take it as a scalar base plus one per-lane byte offset)
@@ -1566,7 +1615,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         }
 
         // ---- this item's powers (the next item's first chunk is in its image already)
-        auto finish = [&](const f8 &A, const f8 &S, int pp) {
+        auto partial = [&](const f8 &A, const f8 &S) {  // a lane's share of sum MA^2 of one pixel, both frames
             f2 P[8];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -1574,17 +1623,20 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
                 P[k] = __builtin_elementwise_fma(f2{0.5f, 0.5f}, Sk, Ak);       // sum f Y      (A was accumulated with f - 1/2: see QuadEntry)
                 P[4 + k] = __builtin_elementwise_fma(f2{0.5f, 0.5f}, Sk, -Ak);  // sum (1 - f) Y
             }
-            const f2 sum = finish_pixel_pair_filtered(P, lane);
-            if (lane == 0 && live[pp]) {
-                a.power[(size_t) (2 * pair) * a.pixel_count + pix[pp]] = sum.x / norm;
-                if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + pix[pp]] = sum.y / norm;
-            }
+            return pixel_pair_partial_filtered(P, lane);
         };
-        finish(A0, T + V0, 0);
-        finish(A1, T, 1);
+        const f2 s0 = partial(A0, T + V0), s1 = partial(A1, T);
         const f8 S2 = T + V2;
-        finish(A2, S2, 2);
-        finish(A3, (kQuadChain ? S2 : T) + V3, 3);  // (the blocks keep V3 = S3 - S2: tools/gen_trip_asm.py, pixels_23_chain)
+        const f2 s2 = partial(A2, S2);
+        const f2 s3 = partial(A3, (kQuadChain ? S2 : T) + V3);  // (the blocks keep V3 = S3 - S2: tools/gen_trip_asm.py, pixels_23_chain)
+        // the eight wave sums together (wave_sum8); the 8-lane group of a lane then holds ONE (pixel, frame) of the quad, whose
+        // first lane divides and stores: one vector division and one store per quad and frame pair instead of eight of each
+        {
+            const float total = wave_sum8(s0.x, s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y, lane);
+            const int row = 4 * row4 + out_pp, frame = 2 * pair + out_frame;
+            if ((lane & 7) == 0 && row < a.rows && col < a.cols && frame < a.batch)
+                a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;
+        }
         if (item_next >= run_end) break;
         item = item_next;
         pair = pair_next;
