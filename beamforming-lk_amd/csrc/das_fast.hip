@@ -225,6 +225,18 @@ __device__ __forceinline__ float wave_sum8(float v0, float v1, float v2, float v
     return z;
 }
 __device__ __forceinline__ constexpr int kWaveSum8Value(int group) { return 4 * (group & 1) + (((group >> 1) & 1) << 1) + (group >> 2); }
+// FOUR partial sums together (a single frame's quad): two fold levels, then the sum over each row of 16 lanes; row r of the
+// result holds, in all 16 lanes, the wave sum of value {0, 2, 1, 3}[r] = kWaveSum4Value(r).
+__device__ __forceinline__ float wave_sum4(float v0, float v1, float v2, float v3) {
+    float z = fold_rows(fold_halves(v0, v1), fold_halves(v2, v3));
+    z += dpp_take<0xB1>(z);   // quad_perm:[1,0,3,2]
+    z += dpp_take<0x4E>(z);   // quad_perm:[2,3,0,1]
+    z += dpp_take<0x141>(z);  // row_half_mirror
+    z += dpp_take<0x140>(z);  // row_mirror
+    return z;
+}
+__device__ __forceinline__ constexpr int kWaveSum4Value(int row) { return ((row & 1) << 1) + (row >> 1); }
+
 // The powers of a wave's four pixels x the two frames of its pair, from the lanes' partial sums s[pp] = (frame 2 pair, frame
 // 2 pair + 1): the eight wave sums together, then the first lane of each 8-lane group divides and stores its (pixel, frame).
 __device__ __forceinline__ void store_powers8(const f2 (&s)[4], const int (&pix)[4], const bool (&live)[4], int pair, int batch,
@@ -1675,7 +1687,7 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
 // G[i+1], i = 1..254, with P = sum f Y = S/2 + A, G = sum (1 - f) Y = S/2 - A (A was accumulated with f - 1/2).  Sample
 // order of a lane's four values: pair 0 low (l), pair 1 low (64 + l), pair 0 high (128 + l), pair 1 high (192 + l).
 // Returns sum MA^2 over the wave (every lane).
-__device__ __forceinline__ float quadh_pixel_power(const f4 &A, const f4 &S, int lane) {
+__device__ __forceinline__ float quadh_pixel_partial(const f4 &A, const f4 &S, int lane) {
     const float Av[4] = {A[0], A[2], A[1], A[3]}, Sv[4] = {S[0], S[2], S[1], S[3]};  // in sample order
     float P[4], G[4];
 #pragma unroll
@@ -1693,7 +1705,7 @@ __device__ __forceinline__ float quadh_pixel_power(const f4 &A, const f4 &S, int
         if (i >= 1 && i <= kSamples - 2) sum = __builtin_fmaf(ma, ma, sum);
         rq = rq_next;
     }
-    return wave_sum(sum);
+    return sum;
 }
 
 // The filtered sample pack_halves_kernel and das_quadh_stationary_kernel stage: Y[i] = X[i]/2 - (X[i+1] + X[i-1])/4 with the
@@ -1820,21 +1832,26 @@ __global__ __launch_bounds__(1024, 4) void das_quadh_kernel(QuadhArgs a) {
         for (int k = 0; k < 5; k++) o[4 + k] = t_ph[k];
     }
     const float norm = (float) (kSamples * a.usable);
-    auto finish = [&](const f4 &A, const f4 &S, int slot) {
-        const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
-        const float sum = quadh_pixel_power(A, S, lane);
-        if (lane == 0 && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = sum / norm;
-    };
-    finish(A0a, Ta + V0a, 0);
-    finish(A1a, Ta, 1);
-    finish(A2a, Ta + V2a, 2);
-    finish(A3a, Ta + V3a, 3);
+    // the wave sums of the quad's pixels together (wave_sum4 / wave_sum8); the first lane of the lane group that holds pixel
+    // `slot` (a-quad: 0..3, b-quad: 4..7; row = slot & 3 of its quad) divides and stores
+    const float p0 = quadh_pixel_partial(A0a, Ta + V0a, lane), p1 = quadh_pixel_partial(A1a, Ta, lane);
+    const float p2 = quadh_pixel_partial(A2a, Ta + V2a, lane), p3 = quadh_pixel_partial(A3a, Ta + V3a, lane);
+    float total;
+    int slot;
+    bool first;
     if constexpr (QPW == 2) {
-        finish(A0b, Tb + V0b, 4);
-        finish(A1b, Tb, 5);
-        finish(A2b, Tb + V2b, 6);
-        finish(A3b, Tb + V3b, 7);
+        const float p4 = quadh_pixel_partial(A0b, Tb + V0b, lane), p5 = quadh_pixel_partial(A1b, Tb, lane);
+        const float p6 = quadh_pixel_partial(A2b, Tb + V2b, lane), p7 = quadh_pixel_partial(A3b, Tb + V3b, lane);
+        total = wave_sum8(p0, p1, p2, p3, p4, p5, p6, p7, lane);
+        slot = kWaveSum8Value(lane >> 3);
+        first = (lane & 7) == 0;
+    } else {
+        total = wave_sum4(p0, p1, p2, p3);
+        slot = kWaveSum4Value(lane >> 4);
+        first = (lane & 15) == 0;
     }
+    const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
+    if (first && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1923,21 +1940,26 @@ __global__ __launch_bounds__(1024, 4) void das_quadh_stationary_kernel(QuadhStat
     }
 
     const float norm = (float) (kSamples * a.usable);
-    auto finish = [&](const f4 &A, const f4 &S, int slot) {
-        const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
-        const float sum = quadh_pixel_power(A, S, lane);
-        if (lane == 0 && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = sum / norm;
-    };
-    finish(A0a, Ta + V0a, 0);
-    finish(A1a, Ta, 1);
-    finish(A2a, Ta + V2a, 2);
-    finish(A3a, Ta + V3a, 3);
+    // the wave sums of the quad's pixels together (wave_sum4 / wave_sum8); the first lane of the lane group that holds pixel
+    // `slot` (a-quad: 0..3, b-quad: 4..7; row = slot & 3 of its quad) divides and stores
+    const float p0 = quadh_pixel_partial(A0a, Ta + V0a, lane), p1 = quadh_pixel_partial(A1a, Ta, lane);
+    const float p2 = quadh_pixel_partial(A2a, Ta + V2a, lane), p3 = quadh_pixel_partial(A3a, Ta + V3a, lane);
+    float total;
+    int slot;
+    bool first;
     if constexpr (QPW == 2) {
-        finish(A0b, Tb + V0b, 4);
-        finish(A1b, Tb, 5);
-        finish(A2b, Tb + V2b, 6);
-        finish(A3b, Tb + V3b, 7);
+        const float p4 = quadh_pixel_partial(A0b, Tb + V0b, lane), p5 = quadh_pixel_partial(A1b, Tb, lane);
+        const float p6 = quadh_pixel_partial(A2b, Tb + V2b, lane), p7 = quadh_pixel_partial(A3b, Tb + V3b, lane);
+        total = wave_sum8(p0, p1, p2, p3, p4, p5, p6, p7, lane);
+        slot = kWaveSum8Value(lane >> 3);
+        first = (lane & 7) == 0;
+    } else {
+        total = wave_sum4(p0, p1, p2, p3);
+        slot = kWaveSum4Value(lane >> 4);
+        first = (lane & 15) == 0;
     }
+    const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
+    if (first && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -42,6 +42,18 @@ __device__ __forceinline__ float wave_sum8(float v0, float v1, float v2, float v
     z += dpp_take<0x141>(z);
     return z;
 }
+__device__ __forceinline__ float wave_sum4(float v0, float v1, float v2, float v3) {
+    float z = fold_rows(fold_halves(v0, v1), fold_halves(v2, v3));
+    z += dpp_take<0xB1>(z);
+    z += dpp_take<0x4E>(z);
+    z += dpp_take<0x141>(z);
+    z += dpp_take<0x140>(z);
+    return z;
+}
+__global__ void sums4(float *o, const float *in) {
+    const int l = threadIdx.x;
+    o[l] = wave_sum4(in[l], in[64 + l], in[128 + l], in[192 + l]);
+}
 __global__ void sums(float *o, const float *in) {  // in [8][64] -> o [64]: wave_sum8; o[64 + k]: stages
     const int l = threadIdx.x;
     float v[8];
@@ -65,6 +77,11 @@ int main() {
         hipMemcpy(hout, dout, sizeof(hout), hipMemcpyDeviceToHost);
         std::printf("wave_sum8 per 8-lane group (expect value k -> 64000 (k+1) + 2016):");
         for (int g = 0; g < 8; g++) std::printf(" g%d: %.0f..%.0f", g, hout[8 * g], hout[8 * g + 7]);
+        hipLaunchKernelGGL(sums4, dim3(1), dim3(64), 0, 0, dout, din);
+        float h4[64];
+        hipMemcpy(h4, dout, sizeof(h4), hipMemcpyDeviceToHost);
+        std::printf("\nwave_sum4 per row of 16 lanes (expect rows = values 0, 2, 1, 3):");
+        for (int r = 0; r < 4; r++) std::printf(" r%d: %.0f..%.0f", r, h4[16 * r], h4[16 * r + 15]);
         std::printf("\nfold_halves(v0, v1) lanes 0, 31, 32, 63: %.0f %.0f %.0f %.0f (expect 2*1000+0+32=2032.., v1: 4032..)\n", hout[64], hout[95], hout[96], hout[127]);
         std::printf("fold_rows rows 0..3 lane 0 of each: %.0f %.0f %.0f %.0f\n", hout[128], hout[144], hout[160], hout[176]);
         std::printf("x + row_ror8 lanes 0, 8 of row 0: %.0f %.0f\n", hout[192], hout[200]);
