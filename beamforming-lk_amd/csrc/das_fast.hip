@@ -1531,14 +1531,8 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         const int row4 = tile / tiles_per_row4;
         const int col = (tile - row4 * tiles_per_row4) * NW + wave;
         const int quad = row4 * tiles_per_row4 * NW + col;
-        int pix[4];
-        bool live[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int row = 4 * row4 + q;
-            live[q] = row < a.rows && col < a.cols;
-            pix[q] = min(row, a.rows - 1) * a.cols + min(col, a.cols - 1);
-        }
+        // (pixels of the quad: rows 4 row4 .. 4 row4 + 3 of column `col`; slots outside the grid sweep a clamped table row --
+        // build_quad_lut -- and are not stored: the epilogue below)
         const QuadEntry *quad_lut = a.lut + (size_t) quad * groups_total * 16;
         const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
         // ---- the item after it
