@@ -1047,8 +1047,9 @@ __device__ __forceinline__ f2 pixel_pair_partial_exact(const f2 (&o)[4], int lan
     }
     return sum;
 }
-// (the reference-order kernels and the FIR8 plane kernel keep one wave sum per pixel and frame: with their register budgets
-// the joint reduction of store_powers8 measured 0.2-0.5 % SLOWER -- gpurun_out/epi3ab, round 4)
+// (das_exact_pair_kernel and the FIR8 plane kernel keep one wave sum per pixel and frame: through store_powers8 -- per-lane
+// selects of the wave's four pixel indices -- the joint reduction measured 0.2-0.5 % SLOWER there, gpurun_out/epi3ab, round 4;
+// das_exact_quad_kernel computes the lane's pixel from row and column like das_quad_kernel and gains 0.65 %, gpurun_out/exq1)
 __device__ __forceinline__ f2 finish_pixel_pair_exact(const f2 (&o)[4], int lane) {
     f2 sum = pixel_pair_partial_exact(o, lane);
     sum.x = wave_sum(sum.x);
@@ -1255,16 +1256,15 @@ __global__ __launch_bounds__(1024, 4) void das_exact_quad_kernel(ExactQuadArgs a
                 if (2 * pair + 1 < a.batch) a.sums[((size_t) (2 * pair + 1) * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k].y;
             }
         }
-        const f2 sum = finish_pixel_pair_exact(o, lane);
-        if (lane == 0 && live) {
-            a.power[(size_t) (2 * pair) * a.pixel_count + p] = sum.x / norm;
-            if (2 * pair + 1 < a.batch) a.power[(size_t) (2 * pair + 1) * a.pixel_count + p] = sum.y / norm;
-        }
+        return pixel_pair_partial_exact(o, lane);
     };
-    finish(O0, 0);
-    finish(O1, 1);
-    finish(O2, 2);
-    finish(O3, 3);
+    const f2 s0 = finish(O0, 0), s1 = finish(O1, 1), s2 = finish(O2, 2), s3 = finish(O3, 3);
+    {   // the eight wave sums together, one division and one store per quad and frame pair (as das_quad_kernel's epilogue)
+        const float total = wave_sum8(s0.x, s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y, lane);
+        const int value = kWaveSum8Value(lane >> 3), row = 4 * row4 + (value >> 1), frame = 2 * pair + (value & 1);
+        if ((lane & 7) == 0 && row < a.rows && col < a.cols && frame < a.batch)
+            a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
