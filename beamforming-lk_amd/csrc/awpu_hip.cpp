@@ -876,10 +876,19 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
                  size_t prepacked_floats = 0) {
     const awpu::FastPlan &pp = plut->plan;
     const size_t need = (size_t) ((h->cfg.max_batch + 1) / 2) * h->usable() * pp.wr * 2;
-    if (!prepacked)
+    // the stationary shape stages its pairs itself, straight from the caller's frames (no pack pre-pass, no packed buffer)
+    const bool self_staged = stationary_tiles > 0 && !prepacked;
+    if (!prepacked && !self_staged)
         if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
     awpu::PairArgs pa{};
-    pa.packed = prepacked ? prepacked : h->d_pack;
+    pa.packed = prepacked ? prepacked : (self_staged ? nullptr : h->d_pack);
+    if (self_staged) {
+        pa.frames = d_frames;
+        pa.index = h->d_index;
+        pa.n_streams = h->cfg.n_streams;
+        pa.hist = hist_eff;
+        pa.wstart = wstart_eff;
+    }
     pa.lut = plut->d;
     pa.power = d_power;
     pa.usable = h->usable();
@@ -903,7 +912,7 @@ int launch_pairs(awpu_hip *h, const awpu_hip::FastLut *plut, const float *d_fram
         pa.debug_out = h->d_diag;
     }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    if (!prepacked)
+    if (!prepacked && !self_staged)
         AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(),
                                              h->usable(), nullptr, pp.wr, batch, h->d_pack, true, s));  // gains ride on the table weights here
     const awpu::Extents have{plut->entries, prepacked ? prepacked_floats : h->pack_cap};
@@ -1092,7 +1101,10 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
             const int rc = build_fast_lut(h, 2, -2, &slut);
             if (rc == AWPU_OK) {
                 // tiles per workgroup: enough to amortise the staging, few enough to leave every CU a workgroup
-                const int tpw = (int) std::max<long>(1, std::min<long>(tiles, pairs * tiles / 256));
+#ifndef AWPU_STATIONARY_WGS
+#define AWPU_STATIONARY_WGS 256  // (tuning builds: -DAWPU_STATIONARY_WGS=512 ... through tools/build_variant.sh)
+#endif
+                const int tpw = (int) std::max<long>(1, std::min<long>(tiles, pairs * tiles / AWPU_STATIONARY_WGS));
                 return launch_pairs(h, slut, d_frames, batch, d_power, s, hist_eff, wstart_eff, tpw);
             }
             if (rc != AWPU_ERR_INVALID) return rc;

@@ -953,7 +953,46 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
     const size_t row_floats = (size_t) a.wp * 2;
     const float *pair_base = a.packed + (size_t) pair * a.usable * row_floats;
 
-    // ---- stage all rows of the pair: one linear LDS-DMA stream (16 bytes per lane, 16 KiB per workgroup pass)
+    if (a.frames) {
+        // ---- stage the pair from the caller's frames (round 4): a wave takes every 16th active stream, a lane every 64th
+        // element of its row, and writes pack_one_row<true>'s value -- the stencil of the two frames' samples, neighbours
+        // outside the history counting as 0 -- straight into the image: the bits pack_pairs_kernel<true> + the LDS-DMA stream
+        // below would have put there, without the pre-pass (a launch and 28 MB of HBM traffic per 128 frames of one 8x8 array)
+        const int fa = min(2 * pair, a.batch - 1), fb = min(2 * pair + 1, a.batch - 1);
+        const int valid = min(a.wp, a.hist - a.wstart);
+        f2 *image = (f2 *) lds;
+        for (int s = wave; s < a.usable; s += NW) {
+            const int stream = __builtin_amdgcn_readfirstlane(a.index[s]);
+            const float *xa = a.frames + ((size_t) fa * a.n_streams + stream) * a.hist + a.wstart;
+            const float *xb = a.frames + ((size_t) fb * a.n_streams + stream) * a.hist + a.wstart;
+            f2 *row = image + (size_t) s * a.wp;
+            // five elements per lane at a time, all their loads in flight together (a row of the reference's array is 286
+            // elements: one round trip per row instead of five)
+            for (int t0 = lane; t0 < a.wp; t0 += 5 * 64) {
+                float c[5][2], l[5][2], h[5][2];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const int t = t0 + 64 * k;
+                    const bool in = t < valid, lo = in && a.wstart + t > 0, hi = in && a.wstart + t + 1 < a.hist;
+                    c[k][0] = in ? xa[t] : 0.0f;
+                    c[k][1] = in ? xb[t] : 0.0f;
+                    l[k][0] = lo ? xa[t - 1] : 0.0f;
+                    l[k][1] = lo ? xb[t - 1] : 0.0f;
+                    h[k][0] = hi ? xa[t + 1] : 0.0f;
+                    h[k][1] = hi ? xb[t + 1] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const int t = t0 + 64 * k;
+                    // (an element past the history is +0 in pack_one_row; here fma(-0.25, 0 + 0, 0.5 * 0) = +0 as well)
+                    const f2 v = __builtin_elementwise_fma(f2{-0.25f, -0.25f}, f2{l[k][0] + h[k][0], l[k][1] + h[k][1]}, 0.5f * f2{c[k][0], c[k][1]});
+                    if (t < a.wp) row[t] = v;
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+    // ---- stage all rows of the (pre-packed) pair: one linear LDS-DMA stream (16 bytes per lane, 16 KiB per workgroup pass)
     const unsigned lane_bytes = threadIdx.x * 16;
     const unsigned n_bytes = (unsigned) ((size_t) a.usable * row_floats * 4);
     for (unsigned base = 0; base < n_bytes; base += kThreads * 16) {
@@ -966,6 +1005,7 @@ __global__ __launch_bounds__(1024, 4) void das_pair_stationary_kernel(PairArgs a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    }
 
     const int rank = wave >> 2;
     const int ng = __builtin_amdgcn_readfirstlane(a.usable_pad >> 2);
@@ -2102,9 +2142,11 @@ hipError_t launch_das_pairs_stationary(const PairArgs &a, int tiles_per_wg, cons
     static LdsFlags attr_set[2] = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
     const int n_tiles = pair_tiles(a.pixel_count, a.cols);
+    // (self-staged pairs read the caller's frames inside [0, hist) of a stream: the kernel clips to the history itself)
     if (tiles_per_wg < 1 || (a.wp & 1) || (size_t) a.usable * a.wp * 8 > (size_t) lds_bytes ||
+        (a.frames && (!a.index || a.n_streams < 1 || a.wstart < 0 || a.wstart >= a.hist)) ||
         !within({pair_table_rows(a.pixel_count, a.cols) * a.usable_pad + kPairTablePrefetch,
-                 (size_t) ((a.batch + 1) / 2) * a.usable * a.wp * 2}, have))
+                 a.frames ? 0 : (size_t) ((a.batch + 1) / 2) * a.usable * a.wp * 2}, have))
         return hipErrorInvalidValue;
     dim3 grid((a.batch + 1) / 2, (n_tiles + tiles_per_wg - 1) / tiles_per_wg);
     if (grid.y > 65535) return hipErrorInvalidValue;

@@ -106,6 +106,12 @@ struct PairArgs {
     int32_t tiles, n_pairs, pair_group;  // das_pair_kernel: 64-pixel tiles; frame pairs, and how many an XCD works on at a time
     unsigned long long *debug_out;
     int32_t debug;
+    // das_pair_stationary_kernel only: frames != null -> the workgroup stages its pair ITSELF from the caller's frames
+    // [batch][n_streams][hist] (pack_pairs_kernel<true>'s expression, straight into the LDS image: the same bits, no pack
+    // pre-pass, `packed` unused); index [usable] = the active streams, wstart = first history sample of the window
+    const float *frames;
+    const int32_t *index;
+    int32_t n_streams, hist, wstart;
 };
 // 64-pixel tiles of the frame-pair sweep: consecutive pixels, or 2 rows x 32 columns when cols > 0
 inline int pair_tiles(int pixel_count, int cols) {
