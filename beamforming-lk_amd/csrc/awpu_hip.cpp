@@ -1020,7 +1020,9 @@ int launch_quadsh(awpu_hip *h, const float *d_frames, int batch, float *d_power,
         qa.debug_out = h->d_diag;
     }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    AWPU_HIP_TRY(awpu::launch_pack_halves(d_frames, h->cfg.n_streams, pitch, hist_eff, wstart_eff, h->d_index, h->usable(),
+    bool identity = true;  // the active-mic list is 0 .. usable-1 (awpu_hip_set_active_mics(NULL)): the pre-pass needs no look-up
+    for (int k = 0; k < h->usable() && identity; k++) identity = h->index[k] == k;
+    AWPU_HIP_TRY(awpu::launch_pack_halves(d_frames, h->cfg.n_streams, pitch, hist_eff, wstart_eff, identity ? nullptr : h->d_index, h->usable(),
                                           pp.usable_pad, h->d_gain, pp.wr, batch, h->d_pack, s));
     AWPU_HIP_TRY(awpu::launch_das_quadh(qa, qpw, {h->quad_lut_entries[kQuadHalves], h->pack_cap}, s));
     rc = finish_launch(h, batch, s, AWPU_KERNEL_QUADH);

@@ -1759,7 +1759,9 @@ __global__ void pack_halves_kernel(const float *frames, int n_streams, int pitch
         for (int t = threadIdx.x; t < wp; t += blockDim.x) dst[t] = f2{0.0f, 0.0f};
         return;
     }
-    const float *x = frames + ((size_t) frame * n_streams + index[s]) * pitch;
+    // (index == null: the identity list -- the common case -- spares the look-up, a dependent round trip in a pass that is
+    // nothing but two of them)
+    const float *x = frames + ((size_t) frame * n_streams + (index ? index[s] : s)) * pitch;
     const float gm = gain ? gain[s] : 1.0f;
     for (int t = threadIdx.x; t < wp; t += blockDim.x)
         dst[t] = f2{filtered_sample(x, wstart + t, hist, gm), filtered_sample(x, wstart + t + 128, hist, gm)};
