@@ -86,6 +86,9 @@ struct awpu_hip {
     size_t quad_lut_entries[5] = {0, 0, 0, 0, 0};                  // ... and of the quad-major tables, by QuadLayout
     awpu::QuadEntry *d_exact_quad_lut = nullptr;  // ... four vertically adjacent pixels per wave (das_exact_quad_kernel): quad-major, raw fractions
     awpu::FastPlan exact_plan{};
+    awpu::QuadEntry *d_exact_nd_lut = nullptr;    // ... on the {next, d} layout (das_exact_nd_kernel): 16-byte elements, quad rows padded to an even count
+    awpu::FastPlan exact_nd_plan{};
+    bool exact_nd_ok = false;     // ... and the window fits the {next, d} image
     bool exact_pairs_ok = false;  // AWPU_MATH_F32_EXACT + LERP and the window fits the pair image
     float *sums_out = nullptr;    // awpu_hip_process_device_sums: where the launch in progress exports out[] (else null)
     awpu::QuadEntry *d_quad_lut = nullptr;  // quad-major table of the quad shape (das_quad_kernel)
@@ -203,7 +206,7 @@ int ensure_diag(awpu_hip *h, size_t words) {
 //   AWPU_SHAPE             force one of the production sweep shapes wherever it can serve the call (tests sweep every shape
 //                          through the oracle this way; the default rule -- launch() below -- picks by table statistics and launch size):
 //                          pair | pair_vertical | pair_horizontal | quad | noquad | stationary | quadh | quadh_chunked | single_db | single_small |
-//                          fir8_planes | exact_pair | exact_verify
+//                          fir8_planes | exact_pair | exact_quad | exact_nd1 | exact_nd2 | exact_verify
 //   AWPU_LIVE_GRAPH=0      awpu_hip_live_block always enqueues its steps one by one (no HIP-graph replay)
 //   AWPU_GROUP_FORCE_COPY  device groups: 1 = a part on devices[0] takes the window-copy path too, 2 = through pinned host
 //                          memory (how one GPU exercises the paths a part on another GPU takes)
@@ -245,6 +248,9 @@ struct EnvKnobs {
             else if (shape == "fir8_planes") fir_planes = 2;
             else if (shape == "exact_verify") exact_pairs = 0;
             else if (shape == "exact_pair") exact_pairs = 2;  // the two-pixel reference-order block even where quads would run
+            else if (shape == "exact_quad") exact_pairs = 3;  // round 4's quad kernel on raw sample pairs (cur - next per pixel)
+            else if (shape == "exact_nd1") exact_pairs = 4;   // the {next, d} kernel with one quad per wave
+            else if (shape == "exact_nd2") exact_pairs = 5;   // ... with two
             else std::fprintf(stderr, "libawpu_hip: AWPU_SHAPE=%s is not a shape of this build; ignored\n", v);
         }
 #ifdef AWPU_TUNING_BUILD
@@ -301,6 +307,7 @@ void release_device(awpu_hip *h) {
     h->fast_luts.clear();
     dev_free(h->d_exact_pair_lut);
     dev_free(h->d_exact_quad_lut);
+    dev_free(h->d_exact_nd_lut);
     dev_free(h->d_quad_lut);
     dev_free(h->d_quadh_lut);
     dev_free(h->d_quadhs_lut);
@@ -371,6 +378,7 @@ int prepare(awpu_hip *h) {
     h->fast_luts.clear();
     dev_free(h->d_exact_pair_lut);
     dev_free(h->d_exact_quad_lut);
+    dev_free(h->d_exact_nd_lut);
     dev_free(h->d_quad_lut);
     dev_free(h->d_quadh_lut);
     dev_free(h->d_quadhs_lut);
@@ -416,6 +424,7 @@ int prepare(awpu_hip *h) {
     }
 
     h->exact_pairs_ok = c.math == AWPU_MATH_F32_EXACT && c.interp == AWPU_INTERP_LERP && awpu::pair_plan(h->window, U, &h->exact_plan);
+    h->exact_nd_ok = h->exact_pairs_ok && awpu::exact_nd_plan(h->window, U, &h->exact_nd_plan);
     if (c.math != AWPU_MATH_F32_FAST || c.interp == AWPU_INTERP_FIR8) {
         int chunk = 0;
         if (awpu::das_exact_lds_bytes(h->window, U, &chunk) == 0)
@@ -577,22 +586,27 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
 // address), quads = groups of four grid rows x columns padded to whole 16-column tiles.  Pixels past the grid
 // carry weight 0 and the address of the nearest pixel inside it (they then follow the shared path and add
 // nothing); padding mics (usable rounded up to 4) carry weight 0 and the address of their own, zero, row.
-enum QuadLayout { kQuadPairs = 0, kQuadHalves = 2, kQuadHalvesStationary = 3, kQuadExact = 4 };
+enum QuadLayout { kQuadPairs = 0, kQuadExactNd = 1, kQuadHalves = 2, kQuadHalvesStationary = 3, kQuadExact = 4 };
 int build_quad_lut(awpu_hip *h, int layout) {
     awpu::QuadEntry *&d_lut = layout == kQuadHalves             ? h->d_quadh_lut
                               : layout == kQuadHalvesStationary ? h->d_quadhs_lut
                               : layout == kQuadExact            ? h->d_exact_quad_lut
+                              : layout == kQuadExactNd          ? h->d_exact_nd_lut
                                                                 : h->d_quad_lut;
     if (d_lut) return AWPU_OK;
     const auto &c = h->cfg;
     const awpu::FastPlan &plan = layout == kQuadHalves             ? h->quadh_plan
                                  : layout == kQuadHalvesStationary ? h->quadhs_plan
                                  : layout == kQuadExact            ? h->exact_plan
+                                 : layout == kQuadExactNd          ? h->exact_nd_plan
                                                                    : h->quad_plan;
-    const float centre = layout == kQuadExact ? 0.0f : 0.5f;  // the reference-order sweep takes the fraction as it is (mimo.cpp:126)
+    const bool raw = layout == kQuadExact || layout == kQuadExactNd;
+    const float centre = raw ? 0.0f : 0.5f;  // the reference-order sweeps take the fraction as it is (mimo.cpp:126)
+    const int elem = layout == kQuadExactNd ? 16 : 8;  // bytes per LDS element: {next, d} of a frame pair, or one sample of a frame pair
     const int U = h->usable(), cols = c.grid_columns, rows = c.pixel_count / cols;
     const int groups = plan.usable_pad / 4;
-    const int cols_pad = (cols + 15) / 16 * 16, rows4 = (rows + 3) / 4;
+    // (the {next, d} kernel gives a wave two quads, one quad row apart: its table has an even number of quad rows, the last one clamped)
+    const int cols_pad = (cols + 15) / 16 * 16, rows4 = layout == kQuadExactNd ? ((rows + 3) / 4 + 1) / 2 * 2 : (rows + 3) / 4;
     const size_t n = (size_t) rows4 * cols_pad * groups * 16 + 2 * awpu::kQuadTablePrefetch;  // spare groups: the sweep prefetches one past the end
     std::vector<awpu::QuadEntry> packed(n, awpu::QuadEntry{0.0f, 0u});
     for (int r4 = 0; r4 < rows4; r4++)
@@ -611,7 +625,7 @@ int build_quad_lut(awpu_hip *h, int layout) {
                         const int id = h->index[s];
                         const int off_rel = orow[id] - h->wstart;
                         e.f = inside ? frow[id] - centre : 0.0f;  // centred weight (das_fast.hip, das_quad_kernel); exact: as it is
-                        e.addr = (uint32_t) (j * plan.row_bytes + off_rel * 8);
+                        e.addr = (uint32_t) (j * plan.row_bytes + off_rel * elem);
                     } else {  // padding mic: silence (the pack passes write zero rows)
                         e.f = 0.0f;
                         e.addr = (uint32_t) (j * plan.row_bytes);
@@ -730,6 +744,12 @@ int build_exact_pair_lut(awpu_hip *h) {
 }
 
 // frame pairs an XCD works on at a time: as many as keep their samples in its 4 MiB L2 beside the table stream (launch_quads)
+int xcd_pair_group_bytes(size_t pair_bytes, int n_pairs) {
+    int g = (int) std::max<size_t>(1, (3u << 20) / pair_bytes);
+    g = g >= 8 ? 8 : g >= 4 ? 4 : g >= 2 ? 2 : 1;
+    while (g > 1 && g > n_pairs) g >>= 1;
+    return g;
+}
 int xcd_pair_group(const awpu::FastPlan &pp, int rows_per_pair, int n_pairs) {
     const size_t pair_bytes = (size_t) rows_per_pair * pp.wr * 8;
     int g = (int) std::max<size_t>(1, (3u << 20) / pair_bytes);
@@ -794,6 +814,37 @@ int launch_exact_quads(awpu_hip *h, const float *d_frames, int batch, float *d_p
                                          h->d_gain, pp.wr, batch, h->d_pack, false, s));
     AWPU_HIP_TRY(awpu::launch_das_exact_quads(a, {h->quad_lut_entries[kQuadExact], h->pack_cap}, s));
     return finish_launch(h, batch, s, AWPU_KERNEL_EXACT_QUAD);
+}
+
+// ... on the {next, d} layout (das_exact_nd_kernel, round 5): cur - next formed once per sample by the pack pass; nq quads per wave
+int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff, int nq) {
+    int rc = build_quad_lut(h, kQuadExactNd);
+    if (rc != AWPU_OK) return rc;
+    const awpu::FastPlan &pp = h->exact_nd_plan;
+    const size_t need = (size_t) ((std::max(h->cfg.max_batch, batch) + 1) / 2) * pp.usable_pad * pp.wr * 4;
+    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
+    awpu::ExactNdArgs a{};
+    a.packed = h->d_pack;
+    a.lut = h->d_exact_nd_lut;
+    a.power = d_power;
+    a.sums = h->sums_out;
+    a.usable = h->usable();
+    a.usable_pad = pp.usable_pad;
+    a.pixel_count = h->cfg.pixel_count;
+    a.wq = pp.wr;
+    a.chunk = pp.chunk;
+    a.batch = batch;
+    a.cols = h->cfg.grid_columns;
+    a.rows = h->cfg.pixel_count / a.cols;
+    a.nq = nq;
+    a.tiles = awpu::nd_tiles(a.rows, a.cols, nq);
+    a.n_pairs = (batch + 1) / 2;
+    a.pair_group = xcd_pair_group_bytes((size_t) pp.usable_pad * pp.row_bytes, a.n_pairs);
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    AWPU_HIP_TRY(awpu::launch_pack_nd(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad, h->d_gain,
+                                      pp.wr, batch, h->d_pack, s));
+    AWPU_HIP_TRY(awpu::launch_das_exact_nd(a, {h->quad_lut_entries[kQuadExactNd], h->pack_cap}, s));
+    return finish_launch(h, batch, s, AWPU_KERNEL_EXACT_ND);
 }
 
 int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
@@ -1079,8 +1130,18 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     if (h->exact_pairs_ok && env().exact_pairs != 0) {
         // vertical pixel quads where the row length is known and vertical neighbours coincide more often than horizontal ones
         // (prepare() counted: pair_cols); AWPU_SHAPE=exact_pair keeps the two-pixel block everywhere
-        if (h->pair_cols > 0 && env().exact_pairs != 2 && h->cfg.pixel_count / h->cfg.grid_columns >= 4)
+        if (h->pair_cols > 0 && env().exact_pairs != 2 && h->cfg.pixel_count / h->cfg.grid_columns >= 4) {
+            // the {next, d} layout (round 5) wherever its image holds a group of mics; two quads per wave where that still fills the chip
+            // (AWPU_SHAPE=exact_quad: round 4's kernel on raw sample pairs; exact_nd1 / exact_nd2: one / two quads per wave)
+            const int ex = env().exact_pairs;
+            if (h->exact_nd_ok && ex != 3) {
+                const int rows = h->cfg.pixel_count / h->cfg.grid_columns;
+                const long wgs2 = (long) awpu::nd_tiles(rows, h->cfg.grid_columns, 2) * ((batch + 1) / 2);
+                const int nq = ex == 4 ? 1 : ex == 5 ? 2 : (rows >= 8 && wgs2 >= 512 ? 2 : 1);
+                return launch_exact_nd(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, nq);
+            }
             return launch_exact_quads(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+        }
         return launch_exact_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
     }
     if (h->sums_out) return fail(AWPU_ERR_STATE, "the pre-epilogue sums are exported by the frame-pair reference-order kernel only");

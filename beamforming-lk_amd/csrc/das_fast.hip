@@ -1308,6 +1308,146 @@ __global__ __launch_bounds__(1024, 4) void das_exact_quad_kernel(ExactQuadArgs a
 }
 
 // ---------------------------------------------------------------------------------------
+// The reference's order on the {next, d} layout (round 5; the default of AWPU_MATH_F32_EXACT wherever the grid's row length is known).
+// delay.cpp:19-25 performs, per pixel, mic and sample:  d = cur - next;  t = fma(frac, d, next);  out += t.  The first operation
+// depends on (mic, sample, frame) only -- never on the pixel or the fraction -- and an fp32 subtraction of the same two operands gives
+// the same bits wherever it is done: pack_nd_kernel forms it ONCE per sample and writes, for the frame pair (a, b) and sample t of a
+// mic's window, the 16-byte element { next_a, next_b, d_a, d_b } (next = X[t+1], d = X[t] - X[t+1]; the per-mic gain, if any, multiplies
+// the samples first, as in das_exact_kernel).  The sweep is then 4 ds_read_b128 per distinct address + v_pk_fma_f32 t, frac, d, next +
+// v_pk_add_f32 out, out, t per register: 8 packed VALU instructions per (pixel, mic, frame pair) flat, where das_exact_quad_kernel paid
+// 8 + 4 per distinct address -- and the pre-epilogue sums are still the reference's bits (a.sums exports them).
+// Workgroup = 16 waves, a wave NQ quads of four vertically adjacent pixels (tile = 4 NQ rows x 16 columns: twice the pixels per
+// barrier, the 16-byte elements halve the mics per chunk); the whole item -- chunk loop, in-block refill, barrier -- runs inside
+// sweep_exact_nd_item<NQ> (tools/gen_trip_asm.py, block_exact_nd).  Epilogue, item order: das_exact_quad_kernel's.
+// ---------------------------------------------------------------------------------------
+__global__ void pack_nd_kernel(const float *frames, int n_streams, int hist, int wstart, const int32_t *index, int usable,
+                               const float *gain, int wq, int batch, float *packed) {
+    const int pair = blockIdx.y, s = blockIdx.x, rows_out = gridDim.x;
+    f4 *dst = (f4 *) packed + ((size_t) pair * rows_out + s) * wq;
+    if (s >= usable) {  // padding rows (whole groups of four mics are swept): next = 0, d = 0 -> t = fma(0, 0, 0) = +0
+        for (int t = threadIdx.x; t < wq; t += blockDim.x) dst[t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        return;
+    }
+    const int fa = min(2 * pair, batch - 1), fb = min(2 * pair + 1, batch - 1);
+    const float *xa = frames + ((size_t) fa * n_streams + index[s]) * hist + wstart;
+    const float *xb = frames + ((size_t) fb * n_streams + index[s]) * hist + wstart;
+    const float gm = gain ? gain[s] : 1.0f;  // x * 1.0f is x
+    const int valid = min(wq, hist - wstart - 1);  // elements whose two samples lie inside the stream's history
+    for (int t = threadIdx.x; t < wq; t += blockDim.x) {
+        f4 v = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (t < valid) {
+            // (explicit roundings: no contraction of the product into the difference)
+            const float ca = __fmul_rn(xa[t], gm), na = __fmul_rn(xa[t + 1], gm);
+            const float cb = __fmul_rn(xb[t], gm), nb = __fmul_rn(xb[t + 1], gm);
+            v = f4{na, nb, __fsub_rn(ca, na), __fsub_rn(cb, nb)};  // delay.cpp:21: cur - next
+        }
+        dst[t] = v;
+    }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
+    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    // items (frame pair, tile) in das_quad_kernel's order: (pair group, tile, pair), one contiguous run per XCD
+    const int total = a.n_pairs * a.tiles;
+    const int per_xcd = (total + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= min(total, ((int) (blockIdx.x & 7) + 1) * per_xcd)) return;  // (uniform for the workgroup)
+    int pair, tile;
+    {
+        const int full_items = (a.n_pairs / a.pair_group) * a.pair_group * a.tiles;
+        const int ga = item < full_items ? a.pair_group : a.n_pairs % a.pair_group;
+        const int rem = item < full_items ? item : item - full_items;
+        const int grp = rem / (a.tiles * ga), in = rem - grp * a.tiles * ga;
+        tile = in / ga;
+        pair = (item < full_items ? grp * a.pair_group : a.n_pairs - ga) + (in - tile * ga);
+    }
+    const int tiles_per_row = (a.cols + NW - 1) / NW;
+    const int rowq = tile / tiles_per_row;  // the tile's first quad row is NQ * rowq
+    const int col = (tile - rowq * tiles_per_row) * NW + wave;
+    const int groups_total = a.usable_pad >> 2;
+    const int quad0 = NQ * rowq * tiles_per_row * NW + col;  // the table's quads: [quad row][columns padded to whole tiles]
+    const QuadEntry *quad_lut = a.lut + (size_t) quad0 * groups_total * 16;
+    const size_t row_floats = (size_t) a.wq * 4;
+    const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
+
+    f8 O[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) O[q][p] = f8{0, 0, 0, 0, 0, 0, 0, 0};  // float out[N_SAMPLES] = {0.0}, mimo.cpp:122
+
+    const int n_chunks = (a.usable_pad + a.chunk - 1) / a.chunk;
+    const int first_mics = min(a.chunk, a.usable_pad), last_mics = a.usable_pad - (n_chunks - 1) * a.chunk;
+    {   // chunk 0 into image 0 (the block refills from chunk 1 on)
+        const int n_pieces = (int) ((size_t) first_mics * row_floats / 4);
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {
+            const int piece = threadIdx.x + k * kThreads;
+            if (piece < n_pieces) {
+                float *dst = lds + (wave * 64 + k * kThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (pair_base + (size_t) piece * 4),
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    {
+        unsigned lane_addr = lds_base + lane * 16;
+        const int ngf = __builtin_amdgcn_readfirstlane(first_mics >> 2), ngl = __builtin_amdgcn_readfirstlane(last_mics >> 2);
+        const unsigned dbf = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) a.chunk * row_floats * 4));
+        const unsigned dbl = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) last_mics * row_floats * 4));
+        const unsigned ddst = __builtin_amdgcn_readfirstlane(lds_base + BUF + wave * 1024);
+        const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
+        const unsigned lane_bytes = threadIdx.x * 16;
+        if constexpr (NQ == 1) {
+            sweep_exact_nd_item1(O[0][0], O[0][1], O[0][2], O[0][3], uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
+                                 lane_addr, rank, uniform_ptr(pair_base), dbf, dbl, ddst, BUF, lane_bytes);
+        } else {
+            static_assert(NQ == 2, "blocks are generated for one and two quads per wave");
+            const int qstride = __builtin_amdgcn_readfirstlane(tiles_per_row * NW * groups_total * 16 * (int) sizeof(QuadEntry));
+            sweep_exact_nd_item2(O[0][0], O[0][1], O[0][2], O[0][3], O[1][0], O[1][1], O[1][2], O[1][3], uniform_ptr(quad_lut), qstride, ngf, ngl,
+                                 __builtin_amdgcn_readfirstlane(n_chunks), lane_addr, rank, uniform_ptr(pair_base), dbf, dbl, ddst, BUF, lane_bytes);
+        }
+    }
+
+    const float norm = (float) (kSamples * a.usable);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int row4 = NQ * rowq + q;
+        auto finish = [&](const f8 &Op, int pp) {
+            const int row = 4 * row4 + pp;
+            const bool live = row < a.rows && col < a.cols;
+            const int p = min(row, a.rows - 1) * a.cols + min(col, a.cols - 1);
+            f2 o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = f2{Op[2 * k], Op[2 * k + 1]};
+            if (a.sums && live) {  // the pre-epilogue sums, for the tests: [batch][pixel_count][256]
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    a.sums[((size_t) (2 * pair) * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k].x;
+                    if (2 * pair + 1 < a.batch) a.sums[((size_t) (2 * pair + 1) * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k].y;
+                }
+            }
+            return pixel_pair_partial_exact(o, lane);
+        };
+        const f2 s0 = finish(O[q][0], 0), s1 = finish(O[q][1], 1), s2 = finish(O[q][2], 2), s3 = finish(O[q][3], 3);
+        // the eight wave sums together, one division and one store per quad and frame pair (das_quad_kernel's epilogue)
+        const float total = wave_sum8(s0.x, s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y, lane);
+        const int value = kWaveSum8Value(lane >> 3), row = 4 * row4 + (value >> 1), frame = 2 * pair + (value & 1);
+        if ((lane & 7) == 0 && row < a.rows && col < a.cols && frame < a.batch)
+            a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // FIR8, four-plane frame-pair layout (the default for FIR8 batches): das_fir8_pair_kernel reads 32 LDS elements for
 // 32 FMAs, and the LDS array -- one per CU, 2 cycles per ds_read_b64, shared by four SIMDs that each want a
 // v_pk_fma_f32 every 4 cycles -- then holds the sweep at half the VALU rate.  Here a lane owns four CONSECUTIVE
@@ -2233,6 +2373,55 @@ hipError_t launch_das_fir8_planes(const PairArgs &a, const void *d_entries, cons
 #endif
     (void) variant;
     return launch_fir8_plane_variant<0>(a, d_entries, d_coeffs, have, stream);
+}
+
+bool exact_nd_plan(int window, int usable, FastPlan *plan) {
+    const int wq = window - 1;  // element t holds X[t+1] and X[t] - X[t+1]: one element less than samples
+    const size_t row_bytes = (size_t) wq * 16;
+    int chunk = (int) ((size_t) kFastLdsBytes / row_bytes);
+    chunk &= ~3;
+    if (chunk > 64) chunk = 64;
+    if (chunk < 4 || wq < kSamples) return false;
+    const int usable_pad = (usable + 3) & ~3;
+    if (chunk > usable_pad) chunk = usable_pad;
+    plan->fpi = 2;
+    plan->wr = wq;
+    plan->chunk = chunk;
+    plan->usable_pad = usable_pad;
+    plan->row_bytes = (int) row_bytes;
+    plan->image_bytes = -4;  // marks the {next, d} layout
+    return true;
+}
+
+hipError_t launch_pack_nd(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index, int usable, int rows_out,
+                          const float *d_gain, int wq, int batch, float *d_packed, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_nd_kernel, dim3(rows_out, (batch + 1) / 2), dim3(128), 0, stream, d_frames, n_streams, hist, wstart, d_index,
+                       usable, d_gain, wq, batch, d_packed);
+    return hipGetLastError();
+}
+
+template <int NQ>
+static hipError_t launch_exact_nd_variant(const ExactNdArgs &a, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (hipError_t e = allow_lds((const void *) das_exact_nd_kernel<NQ>, lds_bytes, attr_set); e != hipSuccess) return e;
+    const long total = (long) a.n_pairs * a.tiles;
+    hipLaunchKernelGGL(das_exact_nd_kernel<NQ>, dim3((unsigned) (8 * ((total + 7) / 8))), dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_das_exact_nd(const ExactNdArgs &a, const Extents &have, hipStream_t stream) {
+    if (a.nq != 1 && a.nq != 2) return hipErrorInvalidValue;
+    if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || a.usable < 1 || a.usable > a.usable_pad || a.wq < kSamples ||
+        (size_t) a.chunk * a.wq * 16 > (size_t) kFastLdsBytes || a.cols < 1 || a.rows * a.cols != a.pixel_count)
+        return hipErrorInvalidValue;
+    if (a.n_pairs != (a.batch + 1) / 2 || a.tiles != nd_tiles(a.rows, a.cols, a.nq) || a.pair_group < 1) return hipErrorInvalidValue;
+    // reach: every quad of the grid padded to whole tiles (quad rows to a multiple of nq) + one group of prefetch; usable_pad rows of wq
+    // 16-byte elements per frame pair
+    if (!within({(size_t) nd_quad_count(a.rows, a.cols, a.nq) * (a.usable_pad / 4) * 16 + kQuadTablePrefetch,
+                 (size_t) a.n_pairs * a.usable_pad * a.wq * 4}, have))
+        return hipErrorInvalidValue;
+    return a.nq == 2 ? launch_exact_nd_variant<2>(a, stream) : launch_exact_nd_variant<1>(a, stream);
 }
 
 hipError_t launch_das_exact_quads(const ExactQuadArgs &a, const Extents &have, hipStream_t stream) {

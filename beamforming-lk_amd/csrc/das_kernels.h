@@ -151,6 +151,26 @@ struct ExactQuadArgs {
     int32_t tiles, n_pairs, pair_group;  // workgroup tiles of 4 rows x 16 columns; frame pairs, and how many an XCD works on at a time
 };
 hipError_t launch_das_exact_quads(const ExactQuadArgs &a, const Extents &have, hipStream_t stream);
+// ---- the reference's order on the {next, d} layout (das_exact_nd_kernel, round 5; the default of AWPU_MATH_F32_EXACT where the
+// row length is known): the pack pass forms delay.cpp:21's `cur - next` ONCE per sample and frame -- element t of a mic's row =
+// { X_a[t+1], X_b[t+1], X_a[t] - X_a[t+1], X_b[t] - X_b[t+1] }, 16 bytes, t counted from wstart -- and the sweep is left with
+// fma(frac, d, next) and the add, in the reference's order (the same fp32 subtraction of the same operands: the same bits).
+struct ExactNdArgs {
+    const float *packed;   // [pairs][usable_pad][wq][4], padding rows zero
+    const struct QuadEntry *lut;  // quad-major, raw fractions, addr = slot * wq * 16 + (off - wstart) * 16; quad rows padded to a multiple of nq
+    float *power;          // [batch][pixel_count]
+    float *sums;           // optional [batch][pixel_count][256]: out[] of every pixel before the epilogue (tests), or null
+    int32_t usable, usable_pad, pixel_count, wq, chunk, batch;
+    int32_t cols, rows;
+    int32_t nq;            // quads per wave: a workgroup tile is 4 nq rows x 16 columns
+    int32_t tiles, n_pairs, pair_group;  // nd_tiles(rows, cols, nq); frame pairs, and how many an XCD works on at a time
+};
+inline int nd_tiles(int rows, int cols, int nq) { return (((rows + 3) / 4 + nq - 1) / nq) * ((cols + 15) / 16); }
+inline int nd_quad_count(int rows, int cols, int nq) { return (((rows + 3) / 4 + nq - 1) / nq) * nq * ((cols + 15) / 16) * 16; }  // table quads incl. padding
+bool exact_nd_plan(int window, int usable, FastPlan *plan);  // plan->wr = elements per row (window - 1), row_bytes = 16 wr
+hipError_t launch_pack_nd(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index, int usable, int rows_out,
+                          const float *d_gain, int wq, int batch, float *d_packed, hipStream_t stream);
+hipError_t launch_das_exact_nd(const ExactNdArgs &a, const Extents &have, hipStream_t stream);
 // FIR8 on the four-plane frame-pair layout (a lane owns four consecutive outputs: 11 LDS reads per 32 FMAs).  Rows packed by
 // launch_pack_planes, `wr` a multiple of 4 (fir8_plane_plan); d_entries [pixel_count][usable_pad] + 4 spare dwords,
 // one per (pixel, mic): fir8_plane_word(LDS byte offset of X[off] in its chunk's image, its plane, coefficient row);

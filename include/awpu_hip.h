@@ -88,7 +88,8 @@ typedef enum {
     AWPU_KERNEL_EXACT_PAIR = 10,      /* das_exact_pair_kernel: the reference's operation order on the frame-pair layout */
     AWPU_KERNEL_EXACT_VERIFY = 11,    /* das_exact_kernel: round-1 verification structure (bf16 accumulator mode, fallback) */
     AWPU_KERNEL_TUNING = 12,          /* a shape only -DAWPU_TUNING_BUILD builds dispatch to */
-    AWPU_KERNEL_EXACT_QUAD = 13       /* das_exact_quad_kernel: the reference's order, four vertically adjacent pixels per wave */
+    AWPU_KERNEL_EXACT_QUAD = 13,      /* das_exact_quad_kernel: the reference's order, four vertically adjacent pixels per wave (round 4) */
+    AWPU_KERNEL_EXACT_ND = 14         /* das_exact_nd_kernel: the reference's order on the {next, d} layout (cur - next formed once per sample) */
 } awpu_kernel_id;
 
 typedef struct awpu_hip awpu_hip_t;

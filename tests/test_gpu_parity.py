@@ -1,6 +1,7 @@
 """Parity of the gfx950 sweep (through the C ABI) with the oracle, the reference-generated
 golden vectors and size-independent properties.  Everything here needs a real MI355X."""
 import importlib
+import os
 from pathlib import Path
 
 import numpy as np
@@ -716,14 +717,15 @@ def test_reference_default_single_frames_run_the_resident_window_kernel(pkg, ora
 def test_reference_order_mode_on_the_ingest_ring(pkg, oracle):
     """AWPU_MATH_F32_EXACT on the live path: frames read in place from the device ring (rows 2048 floats apart) through
     pack_pairs_kernel<false> and the reference-order kernels give the bits the host-buffer entry gives, and the oracle's powers;
-    c2 geometry with the row length (das_exact_quad_kernel) and without (das_exact_pair_kernel)."""
+    c2 geometry with the row length (das_exact_nd_kernel: the {next, d} layout) and without (das_exact_pair_kernel)."""
     S = pkg.synthetic
     spec = S.WORKLOADS["c2"]
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz)
     rng = np.random.default_rng(6)
     names = pkg.binding.KERNEL_NAMES
-    for cols, want in ((spec.res, "exact_quad"), (0, "exact_pair")):
+    forced = {"exact_quad": "exact_quad", "exact_pair": "exact_pair"}.get(os.environ.get("AWPU_SHAPE", ""))
+    for cols, want in ((spec.res, forced or "exact_nd"), (0, "exact_pair")):
         ring = np.zeros((spec.n_mics, 1024), np.float32)
         with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, math=pkg.MATH_F32_EXACT, grid_columns=cols) as eng:
             eng.set_delay_table(off, frac)

@@ -654,6 +654,261 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, un
 """
 
 
+ND_ACC = 10    # block_exact_nd: out[] of quad q, pixel p pinned at v[ND_ACC + 32 q + 8 p ..+7]
+ND_TMP = 74    # its 53 temps (two 16-register slots for the reference pixel's elements, one for whichever pixel leaves it, t, address)
+ND_DMA_STRIDE = 16 * 1024  # one refill piece: 16 waves x 64 lanes x 16 bytes (every wave of the workgroup takes part)
+
+
+def block_exact_nd(name, nq):
+    """Reference-order sweep (AWPU_MATH_F32_EXACT, round 5) of a WHOLE item -- frame pair x tile, `nq` quads of four vertically
+    adjacent pixels per wave -- on the {next, d} layout: pack_nd_kernel stores, per mic and sample t of the window, the 16-byte element
+        { next_a, next_b, d_a, d_b },   next = X[t + 1],  d = X[t] - X[t + 1]      (a, b = the two frames of the pair)
+    i.e. delay.cpp:19-25's first operation done ONCE per sample instead of once per (pixel, mic, sample): the fp32 subtraction of the
+    same two operands gives the same bits wherever it is done.  What is left per pixel, mic and register is
+        t = fma(frac, d, next)    v_pk_fma_f32, frac a scalar operand
+        out = out + t             v_pk_add_f32
+    in the reference's order, mics in table order: the pre-epilogue sums stay the reference's bits.  8 packed VALU instructions per
+    (pixel, mic, frame pair) flat; an item's reads are 4 ds_read_b128 (lane l owns samples l + 64 k: elements 1 KiB apart), shared
+    by every pixel of the column whose entry carries the reference pixel's LDS address.
+
+    One own-sample slot X serves the whole quad: a delay is monotone down a column and steps at most once inside four rows at the
+    resolutions this shape is chosen for, so the pixels that leave the reference (pixel 1) are {0}, {3} or {2, 3} with one address --
+    X is requested a mic ahead for pixel 0 if it differs, else for pixel 3 if it differs; any other pattern reads on the spot.  Per
+    mic: the reference's reads for the NEXT mic go out first, one counted wait (4 younger reads) proves this mic's elements (the
+    reference's and X), then the pixels that sweep X, then the request of X for the next mic, then the pixels on the reference's
+    elements -- so X has three pixels' worth of FMAs to land.
+
+    Item structure (the production quad block's, _block_quad_item): chunk loop, in-block refill of the other LDS image (one 16 KiB
+    piece at the head of each trip), vmcnt wait and workgroup barrier inside the block, the next chunk's first entries already in
+    SGPRs when a chunk begins (a quad's table is contiguous across chunks; the running prefetch switches between the quads' tables
+    one trip before a quad's chunk ends).  nq = 2: per chunk quad A then quad B (`qstride` table bytes apart), each with its own
+    pinned accumulators and its own copy of the trip code."""
+    O = [[ND_ACC + 32 * q + 8 * p for p in range(4)] for q in range(nq)]
+    R = [ND_TMP, ND_TMP + 16]
+    X = ND_TMP + 32
+    TT = ND_TMP + 48
+    addr_t = ND_TMP + 52
+    E = (36, 68)
+    S_NG, S_PFO, S_CH, S_SB, S_TMP, S_PF_, S_LEFT_, S_DST, S_REM, S_K, S_NP, S_M0, S_DELTA = 17, 18, 19, 20, 22, 23, 24, 25, 28, 29, 30, 31, 35
+
+    def f_of(base, p, i):
+        return base + 8 * p + 2 * i
+
+    def a_of(base, p, i):
+        return base + 8 * p + 2 * i + 1
+
+    def quadreg(r, k):
+        return f"v[{r + 4 * k}:{r + 4 * k + 3}]"
+
+    def nxt_of(slot, k):
+        return f"v[{slot + 4 * k}:{slot + 4 * k + 1}]"
+
+    def d_of(slot, k):
+        return f"v[{slot + 4 * k + 2}:{slot + 4 * k + 3}]"
+
+    def opair(r, k):
+        return f"v[{r + 2 * k}:{r + 2 * k + 1}]"
+
+    def reads(slot, addr_sgpr):
+        L = [f"v_add_u32 v{addr_t}, s{addr_sgpr}, %[lane]"]
+        for k in range(4):
+            off = f" offset:{1024 * k}" if k else ""
+            L.append(f"ds_read_b128 {quadreg(slot, k)}, v{addr_t}{off}")
+        return L
+
+    def uid():
+        COUNTER[0] += 1
+        return f"%=_{COUNTER[0]}"
+
+    cold = []
+    qz = [0]  # the quad whose code is being generated
+
+    def terms(p, base, i, slot):  # t_k = fma(frac, d_k, next_k); out_k += t_k   (two t registers, used alternately)
+        fs = f"s[{f_of(base, p, i)}:{f_of(base, p, i) + 1}]"
+        Op = O[qz[0]][p]
+        L = []
+        for k0 in (0, 2):
+            for k in (k0, k0 + 1):
+                L.append(f"v_pk_fma_f32 {opair(TT, k - k0)}, {fs}, {d_of(slot, k)}, {nxt_of(slot, k)} op_sel_hi:[0,1,1]")
+            for k in (k0, k0 + 1):
+                L.append(f"v_pk_add_f32 {opair(Op, k)}, {opair(Op, k)}, {opair(TT, k - k0)}")
+        return L
+
+    def spot(addr_sgpr):  # a pixel's own elements read where they are needed (rare patterns)
+        return reads(X, addr_sgpr) + ["s_waitcnt lgkmcnt(0)"]
+
+    def request_x(base, i):
+        """X for the mic whose entries sit at (base, i): pixel 0's elements if its address differs from the reference's, else pixel 3's"""
+        u = uid()
+        cold.extend([f".Lnx0{u}:"] + reads(X, a_of(base, 0, i)) + [f"s_branch .Lnxb{u}",
+                     f".Lnx3{u}:"] + reads(X, a_of(base, 3, i)) + [f"s_branch .Lnxb{u}"])
+        return [f"s_cmp_lg_u32 s{a_of(base, 0, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lnx0{u}",
+                f"s_cmp_lg_u32 s{a_of(base, 3, i)}, s{a_of(base, REF, i)}", f"s_cbranch_scc1 .Lnx3{u}", f".Lnxb{u}:"]
+
+    def mic_step(base, i, rslot, nbase, ni):
+        u = uid()
+        a0, a1, a2, a3 = (a_of(base, p, i) for p in range(4))
+        t = lambda p, slot: terms(p, base, i, slot)
+        # a-a-a-a
+        hot = ([f"s_cmp_lg_u32 s{a0}, s{a1}", f"s_cbranch_scc1 .Ln0{u}", f"s_cmp_lg_u32 s{a3}, s{a1}", f"s_cbranch_scc1 .Ln3{u}",
+                f"s_cmp_lg_u32 s{a2}, s{a1}", f"s_cbranch_scc1 .Lnslow{u}"] +
+               request_x(nbase, ni) + t(3, rslot) + t(2, rslot) + t(0, rslot) + t(REF, rslot) + [f".Lnjoin{u}:"])
+        # b-a-a-a
+        cold.extend([f".Ln0{u}:", f"s_cmp_lg_u32 s{a3}, s{a1}", f"s_cbranch_scc1 .Lnslow{u}", f"s_cmp_lg_u32 s{a2}, s{a1}", f"s_cbranch_scc1 .Lnslow{u}"] +
+                    t(0, X) + request_x(nbase, ni) + t(3, rslot) + t(2, rslot) + t(REF, rslot) + [f"s_branch .Lnjoin{u}"])
+        # a-a-b-b and a-a-a-b
+        cold.extend([f".Ln3{u}:", f"s_cmp_eq_u32 s{a2}, s{a1}", f"s_cbranch_scc1 .Ln3only{u}", f"s_cmp_lg_u32 s{a2}, s{a3}", f"s_cbranch_scc1 .Lnslow{u}"] +
+                    t(3, X) + t(2, X) + request_x(nbase, ni) + t(0, rslot) + t(REF, rslot) + [f"s_branch .Lnjoin{u}"])
+        cold.extend([f".Ln3only{u}:"] + t(3, X) + request_x(nbase, ni) + t(2, rslot) + t(0, rslot) + t(REF, rslot) + [f"s_branch .Lnjoin{u}"])
+        # anything else (two steps inside the quad, or not monotone): every differing pixel after the slot's owner reads on the spot
+        cold.extend(
+            [f".Lnslow{u}:", f"s_cmp_eq_u32 s{a0}, s{a1}", f"s_cbranch_scc1 .Lns1{u}"] + t(0, X) +
+            [f"s_cmp_eq_u32 s{a3}, s{a1}", f"s_cbranch_scc1 .Lns2{u}"] + spot(a3) + t(3, X) + [f"s_branch .Lns3{u}",
+             f".Lns1{u}:", f"s_cmp_eq_u32 s{a3}, s{a1}", f"s_cbranch_scc1 .Lns2{u}"] + t(3, X) +
+            [f".Lns3{u}:", f"s_cmp_eq_u32 s{a2}, s{a1}", f"s_cbranch_scc1 .Lns4{u}", f"s_cmp_eq_u32 s{a2}, s{a3}", f"s_cbranch_scc1 .Lns3b{u}"] + spot(a2) +
+            [f".Lns3b{u}:"] + t(2, X) + [f"s_branch .Lns4{u}",
+             f".Lns2{u}:", f"s_cmp_eq_u32 s{a2}, s{a1}", f"s_cbranch_scc1 .Lns4{u}"] + spot(a2) + t(2, X) +
+            [f".Lns4{u}:"] + request_x(nbase, ni) +
+            [f"s_cmp_lg_u32 s{a0}, s{a1}", f"s_cbranch_scc1 .Lns5{u}"] + t(0, rslot) +
+            [f".Lns5{u}:", f"s_cmp_lg_u32 s{a3}, s{a1}", f"s_cbranch_scc1 .Lns6{u}"] + t(3, rslot) +
+            [f".Lns6{u}:", f"s_cmp_lg_u32 s{a2}, s{a1}", f"s_cbranch_scc1 .Lns7{u}"] + t(2, rslot) +
+            [f".Lns7{u}:"] + t(REF, rslot) + [f"s_branch .Lnjoin{u}"])
+        return hot
+
+    def load_set(base, off, literal=False):
+        if literal:
+            return [f"s_load_dwordx16 s[{base}:{base + 15}], %[ptr], {hex(off)}",
+                    f"s_load_dwordx16 s[{base + 16}:{base + 31}], %[ptr], {hex(off + 64)}"]
+        return [f"s_load_dwordx16 s[{base}:{base + 15}], %[ptr], s{off}",
+                f"s_add_u32 s{S_TMP}, s{off}, 64",
+                f"s_load_dwordx16 s[{base + 16}:{base + 31}], %[ptr], s{S_TMP}"]
+
+    def dma_piece():
+        """one 16 KiB piece of the refill, if any is left (block_quad's)"""
+        u = uid()
+        return [f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Lndskip{u}",
+                f"v_cmp_gt_u32 vcc, s{S_REM}, %[lbytes]",  # lanes whose 16 bytes lie inside the chunk
+                "s_mov_b64 exec, vcc",
+                f"s_mov_b32 m0, s{S_DST}", "s_nop 0",
+                f"global_load_lds_dwordx4 %[lbytes], s[{S_SB}:{S_SB + 1}]",
+                "s_mov_b64 exec, -1",
+                f"s_add_u32 s{S_SB}, s{S_SB}, {hex(ND_DMA_STRIDE)}", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+                f"s_add_u32 s{S_DST}, s{S_DST}, {hex(ND_DMA_STRIDE)}", f"s_sub_u32 s{S_REM}, s{S_REM}, {hex(ND_DMA_STRIDE)}",
+                f"s_add_u32 s{S_K}, s{S_K}, 1", f".Lndskip{u}:"]
+
+    def trip_n(par):
+        cur, nxt = E[par], E[1 - par]
+        L = dma_piece()
+        L += select_prio(S_PRIO, 1, QUAD_XMAP) if par == 0 else select_prio(S_RANK, 0, QUAD_YMAP)  # rotation / youngest first, trip by trip
+        if nq > 1:  # a quad's last trip of the chunk fetches the OTHER quad's next entries (its own continue where they stopped)
+            u = uid()
+            L += [f"s_cmp_lg_u32 s{S_LEFT_}, 1", f"s_cbranch_scc1 .Lnsw{u}",
+                  f"s_mov_b32 s{S_TMP}, s{S_PF_}", f"s_mov_b32 s{S_PF_}, s{S_PFO}", f"s_mov_b32 s{S_PFO}, s{S_TMP}", f".Lnsw{u}:"]
+        L += load_set(nxt, S_PF_) + [f"s_add_u32 s{S_PF_}, s{S_PF_}, 128"]
+        for st in range(4):
+            rslot = R[st & 1]
+            if st < 3:
+                L += reads(R[(st + 1) & 1], a_of(cur, REF, st + 1))
+                L.append("s_waitcnt lgkmcnt(4)")  # all but the four reads just issued: this mic's elements are in
+                nbase, ni = cur, st + 1
+            else:
+                L.append("s_waitcnt lgkmcnt(0)")  # this mic's elements, and the next trip's entries
+                L += reads(R[0], a_of(nxt, REF, 0))
+                nbase, ni = nxt, 0
+            L += mic_step(cur, st, rslot, nbase, ni)
+        return L
+
+    def first_reads(base):
+        return reads(R[0], a_of(base, REF, 0)) + request_x(base, 0)
+
+    def refill_params(first):
+        """S_SB / S_REM / S_NP / S_K for the refill that runs beside the chunk about to be swept (S_CH = chunks left, that one
+        included): the item's next chunk, dbf bytes on, or nothing after the last."""
+        u = uid()
+        L = []
+        if not first:
+            L += [f"s_lshl_b32 s{S_TMP}, s{S_K}, {ND_DMA_STRIDE.bit_length() - 1}",   # undo the pieces' advance
+                  f"s_sub_u32 s{S_SB}, s{S_SB}, s{S_TMP}", f"s_subb_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+                  f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_TMP}",
+                  f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_DELTA}",            # the refill alternates images like the sweep, one ahead
+                  f"s_sub_u32 s{S_DELTA}, 0, s{S_DELTA}"]
+        L += [f"s_mov_b32 s{S_REM}, 0", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cbranch_scc1 .Lnrset{u}",
+              f"s_add_u32 s{S_SB}, s{S_SB}, %[dbf]", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+              f"s_mov_b32 s{S_REM}, %[dbf]", f"s_cmp_eq_u32 s{S_CH}, 2", f"s_cselect_b32 s{S_REM}, %[dbl], s{S_REM}",
+              f".Lnrset{u}:",
+              f"s_mov_b32 s{S_K}, 0", f"s_add_u32 s{S_NP}, s{S_REM}, {ND_DMA_STRIDE - 1}",
+              f"s_lshr_b32 s{S_NP}, s{S_NP}, {ND_DMA_STRIDE.bit_length() - 1}"]
+        return L
+
+    def chunk_groups():  # S_NG = groups of four mics in the chunk about to be swept
+        return [f"s_mov_b32 s{S_NG}, %[ngf]", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cselect_b32 s{S_NG}, %[ngl], s{S_NG}", f"s_mov_b32 s{S_LEFT_}, s{S_NG}"]
+
+    def boundary(next_set, resume):
+        u = uid()
+        L = ["s_waitcnt lgkmcnt(0)",  # this chunk's last elements, and the reads issued for a trip that does not come
+             f".Lnmore{u}:", f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Lnnomore{u}"] + dma_piece() + [f"s_branch .Lnmore{u}", f".Lnnomore{u}:"]
+        L += ["s_waitcnt vmcnt(0)", "s_barrier",  # my pieces of the next chunk have landed; so has everybody's, and all are done with this image
+              f"s_sub_u32 s{S_CH}, s{S_CH}, 1", f"s_cmp_eq_u32 s{S_CH}, 0", "s_cbranch_scc1 .LNexit_%=",
+              f"v_add_u32 %[lane], s{S_DELTA}, %[lane]"]  # the sweep moves to the image just filled
+        L += refill_params(first=False) + chunk_groups() + first_reads(next_set) + [f"s_branch {resume}"]
+        return L
+
+    L = [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    L += [f"s_mov_b32 s{S_M0}, m0", f"s_mov_b32 s{S_CH}, %[nch]", f"s_mov_b32 s{S_DELTA}, %[delta]",
+          f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[isrc]", f"s_mov_b32 s{S_DST}, %[ddst]"]
+    L += refill_params(first=True)
+    L += load_set(E[0], 0, literal=True)
+    L += chunk_groups() + [f"s_movk_i32 s{S_PF_}, 0x80"]
+    if nq > 1:
+        L += [f"s_mov_b32 s{S_PFO}, %[qstride]"]
+    L += ["s_waitcnt lgkmcnt(0)"] + first_reads(E[0])
+    # quad q's trips: .LNq_0 runs out of set 0, .LNq_1 out of set 1; a quad's chunk that ends on a trip out of set s hands set 1 - s
+    # (already loaded: the next quad's, or -- after the last quad -- the first quad's entries of the next chunk) to what follows
+    for q in range(nq):
+        qz[0] = q
+        last = q == nq - 1
+        after0 = f".LNhand{q}_%=" if not last else ".LNbndA_%="
+        L += [f".LN{q}_0_%=:"] + trip_n(0)
+        L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_eq_u32 s{S_LEFT_}, 0", f"s_cbranch_scc1 {after0}"]
+        L += [f".LN{q}_1_%=:"] + trip_n(1)
+        L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", f"s_cbranch_scc1 .LN{q}_0_%="]
+        if not last:  # ended on a trip out of set 1: the next quad begins on set 0 (falls through); out of set 0: on set 1
+            L += [f"s_mov_b32 s{S_LEFT_}, s{S_NG}", f"s_branch .LN{q + 1}_0_%=",
+                  f".LNhand{q}_%=:", f"s_mov_b32 s{S_LEFT_}, s{S_NG}", f"s_branch .LN{q + 1}_1_%="]
+        else:
+            qz[0] = 0  # (the boundary's first reads belong to no quad's accumulators; request_x / reads use none)
+            L += boundary(E[0], ".LN0_0_%=")
+            L += [".LNbndA_%=:"] + boundary(E[1], ".LN0_1_%=")
+    L += cold
+    L += [".LNexit_%=:", f"s_mov_b32 m0, s{S_M0}", f"s_setprio {QUAD_END_PRIO}"]
+    body = "\n".join(f'        "{l}\\n\\t"' for l in L)
+    vregs = list(range(ND_TMP, addr_t + 1))
+    sregs = sorted({S_NG, S_PFO, S_CH, S_SB, S_SB + 1, S_TMP, S_PF_, S_LEFT_, S_DST, S_RANK, S_PRIO, S_REM, S_K, S_NP, S_M0, S_DELTA}) + list(range(36, 100))
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"', '"vcc"', '"memory"'])
+    acc_params = ", ".join(f"f8 &O{q}{p}" for q in range(nq) for p in range(4))
+    acc_ops = ", ".join(f'"+{{v[{O[q][p]}:{O[q][p] + 7}]}}"(O{q}{p})' for q in range(nq) for p in range(4))
+    qs_param = ", int qstride" if nq > 1 else ""
+    qs_op = ', [qstride] "s"(qstride)' if nq > 1 else ""
+    return f"""// Reference-order sweep of a whole item (frame pair x tile) on the {{next, d}} layout, {nq} quad(s) of four vertically adjacent
+// pixels per wave: tools/gen_trip_asm.py, block_exact_nd.  `row` = the first quad's entries of the item's first group in the quad-major
+// table ([group][pixel][mic] x (fraction, address), contiguous across chunks){"; the second quad's lie qstride bytes on" if nq > 1 else ""}; reads one group
+// past a quad's last.  ngf / ngl = groups of four mics in a full / in the last chunk, nch = chunks, isrc = chunk 0's rows in HBM (chunk c's
+// follow dbf bytes apart; dbl = bytes of the last chunk), ddst = this wave's first LDS-DMA destination in the image chunk 0 does NOT occupy,
+// delta = (that image) - (chunk 0's image) in bytes, lbytes = 16 x thread index; lane_addr = the sweep's LDS address in chunk 0's image.
+// O_qp = out[l + 64 k] of pixel p of quad q, both frames, pinned at v[{ND_ACC} + 32 q + 8 p ..]; temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}.
+// Executes nch s_barrier instructions.
+__device__ __forceinline__ void {name}({acc_params}, const void *row{qs_param}, int ngf, int ngl, int nch, unsigned &lane_addr, int rank,
+                                       const void *isrc, unsigned dbf, unsigned dbl, unsigned ddst, int delta, unsigned lbytes) {{
+    asm volatile(
+{body}
+        : {acc_ops}, [lane] "+v"(lane_addr)
+        : [ptr] "s"(row){qs_op}, [ngf] "s"(ngf), [ngl] "s"(ngl), [nch] "s"(nch), [rank] "s"(rank), [isrc] "s"(isrc), [dbf] "s"(dbf), [dbl] "s"(dbl),
+          [ddst] "s"(ddst), [delta] "s"(delta), [lbytes] "v"(lbytes)
+        : {clobbers});
+}}
+"""
+
+
 # ---------------------------------------------------------------------------------------------------
 # Quad block with a shared integer-delay sum (das_quad_kernel).
 #
@@ -1703,7 +1958,9 @@ def main():
     out.append(block_shared("sweep_duo_shared", 128 - 25 - 3))
     out.append(block_shared("sweep_duo_shared_stamped", 128 - 25 - 3, stamp=True))
     out.append(block_exact_shared("sweep_duo_exact", 128 - 57 - 3))  # das_exact_pair_kernel (AWPU_MATH_F32_EXACT)
-    out.append(block_exact_quad("sweep_quad_exact"))  # das_exact_quad_kernel (AWPU_MATH_F32_EXACT, row length known)
+    out.append(block_exact_quad("sweep_quad_exact"))  # das_exact_quad_kernel (AWPU_MATH_F32_EXACT, row length known; round 4)
+    out.append(block_exact_nd("sweep_exact_nd_item1", 1))  # das_exact_nd_kernel<1>: the {next, d} layout, one quad per wave
+    out.append(block_exact_nd("sweep_exact_nd_item2", 2))  # das_exact_nd_kernel<2>: two quads per wave (the default batch kernel of the reference order)
     out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))
     out.append(block_quad("sweep_quad_item", dma=True, chain=CHAIN, item=True))  # the production batch kernel: one block per item
