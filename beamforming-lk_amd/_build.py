@@ -60,7 +60,7 @@ def generate_blocks(force: bool = False) -> Path:
     import sys
 
     env = {k: v for k, v in os.environ.items()
-           if not k.startswith(("QUAD", "TRIP_", "PAIR_DEPTH", "FIR_PRIO", "BLOCK_END_PRIO"))}  # a shipping build: the defaults
+           if not k.startswith(("QUAD", "TRIP_", "PAIR_DEPTH", "FIR_PRIO", "BLOCK_END_PRIO", "ND_"))}  # a shipping build: the defaults
     proc = subprocess.run([sys.executable, str(GENERATOR)], capture_output=True, text=True, env=env)
     if proc.returncode != 0 or not TRIP_INC.exists():
         raise RuntimeError(f"tools/gen_trip_asm.py failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}")

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <array>
+#include <map>
 #include <vector>
 
 #include "das_kernels.h"
@@ -83,12 +85,15 @@ struct awpu_hip {
     std::vector<FastLut> fast_luts;  // one per (frames per item, LDS image size) in use
     awpu::FastEntry *d_exact_pair_lut = nullptr;  // reference-order sweep on the frame-pair layout (das_exact_pair_kernel)
     size_t exact_pair_lut_entries = 0, fir_plane_lut_entries = 0;  // allocated entries of the tables below and above ...
-    size_t quad_lut_entries[5] = {0, 0, 0, 0, 0};                  // ... and of the quad-major tables, by QuadLayout
+    size_t quad_lut_entries[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // ... and of the quad-major tables, by QuadLayout
     awpu::QuadEntry *d_exact_quad_lut = nullptr;  // ... four vertically adjacent pixels per wave (das_exact_quad_kernel): quad-major, raw fractions
     awpu::FastPlan exact_plan{};
     awpu::QuadEntry *d_exact_nd_lut = nullptr;    // ... on the {next, d} layout (das_exact_nd_kernel): 16-byte elements, quad rows padded to an even count
     awpu::FastPlan exact_nd_plan{};
     bool exact_nd_ok = false;     // ... and the window fits the {next, d} image
+    awpu::QuadEntry *d_exact_ndh_lut = nullptr, *d_exact_ndhs_lut = nullptr;  // single frames: the halves form of that layout, chunked / every mic resident
+    awpu::FastPlan exact_ndh_plan{}, exact_ndhs_plan{};
+    bool exact_ndh_ok = false, exact_ndhs_ok = false;
     bool exact_pairs_ok = false;  // AWPU_MATH_F32_EXACT + LERP and the window fits the pair image
     float *sums_out = nullptr;    // awpu_hip_process_device_sums: where the launch in progress exports out[] (else null)
     awpu::QuadEntry *d_quad_lut = nullptr;  // quad-major table of the quad shape (das_quad_kernel)
@@ -102,6 +107,7 @@ struct awpu_hip {
     bool quadhs_fits = false;     // ... with every active mic's row in LDS at once (das_quadh_stationary_kernel: one 8x8 array does)
     bool quad_ok = false;         // the table's statistics favour the quad shape (decided in prepare)
     double quad_cost = 0.0;       // its expected packed VALU instructions per quad and mic (32 = no sharing at all)
+    double quad_differ = 3.0;     // pixels of a vertical quad (of three) whose integer delay differs from the second pixel's, per mic (table sample)
     int32_t *d_index = nullptr;
     float *d_gain = nullptr;  // [usable] gains in active-mic order, or null
     float *d_calib = nullptr; // [64] per-mic mean squares (calibration)
@@ -308,6 +314,8 @@ void release_device(awpu_hip *h) {
     dev_free(h->d_exact_pair_lut);
     dev_free(h->d_exact_quad_lut);
     dev_free(h->d_exact_nd_lut);
+    dev_free(h->d_exact_ndh_lut);
+    dev_free(h->d_exact_ndhs_lut);
     dev_free(h->d_quad_lut);
     dev_free(h->d_quadh_lut);
     dev_free(h->d_quadhs_lut);
@@ -379,6 +387,8 @@ int prepare(awpu_hip *h) {
     dev_free(h->d_exact_pair_lut);
     dev_free(h->d_exact_quad_lut);
     dev_free(h->d_exact_nd_lut);
+    dev_free(h->d_exact_ndh_lut);
+    dev_free(h->d_exact_ndhs_lut);
     dev_free(h->d_quad_lut);
     dev_free(h->d_quadh_lut);
     dev_free(h->d_quadhs_lut);
@@ -425,6 +435,8 @@ int prepare(awpu_hip *h) {
 
     h->exact_pairs_ok = c.math == AWPU_MATH_F32_EXACT && c.interp == AWPU_INTERP_LERP && awpu::pair_plan(h->window, U, &h->exact_plan);
     h->exact_nd_ok = h->exact_pairs_ok && awpu::exact_nd_plan(h->window, U, &h->exact_nd_plan);
+    h->exact_ndh_ok = h->exact_pairs_ok && awpu::exact_ndh_plan(h->window, U, false, &h->exact_ndh_plan);
+    h->exact_ndhs_ok = h->exact_pairs_ok && awpu::exact_ndh_plan(h->window, U, true, &h->exact_ndhs_plan);
     if (c.math != AWPU_MATH_F32_FAST || c.interp == AWPU_INTERP_FIR8) {
         int chunk = 0;
         if (awpu::das_exact_lds_bytes(h->window, U, &chunk) == 0)
@@ -491,8 +503,8 @@ int prepare(awpu_hip *h) {
     h->quad_cost = 0.0;
     {
         const int cols = c.grid_columns;
-        if (c.math == AWPU_MATH_F32_FAST && c.interp == AWPU_INTERP_LERP && cols > 0 && P % cols == 0 &&
-            c.pixel_begin % cols == 0) {
+        h->quad_differ = 3.0;
+        if (c.interp == AWPU_INTERP_LERP && cols > 0 && P % cols == 0 && c.pixel_begin % cols == 0) {
             const int rows = P / cols;
             long differ = 0, together = 0, seen = 0;  // `together`: pixels 2 and 3 away from the reference as one (4 less)
             const int n_quads = ((rows + 3) / 4) * cols;
@@ -509,8 +521,10 @@ int prepare(awpu_hip *h) {
                 seen += U;
             }
             h->quad_cost = seen ? 20.0 + (8.0 * (double) differ - 4.0 * (double) together) / (double) seen : 32.0;
-            h->quad_ok = h->quad_cost < 31.0 && awpu::pair_plan(h->window, U, &h->quad_plan);
-            if (env().quads >= 0) h->quad_ok = env().quads != 0 && awpu::pair_plan(h->window, U, &h->quad_plan);
+            h->quad_differ = seen ? (double) differ / (double) seen : 3.0;  // pixels of a quad (of three) that leave the reference pixel's address, per mic
+            const bool fast = c.math == AWPU_MATH_F32_FAST;
+            h->quad_ok = fast && h->quad_cost < 31.0 && awpu::pair_plan(h->window, U, &h->quad_plan);
+            if (fast && env().quads >= 0) h->quad_ok = env().quads != 0 && awpu::pair_plan(h->window, U, &h->quad_plan);
             // the halves layout: a row holds the window less 128 samples, as (sample, sample + 128) pairs (its pack pass applies the gains)
             h->quadh_fits = h->quad_ok && awpu::pair_plan(h->window - 128, U, &h->quadh_plan);
             h->quadhs_fits = h->quadh_fits && awpu::quadh_stationary_plan(h->window, U, &h->quadhs_plan);
@@ -586,12 +600,14 @@ int build_fast_lut(awpu_hip *h, int fpi, int image_bytes, const awpu_hip::FastLu
 // address), quads = groups of four grid rows x columns padded to whole 16-column tiles.  Pixels past the grid
 // carry weight 0 and the address of the nearest pixel inside it (they then follow the shared path and add
 // nothing); padding mics (usable rounded up to 4) carry weight 0 and the address of their own, zero, row.
-enum QuadLayout { kQuadPairs = 0, kQuadExactNd = 1, kQuadHalves = 2, kQuadHalvesStationary = 3, kQuadExact = 4 };
+enum QuadLayout { kQuadPairs = 0, kQuadExactNd = 1, kQuadHalves = 2, kQuadHalvesStationary = 3, kQuadExact = 4, kQuadExactNdh = 5, kQuadExactNdhStationary = 6 };
 int build_quad_lut(awpu_hip *h, int layout) {
     awpu::QuadEntry *&d_lut = layout == kQuadHalves             ? h->d_quadh_lut
                               : layout == kQuadHalvesStationary ? h->d_quadhs_lut
                               : layout == kQuadExact            ? h->d_exact_quad_lut
                               : layout == kQuadExactNd          ? h->d_exact_nd_lut
+                              : layout == kQuadExactNdh         ? h->d_exact_ndh_lut
+                              : layout == kQuadExactNdhStationary ? h->d_exact_ndhs_lut
                                                                 : h->d_quad_lut;
     if (d_lut) return AWPU_OK;
     const auto &c = h->cfg;
@@ -599,14 +615,18 @@ int build_quad_lut(awpu_hip *h, int layout) {
                                  : layout == kQuadHalvesStationary ? h->quadhs_plan
                                  : layout == kQuadExact            ? h->exact_plan
                                  : layout == kQuadExactNd          ? h->exact_nd_plan
+                                 : layout == kQuadExactNdh         ? h->exact_ndh_plan
+                                 : layout == kQuadExactNdhStationary ? h->exact_ndhs_plan
                                                                    : h->quad_plan;
-    const bool raw = layout == kQuadExact || layout == kQuadExactNd;
+    const bool halves_nd = layout == kQuadExactNdh || layout == kQuadExactNdhStationary;
+    const bool raw = layout == kQuadExact || layout == kQuadExactNd || halves_nd;
     const float centre = raw ? 0.0f : 0.5f;  // the reference-order sweeps take the fraction as it is (mimo.cpp:126)
-    const int elem = layout == kQuadExactNd ? 16 : 8;  // bytes per LDS element: {next, d} of a frame pair, or one sample of a frame pair
+    const int elem = layout == kQuadExactNd || halves_nd ? 16 : 8;  // bytes per LDS element: {next, d} of a frame pair / of the two halves, or one sample pair
     const int U = h->usable(), cols = c.grid_columns, rows = c.pixel_count / cols;
     const int groups = plan.usable_pad / 4;
-    // (the {next, d} kernel gives a wave two quads, one quad row apart: its table has an even number of quad rows, the last one clamped)
-    const int cols_pad = (cols + 15) / 16 * 16, rows4 = layout == kQuadExactNd ? ((rows + 3) / 4 + 1) / 2 * 2 : (rows + 3) / 4;
+    // (the {next, d} kernel gives a wave two quads, one quad row apart: its table has an even number of quad rows, the last one clamped;
+    // ... the single-frame form two quads one COLUMN apart: its table has whole tiles of 32 columns)
+    const int cols_pad = halves_nd ? (cols + 31) / 32 * 32 : (cols + 15) / 16 * 16, rows4 = layout == kQuadExactNd ? ((rows + 3) / 4 + 1) / 2 * 2 : (rows + 3) / 4;
     const size_t n = (size_t) rows4 * cols_pad * groups * 16 + 2 * awpu::kQuadTablePrefetch;  // spare groups: the sweep prefetches one past the end
     std::vector<awpu::QuadEntry> packed(n, awpu::QuadEntry{0.0f, 0u});
     for (int r4 = 0; r4 < rows4; r4++)
@@ -843,8 +863,117 @@ int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_powe
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_pack_nd(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad, h->d_gain,
                                       pp.wr, batch, h->d_pack, s));
+#ifdef AWPU_TUNING_BUILD
+    const size_t n_wgs = 8 * (((size_t) a.n_pairs * a.tiles + 7) / 8);
+    if (env().debug & 16) {  // per-workgroup timeline (where, when, phases): printed below
+        if (const int drc = ensure_diag(h, n_wgs * 8); drc != AWPU_OK) return drc;
+        AWPU_HIP_TRY(hipMemsetAsync(h->d_diag, 0, n_wgs * 8 * sizeof(unsigned long long), s));
+        a.debug_out = h->d_diag;
+    }
+#endif
     AWPU_HIP_TRY(awpu::launch_das_exact_nd(a, {h->quad_lut_entries[kQuadExactNd], h->pack_cap}, s));
-    return finish_launch(h, batch, s, AWPU_KERNEL_EXACT_ND);
+    rc = finish_launch(h, batch, s, AWPU_KERNEL_EXACT_ND);
+#ifdef AWPU_TUNING_BUILD
+    if (rc == AWPU_OK && (env().debug & 16)) {
+        AWPU_HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned long long> hb(n_wgs * 8);
+        AWPU_HIP_TRY(hipMemcpy(hb.data(), h->d_diag, hb.size() * 8, hipMemcpyDeviceToHost));
+        // group by compute unit (XCC, SE, CU of HW_ID), order by start: busy time, gaps between consecutive workgroups
+        std::map<unsigned long long, std::vector<std::array<unsigned long long, 5>>> by_cu;
+        unsigned long long first = ~0ull, last = 0;
+        double ph[3] = {0, 0, 0};
+        size_t n = 0;
+        for (size_t w = 0; w < n_wgs; w++) {
+            const unsigned long long *o = &hb[8 * w];
+            if (!o[7]) continue;
+            const unsigned hw = (unsigned) o[5], xcc = (unsigned) (o[5] >> 32) & 0xf;
+            const unsigned long long cu = ((unsigned long long) xcc << 16) | ((hw >> 8) & 0xff);  // HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+            by_cu[cu].push_back({o[0], o[1], o[2], o[3], o[4]});
+            first = std::min(first, o[0]);
+            last = std::max(last, o[1]);
+            for (int k = 0; k < 3; k++) ph[k] += (double) o[2 + k];
+            n++;
+        }
+        double busy = 0, gaps = 0, head = 0, tail = 0;
+        size_t n_gaps = 0;
+        for (auto &kv : by_cu) {
+            auto &v = kv.second;
+            std::sort(v.begin(), v.end());
+            head += (double) (v.front()[0] - first);
+            tail += (double) (last - v.back()[1]);
+            for (size_t i = 0; i < v.size(); i++) {
+                busy += (double) (v[i][1] - v[i][0]);
+                if (i) gaps += (double) v[i][0] - (double) v[i - 1][1], n_gaps++;
+            }
+        }
+        {   // per XCD: when its last workgroup ended (relative to the launch's first stamp), mean busy time of its CUs, and the
+            // spread of workgroup durations by position in the item order
+            std::map<unsigned, std::array<double, 4>> xs;  // last end, busy sum, CU count, workgroups
+            for (auto &kv : by_cu) {
+                auto &x = xs[(unsigned) (kv.first >> 16)];
+                x[0] = std::max(x[0], (double) (kv.second.back()[1] - first));
+                for (auto &w : kv.second) x[1] += (double) (w[1] - w[0]);
+                x[2] += 1;
+                x[3] += (double) kv.second.size();
+            }
+            std::fprintf(stderr, "[awpu diag nd] per XCD (last end us / mean busy us / CUs / workgroups):");
+            for (auto &kv : xs) std::fprintf(stderr, " %u: %.0f/%.0f/%.0f/%.0f", kv.first, kv.second[0] * 0.01, kv.second[1] / kv.second[2] * 0.01, kv.second[2], kv.second[3]);
+            std::vector<double> dur;
+            for (size_t w = 0; w < n_wgs; w++) if (hb[8 * w + 7]) dur.push_back((double) (hb[8 * w + 1] - hb[8 * w]) * 0.01);
+            std::sort(dur.begin(), dur.end());
+            if (!dur.empty()) std::fprintf(stderr, "\n[awpu diag nd] workgroup duration us: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f\n", dur.front(), dur[dur.size() / 10],
+                                           dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back());
+        }
+        const double cus = (double) by_cu.size();
+        std::fprintf(stderr, "[awpu diag nd] %zu workgroups on %zu CUs, span %.1f us | per CU: busy %.1f us, gaps %.1f us (%.2f us each), idle before first %.1f us, "
+                     "after last %.1f us | per workgroup cycles: staging %.0f sweep %.0f epilogue %.0f\n", n, by_cu.size(), (double) (last - first) * 0.01,
+                     busy / cus * 0.01, gaps / cus * 0.01, n_gaps ? gaps / (double) n_gaps * 0.01 : 0.0, head / cus * 0.01, tail / cus * 0.01, ph[0] / n, ph[1] / n, ph[2] / n);
+    }
+#endif
+    return rc;
+}
+
+// single frames in the reference's order: the halves form of the {next, d} layout (das_exact_ndh_kernel) -- every mic resident and
+// staged by the workgroups themselves (one array), or chunked behind a pack pre-pass.  `pitch` = floats between two streams of a frame
+int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int pitch, int wstart_eff, bool stationary,
+                     int nq) {
+    int rc = build_quad_lut(h, stationary ? kQuadExactNdhStationary : kQuadExactNdh);
+    if (rc != AWPU_OK) return rc;
+    const awpu::FastPlan &pp = stationary ? h->exact_ndhs_plan : h->exact_ndh_plan;
+    if (!stationary) {
+        const size_t need = std::max((size_t) h->cfg.max_batch, (size_t) batch) * pp.usable_pad * pp.wr * 4;
+        if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
+    }
+    awpu::ExactNdhArgs a{};
+    a.packed = stationary ? nullptr : h->d_pack;
+    a.frames = d_frames;
+    a.lut = stationary ? h->d_exact_ndhs_lut : h->d_exact_ndh_lut;
+    a.index = h->d_index;
+    a.gain = h->d_gain;
+    a.power = d_power;
+    a.sums = h->sums_out;
+    a.n_streams = h->cfg.n_streams;
+    a.pitch = pitch;
+    a.wstart = wstart_eff;
+    a.usable = h->usable();
+    a.usable_pad = pp.usable_pad;
+    a.pixel_count = h->cfg.pixel_count;
+    a.wh = pp.wr;
+    a.chunk = pp.chunk;
+    a.batch = batch;
+    a.cols = h->cfg.grid_columns;
+    a.rows = h->cfg.pixel_count / a.cols;
+    a.nq = nq;
+    a.tiles = awpu::quad1_tiles(a.rows, a.cols, nq);
+    a.lut_cols = (a.cols + 31) / 32 * 32;
+    a.identity = 1;
+    for (int k = 0; k < a.usable && a.identity; k++) a.identity = h->index[k] == k;
+    if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
+    if (!stationary)
+        AWPU_HIP_TRY(awpu::launch_pack_ndh(d_frames, h->cfg.n_streams, pitch, wstart_eff, h->d_index, h->usable(), pp.usable_pad, h->d_gain, pp.wr,
+                                           batch, h->d_pack, s));
+    AWPU_HIP_TRY(awpu::launch_das_exact_ndh(a, stationary, {h->quad_lut_entries[stationary ? kQuadExactNdhStationary : kQuadExactNdh], stationary ? 0 : h->pack_cap}, s));
+    return finish_launch(h, batch, s, stationary ? AWPU_KERNEL_EXACT_NDH_STATIONARY : AWPU_KERNEL_EXACT_NDH);
 }
 
 int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
@@ -1130,12 +1259,22 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
     if (h->exact_pairs_ok && env().exact_pairs != 0) {
         // vertical pixel quads where the row length is known and vertical neighbours coincide more often than horizontal ones
         // (prepare() counted: pair_cols); AWPU_SHAPE=exact_pair keeps the two-pixel block everywhere
-        if (h->pair_cols > 0 && env().exact_pairs != 2 && h->cfg.pixel_count / h->cfg.grid_columns >= 4) {
+        // (quad_differ < 1.5: on average fewer than half of a quad's pixels leave the reference pixel's address for a mic; a square
+        // array's vertical and horizontal neighbours coincide equally often -- pair_cols stays 0 there -- and quads still pay)
+        const bool quads_pay = h->cfg.grid_columns > 0 && h->cfg.pixel_count % h->cfg.grid_columns == 0 &&
+                               h->cfg.pixel_begin % h->cfg.grid_columns == 0 && h->quad_differ < 1.5;
+        if ((h->pair_cols > 0 || quads_pay) && env().exact_pairs != 2 && h->cfg.pixel_count / h->cfg.grid_columns >= 4) {
             // the {next, d} layout (round 5) wherever its image holds a group of mics; two quads per wave where that still fills the chip
             // (AWPU_SHAPE=exact_quad: round 4's kernel on raw sample pairs; exact_nd1 / exact_nd2: one / two quads per wave)
             const int ex = env().exact_pairs;
+            const int rows = h->cfg.pixel_count / h->cfg.grid_columns;
+            // one frame per call (MIMOWorker::update's regime): the halves form of the layout -- the two packed lanes are the two halves of
+            // the block, not a frame and its copy; every mic resident where one array's rows fit the LDS (no pre-pass)
+            if (batch == 1 && ex == 1 && (h->exact_ndhs_ok || h->exact_ndh_ok)) {
+                const int nq = (long) awpu::quad1_tiles(rows, h->cfg.grid_columns, 2) >= 256 ? 2 : 1;
+                return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, h->exact_ndhs_ok, nq);
+            }
             if (h->exact_nd_ok && ex != 3) {
-                const int rows = h->cfg.pixel_count / h->cfg.grid_columns;
                 const long wgs2 = (long) awpu::nd_tiles(rows, h->cfg.grid_columns, 2) * ((batch + 1) / 2);
                 const int nq = ex == 4 ? 1 : ex == 5 ? 2 : (rows >= 8 && wgs2 >= 512 ? 2 : 1);
                 return launch_exact_nd(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, nq);

@@ -1320,6 +1320,15 @@ __global__ __launch_bounds__(1024, 4) void das_exact_quad_kernel(ExactQuadArgs a
 // barrier, the 16-byte elements halve the mics per chunk); the whole item -- chunk loop, in-block refill, barrier -- runs inside
 // sweep_exact_nd_item<NQ> (tools/gen_trip_asm.py, block_exact_nd).  Epilogue, item order: das_exact_quad_kernel's.
 // ---------------------------------------------------------------------------------------
+// (next, cur - next) of one sample with the per-mic gain on both samples first, every operation rounded on its own: hipcc's
+// __fmul_rn / __fsub_rn are plain `*` and `-`, which it contracts into an FMA where it can (caught by the gains case of
+// test_exact_mode_single_frames_are_the_reference_bits); with contraction off in this scope the three roundings survive inlining
+__device__ __forceinline__ f2 next_and_difference(float cur, float next, float gm) {
+#pragma clang fp contract(off)
+    const float c = cur * gm, n = next * gm;  // x * 1.0f is x
+    return f2{n, c - n};                      // delay.cpp:21: cur - next
+}
+
 __global__ void pack_nd_kernel(const float *frames, int n_streams, int hist, int wstart, const int32_t *index, int usable,
                                const float *gain, int wq, int batch, float *packed) {
     const int pair = blockIdx.y, s = blockIdx.x, rows_out = gridDim.x;
@@ -1336,10 +1345,8 @@ __global__ void pack_nd_kernel(const float *frames, int n_streams, int hist, int
     for (int t = threadIdx.x; t < wq; t += blockDim.x) {
         f4 v = f4{0.0f, 0.0f, 0.0f, 0.0f};
         if (t < valid) {
-            // (explicit roundings: no contraction of the product into the difference)
-            const float ca = __fmul_rn(xa[t], gm), na = __fmul_rn(xa[t + 1], gm);
-            const float cb = __fmul_rn(xb[t], gm), nb = __fmul_rn(xb[t + 1], gm);
-            v = f4{na, nb, __fsub_rn(ca, na), __fsub_rn(cb, nb)};  // delay.cpp:21: cur - next
+            const f2 ea = next_and_difference(xa[t], xa[t + 1], gm), eb = next_and_difference(xb[t], xb[t + 1], gm);
+            v = f4{ea.x, eb.x, ea.y, eb.y};
         }
         dst[t] = v;
     }
@@ -1367,6 +1374,11 @@ __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
         tile = in / ga;
         pair = (item < full_items ? grp * a.pair_group : a.n_pairs - ga) + (in - tile * ga);
     }
+#ifdef AWPU_TUNING_BUILD
+    const unsigned long long rt_begin = a.debug_out ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz
+    const long long t_begin = __builtin_readcyclecounter();
+    long long t_staged = 0, t_swept = 0;
+#endif
     const int tiles_per_row = (a.cols + NW - 1) / NW;
     const int rowq = tile / tiles_per_row;  // the tile's first quad row is NQ * rowq
     const int col = (tile - rowq * tiles_per_row) * NW + wave;
@@ -1398,6 +1410,9 @@ __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef AWPU_TUNING_BUILD
+    t_staged = __builtin_readcyclecounter();
+#endif
 
     {
         unsigned lane_addr = lds_base + lane * 16;
@@ -1418,6 +1433,9 @@ __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
         }
     }
 
+#ifdef AWPU_TUNING_BUILD
+    t_swept = __builtin_readcyclecounter();
+#endif
     const float norm = (float) (kSamples * a.usable);
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
@@ -1445,6 +1463,191 @@ __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
         if ((lane & 7) == 0 && row < a.rows && col < a.cols && frame < a.batch)
             a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;
     }
+#ifdef AWPU_TUNING_BUILD
+    if (a.debug_out && threadIdx.x == 0) {  // the workgroup's timeline: which CU it ran on, when, and how long each phase took
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
+        unsigned long long *o = a.debug_out + 8 * (size_t) blockIdx.x;
+        o[0] = rt_begin;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = (unsigned long long) (t_staged - t_begin);
+        o[3] = (unsigned long long) (t_swept - t_staged);
+        o[4] = (unsigned long long) (__builtin_readcyclecounter() - t_swept);
+        o[5] = ((unsigned long long) xcc_id << 32) | hw_id;
+        o[6] = (unsigned long long) item;
+        o[7] = 1;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
+// Single frames in the reference's order (round 5): the halves form of the {next, d} layout.  MIMOWorker::update sweeps ONE
+// 256-sample block per call (worker.h:212-224, mimo.cpp:97-151); das_exact_nd_kernel would sweep it as a pair with itself, half its
+// packed lanes idle.  Here the two packed lanes are the two HALVES of the block (samples i and i + 128), as in das_quadh_kernel:
+// element t of a mic's row = { X[t+1], X[t+129], X[t] - X[t+1], X[t+128] - X[t+129] }, lane l owns samples l and l + 64 of either half
+// (register pair k of a pixel = out[l + 64 k], out[128 + l + 64 k]), an item = 2 ds_read_b128 + 2 x (v_pk_fma_f32, v_pk_add_f32):
+// the three operations of delay.cpp:19-25 per sample in its order, mics in table order -- the pre-epilogue sums are the
+// reference's bits, and the powers equal das_exact_nd_kernel's bit for bit (the same per-lane sums, the same reduction tree).
+// STATIONARY (one array: every active mic's row fits the LDS): the workgroup forms the elements itself from the caller's frame
+// (global loads -> registers -> LDS, no pre-pass, no chunks, nothing staged twice); otherwise rows packed by pack_ndh_kernel, the
+// item block refilling the other image chunk by chunk.  Tile = 4 rows x 16 NQ columns; grid = frames x tiles.
+// ---------------------------------------------------------------------------------------
+__global__ void pack_ndh_kernel(const float *frames, int n_streams, int pitch, int wstart, const int32_t *index, int usable,
+                                const float *gain, int wh, float *packed) {
+    const int frame = blockIdx.y, s = blockIdx.x, rows_out = gridDim.x;
+    f4 *dst = (f4 *) packed + ((size_t) frame * rows_out + s) * wh;
+    if (s >= usable) {
+        for (int t = threadIdx.x; t < wh; t += blockDim.x) dst[t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        return;
+    }
+    const float *x = frames + ((size_t) frame * n_streams + index[s]) * pitch + wstart;
+    const float gm = gain ? gain[s] : 1.0f;
+    for (int t = threadIdx.x; t < wh; t += blockDim.x) {  // (t + 129 <= window - 1: inside the stream's history)
+        const f2 lo = next_and_difference(x[t], x[t + 1], gm), hi = next_and_difference(x[t + 128], x[t + 129], gm);
+        dst[t] = f4{lo.x, hi.x, lo.y, hi.y};
+    }
+}
+
+// a lane's share of sum MA^2 of one pixel (mimo.cpp:131-137) from out[] in sample order o[k] = out[l + 64 k]: the scalar twin of
+// pixel_pair_partial_exact -- the same expressions in the same order, so a frame swept alone gives the bits it gives in a pair
+__device__ __forceinline__ float pixel_partial_exact(const float (&o)[4], int lane) {
+    float sum = 0.0f;
+    float dn = wave_rotate1<kDppWaveRol1>(o[0]);
+    float up_before = wave_rotate1<kDppWaveRor1>(o[0]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float dn_after = k < 3 ? wave_rotate1<kDppWaveRol1>(o[k < 3 ? k + 1 : 3]) : dn;
+        const float up = wave_rotate1<kDppWaveRor1>(o[k]);
+        const float next = lane == 63 ? dn_after : dn;
+        const float prev = lane == 0 ? up_before : up;
+        const int i = lane + 64 * k;
+        const float ma = o[k] * 0.5f - 0.25f * (next + prev);  // mimo.cpp:132-134
+        if (i >= 1 && i <= kSamples - 2) sum += ma * ma;
+        dn = dn_after;
+        up_before = up;
+    }
+    return sum;
+}
+
+template <int NQ, bool STATIONARY>
+__global__ __launch_bounds__(1024, 4) void das_exact_ndh_kernel(ExactNdhArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int frame = blockIdx.x / a.tiles, tile = blockIdx.x - frame * a.tiles;
+    constexpr int tile_cols = NW * NQ;
+    const int tiles_per_row4 = (a.cols + tile_cols - 1) / tile_cols;
+    const int row4 = tile / tiles_per_row4;
+    const int col0 = (tile - row4 * tiles_per_row4) * tile_cols + wave * NQ;  // the wave's NQ quads: columns col0 .. col0 + NQ - 1
+    const int groups_total = a.usable_pad >> 2;
+    const QuadEntry *quad_lut = a.lut + ((size_t) row4 * a.lut_cols + col0) * groups_total * 16;  // (the table's columns: whole tiles of 32)
+    const size_t row_floats = (size_t) a.wh * 4;
+
+    int n_chunks = 1, first_mics = a.usable_pad, last_mics = a.usable_pad;
+    const float *frame_rows = nullptr;
+    if constexpr (STATIONARY) {
+        // every active mic's row, formed here: waves take rows s = wave, wave + 16, ...; per pass 4 (row, 64-element stretch) units = 16
+        // global loads in flight per lane, then the differences and 4 ds_write_b128
+        const float *frame_base = a.frames + (size_t) frame * a.n_streams * a.pitch + a.wstart;
+        const int stretches = (a.wh + 63) >> 6;
+        const int units = ((a.usable_pad - wave + NW - 1) / NW) * stretches;
+        int r = 0, st = 0;  // the unit about to be taken: row wave + 16 r, elements 64 st .. 64 st + 63 (wave-uniform counters)
+        for (int u0 = 0; u0 < units; u0 += 4) {
+            float c0[4], n0[4], c1[4], n1[4], gm[4];
+            int slot[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int s = wave + NW * r, t = 64 * st + lane;
+                const bool on = u0 + j < units && t < a.wh;
+                slot[j] = on ? s * a.wh + t : -1;
+                c0[j] = n0[j] = c1[j] = n1[j] = 0.0f;  // padding mics: silence
+                gm[j] = 1.0f;
+                if (on && s < a.usable) {
+                    const float *x = frame_base + (size_t) (a.identity ? s : a.index[s]) * a.pitch + t;
+                    c0[j] = x[0], n0[j] = x[1], c1[j] = x[128], n1[j] = x[129];
+                    if (a.gain) gm[j] = a.gain[s];
+                }
+                if (++st == stretches) st = 0, r++;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (slot[j] < 0) continue;
+                const f2 lo = next_and_difference(c0[j], n0[j], gm[j]), hi = next_and_difference(c1[j], n1[j], gm[j]);
+                ((f4 *) lds)[slot[j]] = f4{lo.x, hi.x, lo.y, hi.y};
+            }
+        }
+        __syncthreads();
+    } else {
+        constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+        frame_rows = a.packed + (size_t) frame * a.usable_pad * row_floats;
+        n_chunks = (a.usable_pad + a.chunk - 1) / a.chunk;
+        first_mics = min(a.chunk, a.usable_pad);
+        last_mics = a.usable_pad - (n_chunks - 1) * a.chunk;
+        const int n_pieces = (int) ((size_t) first_mics * row_floats / 4);
+#pragma unroll
+        for (int k = 0; k < kPieces; k++) {  // chunk 0 into image 0 (the block refills from chunk 1 on)
+            const int piece = threadIdx.x + k * kThreads;
+            if (piece < n_pieces) {
+                float *dst = lds + (wave * 64 + k * kThreads) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (frame_rows + (size_t) piece * 4),
+                                                 (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    f4 O[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) O[q][p] = f4{0, 0, 0, 0};  // float out[N_SAMPLES] = {0.0}, mimo.cpp:122
+    {
+        unsigned lane_addr = lds_base + lane * 16;
+        const int ngf = __builtin_amdgcn_readfirstlane(first_mics >> 2), ngl = __builtin_amdgcn_readfirstlane(last_mics >> 2);
+        const unsigned dbf = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) a.chunk * row_floats * 4));
+        const unsigned dbl = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) last_mics * row_floats * 4));
+        const unsigned ddst = __builtin_amdgcn_readfirstlane(lds_base + BUF + wave * 1024);
+        const int rank = wave >> 2;
+        const unsigned lane_bytes = threadIdx.x * 16;
+        const void *isrc = uniform_ptr(STATIONARY ? (const void *) a.lut : (const void *) frame_rows);  // (one chunk: nothing is refilled)
+        if constexpr (NQ == 1) {
+            sweep_exact_ndh_item1(O[0][0], O[0][1], O[0][2], O[0][3], uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
+                                  lane_addr, rank, isrc, dbf, dbl, ddst, BUF, lane_bytes);
+        } else {
+            static_assert(NQ == 2, "blocks are generated for one and two quads per wave");
+            const int qstride = __builtin_amdgcn_readfirstlane(groups_total * 16 * (int) sizeof(QuadEntry));  // the next column's quad
+            sweep_exact_ndh_item2(O[0][0], O[0][1], O[0][2], O[0][3], O[1][0], O[1][1], O[1][2], O[1][3], uniform_ptr(quad_lut), qstride, ngf, ngl,
+                                  __builtin_amdgcn_readfirstlane(n_chunks), lane_addr, rank, isrc, dbf, dbl, ddst, BUF, lane_bytes);
+        }
+    }
+
+    const float norm = (float) (kSamples * a.usable);
+    float part[8];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int pp = 0; pp < 4; pp++) {
+            part[4 * q + pp] = 0.0f;
+            if (q >= NQ) continue;
+            const int row = 4 * row4 + pp, col = col0 + q;
+            const bool live = row < a.rows && col < a.cols;
+            const f4 &Op = O[q < NQ ? q : 0][pp];
+            const float o[4] = {Op[0], Op[2], Op[1], Op[3]};  // sample order: l, 64 + l, 128 + l, 192 + l
+            if (a.sums && live) {
+                const size_t p = (size_t) row * a.cols + col;
+#pragma unroll
+                for (int k = 0; k < 4; k++) a.sums[((size_t) frame * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k];
+            }
+            part[4 * q + pp] = pixel_partial_exact(o, lane);
+        }
+    // das_exact_nd_kernel's reduction tree (wave_sum8 of eight per-lane sums) whatever NQ: the same bits as a frame swept in a pair
+    const float total = wave_sum8(part[0], part[1], part[2], part[3], part[4], part[5], part[6], part[7], lane);
+    const int value = kWaveSum8Value(lane >> 3), row = 4 * row4 + (value & 3), col = col0 + (value >> 2);
+    if ((lane & 7) == 0 && (value >> 2) < NQ && row < a.rows && col < a.cols)
+        a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2422,6 +2625,64 @@ hipError_t launch_das_exact_nd(const ExactNdArgs &a, const Extents &have, hipStr
                  (size_t) a.n_pairs * a.usable_pad * a.wq * 4}, have))
         return hipErrorInvalidValue;
     return a.nq == 2 ? launch_exact_nd_variant<2>(a, stream) : launch_exact_nd_variant<1>(a, stream);
+}
+
+bool exact_ndh_plan(int window, int usable, bool stationary, FastPlan *plan) {
+    const int wh = window - 129;  // element t holds samples t, t+1, t+128, t+129 of the window
+    if (wh < kSamples / 2) return false;
+    const size_t row_bytes = (size_t) wh * 16;
+    const int usable_pad = (usable + 3) & ~3;
+    int chunk;
+    if (stationary) {
+        if ((size_t) usable_pad * row_bytes > (size_t) 2 * kFastLdsBytes) return false;
+        chunk = usable_pad;  // every mic has its own slot
+    } else {
+        chunk = (int) ((size_t) kFastLdsBytes / row_bytes) & ~3;
+        if (chunk > 64) chunk = 64;
+        if (chunk < 4) return false;
+        if (chunk > usable_pad) chunk = usable_pad;
+    }
+    plan->fpi = 1;
+    plan->wr = wh;
+    plan->chunk = chunk;
+    plan->usable_pad = usable_pad;
+    plan->row_bytes = (int) row_bytes;
+    plan->image_bytes = stationary ? -6 : -5;  // marks the halves form of the {next, d} layout
+    return true;
+}
+
+hipError_t launch_pack_ndh(const float *d_frames, int n_streams, int pitch, int wstart, const int32_t *d_index, int usable, int rows_out,
+                           const float *d_gain, int wh, int batch, float *d_packed, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_ndh_kernel, dim3(rows_out, batch), dim3(128), 0, stream, d_frames, n_streams, pitch, wstart, d_index, usable, d_gain,
+                       wh, d_packed);
+    return hipGetLastError();
+}
+
+template <int NQ, bool STATIONARY>
+static hipError_t launch_exact_ndh_variant(const ExactNdhArgs &a, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (hipError_t e = allow_lds((const void *) das_exact_ndh_kernel<NQ, STATIONARY>, lds_bytes, attr_set); e != hipSuccess) return e;
+    hipLaunchKernelGGL((das_exact_ndh_kernel<NQ, STATIONARY>), dim3((unsigned) ((long) a.batch * a.tiles)), dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_das_exact_ndh(const ExactNdhArgs &a, bool stationary, const Extents &have, hipStream_t stream) {
+    if (a.nq != 1 && a.nq != 2) return hipErrorInvalidValue;
+    if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || a.usable < 1 || a.usable > a.usable_pad || a.wh < kSamples / 2 || a.cols < 1 ||
+        a.rows * a.cols != a.pixel_count || a.batch < 1 || a.tiles != quad1_tiles(a.rows, a.cols, a.nq) || (long) a.batch * a.tiles > 0x7fffffffL)
+        return hipErrorInvalidValue;
+    if (stationary ? (a.chunk != a.usable_pad || (size_t) a.usable_pad * a.wh * 16 > (size_t) 2 * kFastLdsBytes || !a.frames || !a.index || a.pitch < 1)
+                   : ((size_t) a.chunk * a.wh * 16 > (size_t) kFastLdsBytes || !a.packed))
+        return hipErrorInvalidValue;
+    // reach: every quad of the grid with its columns padded to whole tiles (16 nq) + one group of prefetch; chunked: usable_pad rows of wh
+    // 16-byte elements per frame (stationary: the caller's frames, read inside [wstart, wstart + wh + 129) of a stream)
+    if (a.lut_cols < (a.cols + 16 * a.nq - 1) / (16 * a.nq) * 16 * a.nq) return hipErrorInvalidValue;
+    const size_t quads = (size_t) ((a.rows + 3) / 4) * a.lut_cols;
+    if (!within({quads * (a.usable_pad / 4) * 16 + kQuadTablePrefetch, stationary ? 0 : (size_t) a.batch * a.usable_pad * a.wh * 4}, have))
+        return hipErrorInvalidValue;
+    if (stationary) return a.nq == 2 ? launch_exact_ndh_variant<2, true>(a, stream) : launch_exact_ndh_variant<1, true>(a, stream);
+    return a.nq == 2 ? launch_exact_ndh_variant<2, false>(a, stream) : launch_exact_ndh_variant<1, false>(a, stream);
 }
 
 hipError_t launch_das_exact_quads(const ExactQuadArgs &a, const Extents &have, hipStream_t stream) {

@@ -164,6 +164,7 @@ struct ExactNdArgs {
     int32_t cols, rows;
     int32_t nq;            // quads per wave: a workgroup tile is 4 nq rows x 16 columns
     int32_t tiles, n_pairs, pair_group;  // nd_tiles(rows, cols, nq); frame pairs, and how many an XCD works on at a time
+    unsigned long long *debug_out;       // tuning builds (AWPU_FAST_DEBUG=16): 8 words per workgroup -- where and when it ran -- or null
 };
 inline int nd_tiles(int rows, int cols, int nq) { return (((rows + 3) / 4 + nq - 1) / nq) * ((cols + 15) / 16); }
 inline int nd_quad_count(int rows, int cols, int nq) { return (((rows + 3) / 4 + nq - 1) / nq) * nq * ((cols + 15) / 16) * 16; }  // table quads incl. padding
@@ -171,6 +172,31 @@ bool exact_nd_plan(int window, int usable, FastPlan *plan);  // plan->wr = eleme
 hipError_t launch_pack_nd(const float *d_frames, int n_streams, int hist, int wstart, const int32_t *d_index, int usable, int rows_out,
                           const float *d_gain, int wq, int batch, float *d_packed, hipStream_t stream);
 hipError_t launch_das_exact_nd(const ExactNdArgs &a, const Extents &have, hipStream_t stream);
+// ---- single frames in the reference's order: the HALVES form of the {next, d} layout (das_exact_ndh_kernel, round 5).  Element t of
+// a mic's row = { X[t+1], X[t+129], X[t] - X[t+1], X[t+128] - X[t+129] } (t from wstart; wh = window - 129 elements): the two packed
+// lanes are the two halves of the 256-sample block, as in das_quadh_kernel.  Chunked (rows packed by launch_pack_ndh, the item block
+// refilling the other image) or STATIONARY (every active mic resident, the workgroup forming the elements itself from the caller's
+// frame: no pre-pass, no chunks -- one array at the reference's default resolution).
+struct ExactNdhArgs {
+    const float *packed;   // chunked: [batch][usable_pad][wh][4], padding rows zero; stationary: unused
+    const float *frames;   // stationary: [batch][n_streams][pitch]
+    const struct QuadEntry *lut;  // quad-major, raw fractions, addr = slot * wh * 16 + (off - wstart) * 16; columns padded to 16 nq
+    const int32_t *index;  // stationary: [usable] stream of active mic s
+    const float *gain;     // stationary: [usable] or null
+    float *power;          // [batch][pixel_count]
+    float *sums;           // optional [batch][pixel_count][256], or null
+    int32_t n_streams, pitch, wstart;  // stationary
+    int32_t usable, usable_pad, pixel_count, wh, chunk, batch;
+    int32_t cols, rows;
+    int32_t nq;            // quads per wave: a workgroup tile is 4 rows x 16 nq columns
+    int32_t tiles;         // quad1_tiles(rows, cols, nq)
+    int32_t lut_cols;      // columns of the table (the grid's, padded to whole tiles of 32)
+    int32_t identity;      // stationary: the active-mic list is 0 .. usable-1 (rows need no look-up)
+};
+bool exact_ndh_plan(int window, int usable, bool stationary, FastPlan *plan);  // plan->wr = wh, row_bytes = 16 wh
+hipError_t launch_pack_ndh(const float *d_frames, int n_streams, int pitch, int wstart, const int32_t *d_index, int usable, int rows_out,
+                           const float *d_gain, int wh, int batch, float *d_packed, hipStream_t stream);
+hipError_t launch_das_exact_ndh(const ExactNdhArgs &a, bool stationary, const Extents &have, hipStream_t stream);
 // FIR8 on the four-plane frame-pair layout (a lane owns four consecutive outputs: 11 LDS reads per 32 FMAs).  Rows packed by
 // launch_pack_planes, `wr` a multiple of 4 (fir8_plane_plan); d_entries [pixel_count][usable_pad] + 4 spare dwords,
 // one per (pixel, mic): fir8_plane_word(LDS byte offset of X[off] in its chunk's image, its plane, coefficient row);

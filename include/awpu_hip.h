@@ -89,7 +89,9 @@ typedef enum {
     AWPU_KERNEL_EXACT_VERIFY = 11,    /* das_exact_kernel: round-1 verification structure (bf16 accumulator mode, fallback) */
     AWPU_KERNEL_TUNING = 12,          /* a shape only -DAWPU_TUNING_BUILD builds dispatch to */
     AWPU_KERNEL_EXACT_QUAD = 13,      /* das_exact_quad_kernel: the reference's order, four vertically adjacent pixels per wave (round 4) */
-    AWPU_KERNEL_EXACT_ND = 14         /* das_exact_nd_kernel: the reference's order on the {next, d} layout (cur - next formed once per sample) */
+    AWPU_KERNEL_EXACT_ND = 14,        /* das_exact_nd_kernel: the reference's order on the {next, d} layout (cur - next formed once per sample) */
+    AWPU_KERNEL_EXACT_NDH = 15,       /* das_exact_ndh_kernel: single frames in the reference's order (the two halves of the block in the packed lanes) */
+    AWPU_KERNEL_EXACT_NDH_STATIONARY = 16 /* ... with every active mic resident and staged by the workgroups themselves (the reference's own shape) */
 } awpu_kernel_id;
 
 typedef struct awpu_hip awpu_hip_t;

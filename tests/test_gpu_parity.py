@@ -725,7 +725,7 @@ def test_reference_order_mode_on_the_ingest_ring(pkg, oracle):
     rng = np.random.default_rng(6)
     names = pkg.binding.KERNEL_NAMES
     forced = {"exact_quad": "exact_quad", "exact_pair": "exact_pair"}.get(os.environ.get("AWPU_SHAPE", ""))
-    for cols, want in ((spec.res, forced or "exact_nd"), (0, "exact_pair")):
+    for cols, want in ((spec.res, forced or "exact_ndh"), (0, "exact_pair")):  # (one frame per call: the halves form of the {next, d} layout)
         ring = np.zeros((spec.n_mics, 1024), np.float32)
         with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, math=pkg.MATH_F32_EXACT, grid_columns=cols) as eng:
             eng.set_delay_table(off, frac)
@@ -1715,6 +1715,57 @@ def test_exact_mode_sums_equal_the_oracle_on_every_pixel(pkg, oracle, wl, cols, 
         want_p, want_out = oracle.das_f32(frames[b], off, frac, want_out=True)
         assert np.array_equal(out[b], want_out), (b, np.argwhere(out[b] != want_out)[:4])
         assert util.power_rel_err_unfloored(power[b], want_p) < 3e-6
+
+
+@pytest.mark.parametrize("case", ["ref_default", "ref_default_ragged_gains", "odd_grid", "c2", "c2_short"])
+def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
+    """One frame per call in the reference's order -- MIMOWorker::update's regime (worker.h:212-224, mimo.cpp:97-151) -- on the halves
+    form of the {next, d} layout (das_exact_ndh_kernel): one array at the reference's default resolution with every mic resident
+    (100 x 100, main.cpp:38-41; also a ragged mic list with gains, and an odd grid), four arrays chunked behind the pack pre-pass
+    (and a grid of 30 rows: a last quad of two live pixels).  The pre-epilogue sums equal oracle_das_f32's out[] bit for bit on EVERY
+    pixel (DC-biased plane-wave frames), the powers are the bits the same frame gets inside a batch (das_exact_nd_kernel), and within
+    1e-5 of the oracle on every pixel."""
+    S = pkg.synthetic
+    names = pkg.binding.KERNEL_NAMES
+    index, gains = None, None
+    if case.startswith("c2"):
+        spec = S.WORKLOADS["c2"]
+        xyz = S.geometry(spec)
+        off, frac = S.delay_table(spec, xyz)
+        rows, cols, n_streams, want = (30 if case == "c2_short" else spec.res), spec.res, spec.n_mics, "exact_ndh"
+        off, frac = off[: rows * cols], frac[: rows * cols]
+    else:
+        xyz = pkg.create_antenna()
+        rows = cols = 99 if case == "odd_grid" else 100  # (99: an odd grid, whose centre pixel looks straight ahead)
+        off, frac = pkg.build_delay_table(xyz, rows, cols, 180.0)
+        n_streams, want = 64, "exact_ndh_stationary"
+        if case == "ref_default_ragged_gains":
+            index = np.array([k for k in range(64) if k % 5 != 2], np.int32)
+            gains = (0.5 + np.arange(64) / 64.0).astype(np.float32)
+    frames = (S.make_frames(xyz, 3, seed=55) + np.float32(0.125)).astype(np.float32)
+    P = rows * cols
+    import torch
+
+    with pkg.Engine(n_pixels=P, n_streams=n_streams, math=pkg.MATH_F32_EXACT, max_batch=3, grid_columns=cols) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(index)
+        if gains is not None:
+            eng.set_mic_gains(gains)
+        batch = eng.process(frames)
+        assert names[eng.stats().kernel_variant] == "exact_nd"
+        d_X = torch.from_numpy(frames[1:2].copy()).cuda()
+        d_P = torch.empty((1, P), dtype=torch.float32, device="cuda")
+        d_S = torch.full((1, P, 256), float("nan"), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        eng.process_device_sums(d_X.data_ptr(), 1, d_P.data_ptr(), d_S.data_ptr())
+        eng.synchronize()
+        assert names[eng.stats().kernel_variant] == want
+        single, sums = d_P.cpu().numpy()[0], d_S.cpu().numpy()[0]
+    assert np.array_equal(single, batch[1])  # a frame swept alone = the frame swept in a pair, bit for bit
+    X = frames[1] * gains[:, None] if gains is not None else frames[1]
+    want_p, want_out = oracle.das_f32(X, off, frac, index=index, want_out=True)
+    assert np.array_equal(sums, want_out), np.argwhere(sums != want_out)[:4]
+    check_full_grid(oracle, single, X, off, frac, f"{case}: one frame per call, reference order", index=index)
 
 
 @pytest.mark.parametrize("wl,offset", [("c2", 0.25), ("c2", 1e-2), ("headline", 0.25)])

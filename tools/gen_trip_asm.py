@@ -656,10 +656,11 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, un
 
 ND_ACC = 10    # block_exact_nd: out[] of quad q, pixel p pinned at v[ND_ACC + 32 q + 8 p ..+7]
 ND_TMP = 74    # its 53 temps (two 16-register slots for the reference pixel's elements, one for whichever pixel leaves it, t, address)
+ND_TIMING = os.environ.get("ND_TIMING", "")  # tuning builds only (see the end of block_exact_nd)
 ND_DMA_STRIDE = 16 * 1024  # one refill piece: 16 waves x 64 lanes x 16 bytes (every wave of the workgroup takes part)
 
 
-def block_exact_nd(name, nq):
+def block_exact_nd(name, nq, nk=4):
     """Reference-order sweep (AWPU_MATH_F32_EXACT, round 5) of a WHOLE item -- frame pair x tile, `nq` quads of four vertically
     adjacent pixels per wave -- on the {next, d} layout: pack_nd_kernel stores, per mic and sample t of the window, the 16-byte element
         { next_a, next_b, d_a, d_b },   next = X[t + 1],  d = X[t] - X[t + 1]      (a, b = the two frames of the pair)
@@ -682,12 +683,18 @@ def block_exact_nd(name, nq):
     piece at the head of each trip), vmcnt wait and workgroup barrier inside the block, the next chunk's first entries already in
     SGPRs when a chunk begins (a quad's table is contiguous across chunks; the running prefetch switches between the quads' tables
     one trip before a quad's chunk ends).  nq = 2: per chunk quad A then quad B (`qstride` table bytes apart), each with its own
-    pinned accumulators and its own copy of the trip code."""
-    O = [[ND_ACC + 32 * q + 8 * p for p in range(4)] for q in range(nq)]
-    R = [ND_TMP, ND_TMP + 16]
-    X = ND_TMP + 32
-    TT = ND_TMP + 48
-    addr_t = ND_TMP + 52
+    pinned accumulators and its own copy of the trip code.
+
+    nk = 2: the same block for SINGLE frames on the halves form of the layout (das_exact_ndh_kernel): element t of a mic's row =
+    { X[t+1], X[t+129], X[t] - X[t+1], X[t+128] - X[t+129] }, the two packed lanes are the two halves of the 256-sample block, lane l
+    owns samples l and l + 64 of either half -- two register pairs per pixel, two ds_read_b128 per distinct address, four packed
+    VALU instructions per (pixel, mic)."""
+    w = 2 * nk  # registers per pixel's out[]
+    O = [[ND_ACC + 4 * w * q + w * p for p in range(4)] for q in range(nq)]
+    R = [ND_TMP, ND_TMP + 4 * nk]
+    X = ND_TMP + 8 * nk
+    TT = ND_TMP + 12 * nk
+    addr_t = TT + 4
     E = (36, 68)
     S_NG, S_PFO, S_CH, S_SB, S_TMP, S_PF_, S_LEFT_, S_DST, S_REM, S_K, S_NP, S_M0, S_DELTA = 17, 18, 19, 20, 22, 23, 24, 25, 28, 29, 30, 31, 35
 
@@ -711,7 +718,7 @@ def block_exact_nd(name, nq):
 
     def reads(slot, addr_sgpr):
         L = [f"v_add_u32 v{addr_t}, s{addr_sgpr}, %[lane]"]
-        for k in range(4):
+        for k in range(nk):
             off = f" offset:{1024 * k}" if k else ""
             L.append(f"ds_read_b128 {quadreg(slot, k)}, v{addr_t}{off}")
         return L
@@ -727,7 +734,7 @@ def block_exact_nd(name, nq):
         fs = f"s[{f_of(base, p, i)}:{f_of(base, p, i) + 1}]"
         Op = O[qz[0]][p]
         L = []
-        for k0 in (0, 2):
+        for k0 in range(0, nk, 2):
             for k in (k0, k0 + 1):
                 L.append(f"v_pk_fma_f32 {opair(TT, k - k0)}, {fs}, {d_of(slot, k)}, {nxt_of(slot, k)} op_sel_hi:[0,1,1]")
             for k in (k0, k0 + 1):
@@ -809,7 +816,7 @@ def block_exact_nd(name, nq):
             rslot = R[st & 1]
             if st < 3:
                 L += reads(R[(st + 1) & 1], a_of(cur, REF, st + 1))
-                L.append("s_waitcnt lgkmcnt(4)")  # all but the four reads just issued: this mic's elements are in
+                L.append(f"s_waitcnt lgkmcnt({nk})")  # all but the reads just issued: this mic's elements are in
                 nbase, ni = cur, st + 1
             else:
                 L.append("s_waitcnt lgkmcnt(0)")  # this mic's elements, and the next trip's entries
@@ -881,12 +888,23 @@ def block_exact_nd(name, nq):
             L += [".LNbndA_%=:"] + boundary(E[1], ".LN0_1_%=")
     L += cold
     L += [".LNexit_%=:", f"s_mov_b32 m0, s{S_M0}", f"s_setprio {QUAD_END_PRIO}"]
+    # timing experiments (tools/build_variant.sh with ND_TIMING=...; WRONG results): what the block costs without one of its parts
+    if "nobarrier" in ND_TIMING:
+        L = ["s_nop 0" if l == "s_barrier" else l for l in L]
+    if "nolds" in ND_TIMING:
+        L = [l for l in L if not l.startswith("ds_read")]
+    if "novalu" in ND_TIMING:
+        L = [l for l in L if not l.startswith(("v_pk_fma_f32", "v_pk_add_f32"))]
+    if "nodma" in ND_TIMING:
+        L = [l for l in L if not l.startswith("global_load_lds")]
+    if "noprio" in ND_TIMING:
+        L = [l for l in L if not l.startswith("s_setprio")]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
     vregs = list(range(ND_TMP, addr_t + 1))
     sregs = sorted({S_NG, S_PFO, S_CH, S_SB, S_SB + 1, S_TMP, S_PF_, S_LEFT_, S_DST, S_RANK, S_PRIO, S_REM, S_K, S_NP, S_M0, S_DELTA}) + list(range(36, 100))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"', '"vcc"', '"memory"'])
-    acc_params = ", ".join(f"f8 &O{q}{p}" for q in range(nq) for p in range(4))
-    acc_ops = ", ".join(f'"+{{v[{O[q][p]}:{O[q][p] + 7}]}}"(O{q}{p})' for q in range(nq) for p in range(4))
+    acc_params = ", ".join(f"{'f8' if nk == 4 else 'f4'} &O{q}{p}" for q in range(nq) for p in range(4))
+    acc_ops = ", ".join(f'"+{{v[{O[q][p]}:{O[q][p] + w - 1}]}}"(O{q}{p})' for q in range(nq) for p in range(4))
     qs_param = ", int qstride" if nq > 1 else ""
     qs_op = ', [qstride] "s"(qstride)' if nq > 1 else ""
     return f"""// Reference-order sweep of a whole item (frame pair x tile) on the {{next, d}} layout, {nq} quad(s) of four vertically adjacent
@@ -895,7 +913,7 @@ def block_exact_nd(name, nq):
 // past a quad's last.  ngf / ngl = groups of four mics in a full / in the last chunk, nch = chunks, isrc = chunk 0's rows in HBM (chunk c's
 // follow dbf bytes apart; dbl = bytes of the last chunk), ddst = this wave's first LDS-DMA destination in the image chunk 0 does NOT occupy,
 // delta = (that image) - (chunk 0's image) in bytes, lbytes = 16 x thread index; lane_addr = the sweep's LDS address in chunk 0's image.
-// O_qp = out[l + 64 k] of pixel p of quad q, both frames, pinned at v[{ND_ACC} + 32 q + 8 p ..]; temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}.
+// O_qp = out[l + 64 k] of pixel p of quad q, both {"frames" if nk == 4 else "halves of the block"}, pinned at v[{ND_ACC} + {4 * w} q + {w} p ..]; temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}.
 // Executes nch s_barrier instructions.
 __device__ __forceinline__ void {name}({acc_params}, const void *row{qs_param}, int ngf, int ngl, int nch, unsigned &lane_addr, int rank,
                                        const void *isrc, unsigned dbf, unsigned dbl, unsigned ddst, int delta, unsigned lbytes) {{
@@ -1961,6 +1979,8 @@ def main():
     out.append(block_exact_quad("sweep_quad_exact"))  # das_exact_quad_kernel (AWPU_MATH_F32_EXACT, row length known; round 4)
     out.append(block_exact_nd("sweep_exact_nd_item1", 1))  # das_exact_nd_kernel<1>: the {next, d} layout, one quad per wave
     out.append(block_exact_nd("sweep_exact_nd_item2", 2))  # das_exact_nd_kernel<2>: two quads per wave (the default batch kernel of the reference order)
+    out.append(block_exact_nd("sweep_exact_ndh_item1", 1, nk=2))  # das_exact_ndh_kernel<1, *>: single frames, the halves form of the layout
+    out.append(block_exact_nd("sweep_exact_ndh_item2", 2, nk=2))  # das_exact_ndh_kernel<2, *>
     out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))
     out.append(block_quad("sweep_quad_item", dma=True, chain=CHAIN, item=True))  # the production batch kernel: one block per item

@@ -6,6 +6,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export AWPU_NO_BUILD=1
 cp beamforming-lk_amd/libawpu_hip.so $out/keep.so
+trap 'cp "$out/keep.so" beamforming-lk_amd/libawpu_hip.so' EXIT  # whatever happens below, the shipping library comes back
 for rep in $(seq 1 ${REPS:-3}); do
 for v in "$@"; do
   cp tools/ab/$v beamforming-lk_amd/libawpu_hip.so
@@ -17,4 +18,3 @@ print("%-12s value %.0f frames/s  kernel %.3f ms  valu %.3f  parity %.2e" % (sys
 PY
 done
 done
-cp $out/keep.so beamforming-lk_amd/libawpu_hip.so

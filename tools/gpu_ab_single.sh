@@ -7,6 +7,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export AWPU_NO_BUILD=1
 cp beamforming-lk_amd/libawpu_hip.so $out/keep.so
+trap 'cp "$out/keep.so" beamforming-lk_amd/libawpu_hip.so' EXIT  # whatever happens below, the shipping library comes back
 for rep in $(seq 1 ${REPS:-2}); do
 for v in "$@"; do
   cp tools/ab/$v beamforming-lk_amd/libawpu_hip.so
@@ -14,4 +15,3 @@ for v in "$@"; do
   timeout -k 10 200 python tools/single_frame_rate.py $wl 2>&1 | tee -a $out/single.log
 done
 done
-cp $out/keep.so beamforming-lk_amd/libawpu_hip.so

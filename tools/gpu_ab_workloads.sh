@@ -7,6 +7,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export AWPU_NO_BUILD=1
 cp beamforming-lk_amd/libawpu_hip.so $out/keep.so
+trap 'cp "$out/keep.so" beamforming-lk_amd/libawpu_hip.so' EXIT  # whatever happens below, the shipping library comes back
 for rep in $(seq 1 ${REPS:-2}); do
 for v in "$@"; do
   cp tools/ab/$v beamforming-lk_amd/libawpu_hip.so
@@ -19,4 +20,3 @@ print("%-10s headline %.3f ms" % (sys.argv[2], d["roofline"]["kernel_ms"]), " | 
 PY
 done
 done
-cp $out/keep.so beamforming-lk_amd/libawpu_hip.so

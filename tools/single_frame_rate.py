@@ -3,7 +3,7 @@
 device time per frame by events on the launch stream, and which kernel ran.  Under `rocprofv3 --kernel-trace --stats`
 the trace splits that time into the kernel's own duration and the gap between launches.
 
-    python tools/single_frame_rate.py [workload ...]      (default: ref_default headline)
+    python tools/single_frame_rate.py [--math exact|fast|both] [workload ...]      (default: both modes, ref_default c2 headline)
 """
 import importlib
 import sys
@@ -15,7 +15,12 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 pkg = importlib.import_module("beamforming-lk_amd")
 S = pkg.synthetic
 N = 400
-for name in sys.argv[1:] or ["ref_default", "headline"]:
+args = sys.argv[1:]
+modes = ["exact", "fast"]
+if args[:1] == ["--math"]:
+    modes = ["exact", "fast"] if args[1] == "both" else [args[1]]
+    args = args[2:]
+for name, mode in [(n, m) for n in (args or ["ref_default", "c2", "headline"]) for m in modes]:
     spec = S.WORKLOADS[name]
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz)
@@ -24,7 +29,8 @@ for name in sys.argv[1:] or ["ref_default", "headline"]:
     d_p = torch.zeros((2, spec.n_pixels), dtype=torch.float32, device="cuda")
     stream = torch.cuda.Stream()
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=1, grid_columns=spec.res) as eng:
+    math = pkg.MATH_F32_EXACT if mode == "exact" else pkg.MATH_F32_FAST
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=1, grid_columns=spec.res, math=math) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
         torch.cuda.synchronize()
@@ -39,5 +45,5 @@ for name in sys.argv[1:] or ["ref_default", "headline"]:
         st = eng.stats()
     us = ev[0].elapsed_time(ev[1]) / N * 1e3
     flops = int(st.alg_flops_frame)
-    print(f"{spec.name}: {pkg.binding.KERNEL_NAMES[st.kernel_variant]} {us:.2f} us per frame on the device "
+    print(f"{spec.name} [{mode}]: {pkg.binding.KERNEL_NAMES[st.kernel_variant]} {us:.2f} us per frame on the device "
           f"({flops / (us * 1e-6) / 1e12:.1f} TFLOP/s algorithmic = {flops / (us * 1e-6) / 1e12 / 157.3:.3f} of the fp32 peak)")
