@@ -280,7 +280,7 @@ class Engine:
     """One awpu_hip handle = one MIMO worker's sweep state on one GPU (src/dsp/mimo.h:74-91)."""
 
     def __init__(self, n_pixels: int, n_streams: int = ELEMENTS, lut_stride: Optional[int] = None,
-                 hist: int = HIST, math: int = MATH_F32_FAST, interp: int = INTERP_LERP,
+                 hist: int = HIST, math: Optional[int] = None, interp: int = INTERP_LERP,
                  max_batch: int = 1, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0,
                  grid_columns: int = 0, devices=None, window=None):
         lib = load()
@@ -298,7 +298,8 @@ class Engine:
         cfg.n_pixels = n_pixels
         cfg.lut_stride = n_streams if lut_stride is None else lut_stride
         cfg.interp = interp
-        cfg.math = math
+        if math is not None:  # None: the library's default (awpu_hip_default_cfg: AWPU_MATH_F32_EXACT, the reference's arithmetic)
+            cfg.math = math
         cfg.max_batch = max_batch
         cfg.pixel_begin = pixel_begin
         cfg.pixel_count = pixel_count

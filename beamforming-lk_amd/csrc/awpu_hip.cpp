@@ -837,14 +837,16 @@ int launch_exact_quads(awpu_hip *h, const float *d_frames, int batch, float *d_p
 }
 
 // ... on the {next, d} layout (das_exact_nd_kernel, round 5): cur - next formed once per sample by the pack pass; nq quads per wave
-int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff, int nq) {
+int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff, int nq,
+                    const float *prepacked = nullptr, size_t prepacked_floats = 0) {
     int rc = build_quad_lut(h, kQuadExactNd);
     if (rc != AWPU_OK) return rc;
     const awpu::FastPlan &pp = h->exact_nd_plan;
     const size_t need = (size_t) ((std::max(h->cfg.max_batch, batch) + 1) / 2) * pp.usable_pad * pp.wr * 4;
-    if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
+    if (!prepacked)
+        if (const int prc = ensure_pack(h, need); prc != AWPU_OK) return prc;
     awpu::ExactNdArgs a{};
-    a.packed = h->d_pack;
+    a.packed = prepacked ? prepacked : h->d_pack;
     a.lut = h->d_exact_nd_lut;
     a.power = d_power;
     a.sums = h->sums_out;
@@ -861,8 +863,9 @@ int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_powe
     a.n_pairs = (batch + 1) / 2;
     a.pair_group = xcd_pair_group_bytes((size_t) pp.usable_pad * pp.row_bytes, a.n_pairs);
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
-    AWPU_HIP_TRY(awpu::launch_pack_nd(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad, h->d_gain,
-                                      pp.wr, batch, h->d_pack, s));
+    if (!prepacked)
+        AWPU_HIP_TRY(awpu::launch_pack_nd(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad, h->d_gain,
+                                          pp.wr, batch, h->d_pack, s));
 #ifdef AWPU_TUNING_BUILD
     const size_t n_wgs = 8 * (((size_t) a.n_pairs * a.tiles + 7) / 8);
     if (env().debug & 16) {  // per-workgroup timeline (where, when, phases): printed below
@@ -871,7 +874,7 @@ int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_powe
         a.debug_out = h->d_diag;
     }
 #endif
-    AWPU_HIP_TRY(awpu::launch_das_exact_nd(a, {h->quad_lut_entries[kQuadExactNd], h->pack_cap}, s));
+    AWPU_HIP_TRY(awpu::launch_das_exact_nd(a, {h->quad_lut_entries[kQuadExactNd], prepacked ? prepacked_floats : h->pack_cap}, s));
     rc = finish_launch(h, batch, s, AWPU_KERNEL_EXACT_ND);
 #ifdef AWPU_TUNING_BUILD
     if (rc == AWPU_OK && (env().debug & 16)) {
@@ -931,6 +934,23 @@ int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_powe
     }
 #endif
     return rc;
+}
+
+// Does launch() sweep a batch of AWPU_MATH_F32_EXACT with das_exact_nd_kernel, and with how many quads per wave?  (The rule of launch()
+// and of the packed-frame entry points: asked before anything is packed.)
+bool takes_exact_nd(awpu_hip *h, int batch, int *nq) {
+    if (!h->exact_pairs_ok || !h->exact_nd_ok || h->cfg.grid_columns < 1) return false;
+    const int ex = env().exact_pairs;
+    if (ex == 0 || ex == 2 || ex == 3) return false;  // AWPU_SHAPE=exact_verify / exact_pair / exact_quad
+    const int cols = h->cfg.grid_columns, rows = h->cfg.pixel_count / cols;
+    // (quad_differ < 1.5: on average fewer than half of a quad's pixels leave the reference pixel's address for a mic; a square
+    // array's vertical and horizontal neighbours coincide equally often -- pair_cols stays 0 there -- and quads still pay)
+    const bool quads_pay = h->cfg.pixel_count % cols == 0 && h->cfg.pixel_begin % cols == 0 && h->quad_differ < 1.5;
+    if (!(h->pair_cols > 0 || quads_pay) || rows < 4) return false;
+    // two quads per wave where that still fills the chip (AWPU_SHAPE=exact_nd1 / exact_nd2: one / two everywhere)
+    const long wgs2 = (long) awpu::nd_tiles(rows, cols, 2) * ((batch + 1) / 2);
+    *nq = ex == 4 ? 1 : ex == 5 ? 2 : (rows >= 8 && wgs2 >= 512 ? 2 : 1);
+    return true;
 }
 
 // single frames in the reference's order: the halves form of the {next, d} layout (das_exact_ndh_kernel) -- every mic resident and
@@ -1257,30 +1277,20 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
             return launch_fir8_planes(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
     }
     if (h->exact_pairs_ok && env().exact_pairs != 0) {
-        // vertical pixel quads where the row length is known and vertical neighbours coincide more often than horizontal ones
-        // (prepare() counted: pair_cols); AWPU_SHAPE=exact_pair keeps the two-pixel block everywhere
-        // (quad_differ < 1.5: on average fewer than half of a quad's pixels leave the reference pixel's address for a mic; a square
-        // array's vertical and horizontal neighbours coincide equally often -- pair_cols stays 0 there -- and quads still pay)
-        const bool quads_pay = h->cfg.grid_columns > 0 && h->cfg.pixel_count % h->cfg.grid_columns == 0 &&
-                               h->cfg.pixel_begin % h->cfg.grid_columns == 0 && h->quad_differ < 1.5;
-        if ((h->pair_cols > 0 || quads_pay) && env().exact_pairs != 2 && h->cfg.pixel_count / h->cfg.grid_columns >= 4) {
-            // the {next, d} layout (round 5) wherever its image holds a group of mics; two quads per wave where that still fills the chip
-            // (AWPU_SHAPE=exact_quad: round 4's kernel on raw sample pairs; exact_nd1 / exact_nd2: one / two quads per wave)
-            const int ex = env().exact_pairs;
+        // vertical pixel quads on the {next, d} layout (round 5) where the row length is known and the table's statistics favour them
+        // (takes_exact_nd; AWPU_SHAPE=exact_quad: round 4's kernel on raw sample pairs; exact_pair: the two-pixel block everywhere)
+        int nq = 1;
+        const bool nd = takes_exact_nd(h, batch, &nq);
+        // one frame per call (MIMOWorker::update's regime): the halves form of the layout -- the two packed lanes are the two halves of
+        // the block, not a frame and its copy; every mic resident where one array's rows fit the LDS (no pre-pass)
+        if (nd && batch == 1 && env().exact_pairs == 1 && (h->exact_ndhs_ok || h->exact_ndh_ok)) {
             const int rows = h->cfg.pixel_count / h->cfg.grid_columns;
-            // one frame per call (MIMOWorker::update's regime): the halves form of the layout -- the two packed lanes are the two halves of
-            // the block, not a frame and its copy; every mic resident where one array's rows fit the LDS (no pre-pass)
-            if (batch == 1 && ex == 1 && (h->exact_ndhs_ok || h->exact_ndh_ok)) {
-                const int nq = (long) awpu::quad1_tiles(rows, h->cfg.grid_columns, 2) >= 256 ? 2 : 1;
-                return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, h->exact_ndhs_ok, nq);
-            }
-            if (h->exact_nd_ok && ex != 3) {
-                const long wgs2 = (long) awpu::nd_tiles(rows, h->cfg.grid_columns, 2) * ((batch + 1) / 2);
-                const int nq = ex == 4 ? 1 : ex == 5 ? 2 : (rows >= 8 && wgs2 >= 512 ? 2 : 1);
-                return launch_exact_nd(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, nq);
-            }
-            return launch_exact_quads(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
+            const int nqh = (long) awpu::quad1_tiles(rows, h->cfg.grid_columns, 2) >= 256 ? 2 : 1;
+            return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, h->exact_ndhs_ok, nqh);
         }
+        if (nd) return launch_exact_nd(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, nq);
+        if (env().exact_pairs == 3 && h->pair_cols > 0 && h->cfg.pixel_count / h->cfg.grid_columns >= 4)
+            return launch_exact_quads(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
         return launch_exact_pairs(h, d_frames, batch, d_power, s, hist_eff, wstart_eff);
     }
     if (h->sums_out) return fail(AWPU_ERR_STATE, "the pre-epilogue sums are exported by the frame-pair reference-order kernel only");
@@ -1651,8 +1661,14 @@ int group_process(awpu_hip *g, const float *frames, int batch, float *power) {
 // Would launch() sweep this batch with one of the frame-pair shapes that read the packed layout (quad or pair)?  The rule of
 // awpu_hip_process_packed, asked before anything is packed.
 bool takes_packed_pairs(awpu_hip *h, int batch, awpu::FastPlan *plan) {
-    if (batch < 2 || h->cfg.math != AWPU_MATH_F32_FAST || h->cfg.interp != AWPU_INTERP_LERP) return false;
-    if (h->usable() % 4 != 0 || !h->gain.empty() || env().pairs == 0) return false;
+    if (batch < 2 || h->cfg.interp != AWPU_INTERP_LERP || h->usable() % 4 != 0 || !h->gain.empty()) return false;
+    if (h->cfg.math == AWPU_MATH_F32_EXACT) {  // the reference's order: the {next, d} rows of das_exact_nd_kernel
+        int nq = 1;
+        if (!takes_exact_nd(h, batch, &nq)) return false;
+        *plan = h->exact_nd_plan;
+        return true;
+    }
+    if (h->cfg.math != AWPU_MATH_F32_FAST || env().pairs == 0) return false;
     if (!awpu::pair_plan(h->window, h->usable(), plan)) return false;
     const long pairs = (batch + 1) / 2;
     const bool quad_fills = h->quad_ok && h->quad_plan.wr == plan->wr && h->quad_plan.usable_pad == h->usable() &&
@@ -1661,9 +1677,30 @@ bool takes_packed_pairs(awpu_hip *h, int batch, awpu::FastPlan *plan) {
     return quad_fills || pair_fills;
 }
 
+// floats of `batch` frames in the packed layout of `plan` (rows of plan.row_bytes: sample pairs of a frame pair, or their {next, d}
+// elements), `usable` rows per pair (the packed entry points ask for usable % 4 == 0: no padding rows)
+size_t packed_floats_of(const awpu_hip *h, const awpu::FastPlan &plan, int batch) {
+    return (size_t) ((batch + 1) / 2) * h->usable() * (size_t) (plan.row_bytes / 4);
+}
+// the sweep's pack pass into a caller's buffer: pre-filtered sample pairs (FAST) or {next, d} elements (EXACT)
+int pack_for_sweep(awpu_hip *h, const awpu::FastPlan &plan, const float *d_frames, int batch, float *d_packed, hipStream_t s) {
+    if (h->cfg.math == AWPU_MATH_F32_EXACT)
+        AWPU_HIP_TRY(awpu::launch_pack_nd(d_frames, h->cfg.n_streams, h->cfg.hist, h->wstart, h->d_index, h->usable(), h->usable(), nullptr, plan.wr,
+                                          batch, d_packed, s));
+    else
+        AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, h->cfg.hist, h->wstart, h->d_index, h->usable(), h->usable(), nullptr,
+                                             plan.wr, batch, d_packed, true, s));
+    return AWPU_OK;
+}
+
 // the sweep of packed frame pairs (what awpu_hip_process_packed does once its arguments are checked)
 int sweep_packed(awpu_hip *h, const awpu::FastPlan &plan, const float *d_packed, size_t packed_floats, int batch, float *d_power,
                  hipStream_t s) {
+    if (h->cfg.math == AWPU_MATH_F32_EXACT) {
+        int nq = 1;
+        if (!takes_exact_nd(h, batch, &nq)) return fail(AWPU_ERR_STATE, "packed frames: this batch is not swept by the {next, d} kernel");
+        return launch_exact_nd(h, nullptr, batch, d_power, s, h->cfg.hist, h->wstart, nq, d_packed, packed_floats);
+    }
     const bool quad_fills = h->quad_ok && ((long) awpu::quad_tiles(h->cfg.pixel_count / h->cfg.grid_columns, h->cfg.grid_columns) *
                                                ((batch + 1) / 2) >= 256 || env().quads == 1);
     if (quad_fills && env().pairs != 0 && h->quad_plan.wr == plan.wr && h->quad_plan.usable_pad == h->usable())
@@ -1742,12 +1779,12 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
         if (packed && pplan.wr && (one.wr != pplan.wr || one.usable_pad != pplan.usable_pad)) packed = false;
         pplan = one;
     }
-    const size_t packed_floats = packed ? (size_t) ((batch + 1) / 2) * g->parts[0]->usable() * pplan.wr * 2 : 0;
+    const size_t packed_floats = packed ? packed_floats_of(g->parts[0], pplan, batch) : 0;
     int pb = 0;  // which of the group's two packed buffers this call fills
     AWPU_HIP_TRY(hipSetDevice(dev0));
     if (packed) {
         g->stats.group_exchange = AWPU_EXCHANGE_PACKED_PAIRS;
-        const size_t cap = (size_t) ((g->cfg.max_batch + 1) / 2) * g->parts[0]->usable() * pplan.wr * 2;
+        const size_t cap = packed_floats_of(g->parts[0], pplan, g->cfg.max_batch);
         if (g->fan_cap < cap) {  // (nobody may still be reading the old buffers)
             for (awpu_hip *part : g->parts) {
                 AWPU_HIP_TRY(hipSetDevice(part->cfg.device));
@@ -1768,8 +1805,7 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
         if (g->fan_used[pb])  // buffer pb was read two calls ago: by the peers' copies and by the in-place parts' sweeps
             for (awpu_hip *part : g->parts) AWPU_HIP_TRY(hipStreamWaitEvent(s, in_place(part) ? part->ev_swept[pb] : part->ev_copied[pb], 0));
         awpu_hip *p0 = g->parts[0];
-        AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, p0->cfg.n_streams, p0->cfg.hist, p0->wstart, p0->d_index, p0->usable(), p0->usable(),
-                                             nullptr, pplan.wr, batch, g->d_fan[pb], true, s));
+        if (const int prc = pack_for_sweep(p0, pplan, d_frames, batch, g->d_fan[pb], s); prc != AWPU_OK) return prc;
         g->fan_used[pb] = true;
     }
     AWPU_HIP_TRY(hipEventRecord(g->ev_fan, s));  // the frames (or their packed pairs) are in place once the caller's stream gets here
@@ -1782,7 +1818,7 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
         int lo = 0, w = 0;
         size_t need = 0;
         if (packed) {
-            need = (size_t) ((g->cfg.max_batch + 1) / 2) * g->parts[0]->usable() * pplan.wr * 2;
+            need = packed_floats_of(g->parts[0], pplan, g->cfg.max_batch);
             lo = -1;  // (marks the packed payload: a change of payload re-sizes the staging like a change of window)
             w = (int) pplan.wr;
         } else {
@@ -1849,7 +1885,7 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
             const bool compact = part->compact_hist > 0;
             const int dev_hist = compact ? part->compact_hist : part->cfg.hist;
             const size_t need_window = (size_t) part->cfg.n_streams * dev_hist * part->cfg.max_batch;
-            const size_t need_packed = (size_t) ((part->cfg.max_batch + 1) / 2) * part->usable() * (packed ? pplan.wr : 0) * 2;
+            const size_t need_packed = packed ? packed_floats_of(part, pplan, part->cfg.max_batch) : 0;
             const size_t need = std::max(need_window, need_packed);
             if (part->fan_cap < need) {
                 AWPU_HIP_TRY(hipStreamSynchronize(part->stream));
@@ -1966,7 +2002,7 @@ void awpu_hip_default_cfg(awpu_hip_cfg *cfg) {
     cfg->n_pixels = 0;
     cfg->lut_stride = AWPU_ELEMENTS;
     cfg->interp = AWPU_INTERP_LERP;
-    cfg->math = AWPU_MATH_F32_FAST;
+    cfg->math = AWPU_MATH_F32_EXACT;  // the reference has one arithmetic (delay.cpp:19-25 inside mimo.cpp:121-137): that one; FAST is an opt-in
     cfg->max_batch = 1;
     cfg->pixel_begin = 0;
     cfg->pixel_count = 0;
@@ -2663,10 +2699,17 @@ int packed_plan(awpu_hip *h, int batch, awpu::FastPlan *plan) {
     if (!h->parts.empty()) return fail(AWPU_ERR_STATE, "packed frames: a device group exchanges its frames itself");
     const int rc = check_ready(h, batch);
     if (rc != AWPU_OK) return rc;
-    if (h->cfg.math != AWPU_MATH_F32_FAST || h->cfg.interp != AWPU_INTERP_LERP)
-        return fail(AWPU_ERR_STATE, "packed frames need AWPU_MATH_F32_FAST and AWPU_INTERP_LERP");
+    if ((h->cfg.math != AWPU_MATH_F32_FAST && h->cfg.math != AWPU_MATH_F32_EXACT) || h->cfg.interp != AWPU_INTERP_LERP)
+        return fail(AWPU_ERR_STATE, "packed frames need AWPU_MATH_F32_EXACT or AWPU_MATH_F32_FAST, and AWPU_INTERP_LERP");
     if (h->usable() % 4 != 0 || !h->gain.empty())
-        return fail(AWPU_ERR_STATE, "packed frames need usable % 4 == 0 and no mic gains (the two pair shapes then read one layout)");
+        return fail(AWPU_ERR_STATE, "packed frames need usable % 4 == 0 and no mic gains (the shapes of a mode then read one layout)");
+    if (h->cfg.math == AWPU_MATH_F32_EXACT) {  // the {next, d} rows of das_exact_nd_kernel: where launch() takes that kernel for this batch
+        int nq = 1;
+        if (batch < 2 || !takes_exact_nd(h, batch, &nq))
+            return fail(AWPU_ERR_STATE, "packed frames in the reference's order need the grid's row length (grid_columns) and a batch of two or more");
+        *plan = h->exact_nd_plan;
+        return AWPU_OK;
+    }
     if (!awpu::pair_plan(h->window, h->usable(), plan)) return fail(AWPU_ERR_STATE, "the window does not fit the frame-pair image");
     return AWPU_OK;
 }
@@ -2679,7 +2722,7 @@ int awpu_hip_packed_bytes(awpu_hip_t *h, int32_t batch, uint64_t *bytes) {
     awpu::FastPlan plan;
     const int rc = packed_plan(h, batch, &plan);
     if (rc != AWPU_OK) return rc;
-    *bytes = (uint64_t) ((batch + 1) / 2) * h->usable() * plan.wr * 2 * sizeof(float);
+    *bytes = (uint64_t) packed_floats_of(h, plan, batch) * sizeof(float);
     return AWPU_OK;
 }
 
@@ -2693,9 +2736,7 @@ int awpu_hip_pack_frames(awpu_hip_t *h, const float *d_frames, int32_t batch, fl
     // (Measured: a throttled variant of this pass -- few persistent workgroups, non-temporal accesses -- meant to be gentler
     // on the sweep it runs beside, slowed that sweep MORE the longer it lasted: 256 / 512 / 1024 workgroups cost the ingest
     // rank 0.90 / 0.55 / 0.35 ms per 1024-frame step against 0.23 ms for this full-speed pass.  Short and fast wins.)
-    AWPU_HIP_TRY(awpu::launch_pack_pairs(d_frames, h->cfg.n_streams, h->cfg.hist, h->wstart, h->d_index, h->usable(), h->usable(),
-                                         nullptr, plan.wr, batch, d_packed, true, s));
-    return AWPU_OK;
+    return pack_for_sweep(h, plan, d_frames, batch, d_packed, s);
 }
 
 int awpu_hip_process_packed(awpu_hip_t *h, const float *d_packed, int32_t batch, float *d_power, void *stream) {
@@ -2708,7 +2749,7 @@ int awpu_hip_process_packed(awpu_hip_t *h, const float *d_packed, int32_t batch,
     TimingOff untimed(h);  // asynchronous path: the caller times its own stream
     // the shape awpu_hip_process_device takes for this batch (same rule: same bits), as long as that is a frame-pair shape
     // (the buffer is the caller's: awpu_hip_packed_bytes(batch) of it are taken to be there, and the sweep reads no further)
-    return sweep_packed(h, plan, d_packed, (size_t) ((batch + 1) / 2) * h->usable() * plan.wr * 2, batch, d_power, s);
+    return sweep_packed(h, plan, d_packed, packed_floats_of(h, plan, batch), batch, d_power, s);
 }
 
 int awpu_hip_synchronize(awpu_hip_t *h) {

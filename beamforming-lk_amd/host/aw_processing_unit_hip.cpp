@@ -87,7 +87,7 @@ bool AWProcessingUnitHip::start(const worker_t worker) {  // .cpp:67-95
     // the reference beamforms antennas[0] only (.cpp:74)
     AntennaView view{antennas[0].points.data(), AWPU_ELEMENTS, antennas[0].usable, antennas[0].index.data()};
     auto job = std::make_unique<MIMOWorkerHip>(pipeline, view, &running, small_res, small_res, fov, device,
-                                               /*autostart=*/true, AWPU_MATH_F32_FAST, devices);
+                                               /*autostart=*/true, AWPU_MATH_F32_EXACT, devices);
     if (job->status() != AWPU_OK) return false;
     workers.push_back(std::move(job));
     return true;

@@ -60,7 +60,7 @@ public:
     // `devices` (optional): spread the grid's rows over these GPUs of the node (one engine handle, one slab per
     // device: awpu_hip_cfg.n_devices); empty = the single `device`.
     MIMOWorkerHip(FrameSource *pipeline, const AntennaView &antenna, bool *running, int rows, int columns,
-                  float fov, int device = 0, bool autostart = true, int math = AWPU_MATH_F32_FAST,
+                  float fov, int device = 0, bool autostart = true, int math = AWPU_MATH_F32_EXACT,
                   const std::vector<int> &devices = {});
     ~MIMOWorkerHip();  // worker.h:104-107: looping = false; join
 

@@ -58,11 +58,13 @@ typedef enum {
 
 /* arithmetic of the sweep */
 typedef enum {
-    /* fp32, the reference's operation order per sample (sub, fma, add) and mic order
-     * s = 0..usable-1: the pre-epilogue sums are bit-identical to delay.cpp:19-25 */
+    /* THE DEFAULT.  fp32, the reference's operation order per sample (sub, fma, add) and mic order
+     * s = 0..usable-1: the pre-epilogue sums are bit-identical to delay.cpp:19-25, the powers within 1e-5 of
+     * the reference on ANY input (DC-biased included) */
     AWPU_MATH_F32_EXACT = 0,
-    /* fp32, two FMAs per sample (f*cur + (1-f)*next), LDS-tiled fast kernel; differs from
-     * EXACT by fp32 rounding only */
+    /* opt-in.  fp32, re-ordered (stencil first, two FMAs per sample, shared integer-delay sums): ~1.35 x the rate of
+     * EXACT on batches; within 1e-5 of the reference on zero-mean input only (on DC-biased input it is closer to the exact
+     * sums than the reference is, and for that reason up to 1e-4 .. 1e-3 from the REFERENCE) */
     AWPU_MATH_F32_FAST = 1,
     /* EXACT's structure with the running sum of every sample KEPT in bf16 (rounded to nearest even after
      * every mic; the interpolation term and the epilogue stay fp32).  Not in the reference and not for
@@ -156,7 +158,8 @@ typedef struct {
 #define AWPU_EXCHANGE_WINDOWS 1      /* the touched window of every stream, one 2-D copy per device; every device runs its whole sweep */
 #define AWPU_EXCHANGE_PACKED_PAIRS 2 /* devices[0] packs once, one linear copy per device, every device sweeps the packed pairs */
 
-/* fills cfg with the reference defaults (64 streams, hist 1024, LERP, F32_FAST, batch 1) */
+/* fills cfg with the reference defaults (64 streams, hist 1024, LERP, batch 1) and the reference's arithmetic (AWPU_MATH_F32_EXACT:
+ * results within 1e-5 of the reference on any input; AWPU_MATH_F32_FAST is an explicit opt-in, see INTEGRATION.md "Which math mode") */
 void awpu_hip_default_cfg(awpu_hip_cfg *cfg);
 
 /* replaces: MIMOWorker::MIMOWorker allocation of its state, src/dsp/mimo.cpp:7-13 /
@@ -260,11 +263,15 @@ int awpu_hip_process_device_sums(awpu_hip_t *h, const float *d_frames, int32_t b
  * packed buffer is what travels (the same bytes as the raw window), and every rank sweeps it as it arrives --
  * no window cut on the root, no pack pass on the others.  No reference counterpart (one thread, one array:
  * src/dsp/mimo.cpp:12, :100-103 is the snapshot this replaces).
- * Available for AWPU_MATH_F32_FAST + AWPU_INTERP_LERP, usable % 4 == 0, no mic gains, single-device handles; every
- * rank must have been created with the same n_streams, hist, active mics and cfg.window_begin/window_end.
- * awpu_hip_process_packed(pack_frames(x)) gives the bits awpu_hip_process_device(x) gives wherever that call sweeps
- * frame pairs itself (batches that fill the chip: >= 256 workgroups); for smaller batches, where process_device
- * prefers a single-frame shape, the two agree to fp32 rounding (a few 1e-6).
+ * Available with AWPU_INTERP_LERP, usable % 4 == 0, no mic gains, single-device handles, in both fp32 modes; every rank
+ * must have been created with the same math mode, n_streams, hist, active mics and cfg.window_begin/window_end.
+ *   AWPU_MATH_F32_EXACT (the default): the packed rows are the {next, d} elements das_exact_nd_kernel sweeps --
+ *     [ceil(batch/2)][usable][window - 1] x { X_a[t+1], X_b[t+1], X_a[t] - X_a[t+1], X_b[t] - X_b[t+1] } (16 bytes: delay.cpp:21's
+ *     `cur - next` is formed once, by the pack pass) -- twice the bytes of the raw window; needs cfg.grid_columns and batch >= 2;
+ *     awpu_hip_process_packed(pack_frames(x)) gives the bits of awpu_hip_process_device(x) for every such batch.
+ *   AWPU_MATH_F32_FAST: pre-filtered sample pairs, the same bytes as the raw window; the same bits as
+ *     awpu_hip_process_device(x) wherever that call sweeps frame pairs itself (batches that fill the chip: >= 256 workgroups);
+ *     for smaller batches, where process_device prefers a single-frame shape, the two agree to fp32 rounding (a few 1e-6).
  *   _packed_bytes: *bytes = size of the packed buffer for `batch` frames, AWPU_ERR_STATE when the handle's sweep does
  *                  not take packed frames (the caller then exchanges raw windows and calls awpu_hip_process_device)
  *   _pack_frames:  d_frames [batch][n_streams][hist] -> d_packed, enqueued on `stream` (NULL = the handle's)

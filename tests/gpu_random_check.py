@@ -63,7 +63,7 @@ def main(seed: int, cases: int) -> int:
         X = util.hash_frames(n_streams, hist, seed=1000 + case, batch=batch)
         if FIR8:
             table = util.synthetic_fir_table()
-            with pkg.Engine(n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch,
+            with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=P, n_streams=n_streams, lut_stride=lut_stride, hist=hist, max_batch=batch,
                             interp=pkg.binding.INTERP_FIR8) as eng:
                 eng.set_delay_table(off, frac)
                 eng.set_active_mics(index)

@@ -308,7 +308,7 @@ int main(int argc, char **argv) {
         AntennaView ant{xyz.data(), 64, 64, all.data()};
         for (int b = 0; b < 5; b++) src.publish_block();
         MIMOWorkerHip one(&src, ant, &run, rows, cols, 180.f, 0, false);
-        MIMOWorkerHip two(&src, ant, &run, rows, cols, 180.f, 0, false, AWPU_MATH_F32_FAST, {0, 0});
+        MIMOWorkerHip two(&src, ant, &run, rows, cols, 180.f, 0, false, AWPU_MATH_F32_EXACT, {0, 0});
         CHECK(two.status() == AWPU_OK, "group create: %s", awpu_hip_last_error());
         one.update();
         two.update();

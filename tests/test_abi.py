@@ -61,7 +61,7 @@ def test_cfg_struct_matches_header(pkg):
     pkg.binding.load().awpu_hip_default_cfg(C.byref(cfg))
     assert cfg.struct_size == C.sizeof(pkg.binding.Cfg) == 96
     assert (cfg.n_streams, cfg.hist, cfg.lut_stride, cfg.max_batch) == (64, 1024, 64, 1)
-    assert cfg.math == pkg.MATH_F32_FAST and cfg.interp == 0
+    assert cfg.math == pkg.MATH_F32_EXACT and cfg.interp == 0  # the reference has one arithmetic: that one is the default
 
 
 def test_no_cpu_fallback_without_device(pkg):

@@ -239,7 +239,7 @@ def test_error_paths(pkg, oracle):
     xyz = oracle.create_antenna()
     off, frac = oracle.compute_delay_lut(xyz, 4, 4)
     X = util.hash_frames(64, 1024, seed=1)
-    eng = pkg.Engine(n_pixels=16, max_batch=2)
+    eng = pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=16, max_batch=2)
     with eng:
         with pytest.raises(pkg.AwpuError) as ei:
             eng.process(X)
@@ -277,7 +277,7 @@ def test_host_buffer_entry_split_in_two(pkg, oracle):
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz)
     frames = S.make_frames(xyz, 4, seed=31)
-    engines = [pkg.Engine(n_pixels=spec.n_pixels, max_batch=4) for _ in range(2)]
+    engines = [pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, max_batch=4) for _ in range(2)]
     for eng in engines:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
@@ -309,7 +309,7 @@ def test_device_pointer_entry_with_torch(pkg, oracle):
     d_frames = torch.from_numpy(frames).to(dev)
     d_power = torch.zeros((3, spec.n_pixels), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()  # (torch fills on its own stream; the engine's streams do not wait for it)
-    eng = pkg.Engine(n_pixels=spec.n_pixels, max_batch=3)
+    eng = pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, max_batch=3)
     with eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
@@ -341,7 +341,7 @@ def test_fir8_golden_vectors(pkg, name):
     ax, ay = g["arrays"]
     n = 64 * int(ax) * int(ay)
     X = util.hash_frames(n, int(g["hist"]), seed=int(g["seed"]))[0]
-    eng = pkg.Engine(n_pixels=g["off"].shape[0], n_streams=n, hist=int(g["hist"]), interp=pkg.binding.INTERP_FIR8)
+    eng = pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=g["off"].shape[0], n_streams=n, hist=int(g["hist"]), interp=pkg.binding.INTERP_FIR8)
     with eng:
         eng.set_delay_table(g["off"], g["frac"])
         eng.set_active_mics(g["index"])
@@ -363,7 +363,7 @@ def test_fir8_golden_vectors_on_the_batch_kernel(pkg, name):
     P = g["off"].shape[0]
     reps = -(-(256 * 64 + 1) // P)
     off, frac = np.tile(g["off"], (reps, 1)), np.tile(g["frac"], (reps, 1))
-    with pkg.Engine(n_pixels=P * reps, n_streams=n, hist=int(g["hist"]), interp=pkg.binding.INTERP_FIR8, max_batch=2) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=P * reps, n_streams=n, hist=int(g["hist"]), interp=pkg.binding.INTERP_FIR8, max_batch=2) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(g["index"])
         eng.set_fir_table(measured_fir_table())
@@ -384,7 +384,7 @@ def test_fir8_mode_vs_oracle(pkg, oracle, table_kind):
         n = xyz.shape[1]
         X = util.hash_frames(n, 1024, seed=50 + usable, batch=2)
         index = np.random.default_rng(usable).permutation(n)[:usable].astype(np.int32)
-        eng = pkg.Engine(n_pixels=off.shape[0], n_streams=n, interp=pkg.binding.INTERP_FIR8, max_batch=2)
+        eng = pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=off.shape[0], n_streams=n, interp=pkg.binding.INTERP_FIR8, max_batch=2)
         with eng:
             eng.set_delay_table(off, frac)
             eng.set_active_mics(index)
@@ -409,7 +409,7 @@ def test_fir8_batched_frame_pair_shape(pkg, oracle):
     table = measured_fir_table()
     X = util.hash_frames(64, 1024, seed=91, batch=3)
     index = np.array([m for m in range(64) if m % 7 != 3], np.int32)
-    with pkg.Engine(n_pixels=res * res, interp=pkg.binding.INTERP_FIR8, max_batch=3) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=res * res, interp=pkg.binding.INTERP_FIR8, max_batch=3) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(index)
         eng.set_fir_table(table)
@@ -432,7 +432,7 @@ def test_device_heatmap_equals_populate_heatmap(pkg, oracle):
     frames = S.make_frames(xyz, 3, seed=9)
     frames[2] *= 0.0  # an all-zero frame: max 0 -> 0/0 -> NaN, defined as level 0 (host, device and checker alike)
     dev = torch.device("cuda:0")
-    with pkg.Engine(n_pixels=spec.n_pixels, max_batch=3) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, max_batch=3) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
         power = eng.process(frames)
@@ -467,7 +467,7 @@ def test_device_upscale_and_colour_table(pkg, oracle):
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(91)
     lut = torch.from_numpy(rng.integers(0, 256, (256, 3), dtype=np.uint8)).to(dev)
-    with pkg.Engine(n_streams=64, n_pixels=64, lut_stride=64) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_streams=64, n_pixels=64, lut_stride=64) as eng:
         for (r, c, R, C_, batch) in [(16, 16, 64, 64, 3), (128, 128, 1024, 1024, 2), (12, 20, 50, 33, 1), (64, 64, 64, 64, 1)]:
             img = rng.integers(0, 256, (batch, r, c), dtype=np.uint8)
             d_img = torch.from_numpy(img).to(dev)
@@ -496,7 +496,7 @@ def test_few_beam_das_for_trackers(pkg, oracle):
         g = np.load(GOLDEN / f"{name}.npz")
         X = util.hash_frames(64, 1024, seed=int(g["seed"]))[0]
         d_X = torch.from_numpy(X).to(dev)
-        with pkg.Engine(n_pixels=16) as eng:
+        with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=16) as eng:
             with pytest.raises(pkg.AwpuError) as ei:
                 eng.beams(g["off"], g["frac"], d_X.data_ptr())
             assert ei.value.status == pkg.binding.ERR_STATE  # active mics not set
@@ -515,7 +515,7 @@ def test_few_beam_das_for_trackers(pkg, oracle):
     rng = np.random.default_rng(3)
     xyz = oracle.create_antenna()
     off, frac = pkg.steer_table(xyz, rng.uniform(0, 1.5, 100), rng.uniform(-np.pi, np.pi, 100))
-    with pkg.Engine(n_pixels=16) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=16) as eng:
         eng.set_active_mics(None)
         ring = np.zeros((64, 1024), np.float32)
         for b in range(5):
@@ -540,7 +540,7 @@ def test_device_calibration_equals_restated_loop(pkg, oracle):
     X[64 + 9] *= 40.0     # second array: another loud one
     X[64 + 63] = 0.0
     d_X = torch.from_numpy(X).to(dev)
-    with pkg.Engine(n_streams=128, n_pixels=64, lut_stride=128) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_streams=128, n_pixels=64, lut_stride=128) as eng:
         for array in range(2):
             index, corr, median = eng.calibrate_device(d_X.data_ptr(), array=array)
             want_index, want_corr, want_median = oracle.calibrate(X[64 * array: 64 * array + 64])
@@ -608,7 +608,7 @@ def test_wire_ingest_and_ring_sweep(pkg, oracle):
     rx.bind(("127.0.0.1", 0))
     rx.settimeout(5.0)
     tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
-    with pkg.Engine(n_pixels=off.shape[0], n_streams=n) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=off.shape[0], n_streams=n) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
         with pytest.raises(pkg.AwpuError):
@@ -651,7 +651,7 @@ def test_single_frames_on_the_headline_grid(pkg, oracle):
     off, frac = S.delay_table(spec, xyz)
     rng = np.random.default_rng(3)
     ring = np.zeros((spec.n_mics, 1024), np.float32)
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=2, grid_columns=spec.res) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=2, grid_columns=spec.res) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
         for b in range(4):  # four blocks of 24-bit noise fill the ring
@@ -681,7 +681,7 @@ def test_reference_default_single_frames_run_the_resident_window_kernel(pkg, ora
     names = pkg.binding.KERNEL_NAMES
     rng = np.random.default_rng(4)
     ring = np.zeros((64, 1024), np.float32)
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=64, max_batch=2, grid_columns=spec.res) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=64, max_batch=2, grid_columns=spec.res) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
         for b in range(5):  # five blocks of 24-bit noise: the ring wraps once
@@ -706,7 +706,7 @@ def test_reference_default_single_frames_run_the_resident_window_kernel(pkg, ora
         check_full_grid(oracle, ragged, ring * gains[:, None], off, frac, "reference default, 51 mics with gains", index=keep)
     X = S.make_frames(xyz, 1, seed=14)[0]
     off2, frac2 = pkg.build_delay_table(xyz, 90, 70, 120.0)
-    with pkg.Engine(n_pixels=90 * 70, n_streams=64, grid_columns=70) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=90 * 70, n_streams=64, grid_columns=70) as eng:
         eng.set_delay_table(off2, frac2)
         eng.set_active_mics(None)
         odd = eng.process(X)
@@ -761,7 +761,7 @@ def test_two_handles_from_two_threads(pkg, oracle):
     def work(k):
         try:
             spec, off, frac, frames, batch = jobs[k]
-            with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=batch, grid_columns=spec.res) as eng:
+            with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=batch, grid_columns=spec.res) as eng:
                 eng.set_delay_table(off, frac)
                 eng.set_active_mics(None)
                 for it in range(12):
@@ -794,7 +794,7 @@ def test_host_batches_upload_in_pieces(pkg, oracle):
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz)
     frames = util.hash_frames(spec.n_mics, 1024, seed=77, batch=130)
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=130, grid_columns=spec.res) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=130, grid_columns=spec.res) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
         host = eng.process(frames)
@@ -823,7 +823,7 @@ def test_fir8_single_frames_on_the_headline_grid(pkg, oracle):
     table = measured_fir_table()
     rng = np.random.default_rng(5)
     ring = np.zeros((spec.n_mics, 1024), np.float32)
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=3, grid_columns=spec.res,
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=3, grid_columns=spec.res,
                     interp=pkg.binding.INTERP_FIR8) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
@@ -884,7 +884,7 @@ def test_c4_rank_slab_of_eight(pkg, oracle):
         shard = sharding.shard_rows(spec.res, spec.res, 8, rank)
         assert (shard.row_count, shard.pixel_count) == (32, 8192)
         off, frac = S.delay_table(spec, xyz, shard.row_begin, shard.row_count)
-        eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, lut_stride=spec.n_mics, max_batch=6,
+        eng = pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, lut_stride=spec.n_mics, max_batch=6,
                          pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count, grid_columns=spec.res)
         with eng:
             eng.set_delay_table(off, frac)
@@ -915,7 +915,7 @@ frames = S.make_frames(xyz, 6, seed=21)
 import os
 EXACT = os.environ.get("AWPU_SHAPE") == "noquad"
 def run(devices, batch, **kw):
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=8, grid_columns=spec.res, devices=devices, **kw) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=8, grid_columns=spec.res, devices=devices, **kw) as eng:
         eng.set_delay_table(off, frac); eng.set_active_mics(None)
         host = eng.process(frames[:batch])
         d_X = torch.from_numpy(frames[:batch]).cuda(); d_P = torch.zeros((batch, spec.n_pixels), dtype=torch.float32, device="cuda")
@@ -949,18 +949,18 @@ for batch in (1, 6):
                 assert util.power_rel_err(b, a) < 5e-6, (name, devices, batch)
         assert grp[4].frames == one[4].frames and grp[4].usable == one[4].usable and grp[4].alg_flops_frame == one[4].alg_flops_frame
 staged = os.environ.get("AWPU_GROUP_FORCE_COPY") == "2"
-with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, grid_columns=spec.res, devices=[0, 0, 0]) as eng:
+with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, grid_columns=spec.res, devices=[0, 0, 0]) as eng:
     want = pkg.binding.PEER_HOST_STAGED if staged else pkg.binding.PEER_SAME_DEVICE
     assert eng.peer_status() == [want] * 3, eng.peer_status()
     assert "pinned host memory" not in eng.last_error()  # (equal ordinals have nothing to report; real pairs without peer access do)
-with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics) as eng:
+with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics) as eng:
     assert eng.peer_status() == [pkg.binding.PEER_SAME_DEVICE]
 # uneven slabs (64 rows over 3 devices = 22 + 21 + 21) and a group that owns only part of the grid
-with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, grid_columns=spec.res, devices=[0, 0], pixel_begin=10 * spec.res, pixel_count=7 * spec.res) as eng:
+with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, grid_columns=spec.res, devices=[0, 0], pixel_begin=10 * spec.res, pixel_count=7 * spec.res) as eng:
     eng.set_delay_table(off[10 * spec.res:17 * spec.res], frac[10 * spec.res:17 * spec.res]); eng.set_active_mics(None)
     assert util.power_rel_err(eng.process(frames[0]), run(None, 1)[0][0][10 * spec.res:17 * spec.res]) < (1e-12 if EXACT else 5e-6)
 try:
-    pkg.Engine(n_pixels=4, devices=list(range(9)))
+    pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=4, devices=list(range(9)))
 except pkg.AwpuError as e:
     assert e.status == pkg.binding.ERR_INVALID
 else:
@@ -1002,8 +1002,9 @@ spec = S.WORKLOADS["headline"]
 xyz = S.geometry(spec)
 off, frac = S.delay_table(spec, xyz)
 frames = util.hash_frames(spec.n_mics, 1024, seed=31, batch=10)
+MODE, KERNEL = (pkg.MATH_F32_FAST, "quad") if os.environ.get("TEST_MATH") == "fast" else (pkg.MATH_F32_EXACT, "exact_nd")
 def run(devices, batch, index=None):
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=10, grid_columns=spec.res, devices=devices) as eng:
+    with pkg.Engine(math=MODE, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=10, grid_columns=spec.res, devices=devices) as eng:
         eng.set_delay_table(off, frac); eng.set_active_mics(index)
         d_X = torch.from_numpy(frames[:batch]).cuda(); d_P = torch.zeros((batch, spec.n_pixels), dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
@@ -1015,7 +1016,7 @@ def run(devices, batch, index=None):
         host = eng.process(frames[:batch])
     return d_P.cpu().numpy(), host, stats
 one = run(None, 10)
-assert B.KERNEL_NAMES[one[2].kernel_variant] == "quad"
+assert B.KERNEL_NAMES[one[2].kernel_variant] == KERNEL
 for devices in ([0, 0], [0, 0, 0, 0]):
     grp = run(devices, 10)
     assert grp[2].group_exchange == B.EXCHANGE_PACKED_PAIRS, grp[2].group_exchange
@@ -1030,8 +1031,8 @@ keep = np.array([m for m in range(spec.n_mics) if m % 9 != 2], np.int32)
 grp2 = run([0, 0, 0], 10, keep)
 assert grp2[2].group_exchange == B.EXCHANGE_WINDOWS and grp2[2].group_ranges == 32 // 3 + 1
 assert util.power_rel_err(grp2[0], run(None, 10, keep)[0]) < 5e-6
-# the reference-order mode through a group: raw windows travel, every part runs das_exact_quad_kernel on its row groups --
-# the same quads in the same order as one device: the same bits
+# the reference-order mode through a group, an ODD batch: the {next, d} rows travel (the last pair a frame with itself), every part
+# runs das_exact_nd_kernel on its row groups -- the same quads in the same order as one device: the same bits
 def run_exact(devices):
     with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=3, grid_columns=spec.res, devices=devices, math=pkg.MATH_F32_EXACT) as eng:
         eng.set_delay_table(off, frac); eng.set_active_mics(None)
@@ -1040,7 +1041,7 @@ def run_exact(devices):
         eng.process_device(d_X.data_ptr(), 3, d_P.data_ptr()); eng.synchronize()
         return d_P.cpu().numpy(), eng.stats()
 e1, eg = run_exact(None), run_exact([0, 0, 0])
-assert B.KERNEL_NAMES[e1[1].kernel_variant] == "exact_quad" and eg[1].group_exchange == B.EXCHANGE_WINDOWS
+assert B.KERNEL_NAMES[e1[1].kernel_variant] == "exact_nd" and eg[1].group_exchange == B.EXCHANGE_PACKED_PAIRS
 assert np.array_equal(e1[0], eg[0])
 # one group handle re-targeted: the union window of the first table does not outlive it (a narrower second table gets its
 # own, narrower union -- and the same bits as a fresh single-device handle on that table)
@@ -1048,7 +1049,7 @@ off_b = (off.max() + off.min() - off).astype(off.dtype); frac_b = np.ascontiguou
 off_n = np.clip(off, off.min(), off.min() + 8).astype(off.dtype)
 def sweep_tables(devices, tables):
     res = []
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=10, grid_columns=spec.res, devices=devices) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=10, grid_columns=spec.res, devices=devices) as eng:
         eng.set_active_mics(None)
         d_X = torch.from_numpy(frames).cuda(); d_P = torch.zeros((10, spec.n_pixels), dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
@@ -1069,16 +1070,18 @@ print("GROUP PACKED OK")
 """
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("force_copy", ["0", "1", "2"])
-def test_device_group_exchanges_packed_frame_pairs(force_copy):
+def test_device_group_exchanges_packed_frame_pairs(force_copy, math):
     """Round 4: the in-process device group on the exchange format of the one-process-per-GPU path.  A batch that the parts
     sweep with a frame-pair shape travels as PACKED frame pairs -- devices[0] runs the pack pass once, every other part gets
     one linear copy (force_copy=1: the peer-copy path; 2: through pinned host memory; 0: parts on devices[0] sweep the
     group's packed buffer in place) -- and the grid's rows are dealt to the parts in groups of four, round-robin.  The
     assembled heatmaps equal the single-device handle's BIT FOR BIT (the same quads of the same packed samples through the
-    same kernel); single frames and mic lists that are no multiple of four fall back to raw windows, to rounding."""
+    same kernel); single frames and mic lists that are no multiple of four fall back to raw windows, to rounding.
+    Round 5: in BOTH math modes -- the reference's order (the default) exchanges the {next, d} rows das_exact_nd_kernel sweeps."""
     import os, subprocess, sys
-    env = dict(os.environ, AWPU_GROUP_FORCE_COPY=force_copy)
+    env = dict(os.environ, AWPU_GROUP_FORCE_COPY=force_copy, TEST_MATH=math)
     out = subprocess.run([sys.executable, "-c", GROUP_PACKED_CHILD, str(Path(__file__).resolve().parent.parent)],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "GROUP PACKED OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
@@ -1097,7 +1100,7 @@ xyz = S.geometry(spec)
 off, frac = S.delay_table(spec, xyz)
 frames = S.make_frames(xyz, 6, seed=23)
 def run(devices):
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=8, grid_columns=spec.res, devices=devices) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=8, grid_columns=spec.res, devices=devices) as eng:
         eng.set_delay_table(off, frac); eng.set_active_mics(None)
         host = eng.process(frames)
         d_X = torch.from_numpy(frames).cuda(0); d_P = torch.zeros((6, spec.n_pixels), dtype=torch.float32, device="cuda:0")
@@ -1173,7 +1176,7 @@ def test_c5_1024_frames_512_mics_rank_slab(pkg, oracle):
     for k in range(B // 64):
         frames[64 * k:64 * (k + 1)] = distinct
     del distinct
-    eng = pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, lut_stride=spec.n_mics, max_batch=B,
+    eng = pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, lut_stride=spec.n_mics, max_batch=B,
                      pixel_begin=shard.pixel_begin, pixel_count=shard.pixel_count, grid_columns=spec.res)
     with eng:
         eng.set_delay_table(off, frac)
@@ -1228,7 +1231,7 @@ def test_live_block_equals_the_separate_steps(pkg, oracle):
     off, frac = oracle.compute_delay_lut(xyz, 16, 16)
     blocks = [make_datagrams(rng.integers(-(1 << 23), 1 << 23, (256, 256), dtype=np.int32), counter0=256 * b) for b in range(6)]
     lut = torch.from_numpy(rng.integers(0, 256, (256, 3), dtype=np.uint8)).to("cuda:0")
-    with pkg.Engine(n_pixels=256) as one, pkg.Engine(n_pixels=256) as sep:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=256) as one, pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=256) as sep:
         for eng in (one, sep):
             eng.set_delay_table(off, frac)
             eng.set_active_mics(None)
@@ -1256,7 +1259,7 @@ def test_live_block_replayed_as_a_graph(pkg, oracle):
     off2, frac2 = oracle.compute_delay_lut(xyz, 16, 16, fov_deg=90.0)
     wire = np.zeros(256 * 1032, np.uint8)
     out = (np.zeros(256, np.float32), np.zeros((16, 16), np.uint8), np.zeros((40, 56), np.uint8))
-    with pkg.Engine(n_pixels=256) as one, pkg.Engine(n_pixels=256) as sep:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=256) as one, pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=256) as sep:
         for eng in (one, sep):
             eng.set_delay_table(off, frac)
             eng.set_active_mics(None)
@@ -1275,12 +1278,17 @@ def test_live_block_replayed_as_a_graph(pkg, oracle):
             assert np.array_equal(big, oracle.resize_linear_u8(image, 40, 56)), b
 
 
-def test_packed_frames_split_the_sweep_at_its_pack_pass(pkg, oracle):
+@pytest.mark.parametrize("math", MATHS)
+def test_packed_frames_split_the_sweep_at_its_pack_pass(pkg, oracle, math):
     """awpu_hip_pack_frames + awpu_hip_process_packed = awpu_hip_process_device, bit for bit: the multi-GPU exchange
     format (the ingest rank packs once, every rank sweeps the packed pairs as they arrive).  Quad shape (row length
     given), pair shape (not given), an odd batch; a handle created with a wider staging window than its table needs
-    (cfg.window_begin/window_end: the union over all ranks' slabs) returns the same bits as one without."""
+    (cfg.window_begin/window_end: the union over all ranks' slabs) returns the same bits as one without.
+    Round 5: the reference's order too -- the packed rows are then the {next, d} elements of das_exact_nd_kernel (which needs the
+    grid's row length: without it the entry points say so and nothing is packed)."""
     import torch
+
+    exact = math == "exact"
 
     S = pkg.synthetic
     spec = S.WORKLOADS["c2"]
@@ -1291,9 +1299,14 @@ def test_packed_frames_split_the_sweep_at_its_pack_pass(pkg, oracle):
     want0 = None
     for hint, window in ((spec.res, None), (0, None), (spec.res, (int(off.min()) - 20, int(off.max()) + 257 + 9))):
         for batch in (10, 11, 2):  # 5 and 6 frame pairs x 64 tiles fill the chip; a batch of 2 does not
-            with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=12, grid_columns=hint, window=window) as eng:
+            with pkg.Engine(math=math_id(pkg, math), n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=12, grid_columns=hint, window=window) as eng:
                 eng.set_delay_table(off, frac)
                 eng.set_active_mics(None)
+                if exact and not hint:
+                    with pytest.raises(pkg.AwpuError) as ei:
+                        eng.packed_bytes(batch)
+                    assert ei.value.status == pkg.binding.ERR_STATE
+                    continue
                 n = eng.packed_bytes(batch)
                 assert n % 8 == 0 and n >= ((batch + 1) // 2) * spec.n_mics * 257 * 8
                 d_pk = torch.zeros(n // 4, dtype=torch.float32, device="cuda")
@@ -1307,7 +1320,7 @@ def test_packed_frames_split_the_sweep_at_its_pack_pass(pkg, oracle):
                 st.synchronize()
                 eng.synchronize()
             a, b = d_a.cpu().numpy(), d_b.cpu().numpy()
-            if batch >= 10:  # process_device sweeps frame pairs itself: the same kernel on the same packed samples
+            if batch >= 10 or exact:  # process_device sweeps frame pairs itself: the same kernel on the same packed samples
                 assert a.max() > 0 and np.array_equal(a, b), (hint, window, batch)
             else:            # process_device prefers a single-frame shape for so small a launch: equal to rounding (two
                 # shapes, each within a few 1e-6 of the reference: 2.0e-6 apart on these frames)
@@ -1315,18 +1328,18 @@ def test_packed_frames_split_the_sweep_at_its_pack_pass(pkg, oracle):
             if batch == 10 and hint:
                 if want0 is None:
                     want0 = a
-                    check_full_grid(oracle, a[0], frames[0], off, frac, "c2 through pack_frames + process_packed")
+                    check_full_grid(oracle, a[0], frames[0], off, frac, f"c2 through pack_frames + process_packed ({math})")
                 else:
                     assert np.array_equal(a, want0), "a wider staging window changed the bits"
     # a mic list that is not a multiple of four has no common packed layout: the caller is told, nothing is computed
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=4, grid_columns=spec.res) as eng:
+    with pkg.Engine(math=math_id(pkg, math), n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=4, grid_columns=spec.res) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(np.arange(253, dtype=np.int32))
         with pytest.raises(pkg.AwpuError) as ei:
             eng.packed_bytes(4)
         assert ei.value.status == pkg.binding.ERR_STATE
     with pytest.raises(pkg.AwpuError):
-        pkg.Engine(n_pixels=16, window=(900, 1000))  # narrower than one delay() read
+        pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=16, window=(900, 1000))  # narrower than one delay() read
 
 
 def test_interleaved_row_groups_tile_the_headline_grid(pkg, oracle):
@@ -1352,7 +1365,7 @@ def test_interleaved_row_groups_tile_the_headline_grid(pkg, oracle):
         o, f = S.delay_table_for(spec, xyz, s.row_ranges)
         rows = np.array(s.rows())
         assert np.array_equal(o, off.reshape(spec.res, spec.res, -1)[rows].reshape(-1, spec.n_mics))
-        with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=4, pixel_begin=s.pixel_begin,
+        with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=4, pixel_begin=s.pixel_begin,
                         pixel_count=s.pixel_count, grid_columns=spec.res, window=window) as eng:
             eng.set_delay_table(o, f)
             eng.set_active_mics(None)
@@ -1391,7 +1404,7 @@ def test_live_graphs_are_retired_when_their_buffers_move(pkg, oracle):
     for interp in (pkg.binding.INTERP_LERP, pkg.binding.INTERP_FIR8):
         fir = interp == pkg.binding.INTERP_FIR8
         o = np.minimum(off, 1024 - 263).astype(np.int32) if fir else off
-        with pkg.Engine(n_pixels=256, max_batch=4, interp=interp) as one, pkg.Engine(n_pixels=256, interp=interp) as sep:
+        with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=256, max_batch=4, interp=interp) as one, pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=256, interp=interp) as sep:
             for eng in (one, sep):
                 eng.set_delay_table(o, frac)
                 eng.set_active_mics(None)
@@ -1439,7 +1452,7 @@ def test_calls_refused_while_an_async_call_is_in_flight(pkg, oracle):
     off, frac = oracle.compute_delay_lut(xyz, 16, 16)
     frames = util.hash_frames(64, 1024, seed=5, batch=2)
     wire = make_datagrams(np.zeros((256, 256), np.int32))
-    with pkg.Engine(n_pixels=256, max_batch=2) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=256, max_batch=2) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
         want = eng.process(frames)
@@ -1466,7 +1479,7 @@ for wl, batch, hint in (("c2", 4, True), ("c2", 1, True), ("c2", 3, False), ("c2
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz)
     frames = util.hash_frames(spec.n_mics, 1024, seed=31, batch=batch)
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=batch, grid_columns=spec.res if hint else 0) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=batch, grid_columns=spec.res if hint else 0) as eng:
         eng.set_delay_table(off, frac); eng.set_active_mics(None)
         out.append(eng.process(frames))
 np.savez(sys.argv[2], *out)
@@ -1507,7 +1520,7 @@ def test_ring_sweep_wider_arrays(pkg, oracle, n_streams, usable, P):
     frac = rng.uniform(0, 1, size=(P, n_streams)).astype(np.float32)
     index = np.sort(rng.permutation(n_streams)[:usable]).astype(np.int32)
     ring = np.zeros((n_streams, 1024), np.float32)
-    with pkg.Engine(n_pixels=P, n_streams=n_streams) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=P, n_streams=n_streams) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(index)
         for b in range(9):
@@ -1531,7 +1544,7 @@ def test_random_display_and_beam_shapes(pkg, oracle):
 
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(808)
-    with pkg.Engine(n_pixels=64) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=64) as eng:
         for _ in range(12):
             r, c = int(rng.integers(1, 70)), int(rng.integers(1, 70))
             R, C_ = r + int(rng.integers(0, 200)), c + int(rng.integers(0, 200))
@@ -1562,7 +1575,7 @@ def test_random_display_and_beam_shapes(pkg, oracle):
         index = rng.permutation(n_streams)[:usable].astype(np.int32)
         X = util.hash_frames(n_streams, hist, seed=int(rng.integers(1, 1 << 30)))[0]
         d_X = torch.from_numpy(X).to(dev)
-        with pkg.Engine(n_pixels=4, n_streams=n_streams, lut_stride=stride, hist=hist) as eng:
+        with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=4, n_streams=n_streams, lut_stride=stride, hist=hist) as eng:
             eng.set_active_mics(index)
             power, beams = eng.beams(off, frac, d_X.data_ptr())
         want_p, want_b = oracle.particle_beams(X, off, frac, index)
@@ -1798,7 +1811,7 @@ def test_packed_entry_points_refuse_what_they_cannot_sweep(pkg, oracle):
     off, frac = S.delay_table(spec, xyz)
     d = torch.zeros(1 << 20, dtype=torch.float32, device="cuda")
     B = pkg.binding
-    with pkg.Engine(n_pixels=spec.n_pixels, max_batch=4, grid_columns=spec.res) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, max_batch=4, grid_columns=spec.res) as eng:
         with pytest.raises(pkg.AwpuError) as ei:  # no table, no mic list yet
             eng.packed_bytes(2)
         assert ei.value.status == B.ERR_STATE
@@ -1818,7 +1831,7 @@ def test_packed_entry_points_refuse_what_they_cannot_sweep(pkg, oracle):
         assert ei.value.status == B.ERR_STATE
         eng.set_mic_gains(None)
         assert eng.packed_bytes(2) > 0
-    for kw in (dict(math=pkg.MATH_F32_EXACT), dict(interp=B.INTERP_FIR8)):
+    for kw in (dict(math=pkg.MATH_F32_EXACT), dict(math=pkg.MATH_F32_FAST, interp=B.INTERP_FIR8)):
         with pkg.Engine(n_pixels=spec.n_pixels, max_batch=4, **kw) as eng:
             eng.set_delay_table(np.minimum(off, 1024 - 263).astype(np.int32), frac)
             eng.set_active_mics(None)
@@ -1841,7 +1854,7 @@ def test_reference_cli_default_grid(pkg, oracle, res, fov):
     assert off.shape == (res * res, 64) and off.min() >= 256 - 29 and off.max() <= 256
     frames = pkg.synthetic.make_frames(xyz, 3, seed=77)
     for cols in (res, 0):
-        with pkg.Engine(n_pixels=res * res, n_streams=64, max_batch=3, grid_columns=cols) as eng:
+        with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=res * res, n_streams=64, max_batch=3, grid_columns=cols) as eng:
             eng.set_delay_table(off, frac)
             eng.set_active_mics(None)
             single = eng.process(frames[:1])[0]
@@ -1943,7 +1956,7 @@ def test_fir8_vertical_quads_share_samples_bit_for_bit(pkg, oracle, arrays, res,
     gains = (1.0 + 0.25 * np.sin(np.arange(n))).astype(np.float32)
     out = {}
     for cols in (res, 0):
-        with pkg.Engine(n_pixels=res * res, n_streams=n, interp=pkg.binding.INTERP_FIR8, max_batch=batch, grid_columns=cols) as eng:
+        with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=res * res, n_streams=n, interp=pkg.binding.INTERP_FIR8, max_batch=batch, grid_columns=cols) as eng:
             eng.set_delay_table(off, frac)
             eng.set_active_mics(index)
             eng.set_fir_table(table)
@@ -1972,7 +1985,7 @@ def test_pack_frames_in_slices_equals_one_pass(pkg, oracle):
     frames = S.make_frames(xyz, B, seed=5)
     dev = torch.device("cuda", 0)
     d_frames = torch.from_numpy(frames).to(dev)
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=B, grid_columns=spec.res) as eng:
+    with pkg.Engine(math=pkg.MATH_F32_FAST, n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=B, grid_columns=spec.res) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
         n = eng.packed_bytes(B) // 4
