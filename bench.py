@@ -24,15 +24,16 @@ Workloads: c1, c2, headline, c3, c4 = BASELINE.json configs on the whole grid; c
 in flight on ONE rank's slab of the 256x256 grid (1/8 of the rows; with N GPUs the N first slabs of 8N).
 
 At N = 1 the line also carries, next to the batched `value`:
-  "parity"            GPU vs the oracle on EVERY pixel of frame 0, unfloored (tests/util.parity_report)
-  "single_frame"      one frame per call, the regime the reference's live display runs in
+  "parity"            GPU vs the oracle on EVERY pixel of frame 0, unfloored (tests/util.parity_report); "dc_ok": the run's math mode
+                      within 1e-5 of the reference-built goldens at every DC offset (parity_dc)
+  "single_frame"      one frame per call, the regime the reference's live display runs in; "other_mode": the same in the other fp32 mode
   "pcie_inclusive"    awpu_hip_process on pageable host buffers, upload and read-back inside the clock; never `value`
   "bf16"              the bf16-accumulator mode on the same frames: its ERROR against the fp32 sweep
   "parity_dc"         both math modes on the reference-generated DC-biased goldens: error per offset (exact <= 1e-5 flat)
   "reference_default" the shape the reference ships (64 mics, 100x100, one frame per call) with its CPU time and the
-                      5.24 ms real-time budget of a block beside it
-  "workloads"         the headline shape in AWPU_MATH_F32_EXACT (the reference's operation order), c2, c3 (lerp and the 8-tap
-                      FIR variant) and the c5 slab, a few steps each: kernel ms, VALU fraction, full-grid parity
+                      5.24 ms real-time budget of a block beside it, in both fp32 modes
+  "workloads"         the headline shape in the OTHER fp32 mode (--math fast when the run is the default), then c2, c3 and the c5
+                      slab in the run's mode and c3 with the 8-tap FIR variant, a few steps each: kernel ms, VALU fraction, full-grid parity
   "projected_scaling" rank 0's slab of an 8-rank run through the N > 1 step loop, the collective replaced by a local
                       copy of the same bytes: what one GPU can say about the 8-GPU step (NOT a scaling measurement)
   "projected_scaling_strong"  the same for configs[3]: 512 mics x 256x256 at a FIXED batch, an eighth of the grid per GPU
@@ -77,7 +78,9 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="headline", help="c1 | c2 | headline | c3 | c4 | c5")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per step; default 128 x GPUs (c5: 1024 x GPUs), which keeps every rank's launch at its one-GPU size")
-    ap.add_argument("--math", default="fast", choices=["fast", "exact", "bf16"])
+    ap.add_argument("--math", default="exact", choices=["exact", "fast", "bf16"],
+                    help="exact (the library's default): the reference's operation and mic order, within 1e-5 of it on any input; "
+                         "fast: the re-ordered fp32 sweep (opt-in: within 1e-5 on zero-mean input only)")
     ap.add_argument("--interp", default="lerp", choices=["lerp", "fir8"], help="fir8: the 8-tap variant of delay()")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--no-extras", action="store_true",
@@ -148,14 +151,14 @@ class Watchdog:
     """Exit non-zero when a rendezvous or a first collective does not come back: a rank that waits for a peer that
     never arrives would otherwise sit there until the driver's own limit."""
 
-    def __init__(self, seconds: float, what: str):
-        self.timer = threading.Timer(seconds, self._fire, args=(seconds, what))
+    def __init__(self, seconds: float, what: str, status: int = 4):
+        self.timer = threading.Timer(seconds, self._fire, args=(seconds, what, status))
         self.timer.daemon = True
 
     @staticmethod
-    def _fire(seconds, what):
-        print(f"[bench] {what} did not finish within {seconds:.0f} s: giving up (exit 4)", file=sys.stderr, flush=True)
-        os._exit(4)
+    def _fire(seconds, what, status):
+        print(f"[bench] {what} did not finish within {seconds:.0f} s: giving up (exit {status})", file=sys.stderr, flush=True)
+        os._exit(status)
 
     def __enter__(self):
         self.timer.start()
@@ -219,7 +222,7 @@ def measured_traffic(workload, batch, world, math="fast"):
     """HBM-side bytes per launch from the committed PMC run (profiles/r0N_hbm_traffic.json, collected with
     tools/pmc_hbm.sh as MI355X_MICROARCH.md prescribes; newest round first); (None, None) when it was not
     measured for this exact workload, batch and math mode."""
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         path = REPO / "profiles" / name
         if world != 1 or not path.exists():
             continue
@@ -306,7 +309,7 @@ class RankJob:
             self.win_hist = ((hi - lo + reach + 3) // 4) * 4 + 4
             self.window = (lo, hi + reach)
             self.exchange = os.environ.get("BENCH_EXCHANGE", "packed")
-            if args.math != "fast" or args.interp != "lerp" or B % 2:
+            if args.math == "bf16" or args.interp != "lerp" or B % 2:  # (both fp32 modes have a packed form: awpu_hip_pack_frames)
                 self.exchange = "window"
         self.math = {"fast": pkg.MATH_F32_FAST, "exact": pkg.MATH_F32_EXACT, "bf16": pkg.MATH_BF16_ACC}[args.math]
         self.interp = pkg.binding.INTERP_FIR8 if args.interp == "fir8" else pkg.binding.INTERP_LERP
@@ -656,6 +659,11 @@ def main():
             "config": {
                 "workload": wl_name, "mics": spec.n_mics, "grid": f"{spec.res}x{spec.res}",
                 "block_samples": 256, "frames_per_step": B, "math": args.math, "interp": args.interp,
+                "math_note": {"exact": "AWPU_MATH_F32_EXACT, the library's default: delay.cpp:19-25's operations in its order, mics in "
+                                       "antenna.index[] order -- within 1e-5 of the reference on any input",
+                              "fast": "AWPU_MATH_F32_FAST, an explicit opt-in: re-ordered fp32 (stencil first); within 1e-5 of the reference "
+                                      "on zero-mean input only (parity_dc)",
+                              "bf16": "AWPU_MATH_BF16_ACC: BASELINE configs[4]'s accumulator experiment, not for production"}[args.math],
                 "frames_per_step_rule": ("--batch given: fixed batch" if args.batch else
                                          f"{B // world} x {world} GPU(s): the batch grows with the number of ranks so that a rank's "
                                          f"launch ({B} frames x 1/{world} of the grid) keeps its one-GPU size"),
@@ -693,36 +701,45 @@ def main():
             out["rehearsal"] = "all ranks on one GPU over gloo: logic check only, not a scaling number"
 
     # ---- N = 1: the other regimes of the same path, and the CPU reference, beside the batched value
-    if world == 1 and not args.no_extras and args.math == "fast" and args.interp == "lerp":
-        n1 = 200 if shard.pixel_count * spec.n_mics <= (1 << 23) else 60
-        eng1 = job.make_engine(job.math, 1, off, frac, shard.pixel_begin, shard.pixel_count)
-        ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        d_p1 = torch.zeros((2, shard.pixel_count), dtype=torch.float32, device=dev)
-        torch.cuda.synchronize()  # (the fill runs on torch's stream; `stream` does not wait for it)
-        with torch.cuda.stream(stream):
-            for k in range(10):
-                eng1.process_device(d_full[k % B].data_ptr(), 1, d_p1[1].data_ptr(), stream.cuda_stream)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ev1[0].record(stream)
-            for k in range(n1):
-                eng1.process_device(d_full[k % B].data_ptr(), 1, d_p1[1].data_ptr(), stream.cuda_stream)
-            ev1[1].record(stream)
-            torch.cuda.synchronize()
-            wall1 = time.perf_counter() - t0
-            eng1.process_device(d_full[0].data_ptr(), 1, d_p1[0].data_ptr(), stream.cuda_stream)
-            torch.cuda.synchronize()
-        ms1 = ev1[0].elapsed_time(ev1[1]) / n1
-        parity1 = full_grid_parity(d_p1[0].cpu().numpy(), host_first[0], off, frac)
-        out["single_frame"] = {
-            "value": n1 / wall1, "unit": "frames/s", "calls": n1, "ms_per_frame_device": ms1,
-            "kernel": pkg.binding.KERNEL_NAMES[eng1.stats().kernel_variant],
-            "valu_frac": int(st.alg_flops_frame) / (ms1 * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
-            "hbm_frac": int(st.alg_bytes_frame) / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "parity_max_rel_err": parity1["max_rel_unfloored"], "parity": parity1,
-            "note": "one frame per call (asynchronous device-pointer entry, back to back): the regime of the reference's live path",
-        }
-        eng1.close()
+    if world == 1 and not args.no_extras and args.math in ("exact", "fast") and args.interp == "lerp":
+        other = "fast" if args.math == "exact" else "exact"
+        math_ids = {"fast": pkg.MATH_F32_FAST, "exact": pkg.MATH_F32_EXACT}
+
+        def single_frame_leg(mode):
+            """one frame per call, back to back on the launch stream, in fp32 mode `mode`"""
+            n1 = 200 if shard.pixel_count * spec.n_mics <= (1 << 23) else 60
+            eng1 = job.make_engine(math_ids[mode], 1, off, frac, shard.pixel_begin, shard.pixel_count)
+            ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            d_p1 = torch.zeros((2, shard.pixel_count), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()  # (the fill runs on torch's stream; `stream` does not wait for it)
+            with torch.cuda.stream(stream):
+                for k in range(10):
+                    eng1.process_device(d_full[k % B].data_ptr(), 1, d_p1[1].data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ev1[0].record(stream)
+                for k in range(n1):
+                    eng1.process_device(d_full[k % B].data_ptr(), 1, d_p1[1].data_ptr(), stream.cuda_stream)
+                ev1[1].record(stream)
+                torch.cuda.synchronize()
+                wall1 = time.perf_counter() - t1
+                eng1.process_device(d_full[0].data_ptr(), 1, d_p1[0].data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+            ms1 = ev1[0].elapsed_time(ev1[1]) / n1
+            parity1 = full_grid_parity(d_p1[0].cpu().numpy(), host_first[0], off, frac, mode)
+            rec = {
+                "math": mode, "value": n1 / wall1, "unit": "frames/s", "calls": n1, "ms_per_frame_device": ms1,
+                "kernel": pkg.binding.KERNEL_NAMES[eng1.stats().kernel_variant],
+                "valu_frac": int(st.alg_flops_frame) / (ms1 * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                "hbm_frac": int(st.alg_bytes_frame) / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "parity_max_rel_err": parity1["max_rel_unfloored"], "parity": parity1,
+            }
+            eng1.close()
+            return rec
+
+        out["single_frame"] = single_frame_leg(args.math)
+        out["single_frame"]["note"] = "one frame per call (asynchronous device-pointer entry, back to back): the regime of the reference's live path"
+        out["single_frame"]["other_mode"] = single_frame_leg(other)
 
         # host-buffer entry: pageable host memory in, power out, upload and read-back inside the clock
         nb = min(B, 128)
@@ -764,7 +781,11 @@ def main():
         eng16.close()
 
         out["parity_dc"] = parity_dc(pkg)
-        out["reference_default"] = reference_default(pkg, torch, args, dev, local_rank)
+        # (advisor, round 4) the run's own mode against the reference-built goldens at every offset, beside the zero-mean parity above
+        out["parity"]["dc_ok"] = all(c[f"{args.math}_ok_1e5"] for c in out["parity_dc"]["cases"])
+        out["parity"]["math"] = args.math
+        out["reference_default"] = reference_default(pkg, torch, args, dev, local_rank, args.math)
+        out["reference_default"]["other_mode"] = reference_default(pkg, torch, args, dev, local_rank, other, cpu=False)
         out["workloads"] = other_workloads(pkg, sharding, torch, dist, args, dev, local_rank)
         out["projected_scaling"] = projected_scaling(pkg, sharding, torch, dist, args, spec, dev, local_rank, d_full, B,
                                                      fps_one_gpu=out["value"], ms_one_gpu=out["ms_per_step"])
@@ -776,14 +797,22 @@ def main():
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(spec, off, frac, host_first[0], args.cpu_seconds, args.interp)
         out["cpu_baseline"]["pixels"] = int(shard.pixel_count)
-        out["speedup_vs_cpu_1t"] = out["value"] / out["cpu_baseline"]["value"]
+        out["speedup_vs_cpu_1t"] = out["value"] / out["cpu_baseline"]["value"]  # (the run's math mode: the default unless --math says otherwise)
+        if out.get("workloads") and out["workloads"][0]["workload"].startswith(spec.name):
+            out["speedup_vs_cpu_1t_other_mode"] = {"math": out["workloads"][0]["math"], "value": out["workloads"][0]["value"] / out["cpu_baseline"]["value"]}
     if rank == 0:
         print(json.dumps(out), flush=True)
 
     # ---- N > 1, opt-in: the assembled heatmap of frame 0 must equal what the shards computed (a collective
     # after the result line, so that a rank that fails here cannot cost the run its line)
+    if run_guard:  # the measured part is over: from here on nothing may turn a finished run into exit status 4
+        run_guard.__exit__(None, None, None)
+        run_guard = None
     if world > 1 and os.environ.get("BENCH_GATHER_CHECK", "1") == "1":  # (on by default: the RCCL schedules have only ever run over gloo)
-        try:  # (a check AFTER the result line: whatever happens here must not cost the run its exit status)
+        # (a check AFTER the result line: a collective that hangs here ends the process with status 0 and a line on stderr)
+        check_guard = Watchdog(120, "gather check: timed out -- the result line above stands; the post-run heatmap gather", status=0)
+        check_guard.__enter__()
+        try:
             full = sharding.gather_power(d_power[:1].contiguous(), job.shards, dst=0)
             if rank == 0:
                 cols = spec.res
@@ -797,10 +826,9 @@ def main():
                 print("gather check:", msg, file=sys.stderr)
         except Exception as exc:  # noqa: BLE001
             print(f"gather check: raised on rank {rank}: {exc}", file=sys.stderr)
+        check_guard.__exit__(None, None, None)
 
     job.close()
-    if run_guard:
-        run_guard.__exit__(None, None, None)
     if world > 1:
         dist.destroy_process_group()
 
@@ -815,7 +843,7 @@ def parity_dc(pkg):
     import util
 
     out = {"what": "max unfloored per-pixel error vs the powers the reference's compiled delay() produced (tests/golden/*_dc.npz), "
-                   "hash frames (amplitude 2^-6) + offset; exact = AWPU_MATH_F32_EXACT, fast = AWPU_MATH_F32_FAST (the default)",
+                   "hash frames (amplitude 2^-6) + offset; exact = AWPU_MATH_F32_EXACT (the default), fast = AWPU_MATH_F32_FAST (opt-in)",
            "cases": []}
     for name in ("sweep_c1_dc", "sweep_headline_dc"):
         g = np.load(REPO / "tests" / "golden" / f"{name}.npz")
@@ -831,11 +859,12 @@ def parity_dc(pkg):
                 power = eng.process(frames)
             rec[label] = [util.power_rel_err_unfloored(power[k], g["power"][k]) for k in range(frames.shape[0])]
         rec["exact_ok_1e5"] = bool(max(rec["exact"]) <= 1e-5)
+        rec["fast_ok_1e5"] = bool(max(rec["fast"]) <= 1e-5)  # (False by design once the bias dwarfs the signal: INTEGRATION.md "Which math mode")
         out["cases"].append(rec)
     return out
 
 
-def reference_default(pkg, torch, args, dev, local_rank):
+def reference_default(pkg, torch, args, dev, local_rank, mode="exact", cpu=True):
     """The configuration the reference ships and runs live: ONE 8x8 array, a 100x100 grid (src/main.cpp:38-41: --mimo-res
     100), one frame per call (MIMOWorker::update, once per 256-sample block = every 5.24 ms at 48 828 Hz).  The device time
     per frame, the reference's own delay() on one host thread beside it, and what each makes of the real-time budget."""
@@ -849,7 +878,8 @@ def reference_default(pkg, torch, args, dev, local_rank):
     stream = torch.cuda.Stream(device=dev)
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     n = 400
-    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=1, device=local_rank, grid_columns=spec.res) as eng:
+    math_id = pkg.MATH_F32_EXACT if mode == "exact" else pkg.MATH_F32_FAST
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, max_batch=1, device=local_rank, grid_columns=spec.res, math=math_id) as eng:
         eng.set_delay_table(off, frac)
         eng.set_active_mics(None)
         torch.cuda.synchronize()
@@ -870,10 +900,10 @@ def reference_default(pkg, torch, args, dev, local_rank):
         host_call_ms = (time.perf_counter() - t0) / 20 * 1e3
         kernel_name = pkg.binding.KERNEL_NAMES[eng.stats().kernel_variant]
     ms = ev[0].elapsed_time(ev[1]) / n
-    par = full_grid_parity(d_p[0].cpu().numpy(), frames[0], off, frac)
+    par = full_grid_parity(d_p[0].cpu().numpy(), frames[0], off, frac, mode)
     block_ms = 256 / 48828.0 * 1e3
     out = {
-        "workload": spec.name + ", one frame per call (src/main.cpp:38-41,53-56; aw_processing_unit.cpp:74)",
+        "workload": spec.name + ", one frame per call (src/main.cpp:38-41,53-56; aw_processing_unit.cpp:74)", "math": mode,
         "ms_per_frame_device": ms, "value": 1e3 / ms, "unit": "frames/s", "kernel": kernel_name,
         "ms_per_host_call": host_call_ms,
         "realtime_block_ms": block_ms, "fraction_of_realtime_budget": host_call_ms / block_ms,
@@ -881,7 +911,7 @@ def reference_default(pkg, torch, args, dev, local_rank):
         "note": "device time per frame from back-to-back device-pointer calls; ms_per_host_call = awpu_hip_process on a pageable "
                 "host frame (upload + sweep + read-back), the call MIMOWorker::update would make every 5.24 ms",
     }
-    if args.cpu_seconds > 0:
+    if cpu and args.cpu_seconds > 0:
         cpu = cpu_baseline(spec, off, frac, frames[0], min(3.0, args.cpu_seconds))
         out["cpu_reference_1t"] = {"value": cpu["value"], "unit": "frames/s", "ms_per_frame": 1e3 / cpu["value"],
                                    "fraction_of_realtime_budget": 1e3 / cpu["value"] / block_ms, "kind": cpu["kind"]}
@@ -895,15 +925,19 @@ def other_workloads(pkg, sharding, torch, dist, args, dev, local_rank):
     out = []
     # (steps, warm-up): the short launches get more of both -- three c2 steps after one warm-up step ran 17 % below the
     # rate of a 20-step run of the same workload (profiles/r03_bench_c2.json: the clocks and the caches had not settled)
-    for name, batch, K, W in (("headline exact", 128, 4, 2), ("c2", 128, 12, 6), ("c3", 128, 4, 2), ("c3 fir8", 128, 3, 1), ("c5", 1024, 3, 1)):
+    other = "fast" if args.math == "exact" else "exact"
+    # the headline in the OTHER fp32 mode first; c2 / c3 / c5 in the run's mode; FIR8 in the fast mode (its tuned kernel: the
+    # reference's shipped build never compiles that variant of delay())
+    for name, mode, batch, K, W in (("headline", other, 128, 4, 2), ("c2", args.math, 128, 12, 6), ("c3", args.math, 128, 4, 2),
+                                    ("c3 fir8", "fast", 128, 3, 1), ("c5", args.math, 1024, 3, 1)):
         c5 = name == "c5"
         fir = name.endswith("fir8")  # BASELINE configs[2] read as the 8-tap fractional-delay variant of delay() (delay.cpp:31-40)
-        exact = name.endswith("exact")  # AWPU_MATH_F32_EXACT: delay.cpp:19-25's operation order, mimo.cpp:124-130's mic order
+        exact = mode == "exact"  # AWPU_MATH_F32_EXACT: delay.cpp:19-25's operation order, mimo.cpp:124-130's mic order
         spec = S.WORKLOADS["c4" if c5 else name.split()[0]]
         t0 = time.perf_counter()
         sub = argparse.Namespace(**vars(args))
         sub.interp = "fir8" if fir else "lerp"
-        sub.math = "exact" if exact else "fast"
+        sub.math = mode
         job = RankJob(pkg, sharding, torch, dist, sub, spec, 1, 0, dev, local_rank, batch, c5=c5)
         elapsed, kernel_ms, _ = job.timed(K, W)
         st = job.eng.stats()
@@ -914,8 +948,9 @@ def other_workloads(pkg, sharding, torch, dist, args, dev, local_rank):
         out.append({
             "workload": (f"c5: one rank's slab of 8 of 512 mics x 256x256 ({job.shard.pixel_count} pixels), {batch} frames in flight"
                          if c5 else spec.name + (", 8-tap FIR variant of delay() (--interp fir8)" if fir else "") +
-                         (", AWPU_MATH_F32_EXACT: the reference's operation and mic order (--math exact; das_exact_pair_kernel)" if exact else "")),
-            "frames_per_step": batch, "steps": K, "warmup": W, "value": batch * K / elapsed, "unit": "frames/s",
+                         (", AWPU_MATH_F32_EXACT: the reference's operation and mic order (the default)" if exact else
+                          ", AWPU_MATH_F32_FAST: the re-ordered fp32 sweep (--math fast, opt-in)")),
+            "math": mode, "frames_per_step": batch, "steps": K, "warmup": W, "value": batch * K / elapsed, "unit": "frames/s",
             "kernel": pkg.binding.KERNEL_NAMES[st.kernel_variant],
             "kernel_ms": kernel_ms, "valu_frac": flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
             "hbm_frac": int(st.alg_bytes_frame) * batch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
