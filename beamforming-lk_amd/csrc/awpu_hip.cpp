@@ -88,6 +88,11 @@ struct awpu_hip {
     size_t quad_lut_entries[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // ... and of the quad-major tables, by QuadLayout
     awpu::QuadEntry *d_exact_quad_lut = nullptr;  // ... four vertically adjacent pixels per wave (das_exact_quad_kernel): quad-major, raw fractions
     awpu::FastPlan exact_plan{};
+    unsigned *d_nd_queue = nullptr;               // das_exact_nd_kernel's eight item counters (one per XCD)
+    int2 *d_nd_items = nullptr;                   // ... and its item list (nd_items_kernel), valid for nd_items_key
+    size_t nd_items_cap = 0;
+    long long nd_items_key = -1;                  // (n_pairs, pair group, quads per wave) the list was built for; -1: none
+    int n_cus = 0;                                // compute units of the handle's device (persistent workgroups: one per CU)
     awpu::QuadEntry *d_exact_nd_lut = nullptr;    // ... on the {next, d} layout (das_exact_nd_kernel): 16-byte elements, quad rows padded to an even count
     awpu::FastPlan exact_nd_plan{};
     bool exact_nd_ok = false;     // ... and the window fits the {next, d} image
@@ -146,6 +151,8 @@ struct awpu_hip {
     int32_t *d_row_off_compact = nullptr;  // the same for frames uploaded as [streams][compact_hist] windows
     int compact_hist = 0;                  // 0 = the window cannot be cut out (it touches the newest sample)
     float *d_frames = nullptr;
+    float *h_live_in = nullptr, *h_live_out = nullptr;  // pinned staging of awpu_hip_process's one-frame calls (the live path): window in, powers out
+    size_t live_in_cap = 0, live_out_cap = 0;           // in floats
     float *d_power = nullptr;
     size_t frames_cap = 0, power_cap = 0;  // in floats
     int wstart = 0, window = 0, tau_max = 0;
@@ -313,6 +320,10 @@ void release_device(awpu_hip *h) {
     h->fast_luts.clear();
     dev_free(h->d_exact_pair_lut);
     dev_free(h->d_exact_quad_lut);
+    dev_free(h->d_nd_items);
+    h->nd_items_cap = 0;
+    h->nd_items_key = -1;
+    dev_free(h->d_nd_queue);
     dev_free(h->d_exact_nd_lut);
     dev_free(h->d_exact_ndh_lut);
     dev_free(h->d_exact_ndhs_lut);
@@ -343,6 +354,12 @@ void release_device(awpu_hip *h) {
     dev_free(h->d_fan[1]);
     h->fan_cap = 0;
     for (int b = 0; b < 2; b++) {
+        if (b == 0) {
+            if (h->h_live_in) (void) hipHostFree(h->h_live_in);
+            if (h->h_live_out) (void) hipHostFree(h->h_live_out);
+            h->h_live_in = h->h_live_out = nullptr;
+            h->live_in_cap = h->live_out_cap = 0;
+        }
         if (h->h_stage[b]) (void) hipHostFree(h->h_stage[b]);
         if (h->h_tile[b]) (void) hipHostFree(h->h_tile[b]);
         h->h_stage[b] = h->h_tile[b] = nullptr;
@@ -862,12 +879,38 @@ int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_powe
     a.tiles = awpu::nd_tiles(a.rows, a.cols, nq);
     a.n_pairs = (batch + 1) / 2;
     a.pair_group = xcd_pair_group_bytes((size_t) pp.usable_pad * pp.row_bytes, a.n_pairs);
+    if (!h->d_nd_queue) {
+        AWPU_HIP_TRY(hipMalloc(&h->d_nd_queue, 8 * sizeof(unsigned)));
+        if (hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess || h->n_cus < 1) h->n_cus = 256;
+    }
+    {   // the item list: rebuilt (by the launcher, on the stream) when the batch, the pair group or the tile shape changed
+        const size_t items = (size_t) a.n_pairs * a.tiles;
+        const long long key = ((long long) a.n_pairs << 24) | ((long long) a.pair_group << 8) | nq;
+        if (h->nd_items_cap < items) {
+            retire_live_graphs(h);
+            AWPU_HIP_TRY(hipStreamSynchronize(s));  // (a sweep in flight may still read the old list)
+            dev_free(h->d_nd_items);
+            h->nd_items_cap = 0;
+            AWPU_HIP_TRY(hipMalloc(&h->d_nd_items, items * sizeof(int2)));
+            h->nd_items_cap = items;
+            h->nd_items_key = -1;
+        }
+        a.items = h->d_nd_items;
+        a.build_items = h->nd_items_key != key;
+        h->nd_items_key = key;
+    }
+    a.queue = h->d_nd_queue;
+    a.wgs = h->n_cus;
+    a.queues = 1;
+#ifdef AWPU_TUNING_BUILD
+    if (const char *v = std::getenv("AWPU_ND_QUEUES")) a.queues = std::atoi(v) == 8 ? 8 : 1;
+#endif
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     if (!prepacked)
         AWPU_HIP_TRY(awpu::launch_pack_nd(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad, h->d_gain,
                                           pp.wr, batch, h->d_pack, s));
 #ifdef AWPU_TUNING_BUILD
-    const size_t n_wgs = 8 * (((size_t) a.n_pairs * a.tiles + 7) / 8);
+    const size_t n_wgs = std::min<size_t>((size_t) a.n_pairs * a.tiles, (size_t) a.wgs);
     if (env().debug & 16) {  // per-workgroup timeline (where, when, phases): printed below
         if (const int drc = ensure_diag(h, n_wgs * 8); drc != AWPU_OK) return drc;
         AWPU_HIP_TRY(hipMemsetAsync(h->d_diag, 0, n_wgs * 8 * sizeof(unsigned long long), s));
@@ -929,7 +972,7 @@ int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_powe
         }
         const double cus = (double) by_cu.size();
         std::fprintf(stderr, "[awpu diag nd] %zu workgroups on %zu CUs, span %.1f us | per CU: busy %.1f us, gaps %.1f us (%.2f us each), idle before first %.1f us, "
-                     "after last %.1f us | per workgroup cycles: staging %.0f sweep %.0f epilogue %.0f\n", n, by_cu.size(), (double) (last - first) * 0.01,
+                     "after last %.1f us | per workgroup cycles: outside the block %.0f, in the sweep block %.0f, exit %.0f\n", n, by_cu.size(), (double) (last - first) * 0.01,
                      busy / cus * 0.01, gaps / cus * 0.01, n_gaps ? gaps / (double) n_gaps * 0.01 : 0.0, head / cus * 0.01, tail / cus * 0.01, ph[0] / n, ph[1] / n, ph[2] / n);
     }
 #endif
@@ -1634,6 +1677,57 @@ int enqueue_power_to_host(awpu_hip *h, int batch, float *power, size_t pitch) {
     return AWPU_OK;
 }
 
+int wait_and_time(awpu_hip *h);
+
+// One frame in, one heatmap out, synchronously: the call MIMOWorker::update makes once per 256-sample block (mimo.cpp:100-103 is the
+// snapshot it replaces).  The caller's buffers are pageable (std::vector, mimo.h:83-88): a device copy straight out of / into them goes
+// through the runtime's own bounce buffers in several synchronous steps (measured at the reference's default shape: 58-64 us per call
+// around a 20 us sweep).  Here the touched window of every stream is gathered into a PINNED buffer of the handle by the CPU (64 rows x
+// 1.2 KB), crosses PCIe as ONE asynchronous copy, and the powers come back the same way through a pinned buffer.
+int live_host_call(awpu_hip *h, const float *frames, float *power) {
+    int rc = check_ready(h, 1);
+    if (rc != AWPU_OK) return rc;
+    const bool compact = h->compact_hist > 0;
+    const int dev_hist = compact ? h->compact_hist : h->cfg.hist;
+    const size_t need_frames = (size_t) h->cfg.n_streams * dev_hist;
+    if (h->frames_cap < need_frames) {
+        dev_free(h->d_frames);
+        h->frames_cap = 0;
+        AWPU_HIP_TRY(hipMalloc(&h->d_frames, need_frames * sizeof(float)));
+        h->frames_cap = need_frames;
+    }
+    rc = ensure_power(h, (size_t) h->cfg.pixel_count);
+    if (rc != AWPU_OK) return rc;
+    if (h->live_in_cap < need_frames) {
+        if (h->h_live_in) (void) hipHostFree(h->h_live_in);
+        h->h_live_in = nullptr;
+        h->live_in_cap = 0;
+        AWPU_HIP_TRY(hipHostMalloc(&h->h_live_in, need_frames * sizeof(float), hipHostMallocDefault));
+        h->live_in_cap = need_frames;
+    }
+    if (h->live_out_cap < (size_t) h->cfg.pixel_count) {
+        if (h->h_live_out) (void) hipHostFree(h->h_live_out);
+        h->h_live_out = nullptr;
+        h->live_out_cap = 0;
+        AWPU_HIP_TRY(hipHostMalloc(&h->h_live_out, (size_t) h->cfg.pixel_count * sizeof(float), hipHostMallocDefault));
+        h->live_out_cap = (size_t) h->cfg.pixel_count;
+    }
+    if (compact) {  // rows of compact_hist floats cut out of rows of hist floats
+        for (int s = 0; s < h->cfg.n_streams; s++)
+            std::memcpy(h->h_live_in + (size_t) s * dev_hist, frames + (size_t) s * h->cfg.hist + h->wstart, (size_t) dev_hist * sizeof(float));
+    } else {
+        std::memcpy(h->h_live_in, frames, need_frames * sizeof(float));
+    }
+    AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, h->h_live_in, need_frames * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    rc = launch(h, h->d_frames, 1, h->d_power, h->stream, compact ? kCompact : kFull);
+    if (rc != AWPU_OK) return rc;
+    AWPU_HIP_TRY(hipMemcpyAsync(h->h_live_out, h->d_power, (size_t) h->cfg.pixel_count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    rc = wait_and_time(h);
+    if (rc != AWPU_OK) return rc;
+    std::memcpy(power, h->h_live_out, (size_t) h->cfg.pixel_count * sizeof(float));
+    return AWPU_OK;
+}
+
 int wait_and_time(awpu_hip *h) {
     AWPU_HIP_TRY(hipSetDevice(h->cfg.device));
     AWPU_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -2320,6 +2414,7 @@ int awpu_hip_process(awpu_hip_t *h, const float *frames, int32_t batch, float *p
     if (!frames || !power) return invalid("null argument");
     if (h->in_flight) return fail(AWPU_ERR_STATE, "an awpu_hip_process_async call is in flight on this handle: awpu_hip_wait first");
     if (!h->parts.empty()) return group_process(h, frames, batch, power);
+    if (batch == 1 && h->ranges.empty()) return live_host_call(h, frames, power);
     int rc = enqueue_host_process(h, frames, batch);
     if (rc != AWPU_OK) return rc;
     rc = enqueue_power_to_host(h, batch, power, (size_t) h->cfg.pixel_count);

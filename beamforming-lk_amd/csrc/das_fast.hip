@@ -1352,51 +1352,95 @@ __global__ void pack_nd_kernel(const float *frames, int n_streams, int hist, int
     }
 }
 
-template <int NQ>
+// Work distribution (round 5): PERSISTENT workgroups -- one per CU: the two LDS images leave room for no second -- that take items
+// (frame pair, tile) from eight queues, one per XCD.  The items are ordered (pair group, tile, pair) and cut into eight contiguous
+// runs as before (an XCD's workgroups sweep a few frame pairs x a few tiles at a time: the pairs' samples stay in its 4 MiB L2 while
+// it walks the table), but a run is now a QUEUE (a.queue[x]: an atomic counter, zeroed by the launcher) that the workgroups of XCD x
+// (HW_REG_XCC_ID) drain, and a workgroup whose own queue is empty takes from the next XCD's: measured on the static split, the XCDs
+// of one chip finished 6 % apart (their clocks differ) and every CU idled 3.3 % of the launch waiting for the slowest.  A workgroup
+// knows its next item one item ahead (thread 0 takes it while the current one is swept; the mailbox is two ints behind the images), so
+// the block refills the next item's first chunk beside the current item's last: no staging gap between items (2.2 % before).
+// The item list of das_exact_nd_kernel: items[i] = (frame pair, first table quad of the tile) in the order (pair group, tile, pair) --
+// `pair_group` frame pairs x all tiles, then the next group (the last one may be smaller): consecutive items share a few pairs' samples.
+__global__ void nd_items_kernel(int2 *items, int n_pairs, int tiles, int pair_group, int tiles_per_row, int nq) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_pairs * tiles) return;
+    const int full_items = (n_pairs / pair_group) * pair_group * tiles;
+    const int ga = item < full_items ? pair_group : n_pairs % pair_group;
+    const int rem = item < full_items ? item : item - full_items;
+    const int grp = rem / (tiles * ga), in = rem - grp * tiles * ga;
+    const int tile = in / ga;
+    const int pair = (item < full_items ? grp * pair_group : n_pairs - ga) + (in - tile * ga);
+    const int rowq = tile / tiles_per_row, colt = tile - rowq * tiles_per_row;
+    items[item] = int2{pair, (nq * rowq * tiles_per_row + colt) * 16};
+}
+
+__device__ __forceinline__ int nd_take(unsigned *queue, int x, int per_xcd, int total) {
+    const int begin = x * per_xcd, end = min(total, begin + per_xcd);
+    if (begin >= end) return -1;
+    const unsigned i = atomicAdd(&queue[x], 1u);
+    return i < (unsigned) (end - begin) ? begin + (int) i : -1;
+}
+__device__ __forceinline__ int nd_take_any(unsigned *queue, int xcd, int per_xcd, int total) {
+    int item = -1;
+    for (int y = 0; item < 0 && y < 8; y++) item = nd_take(queue, (xcd + y) & 7, per_xcd, total);
+    return item;
+}
+
+template <int NQ, bool SUMS>
 __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
     constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
-    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
-    // items (frame pair, tile) in das_quad_kernel's order: (pair group, tile, pair), one contiguous run per XCD
+    int *mail = (int *) (lds + 2 * (BUF / 4));  // two ints behind the images: the items thread 0 took for the workgroup
     const int total = a.n_pairs * a.tiles;
-    const int per_xcd = (total + 7) >> 3;
-    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (item >= min(total, ((int) (blockIdx.x & 7) + 1) * per_xcd)) return;  // (uniform for the workgroup)
-    int pair, tile;
-    {
-        const int full_items = (a.n_pairs / a.pair_group) * a.pair_group * a.tiles;
-        const int ga = item < full_items ? a.pair_group : a.n_pairs % a.pair_group;
-        const int rem = item < full_items ? item : item - full_items;
-        const int grp = rem / (a.tiles * ga), in = rem - grp * a.tiles * ga;
-        tile = in / ga;
-        pair = (item < full_items ? grp * a.pair_group : a.n_pairs - ga) + (in - tile * ga);
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    // a.queues = 1: ONE queue for the chip (every workgroup takes the next item of the whole order: at any moment the 256 items in
+    // flight are one pair group's -- 2 pairs x 128 tiles at the headline -- so every XCD's L2 holds the same few pairs' samples);
+    // 8: one run per XCD as before (tuning builds: AWPU_ND_QUEUES)
+    const int per_xcd = a.queues == 1 ? total : (total + 7) >> 3;
+    const int xcd = a.queues == 1 ? 0 : (int) (xcc & 7u);
+    if (threadIdx.x == 0) {
+        const int first = nd_take_any(a.queue, xcd, per_xcd, total);
+        mail[0] = first;
+        mail[1] = first >= 0 ? nd_take_any(a.queue, xcd, per_xcd, total) : -1;
     }
-#ifdef AWPU_TUNING_BUILD
-    const unsigned long long rt_begin = a.debug_out ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz
-    const long long t_begin = __builtin_readcyclecounter();
-    long long t_staged = 0, t_swept = 0;
-#endif
+    __syncthreads();
+    int cur = __builtin_amdgcn_readfirstlane(mail[0]), nxt = __builtin_amdgcn_readfirstlane(mail[1]);
+    if (cur < 0) return;  // (uniform for the workgroup)
+    __syncthreads();      // (the mailbox is written again below)
+
+    // where an item lies: a.items[item] = (frame pair, first quad of the tile in the table), written by nd_items_kernel in the order
+    // (pair group, tile, pair) -- one scalar load per item here instead of five integer divisions and their constants
+    auto decode = [&](int item, int &pair, int &tile_quad) {
+        const int2 d = a.items[item];
+        pair = __builtin_amdgcn_readfirstlane(d.x);
+        tile_quad = __builtin_amdgcn_readfirstlane(d.y);
+    };
     const int tiles_per_row = (a.cols + NW - 1) / NW;
-    const int rowq = tile / tiles_per_row;  // the tile's first quad row is NQ * rowq
-    const int col = (tile - rowq * tiles_per_row) * NW + wave;
     const int groups_total = a.usable_pad >> 2;
-    const int quad0 = NQ * rowq * tiles_per_row * NW + col;  // the table's quads: [quad row][columns padded to whole tiles]
-    const QuadEntry *quad_lut = a.lut + (size_t) quad0 * groups_total * 16;
     const size_t row_floats = (size_t) a.wq * 4;
-    const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
-
-    f8 O[NQ][4];
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-#pragma unroll
-        for (int p = 0; p < 4; p++) O[q][p] = f8{0, 0, 0, 0, 0, 0, 0, 0};  // float out[N_SAMPLES] = {0.0}, mimo.cpp:122
-
     const int n_chunks = (a.usable_pad + a.chunk - 1) / a.chunk;
     const int first_mics = min(a.chunk, a.usable_pad), last_mics = a.usable_pad - (n_chunks - 1) * a.chunk;
-    {   // chunk 0 into image 0 (the block refills from chunk 1 on)
+    const int ngf = __builtin_amdgcn_readfirstlane(first_mics >> 2), ngl = __builtin_amdgcn_readfirstlane(last_mics >> 2);
+    const unsigned dbf = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) a.chunk * row_floats * 4));
+    const unsigned dbl = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) last_mics * row_floats * 4));
+    const unsigned db0 = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) first_mics * row_floats * 4));
+    const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
+    const int own_begin = xcd * per_xcd, own_end = min(total, own_begin + per_xcd);
+
+    int pair, tile;
+    decode(cur, pair, tile);
+#ifdef AWPU_TUNING_BUILD
+    const unsigned long long rt_begin = a.debug_out ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz
+    long long t_sweep = 0, t_other = 0, t_mark = __builtin_readcyclecounter();
+    int n_items = 0;
+#endif
+    {   // the first item's chunk 0 into image 0 (the block refills everything after it, the next item's first chunk included)
+        const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
         const int n_pieces = (int) ((size_t) first_mics * row_floats / 4);
 #pragma unroll
         for (int k = 0; k < kPieces; k++) {
@@ -1410,71 +1454,115 @@ __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#ifdef AWPU_TUNING_BUILD
-    t_staged = __builtin_readcyclecounter();
-#endif
+    unsigned step = 0;  // chunks swept so far: the chunk about to be swept lives in image step & 1
 
-    {
-        unsigned lane_addr = lds_base + lane * 16;
-        const int ngf = __builtin_amdgcn_readfirstlane(first_mics >> 2), ngl = __builtin_amdgcn_readfirstlane(last_mics >> 2);
-        const unsigned dbf = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) a.chunk * row_floats * 4));
-        const unsigned dbl = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) last_mics * row_floats * 4));
-        const unsigned ddst = __builtin_amdgcn_readfirstlane(lds_base + BUF + wave * 1024);
-        const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
-        const unsigned lane_bytes = threadIdx.x * 16;
-        if constexpr (NQ == 1) {
-            sweep_exact_nd_item1(O[0][0], O[0][1], O[0][2], O[0][3], uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
-                                 lane_addr, rank, uniform_ptr(pair_base), dbf, dbl, ddst, BUF, lane_bytes);
-        } else {
-            static_assert(NQ == 2, "blocks are generated for one and two quads per wave");
-            const int qstride = __builtin_amdgcn_readfirstlane(tiles_per_row * NW * groups_total * 16 * (int) sizeof(QuadEntry));
-            sweep_exact_nd_item2(O[0][0], O[0][1], O[0][2], O[0][3], O[1][0], O[1][1], O[1][2], O[1][3], uniform_ptr(quad_lut), qstride, ngf, ngl,
-                                 __builtin_amdgcn_readfirstlane(n_chunks), lane_addr, rank, uniform_ptr(pair_base), dbf, dbl, ddst, BUF, lane_bytes);
-        }
-    }
+    for (;;) {
+        // tile = the table's first quad of the tile ([quad row][columns padded to whole tiles]): quad row NQ * rowq, column 16 x ...
+        const int cols_pad = tiles_per_row * NW;
+        const int rowq = tile / (NQ * cols_pad);  // (one division per item, for the epilogue's rows)
+        const int col = tile - NQ * rowq * cols_pad + wave;
+        const int quad0 = tile + wave;
+        const QuadEntry *quad_lut = a.lut + (size_t) quad0 * groups_total * 16;
+        const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
+        int pair_next = pair, tile_next = tile;
+        if (nxt >= 0) decode(nxt, pair_next, tile_next);
+        const float *next_base = a.packed + (size_t) pair_next * a.usable_pad * row_floats;
+        // Wave 0 asks its XCD's queue for the item after the next one INSIDE the sweep block (qptr: lane 0 adds one to that counter as
+        // the block begins) and thread 0 looks at the answer after the sweep: the atomic's round trip -- microseconds, with every
+        // workgroup of the XCD on the same counter -- runs beside the item, not in front of it.  (From C++ the compiler's atomic
+        // optimizer reads the answer back at once, and any scratch reload in front of the block waits for it with vmcnt(0).)
+        unsigned ticket = 0;
+        const bool asked = wave == 0 && nxt >= 0 && own_begin < own_end;
+        const unsigned *qptr = (const unsigned *) uniform_ptr(asked ? a.queue + xcd : nullptr);
 
+        f8 O[NQ][4];  // (float out[N_SAMPLES] = {0.0}, mimo.cpp:122: the block zeroes them itself)
 #ifdef AWPU_TUNING_BUILD
-    t_swept = __builtin_readcyclecounter();
+        { const long long n = __builtin_readcyclecounter(); t_other += n - t_mark; t_mark = n; }
 #endif
-    const float norm = (float) (kSamples * a.usable);
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        const int row4 = NQ * rowq + q;
-        auto finish = [&](const f8 &Op, int pp) {
-            const int row = 4 * row4 + pp;
-            const bool live = row < a.rows && col < a.cols;
-            const int p = min(row, a.rows - 1) * a.cols + min(col, a.cols - 1);
-            f2 o[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) o[k] = f2{Op[2 * k], Op[2 * k + 1]};
-            if (a.sums && live) {  // the pre-epilogue sums, for the tests: [batch][pixel_count][256]
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    a.sums[((size_t) (2 * pair) * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k].x;
-                    if (2 * pair + 1 < a.batch) a.sums[((size_t) (2 * pair + 1) * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k].y;
-                }
+        {
+            // (per-lane values are derived from the thread index HERE, through a volatile asm that is not hoisted out of the item loop:
+            // the block's 116 pinned and clobbered registers leave the compiler 12, and every per-lane value it keeps across the items
+            // -- it kept five -- is one it spills to scratch)
+            unsigned tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const unsigned lane_bytes = tid * 16;
+            const int buf = (int) (step & 1);
+            unsigned lane_addr = lds_base + buf * BUF + (tid & 63) * 16;
+            const unsigned ddst = __builtin_amdgcn_readfirstlane(lds_base + (buf ^ 1) * BUF + wave * 1024);
+            const int delta = __builtin_amdgcn_readfirstlane(buf ? -BUF : BUF);
+            const unsigned dbn = __builtin_amdgcn_readfirstlane(nxt >= 0 ? db0 : 0u);
+            if constexpr (NQ == 1) {
+                sweep_exact_nd_item1(O[0][0], O[0][1], O[0][2], O[0][3], uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
+                                     lane_addr, rank, uniform_ptr(pair_base), dbf, dbl, uniform_ptr(next_base), dbn, ddst, delta, lane_bytes, qptr, ticket);
+            } else {
+                static_assert(NQ == 2, "blocks are generated for one and two quads per wave");
+                const int qstride = __builtin_amdgcn_readfirstlane(tiles_per_row * NW * groups_total * 16 * (int) sizeof(QuadEntry));
+                sweep_exact_nd_item2(O[0][0], O[0][1], O[0][2], O[0][3], O[1][0], O[1][1], O[1][2], O[1][3], uniform_ptr(quad_lut), qstride, ngf, ngl,
+                                     __builtin_amdgcn_readfirstlane(n_chunks), lane_addr, rank, uniform_ptr(pair_base), dbf, dbl, uniform_ptr(next_base),
+                                     dbn, ddst, delta, lane_bytes, qptr, ticket);
             }
-            return pixel_pair_partial_exact(o, lane);
-        };
-        const f2 s0 = finish(O[q][0], 0), s1 = finish(O[q][1], 1), s2 = finish(O[q][2], 2), s3 = finish(O[q][3], 3);
-        // the eight wave sums together, one division and one store per quad and frame pair (das_quad_kernel's epilogue)
-        const float total = wave_sum8(s0.x, s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y, lane);
-        const int value = kWaveSum8Value(lane >> 3), row = 4 * row4 + (value >> 1), frame = 2 * pair + (value & 1);
-        if ((lane & 7) == 0 && row < a.rows && col < a.cols && frame < a.batch)
-            a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;
+            step += n_chunks;
+        }
+        if (threadIdx.x == 0 && nxt >= 0) {  // the answer, into the mailbox at once (not carried through the epilogue)
+            int got = own_begin < own_end && ticket < (unsigned) (own_end - own_begin) ? own_begin + (int) ticket : -1;
+            if (got < 0) got = nd_take_any(a.queue, (xcd + 1) & 7, per_xcd, total);  // own queue empty: the other XCDs' (only at the launch's tail)
+            mail[0] = got;
+        }
+#ifdef AWPU_TUNING_BUILD
+        { const long long n = __builtin_readcyclecounter(); t_sweep += n - t_mark; t_mark = n; n_items++; }
+#endif
+
+        unsigned tid_e = threadIdx.x;  // (the same for the epilogue's per-lane values)
+        asm volatile("" : "+v"(tid_e));
+        const int lane = (int) (tid_e & 63);
+        const float norm = (float) (kSamples * a.usable);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int row4 = NQ * rowq + q;
+            auto finish = [&](const f8 &Op, int pp) {
+                const int row = 4 * row4 + pp;
+                const bool live = row < a.rows && col < a.cols;
+                const int p = min(row, a.rows - 1) * a.cols + min(col, a.cols - 1);
+                f2 o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = f2{Op[2 * k], Op[2 * k + 1]};
+                if (SUMS && live) {  // the pre-epilogue sums, for the tests: [batch][pixel_count][256] (an instance of its own)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        a.sums[((size_t) (2 * pair) * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k].x;
+                        if (2 * pair + 1 < a.batch) a.sums[((size_t) (2 * pair + 1) * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k].y;
+                    }
+                }
+                return pixel_pair_partial_exact(o, lane);
+            };
+            const f2 s0 = finish(O[q][0], 0), s1 = finish(O[q][1], 1), s2 = finish(O[q][2], 2), s3 = finish(O[q][3], 3);
+            // the eight wave sums together, one division and one store per quad and frame pair (das_quad_kernel's epilogue)
+            const float sum = wave_sum8(s0.x, s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y, lane);
+            const int value = kWaveSum8Value(lane >> 3), row = 4 * row4 + (value >> 1), frame = 2 * pair + (value & 1);
+            if ((lane & 7) == 0 && row < a.rows && col < a.cols && frame < a.batch)
+                a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = sum / norm;
+        }
+
+        if (nxt < 0) break;  // (uniform)
+        __syncthreads();     // (the mailbox was written before the epilogue)
+        cur = nxt;
+        pair = pair_next;
+        tile = tile_next;
+        nxt = __builtin_amdgcn_readfirstlane(mail[0]);
+        __syncthreads();  // (everybody has read the mailbox before thread 0 writes it again)
     }
 #ifdef AWPU_TUNING_BUILD
-    if (a.debug_out && threadIdx.x == 0) {  // the workgroup's timeline: which CU it ran on, when, and how long each phase took
-        unsigned hw_id, xcc_id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_id), "=s"(xcc_id));
+    if (a.debug_out && threadIdx.x == 0) {  // the workgroup's timeline: which CU it ran on, when, how many items, and the share of the sweep block
+        unsigned hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
         unsigned long long *o = a.debug_out + 8 * (size_t) blockIdx.x;
         o[0] = rt_begin;
         o[1] = __builtin_amdgcn_s_memrealtime();
-        o[2] = (unsigned long long) (t_staged - t_begin);
-        o[3] = (unsigned long long) (t_swept - t_staged);
-        o[4] = (unsigned long long) (__builtin_readcyclecounter() - t_swept);
-        o[5] = ((unsigned long long) xcc_id << 32) | hw_id;
-        o[6] = (unsigned long long) item;
+        o[2] = (unsigned long long) t_other;
+        o[3] = (unsigned long long) t_sweep;
+        o[4] = (unsigned long long) (__builtin_readcyclecounter() - t_mark);
+        o[5] = ((unsigned long long) xcc << 32) | hw_id;
+        o[6] = (unsigned long long) n_items;
         o[7] = 1;
     }
 #endif
@@ -1599,11 +1687,7 @@ __global__ __launch_bounds__(1024, 4) void das_exact_ndh_kernel(ExactNdhArgs a) 
         __syncthreads();
     }
 
-    f4 O[NQ][4];
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-#pragma unroll
-        for (int p = 0; p < 4; p++) O[q][p] = f4{0, 0, 0, 0};  // float out[N_SAMPLES] = {0.0}, mimo.cpp:122
+    f4 O[NQ][4];  // (float out[N_SAMPLES] = {0.0}, mimo.cpp:122: the block zeroes them itself)
     {
         unsigned lane_addr = lds_base + lane * 16;
         const int ngf = __builtin_amdgcn_readfirstlane(first_mics >> 2), ngl = __builtin_amdgcn_readfirstlane(last_mics >> 2);
@@ -1613,14 +1697,17 @@ __global__ __launch_bounds__(1024, 4) void das_exact_ndh_kernel(ExactNdhArgs a) 
         const int rank = wave >> 2;
         const unsigned lane_bytes = threadIdx.x * 16;
         const void *isrc = uniform_ptr(STATIONARY ? (const void *) a.lut : (const void *) frame_rows);  // (one chunk: nothing is refilled)
+        const unsigned *no_queue = (const unsigned *) uniform_ptr(nullptr);  // (one item per workgroup: no queue)
+        unsigned no_ticket;
         if constexpr (NQ == 1) {
             sweep_exact_ndh_item1(O[0][0], O[0][1], O[0][2], O[0][3], uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
-                                  lane_addr, rank, isrc, dbf, dbl, ddst, BUF, lane_bytes);
+                                  lane_addr, rank, isrc, dbf, dbl, isrc, 0u, ddst, BUF, lane_bytes, no_queue, no_ticket);
         } else {
             static_assert(NQ == 2, "blocks are generated for one and two quads per wave");
             const int qstride = __builtin_amdgcn_readfirstlane(groups_total * 16 * (int) sizeof(QuadEntry));  // the next column's quad
             sweep_exact_ndh_item2(O[0][0], O[0][1], O[0][2], O[0][3], O[1][0], O[1][1], O[1][2], O[1][3], uniform_ptr(quad_lut), qstride, ngf, ngl,
-                                  __builtin_amdgcn_readfirstlane(n_chunks), lane_addr, rank, isrc, dbf, dbl, ddst, BUF, lane_bytes);
+                                  __builtin_amdgcn_readfirstlane(n_chunks), lane_addr, rank, isrc, dbf, dbl, isrc, 0u, ddst, BUF, lane_bytes, no_queue,
+                                  no_ticket);
         }
     }
 
@@ -2603,18 +2690,23 @@ hipError_t launch_pack_nd(const float *d_frames, int n_streams, int hist, int ws
     return hipGetLastError();
 }
 
-template <int NQ>
+template <int NQ, bool SUMS>
 static hipError_t launch_exact_nd_variant(const ExactNdArgs &a, hipStream_t stream) {
     static LdsFlags attr_set = {};
-    constexpr int lds_bytes = 2 * kFastLdsBytes;
-    if (hipError_t e = allow_lds((const void *) das_exact_nd_kernel<NQ>, lds_bytes, attr_set); e != hipSuccess) return e;
+    constexpr int lds_bytes = 2 * kFastLdsBytes + 64;  // two images + the item mailbox
+    if (hipError_t e = allow_lds((const void *) das_exact_nd_kernel<NQ, SUMS>, lds_bytes, attr_set); e != hipSuccess) return e;
+    // one persistent workgroup per CU (the LDS holds no second one), never more than there are items; the queues start at zero
     const long total = (long) a.n_pairs * a.tiles;
-    hipLaunchKernelGGL(das_exact_nd_kernel<NQ>, dim3((unsigned) (8 * ((total + 7) / 8))), dim3(1024), lds_bytes, stream, a);
+    if (hipError_t e = hipMemsetAsync(a.queue, 0, 8 * sizeof(unsigned), stream); e != hipSuccess) return e;
+    if (a.build_items)
+        hipLaunchKernelGGL(nd_items_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, stream, const_cast<int2 *>(a.items), a.n_pairs,
+                           a.tiles, a.pair_group, (a.cols + 15) / 16, NQ);
+    hipLaunchKernelGGL((das_exact_nd_kernel<NQ, SUMS>), dim3((unsigned) std::min<long>(total, std::max(1, a.wgs))), dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_das_exact_nd(const ExactNdArgs &a, const Extents &have, hipStream_t stream) {
-    if (a.nq != 1 && a.nq != 2) return hipErrorInvalidValue;
+    if ((a.nq != 1 && a.nq != 2) || !a.queue || !a.items || a.wgs < 1) return hipErrorInvalidValue;
     if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || a.usable < 1 || a.usable > a.usable_pad || a.wq < kSamples ||
         (size_t) a.chunk * a.wq * 16 > (size_t) kFastLdsBytes || a.cols < 1 || a.rows * a.cols != a.pixel_count)
         return hipErrorInvalidValue;
@@ -2624,7 +2716,8 @@ hipError_t launch_das_exact_nd(const ExactNdArgs &a, const Extents &have, hipStr
     if (!within({(size_t) nd_quad_count(a.rows, a.cols, a.nq) * (a.usable_pad / 4) * 16 + kQuadTablePrefetch,
                  (size_t) a.n_pairs * a.usable_pad * a.wq * 4}, have))
         return hipErrorInvalidValue;
-    return a.nq == 2 ? launch_exact_nd_variant<2>(a, stream) : launch_exact_nd_variant<1>(a, stream);
+    if (a.sums) return a.nq == 2 ? launch_exact_nd_variant<2, true>(a, stream) : launch_exact_nd_variant<1, true>(a, stream);
+    return a.nq == 2 ? launch_exact_nd_variant<2, false>(a, stream) : launch_exact_nd_variant<1, false>(a, stream);
 }
 
 bool exact_ndh_plan(int window, int usable, bool stationary, FastPlan *plan) {

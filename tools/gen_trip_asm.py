@@ -655,7 +655,7 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, un
 
 
 ND_ACC = 10    # block_exact_nd: out[] of quad q, pixel p pinned at v[ND_ACC + 32 q + 8 p ..+7]
-ND_TMP = 74    # its 53 temps (two 16-register slots for the reference pixel's elements, one for whichever pixel leaves it, t, address)
+ND_TMP = 74    # its 52 temps (two 16-register slots for the reference pixel's elements, one for whichever pixel leaves it, t, address)
 ND_TIMING = os.environ.get("ND_TIMING", "")  # tuning builds only (see the end of block_exact_nd)
 ND_DMA_STRIDE = 16 * 1024  # one refill piece: 16 waves x 64 lanes x 16 bytes (every wave of the workgroup takes part)
 
@@ -694,7 +694,9 @@ def block_exact_nd(name, nq, nk=4):
     R = [ND_TMP, ND_TMP + 4 * nk]
     X = ND_TMP + 8 * nk
     TT = ND_TMP + 12 * nk
-    addr_t = TT + 4
+    # the address temp is t's last register: a reads() sequence (address add, then its ds_reads, which take the address as they
+    # issue) never runs between an FMA into t and the add that consumes it
+    addr_t = TT + 3
     E = (36, 68)
     S_NG, S_PFO, S_CH, S_SB, S_TMP, S_PF_, S_LEFT_, S_DST, S_REM, S_K, S_NP, S_M0, S_DELTA = 17, 18, 19, 20, 22, 23, 24, 25, 28, 29, 30, 31, 35
 
@@ -830,7 +832,8 @@ def block_exact_nd(name, nq, nk=4):
 
     def refill_params(first):
         """S_SB / S_REM / S_NP / S_K for the refill that runs beside the chunk about to be swept (S_CH = chunks left, that one
-        included): the item's next chunk, dbf bytes on, or nothing after the last."""
+        included): the item's next chunk, dbf bytes on, or -- beside the item's last chunk -- the NEXT item's first chunk (nsrc, dbn
+        bytes; dbn = 0: none), so that a persistent workgroup begins its next item on rows that are in the LDS already."""
         u = uid()
         L = []
         if not first:
@@ -839,9 +842,11 @@ def block_exact_nd(name, nq, nk=4):
                   f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_TMP}",
                   f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_DELTA}",            # the refill alternates images like the sweep, one ahead
                   f"s_sub_u32 s{S_DELTA}, 0, s{S_DELTA}"]
-        L += [f"s_mov_b32 s{S_REM}, 0", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cbranch_scc1 .Lnrset{u}",
+        L += [f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cbranch_scc1 .Lnrnext{u}",
               f"s_add_u32 s{S_SB}, s{S_SB}, %[dbf]", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
               f"s_mov_b32 s{S_REM}, %[dbf]", f"s_cmp_eq_u32 s{S_CH}, 2", f"s_cselect_b32 s{S_REM}, %[dbl], s{S_REM}",
+              f"s_branch .Lnrset{u}", f".Lnrnext{u}:",
+              f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[nsrc]", f"s_mov_b32 s{S_REM}, %[dbn]",
               f".Lnrset{u}:",
               f"s_mov_b32 s{S_K}, 0", f"s_add_u32 s{S_NP}, s{S_REM}, {ND_DMA_STRIDE - 1}",
               f"s_lshr_b32 s{S_NP}, s{S_NP}, {ND_DMA_STRIDE.bit_length() - 1}"]
@@ -861,6 +866,15 @@ def block_exact_nd(name, nq, nk=4):
         return L
 
     L = [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
+    # float out[N_SAMPLES] = {0.0} (mimo.cpp:122), here and not in front of the block: the accumulators are outputs only, so the compiler
+    # holds none of their registers while it computes the block's inputs
+    L += [f"v_mov_b32 v{r}, 0" for q in range(nq) for p in range(4) for r in range(O[q][p], O[q][p] + w)]
+    # the persistent kernel's ticket for its next-but-one item: lane 0 of the wave that is handed the queue's address (qptr != 0) adds
+    # one to that counter HERE, where no compiler-made wait can follow it (a scratch reload's vmcnt(0) in front of the block would have
+    # waited for the answer: microseconds); the first chunk boundary's vmcnt(0) proves the answer long before the block ends
+    L += ["s_cmp_eq_u64 %[qptr], 0", "s_cbranch_scc1 .LNnoq_%=", "s_mov_b64 exec, 1",
+          f"v_mov_b32 v{TT}, 0", f"v_mov_b32 v{TT + 1}, 1", f"global_atomic_add %[ticket], v{TT}, v{TT + 1}, %[qptr] sc0",
+          "s_mov_b64 exec, -1", ".LNnoq_%=:"]
     L += [f"s_mov_b32 s{S_M0}, m0", f"s_mov_b32 s{S_CH}, %[nch]", f"s_mov_b32 s{S_DELTA}, %[delta]",
           f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[isrc]", f"s_mov_b32 s{S_DST}, %[ddst]"]
     L += refill_params(first=True)
@@ -904,7 +918,7 @@ def block_exact_nd(name, nq, nk=4):
     sregs = sorted({S_NG, S_PFO, S_CH, S_SB, S_SB + 1, S_TMP, S_PF_, S_LEFT_, S_DST, S_RANK, S_PRIO, S_REM, S_K, S_NP, S_M0, S_DELTA}) + list(range(36, 100))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"', '"vcc"', '"memory"'])
     acc_params = ", ".join(f"{'f8' if nk == 4 else 'f4'} &O{q}{p}" for q in range(nq) for p in range(4))
-    acc_ops = ", ".join(f'"+{{v[{O[q][p]}:{O[q][p] + w - 1}]}}"(O{q}{p})' for q in range(nq) for p in range(4))
+    acc_ops = ", ".join(f'"=&{{v[{O[q][p]}:{O[q][p] + w - 1}]}}"(O{q}{p})' for q in range(nq) for p in range(4))
     qs_param = ", int qstride" if nq > 1 else ""
     qs_op = ', [qstride] "s"(qstride)' if nq > 1 else ""
     return f"""// Reference-order sweep of a whole item (frame pair x tile) on the {{next, d}} layout, {nq} quad(s) of four vertically adjacent
@@ -912,16 +926,19 @@ def block_exact_nd(name, nq, nk=4):
 // table ([group][pixel][mic] x (fraction, address), contiguous across chunks){"; the second quad's lie qstride bytes on" if nq > 1 else ""}; reads one group
 // past a quad's last.  ngf / ngl = groups of four mics in a full / in the last chunk, nch = chunks, isrc = chunk 0's rows in HBM (chunk c's
 // follow dbf bytes apart; dbl = bytes of the last chunk), ddst = this wave's first LDS-DMA destination in the image chunk 0 does NOT occupy,
-// delta = (that image) - (chunk 0's image) in bytes, lbytes = 16 x thread index; lane_addr = the sweep's LDS address in chunk 0's image.
-// O_qp = out[l + 64 k] of pixel p of quad q, both {"frames" if nk == 4 else "halves of the block"}, pinned at v[{ND_ACC} + {4 * w} q + {w} p ..]; temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}.
+// delta = (that image) - (chunk 0's image) in bytes, lbytes = 16 x thread index; lane_addr = the sweep's LDS address in chunk 0's image on
+// entry, in the last chunk's on exit; nsrc / dbn = the NEXT item's first chunk, refilled beside this item's last (dbn = 0: none);
+// qptr != null (one wave of the workgroup): lane 0 adds 1 to that counter (device scope) and `ticket` returns what it held before.
+// O_qp (outputs: the block zeroes them itself) = out[l + 64 k] of pixel p of quad q, both {"frames" if nk == 4 else "halves of the block"}, pinned at v[{ND_ACC} + {4 * w} q + {w} p ..]; temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}.
 // Executes nch s_barrier instructions.
 __device__ __forceinline__ void {name}({acc_params}, const void *row{qs_param}, int ngf, int ngl, int nch, unsigned &lane_addr, int rank,
-                                       const void *isrc, unsigned dbf, unsigned dbl, unsigned ddst, int delta, unsigned lbytes) {{
+                                       const void *isrc, unsigned dbf, unsigned dbl, const void *nsrc, unsigned dbn, unsigned ddst, int delta,
+                                       unsigned lbytes, const unsigned *qptr, unsigned &ticket) {{
     asm volatile(
 {body}
-        : {acc_ops}, [lane] "+v"(lane_addr)
+        : {acc_ops}, [lane] "+v"(lane_addr), [ticket] "=&v"(ticket)
         : [ptr] "s"(row){qs_op}, [ngf] "s"(ngf), [ngl] "s"(ngl), [nch] "s"(nch), [rank] "s"(rank), [isrc] "s"(isrc), [dbf] "s"(dbf), [dbl] "s"(dbl),
-          [ddst] "s"(ddst), [delta] "s"(delta), [lbytes] "v"(lbytes)
+          [nsrc] "s"(nsrc), [dbn] "s"(dbn), [ddst] "s"(ddst), [delta] "s"(delta), [lbytes] "v"(lbytes), [qptr] "s"(qptr)
         : {clobbers});
 }}
 """
