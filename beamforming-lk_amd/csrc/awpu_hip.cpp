@@ -1719,9 +1719,10 @@ int live_host_call(awpu_hip *h, const float *frames, float *power) {
         std::memcpy(h->h_live_in, frames, need_frames * sizeof(float));
     }
     AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, h->h_live_in, need_frames * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    rc = launch(h, h->d_frames, 1, h->d_power, h->stream, compact ? kCompact : kFull);
+    // (the sweep stores its powers straight into the pinned buffer -- one 4-byte store per pixel over PCIe, complete when the kernel
+    // is: a device-to-host copy behind the sweep would be one more DMA start-up, ~10 us, for 40 KB)
+    rc = launch(h, h->d_frames, 1, h->h_live_out, h->stream, compact ? kCompact : kFull);
     if (rc != AWPU_OK) return rc;
-    AWPU_HIP_TRY(hipMemcpyAsync(h->h_live_out, h->d_power, (size_t) h->cfg.pixel_count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     rc = wait_and_time(h);
     if (rc != AWPU_OK) return rc;
     std::memcpy(power, h->h_live_out, (size_t) h->cfg.pixel_count * sizeof(float));

@@ -6,7 +6,7 @@
 // (the reference computes X[off+i+1] + f * (X[off+i] - X[off+i+1]); the two differ by fp32
 // rounding only).  One (pixel, mic) pair = one "item" of 256 samples.
 //
-// Three kernels, one idea:
+// Three kernels, one idea (docs/HISTORY.md 4.2):
 //   das_pair_kernel      frames packed two by two, sample-interleaved; the two lanes of every packed
 //                        FMA are the two FRAMES; the two pixels of a block are swept in mic-major order
 //                        and share a mic's sample reads when their integer delays coincide (vertically
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void das_fast_db_kernel(FastArgs a) {
 // (MA[254] needs Y[off+255], whose X[off+256] the pack pass reads like any other sample).  Y[off] and Y[off+256]
 // -- the two that would need samples outside [off, off+256] -- are never used (MA[0] and MA[255] do not exist).
 // In fp32 the filtered samples are a third of the size of the raw ones at the carrier, and so are all rounding
-// errors downstream: against exact sums this order is closer than the reference's own.
+// errors downstream: against exact sums this order is closer than the reference's own (docs/HISTORY.md 4.2g).
 template <bool FILTER>
 __device__ __forceinline__ void pack_one_row(const float *frames, int n_streams, int hist, int wstart, const int32_t *index,
                                              int usable, const float *gain, int wp, int batch, float *packed, int pair, int s,
@@ -2960,7 +2960,7 @@ hipError_t launch_das_fast(const FastArgs &a, int fpi, int ppw, int nw, const Ex
         if (ppw == 4) return launch_db<16, 4, kFastLdsBytes, 4, false>(a, stream);
         return launch_db<16, 8, kFastLdsBytes, 4, false>(a, stream);
     }
-#ifdef AWPU_TUNING_BUILD  // shapes only AWPU_FAST_VARIANT reaches (measured and not taken: DESIGN.md 8)
+#ifdef AWPU_TUNING_BUILD  // shapes only AWPU_FAST_VARIANT reaches (measured and not taken: docs/HISTORY.md 8)
     if (nw == 24) {  // double-buffered, two 12-wave workgroups per CU, 6 waves per SIMD
         if (a.debug & 16) return launch_db<12, 4, kFastLdsBytesSmall, 6, true>(a, stream);
         return launch_db<12, 4, kFastLdsBytesSmall, 6, false>(a, stream);

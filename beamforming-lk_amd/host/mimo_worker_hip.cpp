@@ -63,6 +63,15 @@ void MIMOWorkerHip::computeDelayLUT() {
         last_status = awpu_hip_set_delay_table(engine, offsetDelays.data(), fractionalDelays.data());
 }
 
+int MIMOWorkerHip::setDelayLUT(const int32_t *off, const float *frac) {
+    if (!engine || !off || !frac) return AWPU_ERR_INVALID;
+    std::lock_guard<std::mutex> guard(lock);
+    offsetDelays.assign(off, off + (size_t) maxIndex * antenna.n);
+    fractionalDelays.assign(frac, frac + (size_t) maxIndex * antenna.n);
+    last_status = awpu_hip_set_delay_table(engine, offsetDelays.data(), fractionalDelays.data());
+    return last_status;
+}
+
 // mimo.cpp:97-151.  The snapshot loop is the reference's (every stream, so that antenna.index can
 // address any of them); the pixel x mic x sample sweep and the epilogue run on the GPU.
 void MIMOWorkerHip::update() {

@@ -72,6 +72,13 @@ public:
     // mimo.cpp:97-151.  Protected in the reference; public here so tests can step it.
     void update();
 
+    // The tables of a caller that keeps the reference's own computeDelayLUT (mimo.cpp:20-59, Eigen arithmetic): off / frac
+    // [rows * columns][antenna.n], pixel-major as mimo.h:86-88 flattens.  They replace the tables the constructor built with the
+    // Eigen-free restatement (awpu_hip_build_delay_table, whose last ulp of tau is unpinned): with the reference's own bits in, the
+    // heatmap is within 1e-5 of the reference's on every pixel, deep nulls included (INTEGRATION.md "Which math mode").
+    // Call between blocks (it takes the worker lock).  Returns the C-ABI status.
+    int setDelayLUT(const int32_t *off, const float *frac);
+
     int status() const { return last_status; }                 // last C-ABI status (0 = OK)
     const std::vector<float> &power() const { return powerdB; }  // mimo.h:91
     const std::vector<int32_t> &offsets() const { return offsetDelays; }

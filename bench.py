@@ -776,7 +776,7 @@ def main():
                     "frames is a like-for-like figure and only that is reported: the mode runs in the untuned verification "
                     "kernel's structure, so its rate says nothing about bf16 (gfx950 has no packed bf16 add; a bf16 running "
                     "sum is an fp32 add plus a convert, strictly more VALU work than the fp32 accumulator).  Percent-level "
-                    "error against a 1e-5 budget: rejected (DESIGN.md 8)",
+                    "error against a 1e-5 budget: rejected (docs/HISTORY.md 8)",
         }
         eng16.close()
 
@@ -838,7 +838,7 @@ def parity_dc(pkg):
     tests/golden/sweep_{c1,headline}_dc.npz -- hash frames + {1e-4, 1e-3, 1e-2, 0.25} through the reference's compiled
     delay() (oracle/_ref, tests/golden/make_golden.py) -- max unfloored per-pixel error against those powers, per offset.
     AWPU_MATH_F32_EXACT keeps the reference's order and stays within 1e-5 at every offset; the re-ordered
-    AWPU_MATH_F32_FAST (stencil on the samples) leaves the REFERENCE's own cancellation noise behind and
+    AWPU_MATH_F32_FAST (stencil on the samples, docs/HISTORY.md 4.2g) leaves the REFERENCE's own cancellation noise behind and
     is therefore further than 1e-5 from it once the bias dwarfs the signal."""
     import util
 

@@ -315,6 +315,30 @@ int main(int argc, char **argv) {
         CHECK(two.status() == AWPU_OK && one.power() == two.power(), "device group differs from the single device");
         std::printf("6. device group {0, 0}: identical heatmap\n");
     }
+    // ---- 7. caller-built tables (the drop-in keeps the reference's own computeDelayLUT and hands its bits over): a table that differs
+    // from the Eigen-free restatement -- every tau one ulp down, an integer boundary crossed where tau sat on it (mimo.cpp:46-54) --
+    // goes in through setDelayLUT, and the worker's heatmap equals the oracle's ON THAT TABLE within 1e-5 on every pixel
+    {
+        SyntheticSource src(xyz.data(), 64, theta, phi);
+        AntennaView ant{xyz.data(), 64, 64, all.data()};
+        for (int b = 0; b < 5; b++) src.publish_block();
+        MIMOWorkerHip w(&src, ant, &run, rows, cols, 180.f, 0, false);
+        std::vector<int32_t> off = w.offsets();
+        std::vector<float> frac = w.fractions();
+        for (size_t i = 0; i < off.size(); i++) {  // tau = (256 - off) + frac, one ulp of the fraction down
+            if (frac[i] > 0.0f) frac[i] = std::nextafter(frac[i], 0.0f);
+            else if (off[i] < 256) { off[i] += 1; frac[i] = std::nextafter(1.0f, 0.0f); }
+        }
+        CHECK(w.setDelayLUT(off.data(), frac.data()) == AWPU_OK, "setDelayLUT: %s", awpu_hip_last_error());
+        CHECK(off == w.offsets() && frac == w.fractions(), "the worker does not hold the caller's tables");
+        w.update();
+        std::vector<float> snap((size_t) 64 * 1024), want(rows * cols);
+        for (int s = 0; s < 64; s++) src.read_stream(s, &snap[(size_t) s * 1024]);
+        oracle_das_f32(snap.data(), 1024, off.data(), frac.data(), rows * cols, 64, all.data(), 64, want.data(), nullptr);
+        const double e = rel_err(w.power(), want);
+        CHECK(w.status() == AWPU_OK && e < 1e-5, "caller-built tables: power rel err %.3e (status %d)", e, w.status());
+        std::printf("7. caller-built tables through setDelayLUT: rel err %.2e\n", e);
+    }
     std::printf(failures ? "FAILED\n" : "OK\n");
     return failures ? 1 : 0;
 }

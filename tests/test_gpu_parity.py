@@ -1620,7 +1620,7 @@ def test_dc_offset_frames_batched_sweep_is_closer_to_exact_than_the_reference(pk
     """Samples with a DC offset (an ADC bias the wire format does not remove): the reference sums 256 mics' worth of
     the offset into every out[i] and lets its moving-average stencil cancel it again -- in fp32 that cancellation costs
     it several digits (its distance to exact fp64 sums grows a hundredfold).  The batched FAST sweep applies the stencil
-    to the samples first, so the offset never enters a sum: its result stays at fp32 precision of the
+    to the samples first (docs/HISTORY.md 4.2g), so the offset never enters a sum: its result stays at fp32 precision of the
     exact one -- and is therefore NOT within 1e-5 of the reference's own fp32 result on such input: the strict `ok` is
     False here, and this is the one test that uses the named allowance `ok_within_reference_noise` (3 x the reference's
     own distance to exact).  AWPU_MATH_F32_EXACT is the mode that stays within 1e-5 of the reference on biased input

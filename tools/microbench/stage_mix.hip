@@ -1,6 +1,6 @@
 // stage_mix.hip -- how well does a SIMD issue SHORT stages of packed FMAs cut up by scalar compare-and-branch pairs, at 4
 // and at 8 waves per SIMD?  Two stage shapes: the quad kernel's frame-pair stage (24 packed VALU + 1 address add + 4 LDS reads
-// + 5 not-taken compare-and-branch pairs) and the half-sample "class" stage sketched in DESIGN.md 11 (12 packed VALU + 1 add
+// + 5 not-taken compare-and-branch pairs) and the half-sample "class" stage sketched in docs/HISTORY.md 11 (12 packed VALU + 1 add
 // + 2 LDS reads + 4 pairs; 64 registers, so eight waves fit a SIMD).  Printed: SIMD cycles per stage of one wave-slot at
 // the in-kernel clock, against the VALU issue floor (4 cycles per VALU instruction x waves).
 // Build: hipcc --offload-arch=gfx950 -O3 -o stage_mix stage_mix.hip ; run on an MI355X: ./stage_mix
