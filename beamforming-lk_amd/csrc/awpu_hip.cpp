@@ -1928,27 +1928,29 @@ int group_process_device(awpu_hip *g, const float *d_frames, int batch, float *d
             w = hi - lo;
             need = (size_t) g->cfg.n_streams * w * g->cfg.max_batch;
         }
-        if (g->stage_cap < need || g->stage_lo != lo || g->stage_w != w) {
+        // (round-4 advisor) Only a buffer that is too SMALL is replaced, behind a synchronize of everybody who may still read it.  A
+        // change of payload -- packed pairs one call, raw windows the next: batches alternating with single frames -- keeps the
+        // buffers and their turn: every reuse of h_stage[gb] already waits for the uploads that read it two calls ago
+        // (ev_staged_read below), whatever they carried.
+        if (g->stage_cap < need) {
             for (awpu_hip *part : g->parts) {  // nobody may still be reading the old staging buffers
                 AWPU_HIP_TRY(hipSetDevice(part->cfg.device));
                 AWPU_HIP_TRY(hipStreamSynchronize(part->copy_stream));
             }
             AWPU_HIP_TRY(hipSetDevice(dev0));
             AWPU_HIP_TRY(hipStreamSynchronize(s));
-            if (g->stage_cap < need) {
-                for (int b = 0; b < 2; b++) {
-                    if (g->h_stage[b]) (void) hipHostFree(g->h_stage[b]);
-                    g->h_stage[b] = nullptr;
-                }
-                g->stage_cap = 0;
-                for (int b = 0; b < 2; b++) AWPU_HIP_TRY(hipHostMalloc(&g->h_stage[b], need * sizeof(float), hipHostMallocPortable));
-                g->stage_cap = need;
+            for (int b = 0; b < 2; b++) {
+                if (g->h_stage[b]) (void) hipHostFree(g->h_stage[b]);
+                g->h_stage[b] = nullptr;
             }
-            g->stage_lo = lo;
-            g->stage_w = w;
+            g->stage_cap = 0;
+            for (int b = 0; b < 2; b++) AWPU_HIP_TRY(hipHostMalloc(&g->h_stage[b], need * sizeof(float), hipHostMallocPortable));
+            g->stage_cap = need;
             g->stage_turn = 0;
             for (awpu_hip *part : g->parts) part->stage_used[0] = part->stage_used[1] = false;
         }
+        g->stage_lo = lo;  // what THIS call's payload is (read by the uploads enqueued below, in this call)
+        g->stage_w = w;
         gb = g->stage_turn++ & 1;
         for (awpu_hip *part : g->parts)  // h_stage[gb] was read by the staged parts' uploads two calls ago
             if (part->peer == kPeerStaged && !in_place(part) && part->stage_used[gb]) AWPU_HIP_TRY(hipStreamWaitEvent(s, part->ev_staged_read[gb], 0));
