@@ -999,7 +999,7 @@ bool takes_exact_nd(awpu_hip *h, int batch, int *nq) {
 // single frames in the reference's order: the halves form of the {next, d} layout (das_exact_ndh_kernel) -- every mic resident and
 // staged by the workgroups themselves (one array), or chunked behind a pack pre-pass.  `pitch` = floats between two streams of a frame
 int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int pitch, int wstart_eff, bool stationary,
-                     int nq) {
+                     int nq, int nw = 16) {
     int rc = build_quad_lut(h, stationary ? kQuadExactNdhStationary : kQuadExactNdh);
     if (rc != AWPU_OK) return rc;
     const awpu::FastPlan &pp = stationary ? h->exact_ndhs_plan : h->exact_ndh_plan;
@@ -1027,7 +1027,8 @@ int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_pow
     a.cols = h->cfg.grid_columns;
     a.rows = h->cfg.pixel_count / a.cols;
     a.nq = nq;
-    a.tiles = awpu::quad1_tiles(a.rows, a.cols, nq);
+    a.nw = nw;
+    a.tiles = awpu::ndh_tiles(a.rows, a.cols, nq, nw);
     a.lut_cols = (a.cols + 31) / 32 * 32;
     a.identity = 1;
     for (int k = 0; k < a.usable && a.identity; k++) a.identity = h->index[k] == k;
@@ -1327,9 +1328,19 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         // one frame per call (MIMOWorker::update's regime): the halves form of the layout -- the two packed lanes are the two halves of
         // the block, not a frame and its copy; every mic resident where one array's rows fit the LDS (no pre-pass)
         if (nd && batch == 1 && env().exact_pairs == 1 && (h->exact_ndhs_ok || h->exact_ndh_ok)) {
-            const int rows = h->cfg.pixel_count / h->cfg.grid_columns;
-            const int nqh = (long) awpu::quad1_tiles(rows, h->cfg.grid_columns, 2) >= 256 ? 2 : 1;
-            return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, h->exact_ndhs_ok, nqh);
+            const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
+            const int nqh = (long) awpu::quad1_tiles(rows, cols, 2) >= 256 ? 2 : 1;
+            // chunked sweeps of grids too small to give every CU a 16-wave workgroup: 8-wave (from 64 on) or 4-wave workgroups -- half or a
+            // quarter of the pixels each, so two or four times as many CUs work on the frame (c2, 64 x 64: 64 -> 256 workgroups)
+            int nw = 16;
+            if (!h->exact_ndhs_ok && nqh == 1) {
+                const long wgs16 = awpu::ndh_tiles(rows, cols, 1, 16);
+                nw = wgs16 >= 192 ? 16 : wgs16 >= 96 ? 8 : 4;
+#ifdef AWPU_TUNING_BUILD
+                if (const char *v = std::getenv("AWPU_NDH_WAVES")) nw = std::atoi(v) == 8 ? 8 : std::atoi(v) == 4 ? 4 : 16;
+#endif
+            }
+            return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, h->exact_ndhs_ok, nqh, nw);
         }
         if (nd) return launch_exact_nd(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, nq);
         if (env().exact_pairs == 3 && h->pair_cols > 0 && h->cfg.pixel_count / h->cfg.grid_columns >= 4)

@@ -193,11 +193,13 @@ struct ExactNdhArgs {
     int32_t n_streams, pitch, wstart;  // stationary
     int32_t usable, usable_pad, pixel_count, wh, chunk, batch;
     int32_t cols, rows;
-    int32_t nq;            // quads per wave: a workgroup tile is 4 rows x 16 nq columns
-    int32_t tiles;         // quad1_tiles(rows, cols, nq)
+    int32_t nq;            // quads per wave: a workgroup tile is 4 rows x nw nq columns
+    int32_t nw;            // waves per workgroup: 16; 8 or 4 (chunked, one quad per wave) for grids too small to give every CU 16 waves
+    int32_t tiles;         // ndh_tiles(rows, cols, nq, nw)
     int32_t lut_cols;      // columns of the table (the grid's, padded to whole tiles of 32)
     int32_t identity;      // stationary: the active-mic list is 0 .. usable-1 (rows need no look-up)
 };
+inline int ndh_tiles(int rows, int cols, int nq, int nw) { return ((rows + 3) / 4) * ((cols + nw * nq - 1) / (nw * nq)); }
 bool exact_ndh_plan(int window, int usable, bool stationary, FastPlan *plan);  // plan->wr = wh, row_bytes = 16 wh
 hipError_t launch_pack_ndh(const float *d_frames, int n_streams, int pitch, int wstart, const int32_t *d_index, int usable, int rows_out,
                            const float *d_gain, int wh, int batch, float *d_packed, hipStream_t stream);

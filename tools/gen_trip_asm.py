@@ -657,10 +657,9 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, un
 ND_ACC = 10    # block_exact_nd: out[] of quad q, pixel p pinned at v[ND_ACC + 32 q + 8 p ..+7]
 ND_TMP = 74    # its 52 temps (two 16-register slots for the reference pixel's elements, one for whichever pixel leaves it, t, address)
 ND_TIMING = os.environ.get("ND_TIMING", "")  # tuning builds only (see the end of block_exact_nd)
-ND_DMA_STRIDE = 16 * 1024  # one refill piece: 16 waves x 64 lanes x 16 bytes (every wave of the workgroup takes part)
 
 
-def block_exact_nd(name, nq, nk=4):
+def block_exact_nd(name, nq, nk=4, nw=16):
     """Reference-order sweep (AWPU_MATH_F32_EXACT, round 5) of a WHOLE item -- frame pair x tile, `nq` quads of four vertically
     adjacent pixels per wave -- on the {next, d} layout: pack_nd_kernel stores, per mic and sample t of the window, the 16-byte element
         { next_a, next_b, d_a, d_b },   next = X[t + 1],  d = X[t] - X[t + 1]      (a, b = the two frames of the pair)
@@ -688,7 +687,10 @@ def block_exact_nd(name, nq, nk=4):
     nk = 2: the same block for SINGLE frames on the halves form of the layout (das_exact_ndh_kernel): element t of a mic's row =
     { X[t+1], X[t+129], X[t] - X[t+1], X[t+128] - X[t+129] }, the two packed lanes are the two halves of the 256-sample block, lane l
     owns samples l and l + 64 of either half -- two register pairs per pixel, two ds_read_b128 per distinct address, four packed
-    VALU instructions per (pixel, mic)."""
+    VALU instructions per (pixel, mic).
+
+    nw = waves per workgroup (16; 8 and 4 for single frames on small grids: a refill piece is nw x 1 KiB)."""
+    DMA_PIECE = nw * 1024
     w = 2 * nk  # registers per pixel's out[]
     O = [[ND_ACC + 4 * w * q + w * p for p in range(4)] for q in range(nq)]
     R = [ND_TMP, ND_TMP + 4 * nk]
@@ -801,13 +803,15 @@ def block_exact_nd(name, nq, nk=4):
                 f"s_mov_b32 m0, s{S_DST}", "s_nop 0",
                 f"global_load_lds_dwordx4 %[lbytes], s[{S_SB}:{S_SB + 1}]",
                 "s_mov_b64 exec, -1",
-                f"s_add_u32 s{S_SB}, s{S_SB}, {hex(ND_DMA_STRIDE)}", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
-                f"s_add_u32 s{S_DST}, s{S_DST}, {hex(ND_DMA_STRIDE)}", f"s_sub_u32 s{S_REM}, s{S_REM}, {hex(ND_DMA_STRIDE)}",
+                f"s_add_u32 s{S_SB}, s{S_SB}, {hex(DMA_PIECE)}", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+                f"s_add_u32 s{S_DST}, s{S_DST}, {hex(DMA_PIECE)}", f"s_sub_u32 s{S_REM}, s{S_REM}, {hex(DMA_PIECE)}",
                 f"s_add_u32 s{S_K}, s{S_K}, 1", f".Lndskip{u}:"]
 
     def trip_n(par):
         cur, nxt = E[par], E[1 - par]
-        L = dma_piece()
+        L = []
+        for _ in range(16 // nw):  # 16 KiB of the refill per trip, whatever the piece
+            L += dma_piece()
         L += select_prio(S_PRIO, 1, QUAD_XMAP) if par == 0 else select_prio(S_RANK, 0, QUAD_YMAP)  # rotation / youngest first, trip by trip
         if nq > 1:  # a quad's last trip of the chunk fetches the OTHER quad's next entries (its own continue where they stopped)
             u = uid()
@@ -837,7 +841,7 @@ def block_exact_nd(name, nq, nk=4):
         u = uid()
         L = []
         if not first:
-            L += [f"s_lshl_b32 s{S_TMP}, s{S_K}, {ND_DMA_STRIDE.bit_length() - 1}",   # undo the pieces' advance
+            L += [f"s_lshl_b32 s{S_TMP}, s{S_K}, {DMA_PIECE.bit_length() - 1}",   # undo the pieces' advance
                   f"s_sub_u32 s{S_SB}, s{S_SB}, s{S_TMP}", f"s_subb_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
                   f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_TMP}",
                   f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_DELTA}",            # the refill alternates images like the sweep, one ahead
@@ -848,8 +852,8 @@ def block_exact_nd(name, nq, nk=4):
               f"s_branch .Lnrset{u}", f".Lnrnext{u}:",
               f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[nsrc]", f"s_mov_b32 s{S_REM}, %[dbn]",
               f".Lnrset{u}:",
-              f"s_mov_b32 s{S_K}, 0", f"s_add_u32 s{S_NP}, s{S_REM}, {ND_DMA_STRIDE - 1}",
-              f"s_lshr_b32 s{S_NP}, s{S_NP}, {ND_DMA_STRIDE.bit_length() - 1}"]
+              f"s_mov_b32 s{S_K}, 0", f"s_add_u32 s{S_NP}, s{S_REM}, {DMA_PIECE - 1}",
+              f"s_lshr_b32 s{S_NP}, s{S_NP}, {DMA_PIECE.bit_length() - 1}"]
         return L
 
     def chunk_groups():  # S_NG = groups of four mics in the chunk about to be swept
@@ -1998,6 +2002,8 @@ def main():
     out.append(block_exact_nd("sweep_exact_nd_item2", 2))  # das_exact_nd_kernel<2>: two quads per wave (the default batch kernel of the reference order)
     out.append(block_exact_nd("sweep_exact_ndh_item1", 1, nk=2))  # das_exact_ndh_kernel<1, *>: single frames, the halves form of the layout
     out.append(block_exact_nd("sweep_exact_ndh_item2", 2, nk=2))  # das_exact_ndh_kernel<2, *>
+    out.append(block_exact_nd("sweep_exact_ndh_item1_w8", 1, nk=2, nw=8))  # ... 8- and 4-wave workgroups: single frames on grids too small to
+    out.append(block_exact_nd("sweep_exact_ndh_item1_w4", 1, nk=2, nw=4))  # give every CU a 16-wave workgroup (c2: 64 of them)
     out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))
     out.append(block_quad("sweep_quad_item", dma=True, chain=CHAIN, item=True))  # the production batch kernel: one block per item
