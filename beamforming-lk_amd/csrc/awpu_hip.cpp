@@ -1330,12 +1330,15 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         if (nd && batch == 1 && env().exact_pairs == 1 && (h->exact_ndhs_ok || h->exact_ndh_ok)) {
             const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
             const int nqh = (long) awpu::quad1_tiles(rows, cols, 2) >= 256 ? 2 : 1;
-            // chunked sweeps of grids too small to give every CU a 16-wave workgroup: 8-wave (from 64 on) or 4-wave workgroups -- half or a
-            // quarter of the pixels each, so two or four times as many CUs work on the frame (c2, 64 x 64: 64 -> 256 workgroups)
+            // chunked sweeps of grids too small to give every CU a 16-wave workgroup: 8- or 4-wave workgroups -- half or a quarter of the
+            // pixels each -- as long as they still run in ONE round of workgroups (c2, 64 x 64: 64 -> 256 workgroups).  Measured, c2, one
+            // frame per call: 76.6 / 71.7 / 68.9 us with 16 / 8 / 4 waves -- a workgroup's time is the chain of its 13 chunk refills, not
+            // its arithmetic; a second round of workgroups costs far more than this gains (headline: 82 / 135 / 251 us)
             int nw = 16;
             if (!h->exact_ndhs_ok && nqh == 1) {
-                const long wgs16 = awpu::ndh_tiles(rows, cols, 1, 16);
-                nw = wgs16 >= 192 ? 16 : wgs16 >= 96 ? 8 : 4;
+                if (h->n_cus < 1 && (hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess || h->n_cus < 1))
+                    h->n_cus = 256;
+                nw = awpu::ndh_tiles(rows, cols, 1, 4) * (long) batch <= h->n_cus ? 4 : awpu::ndh_tiles(rows, cols, 1, 8) * (long) batch <= h->n_cus ? 8 : 16;
 #ifdef AWPU_TUNING_BUILD
                 if (const char *v = std::getenv("AWPU_NDH_WAVES")) nw = std::atoi(v) == 8 ? 8 : std::atoi(v) == 4 ? 4 : 16;
 #endif

@@ -1730,12 +1730,13 @@ def test_exact_mode_sums_equal_the_oracle_on_every_pixel(pkg, oracle, wl, cols, 
         assert util.power_rel_err_unfloored(power[b], want_p) < 3e-6
 
 
-@pytest.mark.parametrize("case", ["ref_default", "ref_default_ragged_gains", "odd_grid", "c2", "c2_short"])
+@pytest.mark.parametrize("case", ["ref_default", "ref_default_ragged_gains", "odd_grid", "c2", "c2_short", "c2_wide"])
 def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
     """One frame per call in the reference's order -- MIMOWorker::update's regime (worker.h:212-224, mimo.cpp:97-151) -- on the halves
     form of the {next, d} layout (das_exact_ndh_kernel): one array at the reference's default resolution with every mic resident
     (100 x 100, main.cpp:38-41; also a ragged mic list with gains, and an odd grid), four arrays chunked behind the pack pre-pass
-    (and a grid of 30 rows: a last quad of two live pixels).  The pre-epilogue sums equal oracle_das_f32's out[] bit for bit on EVERY
+    (and a grid of 30 rows: a last quad of two live pixels; 4-wave workgroups on these small grids, 8-wave ones on the 64 x 96 grid of
+    "c2_wide": das_exact_ndh_kernel<1, false, 4 | 8>).  The pre-epilogue sums equal oracle_das_f32's out[] bit for bit on EVERY
     pixel (DC-biased plane-wave frames), the powers are the bits the same frame gets inside a batch (das_exact_nd_kernel), and within
     1e-5 of the oracle on every pixel."""
     S = pkg.synthetic
@@ -1747,6 +1748,9 @@ def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
         off, frac = S.delay_table(spec, xyz)
         rows, cols, n_streams, want = (30 if case == "c2_short" else spec.res), spec.res, spec.n_mics, "exact_ndh"
         off, frac = off[: rows * cols], frac[: rows * cols]
+        if case == "c2_wide":  # 16 quad rows x 96 columns: 384 four-wave tiles are more than the chip's CUs, 192 eight-wave tiles are not
+            rows, cols = 64, 96
+            off, frac = pkg.build_delay_table(xyz, rows, cols, 180.0)
     else:
         xyz = pkg.create_antenna()
         rows = cols = 99 if case == "odd_grid" else 100  # (99: an odd grid, whose centre pixel looks straight ahead)
