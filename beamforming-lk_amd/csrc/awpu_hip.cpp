@@ -989,7 +989,7 @@ bool takes_exact_nd(awpu_hip *h, int batch, int *nq) {
     // (quad_differ < 1.5: on average fewer than half of a quad's pixels leave the reference pixel's address for a mic; a square
     // array's vertical and horizontal neighbours coincide equally often -- pair_cols stays 0 there -- and quads still pay)
     const bool quads_pay = h->cfg.pixel_count % cols == 0 && h->cfg.pixel_begin % cols == 0 && h->quad_differ < 1.5;
-    if (!(h->pair_cols > 0 || quads_pay) || rows < 4) return false;
+    if ((!(h->pair_cols > 0 || quads_pay) && ex != 4 && ex != 5) || rows < 4) return false;  // (a forced shape runs on any table: the random tests)
     // two quads per wave where that still fills the chip (AWPU_SHAPE=exact_nd1 / exact_nd2: one / two everywhere)
     const long wgs2 = (long) awpu::nd_tiles(rows, cols, 2) * ((batch + 1) / 2);
     *nq = ex == 4 ? 1 : ex == 5 ? 2 : (rows >= 8 && wgs2 >= 512 ? 2 : 1);

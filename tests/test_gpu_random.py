@@ -16,9 +16,12 @@ pytestmark = pytest.mark.gpu
     {"AWPU_SHAPE": "single_db"},                                # double-buffered single-frame shape
     {"AWPU_SHAPE": "single_small"},                             # 8-wave shape, 2 pixels per wave
     {"AWPU_TEST_MATH": "exact"},                                # the reference-order kernel on the frame-pair layout
-    {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},  # ... vertical pixel pairs sharing reads and differences
+    {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},  # the default dispatch on grids: das_exact_nd_kernel for batches, das_exact_ndh_kernel (resident / 4-, 8-, 16-wave chunked) for single frames
     {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1", "AWPU_SHAPE": "exact_pair"},  # ... two-pixel block on the same tables
     {"AWPU_TEST_MATH": "exact", "AWPU_SHAPE": "exact_verify"},  # the round-1 verification kernel (the bf16 mode's structure)
+    {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_SHAPE": "exact_nd2"},  # the {next, d} kernel on RANDOM delays: every pixel leaves the reference's address (its read-on-the-spot paths), batches of one as a pair with itself
+    {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1", "AWPU_SHAPE": "exact_nd1"},  # ... one quad per wave, delays that mostly coincide
+    {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1", "AWPU_SHAPE": "exact_quad"},  # round 4's quad kernel on raw sample pairs (still the fallback)
     {"AWPU_TEST_PATH": "device"},                               # device-resident frames + two pixel shards per case
     {"AWPU_TEST_INTERP": "fir8"},                               # the 8-tap variant of delay()
     {"AWPU_TEST_INTERP": "fir8", "AWPU_SHAPE": "fir8_planes"},  # ... on the four-plane frame-pair kernel for every batch >= 2
@@ -32,7 +35,7 @@ pytestmark = pytest.mark.gpu
     {"AWPU_SHAPE": "quadh", "AWPU_TEST_GRID": "1"},                              # single-frame quad shape on the halves layout for every call
     {"AWPU_SHAPE": "quadh", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},
     {"AWPU_SHAPE": "quadh_chunked", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},  # ... never its resident-window variant
-], ids=["pairs", "db", "small", "exact", "exact_grid", "exact_grid_pairs", "exact_verify", "device", "fir8", "fir8_planes", "reuse", "pairs_vertical",
+], ids=["pairs", "db", "small", "exact", "exact_grid", "exact_grid_pairs", "exact_verify", "exact_nd2_random", "exact_nd1_coincide", "exact_quad_r4", "device", "fir8", "fir8_planes", "reuse", "pairs_vertical",
         "quads_random", "quads_coincide", "pairs_coincide", "stationary", "stationary_grid", "quadh_every_call", "quadh_coincide",
         "quadh_chunked"])
 def test_random_tables(env):

@@ -33,5 +33,9 @@ for seed in ${SEEDS:-11 12 13}; do
   run exact $seed 20 AWPU_TEST_MATH=exact
   run exact_grid $seed 20 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1
   run exact_verify $seed 8 AWPU_TEST_MATH=exact AWPU_SHAPE=exact_verify
+  run exact_nd2_random $seed 20 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_SHAPE=exact_nd2
+  run exact_nd2_coincide $seed 20 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1 AWPU_SHAPE=exact_nd2
+  run exact_nd1_coincide $seed 20 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1 AWPU_SHAPE=exact_nd1
+  run exact_quad_r4 $seed 12 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1 AWPU_SHAPE=exact_quad
 done
 exit $fail
