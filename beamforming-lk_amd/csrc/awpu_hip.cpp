@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1697,7 +1698,10 @@ int wait_and_time(awpu_hip *h);
 // snapshot it replaces).  The caller's buffers are pageable (std::vector, mimo.h:83-88): a device copy straight out of / into them goes
 // through the runtime's own bounce buffers in several synchronous steps (measured at the reference's default shape: 58-64 us per call
 // around a 20 us sweep).  Here the touched window of every stream is gathered into a PINNED buffer of the handle by the CPU (64 rows x
-// 1.2 KB), crosses PCIe as ONE asynchronous copy, and the powers come back the same way through a pinned buffer.
+// 1.2 KB), crosses PCIe in ONE piece read by a small kernel (a DMA-engine copy of 75 KB is mostly start-up), and the sweep stores its
+// powers straight into a pinned buffer.  Measured at the reference's shape (C level; Python adds ~6 us): 53 -> 43 us exact, 48 -> 38 us
+// fast, of which 35 / 32 us are the device's (upload 3 + sweep 22 / 19.5 + two dispatch latencies + the completion signal); spinning on
+// hipStreamQuery instead of hipStreamSynchronize and a stream-written flag (hipStreamWriteValue32) were measured: equal / 18 us slower.
 int live_host_call(awpu_hip *h, const float *frames, float *power) {
     int rc = check_ready(h, 1);
     if (rc != AWPU_OK) return rc;
@@ -1726,20 +1730,61 @@ int live_host_call(awpu_hip *h, const float *frames, float *power) {
         AWPU_HIP_TRY(hipHostMalloc(&h->h_live_out, (size_t) h->cfg.pixel_count * sizeof(float), hipHostMallocDefault));
         h->live_out_cap = (size_t) h->cfg.pixel_count;
     }
+#ifdef AWPU_TUNING_BUILD
+    static const bool live_timing = std::getenv("AWPU_LIVE_TIMING") != nullptr;
+    static double t_acc[5] = {0, 0, 0, 0, 0};
+    static long t_calls = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](int k, std::chrono::steady_clock::time_point &from) {
+        const auto now = std::chrono::steady_clock::now();
+        t_acc[k] += std::chrono::duration<double, std::micro>(now - from).count();
+        from = now;
+    };
+    auto t = t0;
+#endif
     if (compact) {  // rows of compact_hist floats cut out of rows of hist floats
         for (int s = 0; s < h->cfg.n_streams; s++)
             std::memcpy(h->h_live_in + (size_t) s * dev_hist, frames + (size_t) s * h->cfg.hist + h->wstart, (size_t) dev_hist * sizeof(float));
     } else {
         std::memcpy(h->h_live_in, frames, need_frames * sizeof(float));
     }
-    AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, h->h_live_in, need_frames * sizeof(float), hipMemcpyHostToDevice, h->stream));
+#ifdef AWPU_TUNING_BUILD
+    if (live_timing) lap(0, t);
+#endif
+    // the upload: by a kernel that reads the pinned buffer over PCIe (a DMA-engine copy of 75 KB is mostly start-up: 8.6 us measured);
+    // windows that are no whole number of 16-byte pieces (never, with compact rows) take the DMA copy
+    if ((need_frames & 3) == 0) {
+        AWPU_HIP_TRY(awpu::launch_upload_floats(h->h_live_in, h->d_frames, need_frames, h->stream));
+    } else {
+        AWPU_HIP_TRY(hipMemcpyAsync(h->d_frames, h->h_live_in, need_frames * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+#ifdef AWPU_TUNING_BUILD
+    if (live_timing) lap(1, t);
+#endif
     // (the sweep stores its powers straight into the pinned buffer -- one 4-byte store per pixel over PCIe, complete when the kernel
     // is: a device-to-host copy behind the sweep would be one more DMA start-up, ~10 us, for 40 KB)
     rc = launch(h, h->d_frames, 1, h->h_live_out, h->stream, compact ? kCompact : kFull);
     if (rc != AWPU_OK) return rc;
+#ifdef AWPU_TUNING_BUILD
+    if (live_timing) lap(2, t);
+#endif
     rc = wait_and_time(h);
     if (rc != AWPU_OK) return rc;
+#ifdef AWPU_TUNING_BUILD
+    if (live_timing) lap(3, t);
+#endif
     std::memcpy(power, h->h_live_out, (size_t) h->cfg.pixel_count * sizeof(float));
+#ifdef AWPU_TUNING_BUILD
+    if (live_timing) {
+        lap(4, t);
+        if (++t_calls == 5) for (double &v : t_acc) v = 0;  // (the first calls build tables and raise limits)
+        if (t_calls > 5 && (t_calls - 5) % 100 == 0) {
+            std::fprintf(stderr, "[awpu live] per call us: gather %.1f | hipMemcpyAsync H2D %.1f | launch() %.1f | wait %.1f | copy out %.1f\n", t_acc[0] / 100,
+                         t_acc[1] / 100, t_acc[2] / 100, t_acc[3] / 100, t_acc[4] / 100);
+            for (double &v : t_acc) v = 0;
+        }
+    }
+#endif
     return AWPU_OK;
 }
 

@@ -1637,17 +1637,20 @@ __global__ __launch_bounds__(NW * 64) void das_exact_ndh_kernel(ExactNdhArgs a) 
     int n_chunks = 1, first_mics = a.usable_pad, last_mics = a.usable_pad;
     const float *frame_rows = nullptr;
     if constexpr (STATIONARY) {
-        // every active mic's row, formed here: waves take rows s = wave, wave + 16, ...; per pass 4 (row, 64-element stretch) units = 16
-        // global loads in flight per lane, then the differences and 4 ds_write_b128
+        // every active mic's row, formed here: waves take rows s = wave, wave + 16, ...; per pass kUnits (row, 64-element stretch) units =
+        // 48 global loads in flight per lane -- one array's rows (4 rows x 3 stretches per wave) in ONE pass: a frame that has just
+        // arrived by DMA is cold in every cache, and three passes of 16 loads were three memory latencies -- then the differences and
+        // the ds_write_b128s
         const float *frame_base = a.frames + (size_t) frame * a.n_streams * a.pitch + a.wstart;
         const int stretches = (a.wh + 63) >> 6;
         const int units = ((a.usable_pad - wave + NW - 1) / NW) * stretches;
         int r = 0, st = 0;  // the unit about to be taken: row wave + 16 r, elements 64 st .. 64 st + 63 (wave-uniform counters)
-        for (int u0 = 0; u0 < units; u0 += 4) {
-            float c0[4], n0[4], c1[4], n1[4], gm[4];
-            int slot[4];
+        constexpr int kUnits = 12;
+        for (int u0 = 0; u0 < units; u0 += kUnits) {
+            float c0[kUnits], n0[kUnits], c1[kUnits], n1[kUnits], gm[kUnits];
+            int slot[kUnits];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < kUnits; j++) {
                 const int s = wave + NW * r, t = 64 * st + lane;
                 const bool on = u0 + j < units && t < a.wh;
                 slot[j] = on ? s * a.wh + t : -1;
@@ -1661,7 +1664,7 @@ __global__ __launch_bounds__(NW * 64) void das_exact_ndh_kernel(ExactNdhArgs a) 
                 if (++st == stretches) st = 0, r++;
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < kUnits; j++) {
                 if (slot[j] < 0) continue;
                 const f2 lo = next_and_difference(c0[j], n0[j], gm[j]), hi = next_and_difference(c1[j], n1[j], gm[j]);
                 ((f4 *) lds)[slot[j]] = f4{lo.x, hi.x, lo.y, hi.y};

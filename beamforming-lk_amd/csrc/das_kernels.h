@@ -350,6 +350,10 @@ hipError_t launch_upscale(const uint8_t *d_src, int srows, int scols, int batch,
 hipError_t launch_unpack_block(const void *d_datagrams, int stride_bytes, int n_sensors, float *d_ring, int pos,
                                hipStream_t stream);
 
+// n floats (a multiple of 4, both pointers 16-byte aligned) from PINNED HOST memory to device memory by a kernel: the one-frame host
+// call's upload (75 KB at the reference's shape) -- a DMA engine copy of that size is 8-9 us of start-up, a kernel reading over PCIe 3
+hipError_t launch_upload_floats(const float *h_pinned, float *d_dst, size_t n, hipStream_t stream);
+
 // LDS bytes the exact kernel asks for with the given window; 0 if the window cannot fit.
 size_t das_exact_lds_bytes(int window, int usable, int *chunk_out);
 

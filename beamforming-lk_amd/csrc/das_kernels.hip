@@ -481,4 +481,17 @@ hipError_t launch_das_exact(const SweepArgs &a, bool bf16_accumulator, hipStream
     return hipGetLastError();
 }
 
+__global__ void upload_floats_kernel(const float4 *src, float4 *dst, size_t n4) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t) gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+hipError_t launch_upload_floats(const float *h_pinned, float *d_dst, size_t n, hipStream_t stream) {
+    if ((n & 3) || ((uintptr_t) h_pinned & 15) || ((uintptr_t) d_dst & 15)) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    if (n4 == 0) return hipSuccess;
+    const unsigned blocks = (unsigned) std::min<size_t>((n4 + 255) / 256, 256);  // 16 bytes per lane: 64 KB per pass of 16 workgroups
+    hipLaunchKernelGGL(upload_floats_kernel, dim3(blocks), dim3(256), 0, stream, (const float4 *) h_pinned, (float4 *) d_dst, n4);
+    return hipGetLastError();
+}
+
 }  // namespace awpu
