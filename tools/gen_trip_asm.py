@@ -656,6 +656,7 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row, int ng, un
 
 ND_ACC = 10    # block_exact_nd: out[] of quad q, pixel p pinned at v[ND_ACC + 32 q + 8 p ..+7]
 ND_TMP = 74    # its 52 temps (two 16-register slots for the reference pixel's elements, one for whichever pixel leaves it, t, address)
+ND_PPT_H = int(os.environ.get("ND_PPT_H", "1"))  # refill pieces per trip of the single-frame blocks, in units of 16 KiB
 ND_TIMING = os.environ.get("ND_TIMING", "")  # tuning builds only (see the end of block_exact_nd)
 
 
@@ -810,7 +811,9 @@ def block_exact_nd(name, nq, nk=4, nw=16):
     def trip_n(par):
         cur, nxt = E[par], E[1 - par]
         L = []
-        for _ in range(16 // nw):  # 16 KiB of the refill per trip, whatever the piece
+        # 16 KiB of the refill per trip, whatever the piece; the single-frame blocks (nk = 2: a chunk is a handful of short trips) issue
+        # ND_PPT_H times that, so that the last piece is out some trips before the chunk's end and not one (tuning: ND_PPT_H)
+        for _ in range((16 // nw) * (ND_PPT_H if nk == 2 else 1)):
             L += dma_piece()
         L += select_prio(S_PRIO, 1, QUAD_XMAP) if par == 0 else select_prio(S_RANK, 0, QUAD_YMAP)  # rotation / youngest first, trip by trip
         if nq > 1:  # a quad's last trip of the chunk fetches the OTHER quad's next entries (its own continue where they stopped)
