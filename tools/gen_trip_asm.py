@@ -811,8 +811,8 @@ def block_exact_nd(name, nq, nk=4, nw=16):
     def trip_n(par):
         cur, nxt = E[par], E[1 - par]
         L = []
-        # 16 KiB of the refill per trip, whatever the piece; the single-frame blocks (nk = 2: a chunk is a handful of short trips) issue
-        # ND_PPT_H times that, so that the last piece is out some trips before the chunk's end and not one (tuning: ND_PPT_H)
+        # 16 KiB of the refill per trip, whatever the piece (tuning knob ND_PPT_H: x that in the single-frame blocks -- measured SLOWER:
+        # c2 69 -> 71 / 81 us at 2 / 5 pieces per trip; profiles/r05_single_frame_ablation.txt)
         for _ in range((16 // nw) * (ND_PPT_H if nk == 2 else 1)):
             L += dma_piece()
         L += select_prio(S_PRIO, 1, QUAD_XMAP) if par == 0 else select_prio(S_RANK, 0, QUAD_YMAP)  # rotation / youngest first, trip by trip

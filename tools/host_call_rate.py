@@ -1,7 +1,11 @@
+#!/usr/bin/env python3
+"""One frame per SYNCHRONOUS host call (awpu_hip_process on a pageable host frame: upload + sweep + read-back): the call
+MIMOWorker::update makes once per 256-sample block (mimo.cpp:100-103), at the reference's shipped shape, both fp32 modes.
+With a tuning build and AWPU_LIVE_TIMING=1 the library prints the call's breakdown (gather / upload / launch / wait / copy out)."""
 import importlib, sys, time
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 pkg = importlib.import_module("beamforming-lk_amd")
 S = pkg.synthetic
 spec = S.WORKLOADS["ref_default"]
