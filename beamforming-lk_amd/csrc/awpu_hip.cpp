@@ -881,7 +881,7 @@ int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_powe
     a.n_pairs = (batch + 1) / 2;
     a.pair_group = xcd_pair_group_bytes((size_t) pp.usable_pad * pp.row_bytes, a.n_pairs);
     if (!h->d_nd_queue) {
-        AWPU_HIP_TRY(hipMalloc(&h->d_nd_queue, 8 * sizeof(unsigned)));
+        AWPU_HIP_TRY(hipMalloc(&h->d_nd_queue, 9 * sizeof(unsigned)));
         if (hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess || h->n_cus < 1) h->n_cus = 256;
     }
     {   // the item list: rebuilt (by the launcher, on the stream) when the batch, the pair group or the tile shape changed
@@ -902,10 +902,13 @@ int launch_exact_nd(awpu_hip *h, const float *d_frames, int batch, float *d_powe
     }
     a.queue = h->d_nd_queue;
     a.wgs = h->n_cus;
-    a.queues = 1;
+    {   // an eighth of every XCD's run goes to the common queue (the XCDs' speeds differ by ~6 %); short runs: one queue for the chip
+        const int per = (a.n_pairs * a.tiles + 7) / 8;
+        a.tail = per >= 32 ? (per + 7) / 8 : per;
 #ifdef AWPU_TUNING_BUILD
-    if (const char *v = std::getenv("AWPU_ND_QUEUES")) a.queues = std::atoi(v) == 8 ? 8 : 1;
+        if (const char *v = std::getenv("AWPU_ND_TAIL")) a.tail = std::max(1, std::atoi(v) >= 100 ? per : per * std::atoi(v) / 100);  // percent of a run
 #endif
+    }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     if (!prepacked)
         AWPU_HIP_TRY(awpu::launch_pack_nd(d_frames, h->cfg.n_streams, hist_eff, wstart_eff, h->d_index, h->usable(), pp.usable_pad, h->d_gain,

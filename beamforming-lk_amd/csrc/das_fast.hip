@@ -1353,39 +1353,44 @@ __global__ void pack_nd_kernel(const float *frames, int n_streams, int hist, int
 }
 
 // Work distribution (round 5): PERSISTENT workgroups -- one per CU: the two LDS images leave room for no second -- that take items
-// (frame pair, tile) from eight queues, one per XCD.  The items are ordered (pair group, tile, pair) and cut into eight contiguous
-// runs as before (an XCD's workgroups sweep a few frame pairs x a few tiles at a time: the pairs' samples stay in its 4 MiB L2 while
-// it walks the table), but a run is now a QUEUE (a.queue[x]: an atomic counter, zeroed by the launcher) that the workgroups of XCD x
-// (HW_REG_XCC_ID) drain, and a workgroup whose own queue is empty takes from the next XCD's: measured on the static split, the XCDs
-// of one chip finished 6 % apart (their clocks differ) and every CU idled 3.3 % of the launch waiting for the slowest.  A workgroup
-// knows its next item one item ahead (thread 0 takes it while the current one is swept; the mailbox is two ints behind the images), so
-// the block refills the next item's first chunk beside the current item's last: no staging gap between items (2.2 % before).
-// The item list of das_exact_nd_kernel: items[i] = (frame pair, first table quad of the tile) in the order (pair group, tile, pair) --
-// `pair_group` frame pairs x all tiles, then the next group (the last one may be smaller): consecutive items share a few pairs' samples.
-__global__ void nd_items_kernel(int2 *items, int n_pairs, int tiles, int pair_group, int tiles_per_row, int nq) {
-    const int item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= n_pairs * tiles) return;
-    const int full_items = (n_pairs / pair_group) * pair_group * tiles;
-    const int ga = item < full_items ? pair_group : n_pairs % pair_group;
-    const int rem = item < full_items ? item : item - full_items;
-    const int grp = rem / (tiles * ga), in = rem - grp * tiles * ga;
-    const int tile = in / ga;
-    const int pair = (item < full_items ? grp * pair_group : n_pairs - ga) + (in - tile * ga);
-    const int rowq = tile / tiles_per_row, colt = tile - rowq * tiles_per_row;
-    items[item] = int2{pair, (nq * rowq * tiles_per_row + colt) * 16};
-}
-
-__device__ __forceinline__ int nd_take(unsigned *queue, int x, int per_xcd, int total) {
-    const int begin = x * per_xcd, end = min(total, begin + per_xcd);
-    if (begin >= end) return -1;
-    const unsigned i = atomicAdd(&queue[x], 1u);
-    return i < (unsigned) (end - begin) ? begin + (int) i : -1;
-}
-__device__ __forceinline__ int nd_take_any(unsigned *queue, int xcd, int per_xcd, int total) {
-    int item = -1;
-    for (int y = 0; item < 0 && y < 8; y++) item = nd_take(queue, (xcd + y) & 7, per_xcd, total);
-    return item;
-}
+// (frame pair, tile) from queues (NdQueues below).  The items are ordered (pair group, tile, pair) and cut into eight contiguous runs,
+// one per XCD (HW_REG_XCC_ID), as before: an XCD's workgroups sweep a few frame pairs x a few tiles at a time, the pairs' samples stay
+// in its 4 MiB L2 while it walks the table.  Measured on that static split, the XCDs of one chip finished 6 % apart (their clocks
+// differ) and every CU idled 3.3 % of the launch waiting for the slowest; with ONE queue for the whole chip the tail shrank to 1.9 %
+// (-1.6 ... -2.6 %) but every XCD then loaded every pair's rows (L2 hit rate 96 -> 83 %, 2.8 GB instead of 0.7 GB from beyond the L2
+// per launch); a run's last eighth in a common queue keeps both: another -2.3 % (profiles/r05_ablation_nd_kernel.txt).  A workgroup
+// knows its next item one item ahead (thread 0 takes it while the current one is swept; the mailbox is two ints behind the images),
+// so the block refills the next item's first chunk beside the current item's last: no staging gap between items (2.2 % before).
+// The queues.  The item order is cut into eight runs of `per` items, run x = XCD x's: its frame pairs' rows stay in that XCD's L2.  Each
+// run's last `tail` items belong to a NINTH, common queue (dealt run by run, round-robin); queue x < 8 holds the rest of run x.  A
+// workgroup of XCD x drains queue x, then the common queue, then -- last resort -- the other XCDs' queues: the XCDs of a chip finish their
+// equal shares 6 % apart (their clocks differ), and the common tail is what the fast ones take from the slow ones.  tail = the whole
+// run (a.tail >= per) makes it ONE queue for the chip.
+struct NdQueues {
+    unsigned *q;   // [9] counters, zeroed by the launcher
+    int per, total, tail;
+    __device__ __forceinline__ int len(int x) const { return max(0, min(per, total - x * per)); }
+    __device__ __forceinline__ int head(int x) const { return len(x) - min(len(x), tail); }
+    __device__ __forceinline__ int take_head(int x) const {
+        if (head(x) <= 0) return -1;
+        const unsigned i = atomicAdd(&q[x], 1u);
+        return i < (unsigned) head(x) ? x * per + (int) i : -1;
+    }
+    __device__ __forceinline__ int take_common() const {
+        for (;;) {
+            const unsigned j = atomicAdd(&q[8], 1u);
+            const int run = (int) (j & 7u), k = (int) (j >> 3);
+            if (k >= tail) return -1;  // (k only grows: every run's tail is dealt)
+            if (k < len(run) - head(run)) return run * per + head(run) + k;
+        }
+    }
+    __device__ __forceinline__ int take(int xcd) const {  // own queue, the common tail, then anybody's
+        int item = take_head(xcd);
+        if (item < 0) item = take_common();
+        for (int y = 1; item < 0 && y < 8; y++) item = take_head((xcd + y) & 7);
+        return item;
+    }
+};
 
 template <int NQ, bool SUMS>
 __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
@@ -1398,15 +1403,12 @@ __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
     const int total = a.n_pairs * a.tiles;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    // a.queues = 1: ONE queue for the chip (every workgroup takes the next item of the whole order: at any moment the 256 items in
-    // flight are one pair group's -- 2 pairs x 128 tiles at the headline -- so every XCD's L2 holds the same few pairs' samples);
-    // 8: one run per XCD as before (tuning builds: AWPU_ND_QUEUES)
-    const int per_xcd = a.queues == 1 ? total : (total + 7) >> 3;
-    const int xcd = a.queues == 1 ? 0 : (int) (xcc & 7u);
+    const NdQueues Q{a.queue, (total + 7) >> 3, total, a.tail};
+    const int xcd = (int) (xcc & 7u);
     if (threadIdx.x == 0) {
-        const int first = nd_take_any(a.queue, xcd, per_xcd, total);
+        const int first = Q.take(xcd);
         mail[0] = first;
-        mail[1] = first >= 0 ? nd_take_any(a.queue, xcd, per_xcd, total) : -1;
+        mail[1] = first >= 0 ? Q.take(xcd) : -1;
     }
     __syncthreads();
     int cur = __builtin_amdgcn_readfirstlane(mail[0]), nxt = __builtin_amdgcn_readfirstlane(mail[1]);
@@ -1430,7 +1432,7 @@ __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
     const unsigned dbl = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) last_mics * row_floats * 4));
     const unsigned db0 = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) first_mics * row_floats * 4));
     const int rank = wave >> 2;  // age order of this wave among the four that share its SIMD
-    const int own_begin = xcd * per_xcd, own_end = min(total, own_begin + per_xcd);
+    const int own_head = Q.head(xcd);  // items of this XCD's own queue
 
     int pair, tile;
     decode(cur, pair, tile);
@@ -1472,7 +1474,7 @@ __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
         // workgroup of the XCD on the same counter -- runs beside the item, not in front of it.  (From C++ the compiler's atomic
         // optimizer reads the answer back at once, and any scratch reload in front of the block waits for it with vmcnt(0).)
         unsigned ticket = 0;
-        const bool asked = wave == 0 && nxt >= 0 && own_begin < own_end;
+        const bool asked = wave == 0 && nxt >= 0 && own_head > 0;
         const unsigned *qptr = (const unsigned *) uniform_ptr(asked ? a.queue + xcd : nullptr);
 
         f8 O[NQ][4];  // (float out[N_SAMPLES] = {0.0}, mimo.cpp:122: the block zeroes them itself)
@@ -1504,8 +1506,11 @@ __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
             step += n_chunks;
         }
         if (threadIdx.x == 0 && nxt >= 0) {  // the answer, into the mailbox at once (not carried through the epilogue)
-            int got = own_begin < own_end && ticket < (unsigned) (own_end - own_begin) ? own_begin + (int) ticket : -1;
-            if (got < 0) got = nd_take_any(a.queue, (xcd + 1) & 7, per_xcd, total);  // own queue empty: the other XCDs' (only at the launch's tail)
+            int got = own_head > 0 && ticket < (unsigned) own_head ? xcd * Q.per + (int) ticket : -1;
+            if (got < 0) {  // own queue empty: the common tail, then anybody's (only near the launch's end)
+                got = Q.take_common();
+                for (int y = 1; got < 0 && y < 8; y++) got = Q.take_head((xcd + y) & 7);
+            }
             mail[0] = got;
         }
 #ifdef AWPU_TUNING_BUILD
@@ -2707,7 +2712,7 @@ static hipError_t launch_exact_nd_variant(const ExactNdArgs &a, hipStream_t stre
     if (hipError_t e = allow_lds((const void *) das_exact_nd_kernel<NQ, SUMS>, lds_bytes, attr_set); e != hipSuccess) return e;
     // one persistent workgroup per CU (the LDS holds no second one), never more than there are items; the queues start at zero
     const long total = (long) a.n_pairs * a.tiles;
-    if (hipError_t e = hipMemsetAsync(a.queue, 0, 8 * sizeof(unsigned), stream); e != hipSuccess) return e;
+    if (hipError_t e = hipMemsetAsync(a.queue, 0, 9 * sizeof(unsigned), stream); e != hipSuccess) return e;
     if (a.build_items)
         hipLaunchKernelGGL(nd_items_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, stream, const_cast<int2 *>(a.items), a.n_pairs,
                            a.tiles, a.pair_group, (a.cols + 15) / 16, NQ);
@@ -2716,7 +2721,7 @@ static hipError_t launch_exact_nd_variant(const ExactNdArgs &a, hipStream_t stre
 }
 
 hipError_t launch_das_exact_nd(const ExactNdArgs &a, const Extents &have, hipStream_t stream) {
-    if ((a.nq != 1 && a.nq != 2) || !a.queue || !a.items || a.wgs < 1) return hipErrorInvalidValue;
+    if ((a.nq != 1 && a.nq != 2) || !a.queue || !a.items || a.wgs < 1 || a.tail < 1) return hipErrorInvalidValue;
     if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || a.usable < 1 || a.usable > a.usable_pad || a.wq < kSamples ||
         (size_t) a.chunk * a.wq * 16 > (size_t) kFastLdsBytes || a.cols < 1 || a.rows * a.cols != a.pixel_count)
         return hipErrorInvalidValue;

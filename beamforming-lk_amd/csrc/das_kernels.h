@@ -164,9 +164,9 @@ struct ExactNdArgs {
     int32_t cols, rows;
     int32_t nq;            // quads per wave: a workgroup tile is 4 nq rows x 16 columns
     int32_t tiles, n_pairs, pair_group;  // nd_tiles(rows, cols, nq); frame pairs, and how many an XCD works on at a time
-    unsigned *queue;                     // [8] item counters, one per XCD: device memory of the handle, zeroed by the launcher on the stream
+    unsigned *queue;                     // [9] item counters (one per XCD + the common tail): device memory of the handle, zeroed by the launcher on the stream
     int32_t wgs;                         // persistent workgroups to launch: the device's CUs (one fits a CU)
-    int32_t queues;                      // 1: one item queue for the chip; 8: one per XCD (contiguous runs of the item order)
+    int32_t tail;                        // items at the end of every XCD's run that go to the common queue (>= the run: one queue for the chip)
     const int2 *items;                   // [n_pairs * tiles] (frame pair, first table quad of the tile), item order; device memory of the handle
     int32_t build_items;                 // the launcher runs nd_items_kernel first (the list is stale: another batch size, nq or pair group)
     unsigned long long *debug_out;       // tuning builds (AWPU_FAST_DEBUG=16): 8 words per workgroup -- where and when it ran -- or null
