@@ -1361,6 +1361,21 @@ __global__ void pack_nd_kernel(const float *frames, int n_streams, int hist, int
 // per launch); a run's last eighth in a common queue keeps both: another -2.3 % (profiles/r05_ablation_nd_kernel.txt).  A workgroup
 // knows its next item one item ahead (thread 0 takes it while the current one is swept; the mailbox is two ints behind the images),
 // so the block refills the next item's first chunk beside the current item's last: no staging gap between items (2.2 % before).
+// The item list of das_exact_nd_kernel: items[i] = (frame pair, first table quad of the tile) in the order (pair group, tile, pair) --
+// `pair_group` frame pairs x all tiles, then the next group (the last one may be smaller): consecutive items share a few pairs' samples.
+__global__ void nd_items_kernel(int2 *items, int n_pairs, int tiles, int pair_group, int tiles_per_row, int nq) {
+    const int item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= n_pairs * tiles) return;
+    const int full_items = (n_pairs / pair_group) * pair_group * tiles;
+    const int ga = item < full_items ? pair_group : n_pairs % pair_group;
+    const int rem = item < full_items ? item : item - full_items;
+    const int grp = rem / (tiles * ga), in = rem - grp * tiles * ga;
+    const int tile = in / ga;
+    const int pair = (item < full_items ? grp * pair_group : n_pairs - ga) + (in - tile * ga);
+    const int rowq = tile / tiles_per_row, colt = tile - rowq * tiles_per_row;
+    items[item] = int2{pair, (nq * rowq * tiles_per_row + colt) * 16};
+}
+
 // The queues.  The item order is cut into eight runs of `per` items, run x = XCD x's: its frame pairs' rows stay in that XCD's L2.  Each
 // run's last `tail` items belong to a NINTH, common queue (dealt run by run, round-robin); queue x < 8 holds the rest of run x.  A
 // workgroup of XCD x drains queue x, then the common queue, then -- last resort -- the other XCDs' queues: the XCDs of a chip finish their
