@@ -1218,6 +1218,20 @@ int launch_quads(awpu_hip *h, const float *d_frames, int batch, float *d_power, 
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device) == hipSuccess) qa.wgs = n_cu;
     }
     if (qa.wgs < 0) qa.wgs = 0;  // AWPU_FAST_WGS=-1: one workgroup per item everywhere
+    // Round 5: the persistent workgroups take their items from queues (one per XCD, a run's last eighth common to the chip) instead of
+    // static shares -- balanced whatever the XCDs' clocks and whoever else holds CUs, so a rank's slab takes them too
+    if (env().wgs == 0) {
+        if (!h->d_nd_queue) {
+            AWPU_HIP_TRY(hipMalloc(&h->d_nd_queue, 9 * sizeof(unsigned)));
+            if (hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess || h->n_cus < 1) h->n_cus = 256;
+        }
+        if (h->n_cus < 1 && (hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess || h->n_cus < 1))
+            h->n_cus = 256;
+        qa.queue = h->d_nd_queue;
+        qa.wgs = h->n_cus;
+        const int per = (qa.n_pairs * qa.tiles + 7) / 8;
+        qa.tail = per >= 32 ? (per + 7) / 8 : per;
+    }
     qa.debug_out = nullptr;
     size_t n_waves = 0;
     if (qa.debug & 16) {

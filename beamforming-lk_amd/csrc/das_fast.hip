@@ -1979,8 +1979,32 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         tile = in / ga;
         pair = (item < full_items ? grp * a.pair_group : a.n_pairs - ga) + (in - tile * ga);
     };
-    int item = run_begin + (blockIdx.x >> 3);
-    if (item >= run_end) return;  // (uniform for the workgroup)
+    // a.queue (the production launch): persistent workgroups that take their items from the queues of das_exact_nd_kernel (NdQueues:
+    // one per XCD -- the run above -- whose last eighth is common to the chip) instead of every (gridDim / 8)-th item of their XCD's
+    // run: the XCDs of a chip finish equal shares 6 % apart.  The item after the next is taken inside the sweep block (qptr).
+    const bool queued = !DIAG && VAR == 0 && a.queue != nullptr;
+    const NdQueues Q{a.queue, per_xcd, total, a.tail};
+    int *mail = (int *) (lds + 2 * (BUF / 4));  // two ints behind the images
+    int xcd = (int) (blockIdx.x & 7);
+    int item, nxt = -1;
+    if (queued) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcd = (int) (xcc & 7u);
+        if (threadIdx.x == 0) {
+            const int first = Q.take(xcd);
+            mail[0] = first;
+            mail[1] = first >= 0 ? Q.take(xcd) : -1;
+        }
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(mail[0]);
+        nxt = __builtin_amdgcn_readfirstlane(mail[1]);
+        if (item < 0) return;  // (uniform for the workgroup)
+        __syncthreads();
+    } else {
+        item = run_begin + (blockIdx.x >> 3);
+        if (item >= run_end) return;  // (uniform for the workgroup)
+    }
 
     const int tiles_per_row4 = (a.cols + NW - 1) / NW;
     const int groups_total = a.usable_pad >> 2;
@@ -2036,9 +2060,10 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
         const QuadEntry *quad_lut = a.lut + (size_t) quad * groups_total * 16;
         const float *pair_base = a.packed + (size_t) pair * a.usable_pad * row_floats;
         // ---- the item after it
-        const int item_next = item + wgs_per_xcd;
+        const int item_next = queued ? nxt : item + wgs_per_xcd;
+        const bool more = queued ? nxt >= 0 : item_next < run_end;
         int pair_next = 0, tile_next = 0;
-        if (item_next < run_end) decode(item_next, pair_next, tile_next);
+        if (more) decode(item_next, pair_next, tile_next);
 
         f8 A0 = {0, 0, 0, 0, 0, 0, 0, 0}, A1 = A0, A2 = A0, A3 = A0, T = A0, V0 = A0, V2 = A0, V3 = A0;
         if constexpr (!DIAG && VAR == 0) {
@@ -2050,14 +2075,24 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
             const int ngl = __builtin_amdgcn_readfirstlane(chunk_mics((n_chunks - 1) * a.chunk) >> 2);
             const unsigned dbf = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) a.chunk * row_floats * 4));
             const unsigned dbl = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) ngl * 4 * row_floats * 4));
-            const bool more = item_next < run_end;
             const float *nsrc = more ? a.packed + (size_t) pair_next * a.usable_pad * row_floats : pair_base;
             const unsigned dbn = __builtin_amdgcn_readfirstlane(more ? (unsigned) ((size_t) chunk_mics(0) * row_floats * 4) : 0u);
             const unsigned ddst = __builtin_amdgcn_readfirstlane(lds_base + (buf ^ 1) * BUF + wave * 1024);
             const int delta = __builtin_amdgcn_readfirstlane(buf ? -BUF : BUF);
+            unsigned ticket = 0;
+            const bool asked = queued && wave == 0 && more && Q.head(xcd) > 0;
+            const unsigned *qptr = (const unsigned *) uniform_ptr(asked ? a.queue + xcd : nullptr);
             sweep_quad_item(A0, A1, A2, A3, T, V0, V2, V3, uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
-                            lane_addr, rank, uniform_ptr(pair_base), dbf, dbl, uniform_ptr(nsrc), dbn, ddst, delta, lane_bytes, wave);
+                            lane_addr, rank, uniform_ptr(pair_base), dbf, dbl, uniform_ptr(nsrc), dbn, ddst, delta, lane_bytes, qptr, ticket);
             step += n_chunks;
+            if (queued && threadIdx.x == 0 && more) {  // the answer, into the mailbox at once (not carried through the epilogue)
+                int got = Q.head(xcd) > 0 && ticket < (unsigned) Q.head(xcd) ? xcd * Q.per + (int) ticket : -1;
+                if (got < 0) {  // own queue empty: the common tail, then anybody's (only near the launch's end)
+                    got = Q.take_common();
+                    for (int y = 1; got < 0 && y < 8; y++) got = Q.take_head((xcd + y) & 7);
+                }
+                mail[0] = got;
+            }
         } else
         for (int c = 0; c < n_chunks; c++, step++) {
             const int m0 = c * a.chunk;
@@ -2143,10 +2178,15 @@ __global__ __launch_bounds__(1024, 4) void das_quad_kernel(QuadArgs a) {
             if ((lane & 7) == 0 && row < a.rows && col < a.cols && frame < a.batch)
                 a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;
         }
-        if (item_next >= run_end) break;
+        if (!more) break;
         item = item_next;
         pair = pair_next;
         tile = tile_next;
+        if (queued) {
+            __syncthreads();  // (the mailbox was written before the epilogue)
+            nxt = __builtin_amdgcn_readfirstlane(mail[0]);
+            __syncthreads();  // (everybody has read it before thread 0 writes it again)
+        }
     }
 
     if (DIAG && a.debug_out && lane == 0) {
@@ -2853,7 +2893,7 @@ hipError_t launch_das_pairs(const PairArgs &a, const Extents &have, hipStream_t 
 template <bool DIAG, int VAR>
 static hipError_t launch_quad_variant(const QuadArgs &a, const Extents &have, hipStream_t stream) {
     static LdsFlags attr_set = {};
-    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    constexpr int lds_bytes = 2 * kFastLdsBytes + 64;  // two images + the item mailbox of the queued launch
     if (hipError_t e = allow_lds((const void *) das_quad_kernel<DIAG, VAR>, lds_bytes, attr_set); e != hipSuccess) return e;
     // One workgroup per item by default: the hardware hands items to CUs as they free up, which stays balanced when
     // something else (an RCCL broadcast of the next batch) holds a few CUs.  a.wgs > 0 (AWPU_FAST_WGS) launches that
@@ -2866,9 +2906,17 @@ static hipError_t launch_quad_variant(const QuadArgs &a, const Extents &have, hi
     if (!within({quad_table_reach(a.rows, a.cols, a.usable_pad), (size_t) a.n_pairs * a.usable_pad * a.wp * 2}, have)) return hipErrorInvalidValue;
     const long items = (long) a.n_pairs * a.tiles;
     const long per_xcd = (items + 7) / 8;
+    if (!DIAG && VAR == 0 && a.queue && a.wgs > 0) {  // persistent workgroups on the item queues (das_quad_kernel: `queued`)
+        if (a.tail < 1) return hipErrorInvalidValue;
+        if (hipError_t e = hipMemsetAsync(a.queue, 0, 9 * sizeof(unsigned), stream); e != hipSuccess) return e;
+        hipLaunchKernelGGL((das_quad_kernel<DIAG, VAR>), dim3((unsigned) std::min<long>(items, a.wgs)), dim3(1024), lds_bytes, stream, a);
+        return hipGetLastError();
+    }
+    QuadArgs b = a;
+    b.queue = nullptr;  // (the stamped and the tuning instances keep the static shares)
     const long wgs_per_xcd = a.wgs > 0 ? std::min<long>(per_xcd, std::max(1, a.wgs / 8)) : per_xcd;
     if (8 * wgs_per_xcd > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((das_quad_kernel<DIAG, VAR>), dim3((unsigned) (8 * wgs_per_xcd)), dim3(1024), lds_bytes, stream, a);
+    hipLaunchKernelGGL((das_quad_kernel<DIAG, VAR>), dim3((unsigned) (8 * wgs_per_xcd)), dim3(1024), lds_bytes, stream, b);
     return hipGetLastError();
 }
 

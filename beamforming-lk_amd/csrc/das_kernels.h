@@ -240,6 +240,8 @@ struct QuadArgs {
     int32_t n_pairs, pair_group;  // frame pairs, and how many of them one XCD works on at a time
     int32_t variant;              // tuning builds only (AWPU_QUAD_VARIANT)
     int32_t wgs;                  // persistent workgroups to launch (0 = one workgroup per item; AWPU_FAST_WGS)
+    unsigned *queue;              // [9] item counters (NdQueues: one per XCD + the common tail), zeroed by the launcher; null: the static shares
+    int32_t tail;                 // with `queue`: items at the end of every XCD's run that go to the common queue
     unsigned long long *debug_out;
     int32_t debug;
 };

@@ -1328,8 +1328,7 @@ def _block_quad_item(name, env):
               f".Lrset{u}:",
               f"s_mov_b32 s{S_K}, 0", f"s_add_u32 s{S_NP}, s{S_REM}, {DMA_STRIDE - 1}",
               f"s_lshr_b32 s{S_NP}, s{S_NP}, {DMA_STRIDE.bit_length() - 1}"]
-        if DMA_WAVES < 16:
-            L += [f"s_cmp_ge_u32 %[wave], {DMA_WAVES}", f"s_cselect_b32 s{S_NP}, 0, s{S_NP}"]
+        assert DMA_WAVES == 16, "round 5 dropped the block's wave input (the refill by fewer than 16 waves was measured slower in round 2)"
         return L
 
     def boundary(next_set, resume):
@@ -1347,6 +1346,11 @@ def _block_quad_item(name, env):
     L = [f"s_mov_b32 s{S_PRIO}, %[rank]", f"s_mov_b32 s{S_RANK}, %[rank]"]
     if prio == 4:
         L += select_prio(S_RANK, 0)
+    # the persistent kernel's ticket for its next-but-one item (round 5, as in block_exact_nd): lane 0 of the wave that is handed a
+    # queue's address adds one to that counter here, beside the sweep; the first chunk boundary's vmcnt(0) proves the answer
+    L += ["s_cmp_eq_u64 %[qptr], 0", "s_cbranch_scc1 .LQnoq_%=", "s_mov_b64 exec, 1",
+          f"v_mov_b32 v{R[1]}, 0", f"v_mov_b32 v{R[1] + 1}, 1", f"global_atomic_add %[ticket], v{R[1]}, v{R[1] + 1}, %[qptr] sc0",
+          "s_mov_b64 exec, -1", ".LQnoq_%=:"]
     L += [f"s_mov_b32 s{S_M0}, m0", f"s_mov_b32 s{S_CH}, %[nch]", f"s_mov_b32 s{S_DELTA}, %[delta]",
           f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[isrc]", f"s_mov_b32 s{S_DST}, %[ddst]"]
     L += refill_params(first=True)
@@ -1378,12 +1382,12 @@ def _block_quad_item(name, env):
 // on exit (the caller tracks the image by the chunk count).  Executes nch s_barrier instructions.
 __device__ __forceinline__ void {name}({acc_params}, const void *row, int ngf, int ngl, int nch, unsigned &lane_addr, int rank,
                                        const void *isrc, unsigned dbf, unsigned dbl, const void *nsrc, unsigned dbn, unsigned ddst,
-                                       int delta, unsigned lbytes, int wave) {{
+                                       int delta, unsigned lbytes, const unsigned *qptr, unsigned &ticket) {{
     asm volatile(
 {body}
-        : {acc_ops}, [lane] "+v"(lane_addr)
+        : {acc_ops}, [lane] "+v"(lane_addr), [ticket] "=&v"(ticket)
         : [ptr] "s"(row), [ngf] "s"(ngf), [ngl] "s"(ngl), [nch] "s"(nch), [rank] "s"(rank), [isrc] "s"(isrc), [dbf] "s"(dbf), [dbl] "s"(dbl),
-          [nsrc] "s"(nsrc), [dbn] "s"(dbn), [ddst] "s"(ddst), [delta] "s"(delta), [lbytes] "v"(lbytes), [wave] "s"(wave)
+          [nsrc] "s"(nsrc), [dbn] "s"(dbn), [ddst] "s"(ddst), [delta] "s"(delta), [lbytes] "v"(lbytes), [qptr] "s"(qptr)
         : {clobbers});
 }}
 """
