@@ -74,7 +74,7 @@ PEER_SAME_DEVICE, PEER_DIRECT, PEER_HOST_STAGED = 0, 1, 2
 EXCHANGE_NONE, EXCHANGE_WINDOWS, EXCHANGE_PACKED_PAIRS = 0, 1, 2  # Stats.group_exchange
 # awpu_kernel_id (include/awpu_hip.h): Stats.kernel_variant after a launch
 KERNEL_NAMES = ("none", "quad", "pair", "pair_stationary", "quadh", "quadh_stationary", "single_db", "single_small", "fir8_planes",
-                "fir8", "exact_pair", "exact_verify", "tuning", "exact_quad", "exact_nd", "exact_ndh", "exact_ndh_stationary")
+                "fir8", "exact_pair", "exact_verify", "tuning", "exact_quad", "exact_nd", "exact_ndh", "exact_ndh_stationary", "exact_ndp")
 
 _lib: Optional[C.CDLL] = None
 

@@ -220,7 +220,7 @@ int ensure_diag(awpu_hip *h, size_t words) {
 //   AWPU_SHAPE             force one of the production sweep shapes wherever it can serve the call (tests sweep every shape
 //                          through the oracle this way; the default rule -- launch() below -- picks by table statistics and launch size):
 //                          pair | pair_vertical | pair_horizontal | quad | noquad | stationary | quadh | quadh_chunked | single_db | single_small |
-//                          fir8_planes | exact_pair | exact_quad | exact_nd1 | exact_nd2 | exact_verify
+//                          fir8_planes | exact_pair | exact_quad | exact_nd1 | exact_nd2 | exact_ndp | exact_verify
 //   AWPU_LIVE_GRAPH=0      awpu_hip_live_block always enqueues its steps one by one (no HIP-graph replay)
 //   AWPU_GROUP_FORCE_COPY  device groups: 1 = a part on devices[0] takes the window-copy path too, 2 = through pinned host
 //                          memory (how one GPU exercises the paths a part on another GPU takes)
@@ -265,6 +265,7 @@ struct EnvKnobs {
             else if (shape == "exact_quad") exact_pairs = 3;  // round 4's quad kernel on raw sample pairs (cur - next per pixel)
             else if (shape == "exact_nd1") exact_pairs = 4;   // the {next, d} kernel with one quad per wave
             else if (shape == "exact_nd2") exact_pairs = 5;   // ... with two
+            else if (shape == "exact_ndp") exact_pairs = 6;   // single frames: one pixel per wave (das_exact_ndp_kernel) wherever its rows can be chunked
             else std::fprintf(stderr, "libawpu_hip: AWPU_SHAPE=%s is not a shape of this build; ignored\n", v);
         }
 #ifdef AWPU_TUNING_BUILD
@@ -993,7 +994,7 @@ bool takes_exact_nd(awpu_hip *h, int batch, int *nq) {
     // (quad_differ < 1.5: on average fewer than half of a quad's pixels leave the reference pixel's address for a mic; a square
     // array's vertical and horizontal neighbours coincide equally often -- pair_cols stays 0 there -- and quads still pay)
     const bool quads_pay = h->cfg.pixel_count % cols == 0 && h->cfg.pixel_begin % cols == 0 && h->quad_differ < 1.5;
-    if ((!(h->pair_cols > 0 || quads_pay) && ex != 4 && ex != 5) || rows < 4) return false;  // (a forced shape runs on any table: the random tests)
+    if ((!(h->pair_cols > 0 || quads_pay) && ex != 4 && ex != 5 && ex != 6) || rows < 4) return false;  // (a forced shape runs on any table: the random tests)
     // two quads per wave where that still fills the chip (AWPU_SHAPE=exact_nd1 / exact_nd2: one / two everywhere)
     const long wgs2 = (long) awpu::nd_tiles(rows, cols, 2) * ((batch + 1) / 2);
     *nq = ex == 4 ? 1 : ex == 5 ? 2 : (rows >= 8 && wgs2 >= 512 ? 2 : 1);
@@ -1003,7 +1004,7 @@ bool takes_exact_nd(awpu_hip *h, int batch, int *nq) {
 // single frames in the reference's order: the halves form of the {next, d} layout (das_exact_ndh_kernel) -- every mic resident and
 // staged by the workgroups themselves (one array), or chunked behind a pack pre-pass.  `pitch` = floats between two streams of a frame
 int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int pitch, int wstart_eff, bool stationary,
-                     int nq, int nw = 16) {
+                     int nq, int nw = 16, bool pixel_per_wave = false) {
     int rc = build_quad_lut(h, stationary ? kQuadExactNdhStationary : kQuadExactNdh);
     if (rc != AWPU_OK) return rc;
     const awpu::FastPlan &pp = stationary ? h->exact_ndhs_plan : h->exact_ndh_plan;
@@ -1032,7 +1033,7 @@ int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_pow
     a.rows = h->cfg.pixel_count / a.cols;
     a.nq = nq;
     a.nw = nw;
-    a.tiles = awpu::ndh_tiles(a.rows, a.cols, nq, nw);
+    a.tiles = pixel_per_wave ? awpu::ndp_tiles(a.rows, a.cols) : awpu::ndh_tiles(a.rows, a.cols, nq, nw);
     a.lut_cols = (a.cols + 31) / 32 * 32;
     a.identity = 1;
     for (int k = 0; k < a.usable && a.identity; k++) a.identity = h->index[k] == k;
@@ -1040,6 +1041,10 @@ int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_pow
     if (!stationary)
         AWPU_HIP_TRY(awpu::launch_pack_ndh(d_frames, h->cfg.n_streams, pitch, wstart_eff, h->d_index, h->usable(), pp.usable_pad, h->d_gain, pp.wr,
                                            batch, h->d_pack, s));
+    if (pixel_per_wave) {
+        AWPU_HIP_TRY(awpu::launch_das_exact_ndp(a, {h->quad_lut_entries[kQuadExactNdh], h->pack_cap}, s));
+        return finish_launch(h, batch, s, AWPU_KERNEL_EXACT_NDP);
+    }
     AWPU_HIP_TRY(awpu::launch_das_exact_ndh(a, stationary, {h->quad_lut_entries[stationary ? kQuadExactNdhStationary : kQuadExactNdh], stationary ? 0 : h->pack_cap}, s));
     return finish_launch(h, batch, s, stationary ? AWPU_KERNEL_EXACT_NDH_STATIONARY : AWPU_KERNEL_EXACT_NDH);
 }
@@ -1345,9 +1350,19 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         const bool nd = takes_exact_nd(h, batch, &nq);
         // one frame per call (MIMOWorker::update's regime): the halves form of the layout -- the two packed lanes are the two halves of
         // the block, not a frame and its copy; every mic resident where one array's rows fit the LDS (no pre-pass)
-        if (nd && batch == 1 && env().exact_pairs == 1 && (h->exact_ndhs_ok || h->exact_ndh_ok)) {
+        if (nd && batch == 1 && (env().exact_pairs == 1 || env().exact_pairs == 6) && (h->exact_ndhs_ok || h->exact_ndh_ok)) {
             const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
             const int nqh = (long) awpu::quad1_tiles(rows, cols, 2) >= 256 ? 2 : 1;
+            if (h->n_cus < 1 && (hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess || h->n_cus < 1))
+                h->n_cus = 256;
+            // chunked sweeps of grids of at most 16 pixels per CU: one PIXEL per wave (das_exact_ndp_kernel) -- a quad kernel leaves such a
+            // grid one wave per SIMD, and the frame then takes as long as that wave's instruction issue (c2, 64 x 64 x 256 mics)
+            bool solo = h->exact_ndh_ok && !h->exact_ndhs_ok && awpu::ndp_tiles(rows, cols) * (long) batch <= h->n_cus;
+            if (env().exact_pairs == 6) solo = h->exact_ndh_ok;
+#ifdef AWPU_TUNING_BUILD
+            if (const char *v = std::getenv("AWPU_NDH_WAVES")) solo = std::atoi(v) == 1 && h->exact_ndh_ok;
+#endif
+            if (solo) return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, false, 1, 16, true);
             // chunked sweeps of grids too small to give every CU a 16-wave workgroup: 8- or 4-wave workgroups -- half or a quarter of the
             // pixels each -- as long as they still run in ONE round of workgroups (c2, 64 x 64: 64 -> 256 workgroups).  Measured, c2, one
             // frame per call: 76.6 / 71.7 / 68.9 us with 16 / 8 / 4 waves -- a workgroup's time is the chain of its 13 chunk refills, not

@@ -1768,6 +1768,73 @@ __global__ __launch_bounds__(NW * 64) void das_exact_ndh_kernel(ExactNdhArgs a) 
 }
 
 // ---------------------------------------------------------------------------------------
+// Single frames in the reference's order, ONE PIXEL PER WAVE (round 5): das_exact_ndh_kernel's layout, table, arithmetic and
+// epilogue for grids that have too few quads to give every SIMD more than one wave (c2: 64 x 64 pixels = 1024 quads on 1024 SIMDs).
+// A quad block's trip is ~150 instructions issued by one wave, 64 of them arithmetic; with nothing else to run beside it the
+// frame takes as long as that wave's instruction issue (profiles/r05_single_frame_ablation.txt: 58 of c2's 69 us remain with NO
+// arithmetic at all).  Here a wave owns one pixel: no sharing of reads, hence no compare tree -- sweep_exact_ndp_item
+// (tools/gen_trip_asm.py: block_exact_solo), ~45 instructions per trip of which 16 are arithmetic -- and four times the waves: a
+// workgroup is 4 rows x 4 columns (16 waves; wave = 4 x column + row), 16 pixels per CU when the grid fits one round of workgroups.
+// The same per-lane sums and the same reduction tree as every other reference-order kernel: the same bits.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void das_exact_ndp_kernel(ExactNdhArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int kThreads = 1024, BUF = kFastLdsBytes;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
+    const int frame = blockIdx.x / a.tiles, tile = blockIdx.x - frame * a.tiles;
+    const int tiles_per_row4 = (a.cols + 3) >> 2;
+    const int row4 = tile / tiles_per_row4;
+    const int col = (tile - row4 * tiles_per_row4) * 4 + (wave >> 2), pp = wave & 3;  // (col < the table's columns: padded to 32)
+    const int groups_total = a.usable_pad >> 2;
+    const QuadEntry *pixel_lut = a.lut + ((size_t) row4 * a.lut_cols + col) * groups_total * 16 + pp * 4;  // 32 bytes of every 128-byte group
+    const size_t row_floats = (size_t) a.wh * 4;
+
+    constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
+    const float *frame_rows = a.packed + (size_t) frame * a.usable_pad * row_floats;
+    const int n_chunks = (a.usable_pad + a.chunk - 1) / a.chunk;
+    const int first_mics = min(a.chunk, a.usable_pad);
+    const int last_mics = a.usable_pad - (n_chunks - 1) * a.chunk;
+    const int n_pieces = (int) ((size_t) first_mics * row_floats / 4);
+#pragma unroll
+    for (int k = 0; k < kPieces; k++) {  // chunk 0 into image 0 (the block refills from chunk 1 on)
+        const int piece = threadIdx.x + k * kThreads;
+        if (piece < n_pieces) {
+            float *dst = lds + (wave * 64 + k * kThreads) * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (frame_rows + (size_t) piece * 4),
+                                             (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f4 O;  // (float out[N_SAMPLES] = {0.0}, mimo.cpp:122: the block zeroes it itself)
+    {
+        unsigned lane_addr = lds_base + lane * 16;
+        const int ngf = __builtin_amdgcn_readfirstlane(first_mics >> 2), ngl = __builtin_amdgcn_readfirstlane(last_mics >> 2);
+        const unsigned dbf = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) a.chunk * row_floats * 4));
+        const unsigned dbl = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) last_mics * row_floats * 4));
+        const unsigned ddst = __builtin_amdgcn_readfirstlane(lds_base + BUF + wave * 1024);
+        const unsigned lane_bytes = threadIdx.x * 16;
+        sweep_exact_ndp_item(O, uniform_ptr(pixel_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks), lane_addr, uniform_ptr(frame_rows), dbf,
+                             dbl, ddst, BUF, lane_bytes);
+    }
+
+    const int row = 4 * row4 + pp;
+    const bool live = row < a.rows && col < a.cols;
+    const float o[4] = {O[0], O[2], O[1], O[3]};  // sample order: l, 64 + l, 128 + l, 192 + l
+    if (a.sums && live) {
+        const size_t p = (size_t) row * a.cols + col;
+#pragma unroll
+        for (int k = 0; k < 4; k++) a.sums[((size_t) frame * a.pixel_count + p) * kSamples + lane + 64 * k] = o[k];
+    }
+    // the other kernels' reduction tree (wave_sum8; a value's tree does not depend on which of the eight places it takes)
+    const float total = wave_sum8(pixel_partial_exact(o, lane), 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, lane);
+    if (lane == 0 && live) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / (float) (kSamples * a.usable);
+}
+
+// ---------------------------------------------------------------------------------------
 // FIR8, four-plane frame-pair layout (the default for FIR8 batches): das_fir8_pair_kernel reads 32 LDS elements for
 // 32 FMAs, and the LDS array -- one per CU, 2 cycles per ds_read_b64, shared by four SIMDs that each want a
 // v_pk_fma_f32 every 4 cycles -- then holds the sweep at half the VALU rate.  Here a lane owns four CONSECUTIVE
@@ -2848,6 +2915,21 @@ hipError_t launch_das_exact_ndh(const ExactNdhArgs &a, bool stationary, const Ex
     if (a.nw == 8) return launch_exact_ndh_variant<1, false, 8>(a, stream);
     if (a.nw == 4) return launch_exact_ndh_variant<1, false, 4>(a, stream);
     return a.nq == 2 ? launch_exact_ndh_variant<2, false>(a, stream) : launch_exact_ndh_variant<1, false>(a, stream);
+}
+
+hipError_t launch_das_exact_ndp(const ExactNdhArgs &a, const Extents &have, hipStream_t stream) {
+    static LdsFlags attr_set = {};
+    constexpr int lds_bytes = 2 * kFastLdsBytes;
+    if (hipError_t e = allow_lds((const void *) das_exact_ndp_kernel, lds_bytes, attr_set); e != hipSuccess) return e;
+    if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || a.usable < 1 || a.usable > a.usable_pad || a.wh < kSamples / 2 || a.cols < 1 ||
+        a.rows * a.cols != a.pixel_count || a.batch < 1 || a.tiles != ndp_tiles(a.rows, a.cols) || (long) a.batch * a.tiles > 0x7fffffffL ||
+        (size_t) a.chunk * a.wh * 16 > (size_t) kFastLdsBytes || !a.packed || a.lut_cols < (a.cols + 3) / 4 * 4)
+        return hipErrorInvalidValue;
+    // reach: every quad of the table + TWO groups of prefetch (the block requests entries two trips ahead); usable_pad rows of wh elements per frame
+    const size_t quads = (size_t) ((a.rows + 3) / 4) * a.lut_cols;
+    if (!within({quads * (a.usable_pad / 4) * 16 + 2 * kQuadTablePrefetch, (size_t) a.batch * a.usable_pad * a.wh * 4}, have)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(das_exact_ndp_kernel, dim3((unsigned) ((long) a.batch * a.tiles)), dim3(1024), lds_bytes, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_das_exact_quads(const ExactQuadArgs &a, const Extents &have, hipStream_t stream) {

@@ -204,6 +204,10 @@ bool exact_ndh_plan(int window, int usable, bool stationary, FastPlan *plan);  /
 hipError_t launch_pack_ndh(const float *d_frames, int n_streams, int pitch, int wstart, const int32_t *d_index, int usable, int rows_out,
                            const float *d_gain, int wh, int batch, float *d_packed, hipStream_t stream);
 hipError_t launch_das_exact_ndh(const ExactNdhArgs &a, bool stationary, const Extents &have, hipStream_t stream);
+// ... one PIXEL per wave (das_exact_ndp_kernel: chunked, 16-wave workgroups of 4 rows x 4 columns; nq / nw unused): grids with too few quads
+// to give every SIMD more than one wave
+inline int ndp_tiles(int rows, int cols) { return ((rows + 3) / 4) * ((cols + 3) / 4); }
+hipError_t launch_das_exact_ndp(const ExactNdhArgs &a, const Extents &have, hipStream_t stream);
 // FIR8 on the four-plane frame-pair layout (a lane owns four consecutive outputs: 11 LDS reads per 32 FMAs).  Rows packed by
 // launch_pack_planes, `wr` a multiple of 4 (fir8_plane_plan); d_entries [pixel_count][usable_pad] + 4 spare dwords,
 // one per (pixel, mic): fir8_plane_word(LDS byte offset of X[off] in its chunk's image, its plane, coefficient row);

@@ -1730,13 +1730,13 @@ def test_exact_mode_sums_equal_the_oracle_on_every_pixel(pkg, oracle, wl, cols, 
         assert util.power_rel_err_unfloored(power[b], want_p) < 3e-6
 
 
-@pytest.mark.parametrize("case", ["ref_default", "ref_default_ragged_gains", "odd_grid", "c2", "c2_short", "c2_wide"])
+@pytest.mark.parametrize("case", ["ref_default", "ref_default_ragged_gains", "odd_grid", "c2", "c2_short", "c2_wide", "c2_ragged_gains"])
 def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
     """One frame per call in the reference's order -- MIMOWorker::update's regime (worker.h:212-224, mimo.cpp:97-151) -- on the halves
     form of the {next, d} layout (das_exact_ndh_kernel): one array at the reference's default resolution with every mic resident
     (100 x 100, main.cpp:38-41; also a ragged mic list with gains, and an odd grid), four arrays chunked behind the pack pre-pass
-    (and a grid of 30 rows: a last quad of two live pixels; 4-wave workgroups on these small grids, 8-wave ones on the 64 x 96 grid of
-    "c2_wide": das_exact_ndh_kernel<1, false, 4 | 8>).  The pre-epilogue sums equal oracle_das_f32's out[] bit for bit on EVERY
+    (64 x 64 and 30 x 64 -- a last quad of two live pixels --: one pixel per wave, das_exact_ndp_kernel; the 64 x 96 grid of "c2_wide":
+    quads in 8-wave workgroups, das_exact_ndh_kernel<1, false, 8>; a ragged mic list with gains there too).  The pre-epilogue sums equal oracle_das_f32's out[] bit for bit on EVERY
     pixel (DC-biased plane-wave frames), the powers are the bits the same frame gets inside a batch (das_exact_nd_kernel), and within
     1e-5 of the oracle on every pixel."""
     S = pkg.synthetic
@@ -1746,11 +1746,15 @@ def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
         spec = S.WORKLOADS["c2"]
         xyz = S.geometry(spec)
         off, frac = S.delay_table(spec, xyz)
-        rows, cols, n_streams, want = (30 if case == "c2_short" else spec.res), spec.res, spec.n_mics, "exact_ndh"
+        # (64 x 64 and 30 x 64: at most 16 pixels per CU -> one pixel per wave, das_exact_ndp_kernel)
+        rows, cols, n_streams, want = (30 if case == "c2_short" else spec.res), spec.res, spec.n_mics, "exact_ndp"
         off, frac = off[: rows * cols], frac[: rows * cols]
-        if case == "c2_wide":  # 16 quad rows x 96 columns: 384 four-wave tiles are more than the chip's CUs, 192 eight-wave tiles are not
-            rows, cols = 64, 96
+        if case == "c2_wide":  # 16 quad rows x 96 columns: 384 tiles of 16 pixels are more than the chip's CUs, 192 eight-wave tiles of quads are not
+            rows, cols, want = 64, 96, "exact_ndh"
             off, frac = pkg.build_delay_table(xyz, rows, cols, 180.0)
+        if case == "c2_ragged_gains":  # 205 active mics (a last group of one live mic + three silent ones), gains on
+            index = np.array([k for k in range(256) if k % 5 != 2], np.int32)
+            gains = (0.5 + np.arange(256) / 256.0).astype(np.float32)
     else:
         xyz = pkg.create_antenna()
         rows = cols = 99 if case == "odd_grid" else 100  # (99: an odd grid, whose centre pixel looks straight ahead)

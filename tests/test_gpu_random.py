@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
     {"AWPU_TEST_MATH": "exact", "AWPU_SHAPE": "exact_verify"},  # the round-1 verification kernel (the bf16 mode's structure)
     {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_SHAPE": "exact_nd2"},  # the {next, d} kernel on RANDOM delays: every pixel leaves the reference's address (its read-on-the-spot paths), batches of one as a pair with itself
     {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1", "AWPU_SHAPE": "exact_nd1"},  # ... one quad per wave, delays that mostly coincide
+    {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_SHAPE": "exact_ndp"},  # single frames: one pixel per wave, on random delays (batches >= 2: the {next, d} kernel)
     {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1", "AWPU_SHAPE": "exact_quad"},  # round 4's quad kernel on raw sample pairs (still the fallback)
     {"AWPU_TEST_PATH": "device"},                               # device-resident frames + two pixel shards per case
     {"AWPU_TEST_INTERP": "fir8"},                               # the 8-tap variant of delay()
@@ -35,7 +36,7 @@ pytestmark = pytest.mark.gpu
     {"AWPU_SHAPE": "quadh", "AWPU_TEST_GRID": "1"},                              # single-frame quad shape on the halves layout for every call
     {"AWPU_SHAPE": "quadh", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},
     {"AWPU_SHAPE": "quadh_chunked", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1"},  # ... never its resident-window variant
-], ids=["pairs", "db", "small", "exact", "exact_grid", "exact_grid_pairs", "exact_verify", "exact_nd2_random", "exact_nd1_coincide", "exact_quad_r4", "device", "fir8", "fir8_planes", "reuse", "pairs_vertical",
+], ids=["pairs", "db", "small", "exact", "exact_grid", "exact_grid_pairs", "exact_verify", "exact_nd2_random", "exact_nd1_coincide", "exact_ndp_random", "exact_quad_r4", "device", "fir8", "fir8_planes", "reuse", "pairs_vertical",
         "quads_random", "quads_coincide", "pairs_coincide", "stationary", "stationary_grid", "quadh_every_call", "quadh_coincide",
         "quadh_chunked"])
 def test_random_tables(env):

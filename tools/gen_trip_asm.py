@@ -951,6 +951,148 @@ __device__ __forceinline__ void {name}({acc_params}, const void *row{qs_param}, 
 """
 
 
+SOLO_ACC = 10   # block_exact_solo: out[] of the wave's pixel pinned at v[10:13]
+SOLO_TMP = 14   # two sets of four 8-register slots (a trip's elements: the set being swept, the set in flight), t, two address temps
+
+
+def block_exact_solo(name, nw=16):
+    """Reference-order sweep of ONE pixel per wave, single frames on the halves form of the {next, d} layout (das_exact_ndp_kernel):
+    block_exact_nd(nk = 2)'s arithmetic and item structure without the quad.  A quad block's trip of four mics is ~150 instructions
+    of which 64 are arithmetic (the rest picks, per mic, which pixels share the reference pixel's reads), issued by ONE wave: on a
+    grid of a few thousand pixels there are too few quads to give every SIMD more than one wave, and the frame waits for that one
+    wave's instruction issue (c2, 64x64 x 256 mics: 69 us, 58 of them with no arithmetic at all; profiles/r05_single_frame_ablation.txt).
+    A pixel per wave has four times the waves, no sharing and therefore no compare tree: per trip one s_load_dwordx8 (the pixel's
+    32 bytes of the quad's 128-byte line), 4 address adds + 8 ds_read_b128 for the NEXT trip, 16 packed VALU for this one, and ONE
+    wait -- lgkmcnt(0) at the head of a trip, for reads and entries that were requested a whole trip earlier.
+
+    Registers: E0 / E1 (8 SGPRs each) alternate trip by trip; at the head of trip n the set `cur` holds entries(n) and `nxt` entries(n+1):
+    cur's four (fraction, address) pairs are copied to F (the trip's arithmetic reads fractions from there), cur is reloaded with
+    entries(n+2), nxt's addresses issue the reads of trip n+1 into the other slot set.  A chunk's last trip issues no reads (the
+    next trip's rows are in the image still being refilled): the boundary does, after the barrier.  Reads two groups past the
+    pixel's last (never used)."""
+    DMA_PIECE = nw * 1024
+    O = SOLO_ACC
+    SL = [[SOLO_TMP + 32 * s + 8 * i for i in range(4)] for s in range(2)]
+    TT = SOLO_TMP + 64
+    AT = (TT + 4, TT + 5)
+    E = (36, 44)
+    F = 52
+    S_NG, S_CH, S_SB, S_TMP, S_PF_, S_LEFT_, S_DST, S_REM, S_K, S_NP, S_M0, S_DELTA = 17, 19, 20, 22, 23, 24, 25, 28, 29, 30, 31, 35
+
+    def uid():
+        COUNTER[0] += 1
+        return f"%=_{COUNTER[0]}"
+
+    def reads(slots, base):
+        L = []
+        for i in range(4):
+            L.append(f"v_add_u32 v{AT[i & 1]}, s{base + 2 * i + 1}, %[lane]")
+            L.append(f"ds_read_b128 v[{slots[i]}:{slots[i] + 3}], v{AT[i & 1]}")
+            L.append(f"ds_read_b128 v[{slots[i] + 4}:{slots[i] + 7}], v{AT[i & 1]} offset:1024")
+        return L
+
+    def terms(i, slot):  # t_k = fma(frac, d_k, next_k); out_k += t_k  (delay.cpp:21-25 on {next, d}), k = the lane's two sample pairs
+        fs = f"s[{F + 2 * i}:{F + 2 * i + 1}]"
+        L = [f"v_pk_fma_f32 v[{TT + 2 * k}:{TT + 2 * k + 1}], {fs}, v[{slot + 4 * k + 2}:{slot + 4 * k + 3}], v[{slot + 4 * k}:{slot + 4 * k + 1}] op_sel_hi:[0,1,1]"
+             for k in range(2)]
+        L += [f"v_pk_add_f32 v[{O + 2 * k}:{O + 2 * k + 1}], v[{O + 2 * k}:{O + 2 * k + 1}], v[{TT + 2 * k}:{TT + 2 * k + 1}]" for k in range(2)]
+        return L
+
+    def dma_piece():
+        u = uid()
+        return [f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Lpdskip{u}",
+                f"v_cmp_gt_u32 vcc, s{S_REM}, %[lbytes]", "s_mov_b64 exec, vcc",
+                f"s_mov_b32 m0, s{S_DST}", "s_nop 0",
+                f"global_load_lds_dwordx4 %[lbytes], s[{S_SB}:{S_SB + 1}]",
+                "s_mov_b64 exec, -1",
+                f"s_add_u32 s{S_SB}, s{S_SB}, {hex(DMA_PIECE)}", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+                f"s_add_u32 s{S_DST}, s{S_DST}, {hex(DMA_PIECE)}", f"s_sub_u32 s{S_REM}, s{S_REM}, {hex(DMA_PIECE)}",
+                f"s_add_u32 s{S_K}, s{S_K}, 1", f".Lpdskip{u}:"]
+
+    def refill_params(first):  # block_exact_nd's, without a next item: beside the last chunk nothing is refilled
+        u = uid()
+        L = []
+        if not first:
+            L += [f"s_lshl_b32 s{S_TMP}, s{S_K}, {DMA_PIECE.bit_length() - 1}",
+                  f"s_sub_u32 s{S_SB}, s{S_SB}, s{S_TMP}", f"s_subb_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+                  f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_TMP}",
+                  f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_DELTA}",
+                  f"s_sub_u32 s{S_DELTA}, 0, s{S_DELTA}"]
+        L += [f"s_mov_b32 s{S_REM}, 0", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cbranch_scc1 .Lprset{u}",
+              f"s_add_u32 s{S_SB}, s{S_SB}, %[dbf]", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+              f"s_mov_b32 s{S_REM}, %[dbf]", f"s_cmp_eq_u32 s{S_CH}, 2", f"s_cselect_b32 s{S_REM}, %[dbl], s{S_REM}",
+              f".Lprset{u}:",
+              f"s_mov_b32 s{S_K}, 0", f"s_add_u32 s{S_NP}, s{S_REM}, {DMA_PIECE - 1}",
+              f"s_lshr_b32 s{S_NP}, s{S_NP}, {DMA_PIECE.bit_length() - 1}"]
+        return L
+
+    def chunk_groups():
+        return [f"s_mov_b32 s{S_NG}, %[ngf]", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cselect_b32 s{S_NG}, %[ngl], s{S_NG}", f"s_mov_b32 s{S_LEFT_}, s{S_NG}"]
+
+    def trip_p(par):
+        cur, nxt = E[par], E[1 - par]
+        u = uid()
+        L = ["s_waitcnt lgkmcnt(0)"]  # this trip's elements (requested a trip ago) and entries(n+1)
+        L += [f"s_mov_b64 s[{F + 2 * i}:{F + 2 * i + 1}], s[{cur + 2 * i}:{cur + 2 * i + 1}]" for i in range(4)]
+        L += [f"s_load_dwordx8 s[{cur}:{cur + 7}], %[ptr], s{S_PF_}", f"s_add_u32 s{S_PF_}, s{S_PF_}, 128"]
+        L += [f"s_cmp_eq_u32 s{S_LEFT_}, 1", f"s_cbranch_scc1 .Lpnr{u}"] + reads(SL[1 - par], nxt) + [f".Lpnr{u}:"]
+        L += dma_piece()
+        for i in range(4):
+            L += terms(i, SL[par][i])
+        return L
+
+    def boundary(par_next):
+        u = uid()
+        L = ["s_waitcnt lgkmcnt(0)",
+             f".Lpmore{u}:", f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Lpnomore{u}"] + dma_piece() + [f"s_branch .Lpmore{u}", f".Lpnomore{u}:"]
+        L += ["s_waitcnt vmcnt(0)", "s_barrier",
+              f"s_sub_u32 s{S_CH}, s{S_CH}, 1", f"s_cmp_eq_u32 s{S_CH}, 0", "s_cbranch_scc1 .LPexit_%=",
+              f"v_add_u32 %[lane], s{S_DELTA}, %[lane]"]
+        L += refill_params(first=False) + chunk_groups() + reads(SL[par_next], E[par_next]) + [f"s_branch .LP{par_next}_%="]
+        return L
+
+    L = [f"v_mov_b32 v{r}, 0" for r in range(O, O + 4)]  # float out[N_SAMPLES] = {0.0} (mimo.cpp:122)
+    L += [f"s_mov_b32 s{S_M0}, m0", f"s_mov_b32 s{S_CH}, %[nch]", f"s_mov_b32 s{S_DELTA}, %[delta]",
+          f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[isrc]", f"s_mov_b32 s{S_DST}, %[ddst]"]
+    L += refill_params(first=True)
+    L += [f"s_load_dwordx8 s[{E[0]}:{E[0] + 7}], %[ptr], 0x0", f"s_load_dwordx8 s[{E[1]}:{E[1] + 7}], %[ptr], 0x80"]
+    L += chunk_groups() + [f"s_movk_i32 s{S_PF_}, 0x100", "s_waitcnt lgkmcnt(0)"] + reads(SL[0], E[0])
+    L += [".LP0_%=:"] + trip_p(0)
+    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_eq_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LPbndA_%="]
+    L += [".LP1_%=:"] + trip_p(1)
+    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LP0_%="]
+    L += boundary(0)
+    L += [".LPbndA_%=:"] + boundary(1)
+    L += [".LPexit_%=:", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 m0, s{S_M0}"]
+    if "nobarrier" in ND_TIMING:
+        L = ["s_nop 0" if l == "s_barrier" else l for l in L]
+    if "nolds" in ND_TIMING:
+        L = [l for l in L if not l.startswith("ds_read")]
+    if "novalu" in ND_TIMING:
+        L = [l for l in L if not l.startswith(("v_pk_fma_f32", "v_pk_add_f32"))]
+    if "nodma" in ND_TIMING:
+        L = [l for l in L if not l.startswith("global_load_lds")]
+    body = "\n".join(f'        "{l}\\n\\t"' for l in L)
+    vregs = list(range(SOLO_TMP, AT[1] + 1))
+    sregs = sorted({S_NG, S_CH, S_SB, S_SB + 1, S_TMP, S_PF_, S_LEFT_, S_DST, S_REM, S_K, S_NP, S_M0, S_DELTA}) + list(range(36, 60))
+    clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"', '"vcc"', '"memory"'])
+    return f"""// Reference-order sweep of one pixel's whole item (one frame x tile) on the halves form of the {{next, d}} layout: tools/gen_trip_asm.py,
+// block_exact_solo.  `row` = the PIXEL's entries of the item's first group in the quad-major table (32 bytes of each group's 128-byte line:
+// [mic] x (fraction, address); groups 128 bytes apart, contiguous across chunks); reads two groups past the last.  ngf / ngl / nch / isrc /
+// dbf / dbl / ddst / delta / lbytes / lane_addr as sweep_exact_ndh_item1.  O (output: zeroed here) = out[l + 64 k] of either half, pinned
+// at v[{O}:{O + 3}]; temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}.  Executes nch s_barrier instructions.
+__device__ __forceinline__ void {name}(f4 &O, const void *row, int ngf, int ngl, int nch, unsigned &lane_addr, const void *isrc, unsigned dbf,
+                                       unsigned dbl, unsigned ddst, int delta, unsigned lbytes) {{
+    asm volatile(
+{body}
+        : "=&{{v[{O}:{O + 3}]}}"(O), [lane] "+v"(lane_addr)
+        : [ptr] "s"(row), [ngf] "s"(ngf), [ngl] "s"(ngl), [nch] "s"(nch), [isrc] "s"(isrc), [dbf] "s"(dbf), [dbl] "s"(dbl), [ddst] "s"(ddst),
+          [delta] "s"(delta), [lbytes] "v"(lbytes)
+        : {clobbers});
+}}
+"""
+
+
 # ---------------------------------------------------------------------------------------------------
 # Quad block with a shared integer-delay sum (das_quad_kernel).
 #
@@ -2011,6 +2153,7 @@ def main():
     out.append(block_exact_nd("sweep_exact_ndh_item2", 2, nk=2))  # das_exact_ndh_kernel<2, *>
     out.append(block_exact_nd("sweep_exact_ndh_item1_w8", 1, nk=2, nw=8))  # ... 8- and 4-wave workgroups: single frames on grids too small to
     out.append(block_exact_nd("sweep_exact_ndh_item1_w4", 1, nk=2, nw=4))  # give every CU a 16-wave workgroup (c2: 64 of them)
+    out.append(block_exact_solo("sweep_exact_ndp_item"))  # das_exact_ndp_kernel: one pixel per wave (grids of at most 16 pixels per CU)
     out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))
     out.append(block_quad("sweep_quad_item", dma=True, chain=CHAIN, item=True))  # the production batch kernel: one block per item
