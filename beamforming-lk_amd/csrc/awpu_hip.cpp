@@ -1004,7 +1004,7 @@ bool takes_exact_nd(awpu_hip *h, int batch, int *nq) {
 // single frames in the reference's order: the halves form of the {next, d} layout (das_exact_ndh_kernel) -- every mic resident and
 // staged by the workgroups themselves (one array), or chunked behind a pack pre-pass.  `pitch` = floats between two streams of a frame
 int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int pitch, int wstart_eff, bool stationary,
-                     int nq, int nw = 16, bool pixel_per_wave = false) {
+                     int nq, bool pixel_per_wave = false) {
     int rc = build_quad_lut(h, stationary ? kQuadExactNdhStationary : kQuadExactNdh);
     if (rc != AWPU_OK) return rc;
     const awpu::FastPlan &pp = stationary ? h->exact_ndhs_plan : h->exact_ndh_plan;
@@ -1032,8 +1032,7 @@ int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_pow
     a.cols = h->cfg.grid_columns;
     a.rows = h->cfg.pixel_count / a.cols;
     a.nq = nq;
-    a.nw = nw;
-    a.tiles = pixel_per_wave ? awpu::ndp_tiles(a.rows, a.cols) : awpu::ndh_tiles(a.rows, a.cols, nq, nw);
+    a.tiles = pixel_per_wave ? awpu::ndp_tiles(a.rows, a.cols) : awpu::ndh_tiles(a.rows, a.cols, nq);
     a.lut_cols = (a.cols + 31) / 32 * 32;
     a.identity = 1;
     for (int k = 0; k < a.usable && a.identity; k++) a.identity = h->index[k] == k;
@@ -1350,33 +1349,28 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         const bool nd = takes_exact_nd(h, batch, &nq);
         // one frame per call (MIMOWorker::update's regime): the halves form of the layout -- the two packed lanes are the two halves of
         // the block, not a frame and its copy; every mic resident where one array's rows fit the LDS (no pre-pass)
-        if (nd && batch == 1 && (env().exact_pairs == 1 || env().exact_pairs == 6) && (h->exact_ndhs_ok || h->exact_ndh_ok)) {
+        const int ex = env().exact_pairs;
+        const bool grid_known = h->cfg.grid_columns >= 1 && h->cfg.pixel_count % h->cfg.grid_columns == 0;
+        if (batch == 1 && (ex == 1 || ex == 6) && grid_known && (h->exact_ndhs_ok || h->exact_ndh_ok)) {
             const int rows = h->cfg.pixel_count / h->cfg.grid_columns, cols = h->cfg.grid_columns;
-            const int nqh = (long) awpu::quad1_tiles(rows, cols, 2) >= 256 ? 2 : 1;
             if (h->n_cus < 1 && (hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess || h->n_cus < 1))
                 h->n_cus = 256;
-            // chunked sweeps of grids of at most 16 pixels per CU: one PIXEL per wave (das_exact_ndp_kernel) -- a quad kernel leaves such a
-            // grid one wave per SIMD, and the frame then takes as long as that wave's instruction issue (c2, 64 x 64 x 256 mics)
-            bool solo = h->exact_ndh_ok && !h->exact_ndhs_ok && awpu::ndp_tiles(rows, cols) * (long) batch <= h->n_cus;
-            if (env().exact_pairs == 6) solo = h->exact_ndh_ok;
+            // grids of at most 32 pixels per CU (two rounds of 16-wave workgroups): one PIXEL per wave (das_exact_ndp_kernel) -- a quad
+            // kernel leaves such a grid one or two waves per SIMD, and the frame then takes as long as one wave's instruction issue.
+            // Measured, 256 mics, one frame per call, quads -> pixels: 64 x 64 69.1 -> 31.6 us; 72^2 69.3 -> 52.1; 80^2 67.2 -> 53.3;
+            // 88^2 66.1 -> 56.5; 96^2 (a third round) 81.1 -> 76.4; 100^2 69.3 -> 77.9 (profiles/r05_single_frame_ablation.txt).  It shares
+            // no reads between pixels, so it also serves tables whose quads do not share (where the quad kernels are not chosen at all)
+            // One array (every mic resident in the quad kernel, no pre-pass) against pixels behind the pre-pass: 32^2 (its quads do not
+            // share: das_exact_pair_kernel) 36.9 -> 10.4 us; 48^2 22.3 -> 10.8; 64^2 21.1 -> 11.5; 80^2 20.3 -> 18.6; 100^2 (three rounds) 21.3 -> 26.0
+            bool solo = h->exact_ndh_ok && awpu::ndp_tiles(rows, cols) * (long) batch <= 2L * h->n_cus;
+            if (ex == 6) solo = h->exact_ndh_ok;
 #ifdef AWPU_TUNING_BUILD
             if (const char *v = std::getenv("AWPU_NDH_WAVES")) solo = std::atoi(v) == 1 && h->exact_ndh_ok;
 #endif
-            if (solo) return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, false, 1, 16, true);
-            // chunked sweeps of grids too small to give every CU a 16-wave workgroup: 8- or 4-wave workgroups -- half or a quarter of the
-            // pixels each -- as long as they still run in ONE round of workgroups (c2, 64 x 64: 64 -> 256 workgroups).  Measured, c2, one
-            // frame per call: 76.6 / 71.7 / 68.9 us with 16 / 8 / 4 waves -- a workgroup's time is the chain of its 13 chunk refills, not
-            // its arithmetic; a second round of workgroups costs far more than this gains (headline: 82 / 135 / 251 us)
-            int nw = 16;
-            if (!h->exact_ndhs_ok && nqh == 1) {
-                if (h->n_cus < 1 && (hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess || h->n_cus < 1))
-                    h->n_cus = 256;
-                nw = awpu::ndh_tiles(rows, cols, 1, 4) * (long) batch <= h->n_cus ? 4 : awpu::ndh_tiles(rows, cols, 1, 8) * (long) batch <= h->n_cus ? 8 : 16;
-#ifdef AWPU_TUNING_BUILD
-                if (const char *v = std::getenv("AWPU_NDH_WAVES")) nw = std::atoi(v) == 8 ? 8 : std::atoi(v) == 4 ? 4 : 16;
-#endif
-            }
-            return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, h->exact_ndhs_ok, nqh, nw);
+            if (solo) return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, false, 1, true);
+            // (smaller workgroups of quads -- 8 or 4 waves, one round -- were the first answer to such grids: c2 76.6 -> 71.7 / 68.9 us;
+            // one pixel per wave replaced them)
+            if (nd) return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, h->exact_ndhs_ok, (long) awpu::quad1_tiles(rows, cols, 2) >= 256 ? 2 : 1);
         }
         if (nd) return launch_exact_nd(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, nq);
         if (env().exact_pairs == 3 && h->pair_cols > 0 && h->cfg.pixel_count / h->cfg.grid_columns >= 4)

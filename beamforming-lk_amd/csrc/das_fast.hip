@@ -1637,11 +1637,10 @@ __device__ __forceinline__ float pixel_partial_exact(const float (&o)[4], int la
     return sum;
 }
 
-template <int NQ, bool STATIONARY, int NW = 16>
-__global__ __launch_bounds__(NW * 64) void das_exact_ndh_kernel(ExactNdhArgs a) {
+template <int NQ, bool STATIONARY>
+__global__ __launch_bounds__(1024) void das_exact_ndh_kernel(ExactNdhArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int kThreads = NW * 64, BUF = kFastLdsBytes;
-    static_assert(NW == 16 || (NQ == 1 && !STATIONARY && (NW == 8 || NW == 4)), "8- and 4-wave workgroups: one quad per wave, chunked");
+    constexpr int NW = 16, kThreads = NW * 64, BUF = kFastLdsBytes;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds_base = (unsigned) (unsigned long long) (const __attribute__((address_space(3))) char *) lds;
@@ -1718,18 +1717,12 @@ __global__ __launch_bounds__(NW * 64) void das_exact_ndh_kernel(ExactNdhArgs a) 
         const unsigned dbf = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) a.chunk * row_floats * 4));
         const unsigned dbl = __builtin_amdgcn_readfirstlane((unsigned) ((size_t) last_mics * row_floats * 4));
         const unsigned ddst = __builtin_amdgcn_readfirstlane(lds_base + BUF + wave * 1024);
-        const int rank = wave >> 2;  // (age order among the waves that share a SIMD: 0 with four waves per workgroup)
+        const int rank = wave >> 2;  // (age order among the waves that share a SIMD)
         const unsigned lane_bytes = threadIdx.x * 16;
         const void *isrc = uniform_ptr(STATIONARY ? (const void *) a.lut : (const void *) frame_rows);  // (one chunk: nothing is refilled)
         const unsigned *no_queue = (const unsigned *) uniform_ptr(nullptr);  // (one item per workgroup: no queue)
         unsigned no_ticket;
-        if constexpr (NQ == 1 && NW == 8) {
-            sweep_exact_ndh_item1_w8(O[0][0], O[0][1], O[0][2], O[0][3], uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
-                                     lane_addr, rank, isrc, dbf, dbl, isrc, 0u, ddst, BUF, lane_bytes, no_queue, no_ticket);
-        } else if constexpr (NQ == 1 && NW == 4) {
-            sweep_exact_ndh_item1_w4(O[0][0], O[0][1], O[0][2], O[0][3], uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
-                                     lane_addr, rank, isrc, dbf, dbl, isrc, 0u, ddst, BUF, lane_bytes, no_queue, no_ticket);
-        } else if constexpr (NQ == 1) {
+        if constexpr (NQ == 1) {
             sweep_exact_ndh_item1(O[0][0], O[0][1], O[0][2], O[0][3], uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
                                   lane_addr, rank, isrc, dbf, dbl, isrc, 0u, ddst, BUF, lane_bytes, no_queue, no_ticket);
         } else {
@@ -2883,37 +2876,35 @@ bool exact_ndh_plan(int window, int usable, bool stationary, FastPlan *plan) {
 
 hipError_t launch_pack_ndh(const float *d_frames, int n_streams, int pitch, int wstart, const int32_t *d_index, int usable, int rows_out,
                            const float *d_gain, int wh, int batch, float *d_packed, hipStream_t stream) {
-    hipLaunchKernelGGL(pack_ndh_kernel, dim3(rows_out, batch), dim3(128), 0, stream, d_frames, n_streams, pitch, wstart, d_index, usable, d_gain,
+    hipLaunchKernelGGL(pack_ndh_kernel, dim3(rows_out, batch), dim3(256), 0, stream, d_frames, n_streams, pitch, wstart, d_index, usable, d_gain,
                        wh, d_packed);
     return hipGetLastError();
 }
 
-template <int NQ, bool STATIONARY, int NW = 16>
+template <int NQ, bool STATIONARY>
 static hipError_t launch_exact_ndh_variant(const ExactNdhArgs &a, hipStream_t stream) {
     static LdsFlags attr_set = {};
     constexpr int lds_bytes = 2 * kFastLdsBytes;
-    if (hipError_t e = allow_lds((const void *) das_exact_ndh_kernel<NQ, STATIONARY, NW>, lds_bytes, attr_set); e != hipSuccess) return e;
-    hipLaunchKernelGGL((das_exact_ndh_kernel<NQ, STATIONARY, NW>), dim3((unsigned) ((long) a.batch * a.tiles)), dim3(NW * 64), lds_bytes, stream, a);
+    if (hipError_t e = allow_lds((const void *) das_exact_ndh_kernel<NQ, STATIONARY>, lds_bytes, attr_set); e != hipSuccess) return e;
+    hipLaunchKernelGGL((das_exact_ndh_kernel<NQ, STATIONARY>), dim3((unsigned) ((long) a.batch * a.tiles)), dim3(1024), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_das_exact_ndh(const ExactNdhArgs &a, bool stationary, const Extents &have, hipStream_t stream) {
-    if ((a.nq != 1 && a.nq != 2) || (a.nw != 16 && a.nw != 8 && a.nw != 4) || (a.nw != 16 && (a.nq != 1 || stationary))) return hipErrorInvalidValue;
+    if (a.nq != 1 && a.nq != 2) return hipErrorInvalidValue;
     if (a.chunk < 4 || (a.chunk & 3) || (a.usable_pad & 3) || a.usable < 1 || a.usable > a.usable_pad || a.wh < kSamples / 2 || a.cols < 1 ||
-        a.rows * a.cols != a.pixel_count || a.batch < 1 || a.tiles != ndh_tiles(a.rows, a.cols, a.nq, a.nw) || (long) a.batch * a.tiles > 0x7fffffffL)
+        a.rows * a.cols != a.pixel_count || a.batch < 1 || a.tiles != ndh_tiles(a.rows, a.cols, a.nq) || (long) a.batch * a.tiles > 0x7fffffffL)
         return hipErrorInvalidValue;
     if (stationary ? (a.chunk != a.usable_pad || (size_t) a.usable_pad * a.wh * 16 > (size_t) 2 * kFastLdsBytes || !a.frames || !a.index || a.pitch < 1)
                    : ((size_t) a.chunk * a.wh * 16 > (size_t) kFastLdsBytes || !a.packed))
         return hipErrorInvalidValue;
     // reach: every quad of the grid with its columns padded to whole tiles (16 nq) + one group of prefetch; chunked: usable_pad rows of wh
     // 16-byte elements per frame (stationary: the caller's frames, read inside [wstart, wstart + wh + 129) of a stream)
-    if (a.lut_cols < (a.cols + a.nw * a.nq - 1) / (a.nw * a.nq) * a.nw * a.nq) return hipErrorInvalidValue;
+    if (a.lut_cols < (a.cols + 16 * a.nq - 1) / (16 * a.nq) * 16 * a.nq) return hipErrorInvalidValue;
     const size_t quads = (size_t) ((a.rows + 3) / 4) * a.lut_cols;
     if (!within({quads * (a.usable_pad / 4) * 16 + kQuadTablePrefetch, stationary ? 0 : (size_t) a.batch * a.usable_pad * a.wh * 4}, have))
         return hipErrorInvalidValue;
     if (stationary) return a.nq == 2 ? launch_exact_ndh_variant<2, true>(a, stream) : launch_exact_ndh_variant<1, true>(a, stream);
-    if (a.nw == 8) return launch_exact_ndh_variant<1, false, 8>(a, stream);
-    if (a.nw == 4) return launch_exact_ndh_variant<1, false, 4>(a, stream);
     return a.nq == 2 ? launch_exact_ndh_variant<2, false>(a, stream) : launch_exact_ndh_variant<1, false>(a, stream);
 }
 

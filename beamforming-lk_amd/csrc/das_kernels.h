@@ -193,18 +193,17 @@ struct ExactNdhArgs {
     int32_t n_streams, pitch, wstart;  // stationary
     int32_t usable, usable_pad, pixel_count, wh, chunk, batch;
     int32_t cols, rows;
-    int32_t nq;            // quads per wave: a workgroup tile is 4 rows x nw nq columns
-    int32_t nw;            // waves per workgroup: 16; 8 or 4 (chunked, one quad per wave) for grids too small to give every CU 16 waves
-    int32_t tiles;         // ndh_tiles(rows, cols, nq, nw)
+    int32_t nq;            // quads per wave: a workgroup tile is 4 rows x 16 nq columns
+    int32_t tiles;         // ndh_tiles(rows, cols, nq)
     int32_t lut_cols;      // columns of the table (the grid's, padded to whole tiles of 32)
     int32_t identity;      // stationary: the active-mic list is 0 .. usable-1 (rows need no look-up)
 };
-inline int ndh_tiles(int rows, int cols, int nq, int nw) { return ((rows + 3) / 4) * ((cols + nw * nq - 1) / (nw * nq)); }
+inline int ndh_tiles(int rows, int cols, int nq) { return ((rows + 3) / 4) * ((cols + 16 * nq - 1) / (16 * nq)); }
 bool exact_ndh_plan(int window, int usable, bool stationary, FastPlan *plan);  // plan->wr = wh, row_bytes = 16 wh
 hipError_t launch_pack_ndh(const float *d_frames, int n_streams, int pitch, int wstart, const int32_t *d_index, int usable, int rows_out,
                            const float *d_gain, int wh, int batch, float *d_packed, hipStream_t stream);
 hipError_t launch_das_exact_ndh(const ExactNdhArgs &a, bool stationary, const Extents &have, hipStream_t stream);
-// ... one PIXEL per wave (das_exact_ndp_kernel: chunked, 16-wave workgroups of 4 rows x 4 columns; nq / nw unused): grids with too few quads
+// ... one PIXEL per wave (das_exact_ndp_kernel: chunked, 16-wave workgroups of 4 rows x 4 columns; nq unused): grids with too few quads
 // to give every SIMD more than one wave
 inline int ndp_tiles(int rows, int cols) { return ((rows + 3) / 4) * ((cols + 3) / 4); }
 hipError_t launch_das_exact_ndp(const ExactNdhArgs &a, const Extents &have, hipStream_t stream);

@@ -717,7 +717,8 @@ def test_reference_default_single_frames_run_the_resident_window_kernel(pkg, ora
 def test_reference_order_mode_on_the_ingest_ring(pkg, oracle):
     """AWPU_MATH_F32_EXACT on the live path: frames read in place from the device ring (rows 2048 floats apart) through
     pack_pairs_kernel<false> and the reference-order kernels give the bits the host-buffer entry gives, and the oracle's powers;
-    c2 geometry with the row length (das_exact_nd_kernel: the {next, d} layout) and without (das_exact_pair_kernel)."""
+    c2 geometry with the row length (one frame per call: das_exact_ndp_kernel on the halves form of the {next, d} layout) and without
+    (das_exact_pair_kernel)."""
     S = pkg.synthetic
     spec = S.WORKLOADS["c2"]
     xyz = S.geometry(spec)
@@ -725,7 +726,7 @@ def test_reference_order_mode_on_the_ingest_ring(pkg, oracle):
     rng = np.random.default_rng(6)
     names = pkg.binding.KERNEL_NAMES
     forced = {"exact_quad": "exact_quad", "exact_pair": "exact_pair"}.get(os.environ.get("AWPU_SHAPE", ""))
-    for cols, want in ((spec.res, forced or "exact_ndh"), (0, "exact_pair")):  # (one frame per call: the halves form of the {next, d} layout)
+    for cols, want in ((spec.res, forced or "exact_ndp"), (0, "exact_pair")):  # (one frame per call: the halves form of the {next, d} layout)
         ring = np.zeros((spec.n_mics, 1024), np.float32)
         with pkg.Engine(n_pixels=spec.n_pixels, n_streams=spec.n_mics, math=pkg.MATH_F32_EXACT, grid_columns=cols) as eng:
             eng.set_delay_table(off, frac)
@@ -1730,18 +1731,20 @@ def test_exact_mode_sums_equal_the_oracle_on_every_pixel(pkg, oracle, wl, cols, 
         assert util.power_rel_err_unfloored(power[b], want_p) < 3e-6
 
 
-@pytest.mark.parametrize("case", ["ref_default", "ref_default_ragged_gains", "odd_grid", "c2", "c2_short", "c2_wide", "c2_ragged_gains"])
+@pytest.mark.parametrize("case", ["ref_default", "ref_default_ragged_gains", "odd_grid", "c2", "c2_short", "c2_wide", "c2_ragged_gains", "c2_96", "c1"])
 def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
     """One frame per call in the reference's order -- MIMOWorker::update's regime (worker.h:212-224, mimo.cpp:97-151) -- on the halves
     form of the {next, d} layout (das_exact_ndh_kernel): one array at the reference's default resolution with every mic resident
     (100 x 100, main.cpp:38-41; also a ragged mic list with gains, and an odd grid), four arrays chunked behind the pack pre-pass
-    (64 x 64 and 30 x 64 -- a last quad of two live pixels --: one pixel per wave, das_exact_ndp_kernel; the 64 x 96 grid of "c2_wide":
-    quads in 8-wave workgroups, das_exact_ndh_kernel<1, false, 8>; a ragged mic list with gains there too).  The pre-epilogue sums equal oracle_das_f32's out[] bit for bit on EVERY
+    (64 x 64, 30 x 64 -- a last quad of two live pixels -- and 64 x 96 -- two rounds of workgroups --: one pixel per wave,
+    das_exact_ndp_kernel, a ragged mic list with gains there too; 96 x 96: quads, das_exact_ndh_kernel<1, false>), and c1, whose
+    table's quads do not share (batches go to das_exact_pair_kernel there, whose powers are reduced in another order: no bit-equality
+    with the batch is asked of it).  The pre-epilogue sums equal oracle_das_f32's out[] bit for bit on EVERY
     pixel (DC-biased plane-wave frames), the powers are the bits the same frame gets inside a batch (das_exact_nd_kernel), and within
     1e-5 of the oracle on every pixel."""
     S = pkg.synthetic
     names = pkg.binding.KERNEL_NAMES
-    index, gains = None, None
+    index, gains, want_batch = None, None, "exact_nd"
     if case.startswith("c2"):
         spec = S.WORKLOADS["c2"]
         xyz = S.geometry(spec)
@@ -1749,12 +1752,20 @@ def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
         # (64 x 64 and 30 x 64: at most 16 pixels per CU -> one pixel per wave, das_exact_ndp_kernel)
         rows, cols, n_streams, want = (30 if case == "c2_short" else spec.res), spec.res, spec.n_mics, "exact_ndp"
         off, frac = off[: rows * cols], frac[: rows * cols]
-        if case == "c2_wide":  # 16 quad rows x 96 columns: 384 tiles of 16 pixels are more than the chip's CUs, 192 eight-wave tiles of quads are not
-            rows, cols, want = 64, 96, "exact_ndh"
+        if case == "c2_wide":  # 16 quad rows x 96 columns: 384 tiles of 16 pixels = two rounds of workgroups
+            rows, cols = 64, 96
+            off, frac = pkg.build_delay_table(xyz, rows, cols, 180.0)
+        if case == "c2_96":  # 576 tiles of 16 pixels would be a third round: quads
+            rows, cols, want = 96, 96, "exact_ndh"
             off, frac = pkg.build_delay_table(xyz, rows, cols, 180.0)
         if case == "c2_ragged_gains":  # 205 active mics (a last group of one live mic + three silent ones), gains on
             index = np.array([k for k in range(256) if k % 5 != 2], np.int32)
             gains = (0.5 + np.arange(256) / 256.0).astype(np.float32)
+    elif case == "c1":
+        spec = S.WORKLOADS["c1"]
+        xyz = S.geometry(spec)
+        off, frac = S.delay_table(spec, xyz)
+        rows, cols, n_streams, want, want_batch = spec.res, spec.res, spec.n_mics, "exact_ndp", "exact_pair"
     else:
         xyz = pkg.create_antenna()
         rows = cols = 99 if case == "odd_grid" else 100  # (99: an odd grid, whose centre pixel looks straight ahead)
@@ -1773,7 +1784,7 @@ def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
         if gains is not None:
             eng.set_mic_gains(gains)
         batch = eng.process(frames)
-        assert names[eng.stats().kernel_variant] == "exact_nd"
+        assert names[eng.stats().kernel_variant] == want_batch
         d_X = torch.from_numpy(frames[1:2].copy()).cuda()
         d_P = torch.empty((1, P), dtype=torch.float32, device="cuda")
         d_S = torch.full((1, P, 256), float("nan"), dtype=torch.float32, device="cuda")
@@ -1782,7 +1793,8 @@ def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
         eng.synchronize()
         assert names[eng.stats().kernel_variant] == want
         single, sums = d_P.cpu().numpy()[0], d_S.cpu().numpy()[0]
-    assert np.array_equal(single, batch[1])  # a frame swept alone = the frame swept in a pair, bit for bit
+    if want_batch == "exact_nd":
+        assert np.array_equal(single, batch[1])  # a frame swept alone = the frame swept in a pair, bit for bit
     X = frames[1] * gains[:, None] if gains is not None else frames[1]
     want_p, want_out = oracle.das_f32(X, off, frac, index=index, want_out=True)
     assert np.array_equal(sums, want_out), np.argwhere(sums != want_out)[:4]

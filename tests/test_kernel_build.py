@@ -46,7 +46,7 @@ def test_generated_blocks_are_current(pkg, tmp_path):
 PRODUCTION = [r"das_quad_kernelILb0ELi0E", r"das_quadh_kernelILi[12]ELb0E", r"das_quadh_stationary_kernelILi[12]E", r"das_pair_kernelILi4ELb0ELb1E",
               r"das_pair_stationary_kernelILb1E", r"das_fast_db_kernelILi16ELi[48]ELi\d+ELi4ELb0E",
               r"das_fast_kernelILi8ELi[24]ELi1ELi4E", r"das_fir8_plane_kernelILi0E", r"das_exact_pair_kernel", r"das_exact_quad_kernel",
-              r"das_exact_nd_kernelILi[12]ELb0E", r"das_exact_ndh_kernelILi[12]ELb[01]ELi(16|8|4)E"]
+              r"das_exact_nd_kernelILi[12]ELb0E", r"das_exact_ndh_kernelILi[12]ELb[01]E", r"das_exact_ndp_kernel"]
 
 
 def test_sweep_kernels_do_not_spill(kernel_metadata):
@@ -57,7 +57,7 @@ def test_sweep_kernels_do_not_spill(kernel_metadata):
         checked += 1
         assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (name, m)
         assert m["vgpr_count"] <= 128, (name, m)
-    assert checked >= 21, sorted(kernel_metadata)
+    assert checked >= 20, sorted(kernel_metadata)
 
 
 def test_tuning_build_still_links(pkg, tmp_path):

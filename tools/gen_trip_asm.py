@@ -690,7 +690,8 @@ def block_exact_nd(name, nq, nk=4, nw=16):
     owns samples l and l + 64 of either half -- two register pairs per pixel, two ds_read_b128 per distinct address, four packed
     VALU instructions per (pixel, mic).
 
-    nw = waves per workgroup (16; 8 and 4 for single frames on small grids: a refill piece is nw x 1 KiB)."""
+    nw = waves per workgroup (a refill piece is nw x 1 KiB): 16.  (8 and 4 were built for single frames on small grids -- c2 76.6 ->
+    71.7 / 68.9 us -- until one pixel per wave, block_exact_solo, replaced them.)"""
     DMA_PIECE = nw * 1024
     w = 2 * nk  # registers per pixel's out[]
     O = [[ND_ACC + 4 * w * q + w * p for p in range(4)] for q in range(nq)]
@@ -975,9 +976,10 @@ def block_exact_solo(name, nw=16):
     SL = [[SOLO_TMP + 32 * s + 8 * i for i in range(4)] for s in range(2)]
     TT = SOLO_TMP + 64
     AT = (TT + 4, TT + 5)
+    LB = TT + 6  # the refill's running byte offset of this lane inside the chunk being fetched (lbytes + pieces issued x the piece)
     E = (36, 44)
     F = 52
-    S_NG, S_CH, S_SB, S_TMP, S_PF_, S_LEFT_, S_DST, S_REM, S_K, S_NP, S_M0, S_DELTA = 17, 19, 20, 22, 23, 24, 25, 28, 29, 30, 31, 35
+    S_NG, S_CH, S_SB, S_PF_, S_LEFT_, S_DST, S_REM, S_M0, S_DELTA = 17, 19, 20, 23, 24, 25, 28, 31, 35
 
     def uid():
         COUNTER[0] += 1
@@ -999,31 +1001,28 @@ def block_exact_solo(name, nw=16):
         return L
 
     def dma_piece():
+        """one piece (a 16-byte element per lane) of the refill, if a lane still has one inside the chunk: seven instructions -- M0 is the
+        running LDS destination, v{LB} the running offset (no piece counter, no scalar copy of either)"""
         u = uid()
-        return [f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Lpdskip{u}",
-                f"v_cmp_gt_u32 vcc, s{S_REM}, %[lbytes]", "s_mov_b64 exec, vcc",
-                f"s_mov_b32 m0, s{S_DST}", "s_nop 0",
-                f"global_load_lds_dwordx4 %[lbytes], s[{S_SB}:{S_SB + 1}]",
+        return [f"v_cmp_gt_u32 vcc, s{S_REM}, v{LB}",  # lanes whose 16 bytes lie inside the chunk
+                f"s_cbranch_vccz .Lpdskip{u}",
+                "s_mov_b64 exec, vcc",
+                f"global_load_lds_dwordx4 v{LB}, s[{S_SB}:{S_SB + 1}]",
                 "s_mov_b64 exec, -1",
-                f"s_add_u32 s{S_SB}, s{S_SB}, {hex(DMA_PIECE)}", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
-                f"s_add_u32 s{S_DST}, s{S_DST}, {hex(DMA_PIECE)}", f"s_sub_u32 s{S_REM}, s{S_REM}, {hex(DMA_PIECE)}",
-                f"s_add_u32 s{S_K}, s{S_K}, 1", f".Lpdskip{u}:"]
+                f"v_add_u32 v{LB}, {hex(DMA_PIECE)}, v{LB}",
+                f"s_add_u32 m0, m0, {hex(DMA_PIECE)}", f".Lpdskip{u}:"]
 
     def refill_params(first):  # block_exact_nd's, without a next item: beside the last chunk nothing is refilled
         u = uid()
         L = []
         if not first:
-            L += [f"s_lshl_b32 s{S_TMP}, s{S_K}, {DMA_PIECE.bit_length() - 1}",
-                  f"s_sub_u32 s{S_SB}, s{S_SB}, s{S_TMP}", f"s_subb_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
-                  f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_TMP}",
-                  f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_DELTA}",
+            L += [f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_DELTA}",   # the refill alternates images like the sweep, one ahead
                   f"s_sub_u32 s{S_DELTA}, 0, s{S_DELTA}"]
         L += [f"s_mov_b32 s{S_REM}, 0", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cbranch_scc1 .Lprset{u}",
               f"s_add_u32 s{S_SB}, s{S_SB}, %[dbf]", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
               f"s_mov_b32 s{S_REM}, %[dbf]", f"s_cmp_eq_u32 s{S_CH}, 2", f"s_cselect_b32 s{S_REM}, %[dbl], s{S_REM}",
               f".Lprset{u}:",
-              f"s_mov_b32 s{S_K}, 0", f"s_add_u32 s{S_NP}, s{S_REM}, {DMA_PIECE - 1}",
-              f"s_lshr_b32 s{S_NP}, s{S_NP}, {DMA_PIECE.bit_length() - 1}"]
+              f"v_mov_b32 v{LB}, %[lbytes]", f"s_mov_b32 m0, s{S_DST}"]
         return L
 
     def chunk_groups():
@@ -1043,8 +1042,8 @@ def block_exact_solo(name, nw=16):
 
     def boundary(par_next):
         u = uid()
-        L = ["s_waitcnt lgkmcnt(0)",
-             f".Lpmore{u}:", f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Lpnomore{u}"] + dma_piece() + [f"s_branch .Lpmore{u}", f".Lpnomore{u}:"]
+        piece = dma_piece()
+        L = ["s_waitcnt lgkmcnt(0)", f".Lpmore{u}:"] + piece[:-1] + [f"s_branch .Lpmore{u}"] + piece[-1:]  # the pieces the trips did not get to
         L += ["s_waitcnt vmcnt(0)", "s_barrier",
               f"s_sub_u32 s{S_CH}, s{S_CH}, 1", f"s_cmp_eq_u32 s{S_CH}, 0", "s_cbranch_scc1 .LPexit_%=",
               f"v_add_u32 %[lane], s{S_DELTA}, %[lane]"]
@@ -1073,8 +1072,8 @@ def block_exact_solo(name, nw=16):
     if "nodma" in ND_TIMING:
         L = [l for l in L if not l.startswith("global_load_lds")]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
-    vregs = list(range(SOLO_TMP, AT[1] + 1))
-    sregs = sorted({S_NG, S_CH, S_SB, S_SB + 1, S_TMP, S_PF_, S_LEFT_, S_DST, S_REM, S_K, S_NP, S_M0, S_DELTA}) + list(range(36, 60))
+    vregs = list(range(SOLO_TMP, LB + 1))
+    sregs = sorted({S_NG, S_CH, S_SB, S_SB + 1, S_PF_, S_LEFT_, S_DST, S_REM, S_M0, S_DELTA}) + list(range(36, 60))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"', '"vcc"', '"memory"'])
     return f"""// Reference-order sweep of one pixel's whole item (one frame x tile) on the halves form of the {{next, d}} layout: tools/gen_trip_asm.py,
 // block_exact_solo.  `row` = the PIXEL's entries of the item's first group in the quad-major table (32 bytes of each group's 128-byte line:
@@ -2151,8 +2150,6 @@ def main():
     out.append(block_exact_nd("sweep_exact_nd_item2", 2))  # das_exact_nd_kernel<2>: two quads per wave (the default batch kernel of the reference order)
     out.append(block_exact_nd("sweep_exact_ndh_item1", 1, nk=2))  # das_exact_ndh_kernel<1, *>: single frames, the halves form of the layout
     out.append(block_exact_nd("sweep_exact_ndh_item2", 2, nk=2))  # das_exact_ndh_kernel<2, *>
-    out.append(block_exact_nd("sweep_exact_ndh_item1_w8", 1, nk=2, nw=8))  # ... 8- and 4-wave workgroups: single frames on grids too small to
-    out.append(block_exact_nd("sweep_exact_ndh_item1_w4", 1, nk=2, nw=4))  # give every CU a 16-wave workgroup (c2: 64 of them)
     out.append(block_exact_solo("sweep_exact_ndp_item"))  # das_exact_ndp_kernel: one pixel per wave (grids of at most 16 pixels per CU)
     out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))

@@ -3,7 +3,8 @@
 device time per frame by events on the launch stream, and which kernel ran.  Under `rocprofv3 --kernel-trace --stats`
 the trace splits that time into the kernel's own duration and the gap between launches.
 
-    python tools/single_frame_rate.py [--math exact|fast|both] [workload ...]      (default: both modes, ref_default c2 headline)
+    python tools/single_frame_rate.py [--math exact|fast|both] [workload ...]      (default: both modes, ref_default c2 headline;
+                                                                                    "c2@80" = c2's arrays on an 80 x 80 grid)
 """
 import importlib
 import sys
@@ -21,7 +22,12 @@ if args[:1] == ["--math"]:
     modes = ["exact", "fast"] if args[1] == "both" else [args[1]]
     args = args[2:]
 for name, mode in [(n, m) for n in (args or ["ref_default", "c2", "headline"]) for m in modes]:
-    spec = S.WORKLOADS[name]
+    base, _, res = name.partition("@")  # "c2@80": c2's arrays on an 80 x 80 grid
+    spec = S.WORKLOADS[base]
+    if res:
+        import dataclasses
+
+        spec = dataclasses.replace(spec, name=f"{spec.name.split(':')[0]}@{res}: {spec.n_mics} mics x {res}x{res} x 256", res=int(res))
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz)
     frames = S.make_frames(xyz, 4, seed=1)
