@@ -966,19 +966,19 @@ def block_exact_solo(name, nw=16):
     32 bytes of the quad's 128-byte line), 4 address adds + 8 ds_read_b128 for the NEXT trip, 16 packed VALU for this one, and ONE
     wait -- lgkmcnt(0) at the head of a trip, for reads and entries that were requested a whole trip earlier.
 
-    Registers: E0 / E1 (8 SGPRs each) alternate trip by trip; at the head of trip n the set `cur` holds entries(n) and `nxt` entries(n+1):
-    cur's four (fraction, address) pairs are copied to F (the trip's arithmetic reads fractions from there), cur is reloaded with
-    entries(n+2), nxt's addresses issue the reads of trip n+1 into the other slot set.  A chunk's last trip issues no reads (the
-    next trip's rows are in the image still being refilled): the boundary does, after the barrier.  Reads two groups past the
-    pixel's last (never used)."""
+    Registers: three sets of 8 SGPRs and three sets of four 8-register slots rotate trip by trip (the trip code exists three times):
+    at the head of trip n the set n % 3 holds entries(n) -- its fractions feed this trip's arithmetic -- and set (n+1) % 3 entries(n+1),
+    whose addresses issue the reads of trip n+1 into slot set (n+1) % 3; set (n+2) % 3 (entries(n-1): dead) is reloaded with
+    entries(n+2).  A chunk's last trip issues no reads (the next trip's rows are in the image still being refilled): it runs a copy
+    of the trip's tail that ends in the chunk boundary, which issues them after the barrier.  Reads two groups past the pixel's last
+    (never used)."""
     DMA_PIECE = nw * 1024
     O = SOLO_ACC
-    SL = [[SOLO_TMP + 32 * s + 8 * i for i in range(4)] for s in range(2)]
-    TT = SOLO_TMP + 64
+    SL = [[SOLO_TMP + 32 * s + 8 * i for i in range(4)] for s in range(3)]
+    TT = SOLO_TMP + 96
     AT = (TT + 4, TT + 5)
     LB = TT + 6  # the refill's running byte offset of this lane inside the chunk being fetched (lbytes + pieces issued x the piece)
-    E = (36, 44)
-    F = 52
+    E = (36, 44, 52)
     S_NG, S_CH, S_SB, S_PF_, S_LEFT_, S_DST, S_REM, S_M0, S_DELTA = 17, 19, 20, 23, 24, 25, 28, 31, 35
 
     def uid():
@@ -993,8 +993,8 @@ def block_exact_solo(name, nw=16):
             L.append(f"ds_read_b128 v[{slots[i] + 4}:{slots[i] + 7}], v{AT[i & 1]} offset:1024")
         return L
 
-    def terms(i, slot):  # t_k = fma(frac, d_k, next_k); out_k += t_k  (delay.cpp:21-25 on {next, d}), k = the lane's two sample pairs
-        fs = f"s[{F + 2 * i}:{F + 2 * i + 1}]"
+    def terms(base, i, slot):  # t_k = fma(frac, d_k, next_k); out_k += t_k  (delay.cpp:21-25 on {next, d}), k = the lane's two sample pairs
+        fs = f"s[{base + 2 * i}:{base + 2 * i + 1}]"
         L = [f"v_pk_fma_f32 v[{TT + 2 * k}:{TT + 2 * k + 1}], {fs}, v[{slot + 4 * k + 2}:{slot + 4 * k + 3}], v[{slot + 4 * k}:{slot + 4 * k + 1}] op_sel_hi:[0,1,1]"
              for k in range(2)]
         L += [f"v_pk_add_f32 v[{O + 2 * k}:{O + 2 * k + 1}], v[{O + 2 * k}:{O + 2 * k + 1}], v[{TT + 2 * k}:{TT + 2 * k + 1}]" for k in range(2)]
@@ -1028,26 +1028,32 @@ def block_exact_solo(name, nw=16):
     def chunk_groups():
         return [f"s_mov_b32 s{S_NG}, %[ngf]", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cselect_b32 s{S_NG}, %[ngl], s{S_NG}", f"s_mov_b32 s{S_LEFT_}, s{S_NG}"]
 
-    def trip_p(par):
-        cur, nxt = E[par], E[1 - par]
-        u = uid()
-        L = ["s_waitcnt lgkmcnt(0)"]  # this trip's elements (requested a trip ago) and entries(n+1)
-        L += [f"s_mov_b64 s[{F + 2 * i}:{F + 2 * i + 1}], s[{cur + 2 * i}:{cur + 2 * i + 1}]" for i in range(4)]
-        L += [f"s_load_dwordx8 s[{cur}:{cur + 7}], %[ptr], s{S_PF_}", f"s_add_u32 s{S_PF_}, s{S_PF_}, 128"]
-        L += [f"s_cmp_eq_u32 s{S_LEFT_}, 1", f"s_cbranch_scc1 .Lpnr{u}"] + reads(SL[1 - par], nxt) + [f".Lpnr{u}:"]
-        L += dma_piece()
-        for i in range(4):
-            L += terms(i, SL[par][i])
-        return L
+    cold = []
 
-    def boundary(par_next):
+    def boundary(j_next):
         u = uid()
         piece = dma_piece()
         L = ["s_waitcnt lgkmcnt(0)", f".Lpmore{u}:"] + piece[:-1] + [f"s_branch .Lpmore{u}"] + piece[-1:]  # the pieces the trips did not get to
         L += ["s_waitcnt vmcnt(0)", "s_barrier",
               f"s_sub_u32 s{S_CH}, s{S_CH}, 1", f"s_cmp_eq_u32 s{S_CH}, 0", "s_cbranch_scc1 .LPexit_%=",
               f"v_add_u32 %[lane], s{S_DELTA}, %[lane]"]
-        L += refill_params(first=False) + chunk_groups() + reads(SL[par_next], E[par_next]) + [f"s_branch .LP{par_next}_%="]
+        L += refill_params(first=False) + chunk_groups() + reads(SL[j_next], E[j_next]) + [f"s_branch .LP{j_next}_%="]
+        return L
+
+    def trip_p(j):
+        cur, nxt, nn = E[j], E[(j + 1) % 3], E[(j + 2) % 3]
+        u = uid()
+        L = [f".LP{j}_%=:", "s_waitcnt lgkmcnt(0)",  # this trip's elements (requested a trip ago) and entries(n+1)
+             f"s_load_dwordx8 s[{nn}:{nn + 7}], %[ptr], s{S_PF_}", f"s_add_u32 s{S_PF_}, s{S_PF_}, 128",
+             f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_eq_u32 s{S_LEFT_}, 0", f"s_cbranch_scc1 .LPlast{u}"]
+        L += reads(SL[(j + 1) % 3], nxt) + dma_piece()
+        tail = []
+        for i in range(4):
+            tail += terms(cur, i, SL[j][i])
+        L += tail
+        if j == 2:
+            L.append("s_branch .LP0_%=")
+        cold.extend([f".LPlast{u}:"] + dma_piece() + tail + boundary((j + 1) % 3))  # the chunk's last trip
         return L
 
     L = [f"v_mov_b32 v{r}, 0" for r in range(O, O + 4)]  # float out[N_SAMPLES] = {0.0} (mimo.cpp:122)
@@ -1056,12 +1062,7 @@ def block_exact_solo(name, nw=16):
     L += refill_params(first=True)
     L += [f"s_load_dwordx8 s[{E[0]}:{E[0] + 7}], %[ptr], 0x0", f"s_load_dwordx8 s[{E[1]}:{E[1] + 7}], %[ptr], 0x80"]
     L += chunk_groups() + [f"s_movk_i32 s{S_PF_}, 0x100", "s_waitcnt lgkmcnt(0)"] + reads(SL[0], E[0])
-    L += [".LP0_%=:"] + trip_p(0)
-    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_eq_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LPbndA_%="]
-    L += [".LP1_%=:"] + trip_p(1)
-    L += [f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_lg_u32 s{S_LEFT_}, 0", "s_cbranch_scc1 .LP0_%="]
-    L += boundary(0)
-    L += [".LPbndA_%=:"] + boundary(1)
+    L += trip_p(0) + trip_p(1) + trip_p(2) + cold
     L += [".LPexit_%=:", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 m0, s{S_M0}"]
     if "nobarrier" in ND_TIMING:
         L = ["s_nop 0" if l == "s_barrier" else l for l in L]
