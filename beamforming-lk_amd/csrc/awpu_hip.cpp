@@ -99,7 +99,7 @@ struct awpu_hip {
     bool exact_nd_ok = false;     // ... and the window fits the {next, d} image
     awpu::QuadEntry *d_exact_ndh_lut = nullptr, *d_exact_ndhs_lut = nullptr;  // single frames: the halves form of that layout, chunked / every mic resident
     awpu::FastPlan exact_ndh_plan{}, exact_ndhs_plan{};
-    bool exact_ndh_ok = false, exact_ndhs_ok = false;
+    bool exact_ndh_ok = false, exact_ndhs_ok = false, fast_ndp_ok = false;
     bool exact_pairs_ok = false;  // AWPU_MATH_F32_EXACT + LERP and the window fits the pair image
     float *sums_out = nullptr;    // awpu_hip_process_device_sums: where the launch in progress exports out[] (else null)
     awpu::QuadEntry *d_quad_lut = nullptr;  // quad-major table of the quad shape (das_quad_kernel)
@@ -455,6 +455,9 @@ int prepare(awpu_hip *h) {
     h->exact_pairs_ok = c.math == AWPU_MATH_F32_EXACT && c.interp == AWPU_INTERP_LERP && awpu::pair_plan(h->window, U, &h->exact_plan);
     h->exact_nd_ok = h->exact_pairs_ok && awpu::exact_nd_plan(h->window, U, &h->exact_nd_plan);
     h->exact_ndh_ok = h->exact_pairs_ok && awpu::exact_ndh_plan(h->window, U, false, &h->exact_ndh_plan);
+    // (AWPU_MATH_F32_FAST sweeps single frames on small grids with the reference-order pixel-per-wave kernel too -- launch() -- : the
+    // same plan, the same table)
+    h->fast_ndp_ok = c.math == AWPU_MATH_F32_FAST && c.interp == AWPU_INTERP_LERP && awpu::exact_ndh_plan(h->window, U, false, &h->exact_ndh_plan);
     h->exact_ndhs_ok = h->exact_pairs_ok && awpu::exact_ndh_plan(h->window, U, true, &h->exact_ndhs_plan);
     if (c.math != AWPU_MATH_F32_FAST || c.interp == AWPU_INTERP_FIR8) {
         int chunk = 0;
@@ -1413,6 +1416,17 @@ int launch(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStr
         // a window too wide for the pair image is served by the single-frame shapes below; anything
         // else (an allocation or copy that failed) is the caller's to know about
         if (rc != AWPU_ERR_INVALID) return rc;
+    }
+    // ---- single frames on grids of at most 16 pixels per CU: the reference-order kernel with one pixel per wave
+    // (das_exact_ndp_kernel) is the fastest sweep this library has for them in ANY mode (c2, one frame per call: 47.6 us on this
+    // mode's 8-wave shape, 29.9 us there; c1 11.7 -> 10.1) and its powers are the reference's own arithmetic -- inside this
+    // mode's contract on any input.  Not when a shape of this mode is forced (AWPU_SHAPE: the tests sweep each through the oracle)
+    if (h->fast_ndp_ok && h->cfg.grid_columns >= 1 && h->cfg.pixel_count % h->cfg.grid_columns == 0 && env().fpi == 0 &&
+        env().halves == -1 && env().quads == -1 && env_pairs == -1 && env().stationary == -1) {
+        if (h->n_cus < 1 && (hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess || h->n_cus < 1))
+            h->n_cus = 256;
+        if (awpu::ndp_tiles(h->cfg.pixel_count / h->cfg.grid_columns, h->cfg.grid_columns) * (long) batch <= h->n_cus)
+            return launch_exact_ndh(h, d_frames, batch, d_power, s, hist_eff, wstart_eff, false, 1, true);
     }
     // ---- single frames on a grid whose table favours the quad shape (a forced single-frame shape goes past): the halves
     // layout behind a pack + filter pre-pass

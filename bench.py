@@ -30,6 +30,7 @@ At N = 1 the line also carries, next to the batched `value`:
   "pcie_inclusive"    awpu_hip_process on pageable host buffers, upload and read-back inside the clock; never `value`
   "bf16"              the bf16-accumulator mode on the same frames: its ERROR against the fp32 sweep
   "parity_dc"         both math modes on the reference-generated DC-biased goldens: error per offset (exact <= 1e-5 flat)
+  "single_frame_c2"   BASELINE configs[1]'s shape (256 mics, 64x64) one frame per call, in the run's mode
   "reference_default" the shape the reference ships (64 mics, 100x100, one frame per call) with its CPU time and the
                       5.24 ms real-time budget of a block beside it, in both fp32 modes
   "workloads"         the headline shape in the OTHER fp32 mode (--math fast when the run is the default), then c2, c3 and the c5
@@ -786,6 +787,8 @@ def main():
         out["parity"]["math"] = args.math
         out["reference_default"] = reference_default(pkg, torch, args, dev, local_rank, args.math)
         out["reference_default"]["other_mode"] = reference_default(pkg, torch, args, dev, local_rank, other, cpu=False)
+        # the mid-size live case: four arrays (one AWPU) on a 64 x 64 grid, one frame per call, in the run's mode
+        out["single_frame_c2"] = reference_default(pkg, torch, args, dev, local_rank, args.math, cpu=False, workload="c2")
         out["workloads"] = other_workloads(pkg, sharding, torch, dist, args, dev, local_rank)
         out["projected_scaling"] = projected_scaling(pkg, sharding, torch, dist, args, spec, dev, local_rank, d_full, B,
                                                      fps_one_gpu=out["value"], ms_one_gpu=out["ms_per_step"])
@@ -864,12 +867,12 @@ def parity_dc(pkg):
     return out
 
 
-def reference_default(pkg, torch, args, dev, local_rank, mode="exact", cpu=True):
+def reference_default(pkg, torch, args, dev, local_rank, mode="exact", cpu=True, workload="ref_default"):
     """The configuration the reference ships and runs live: ONE 8x8 array, a 100x100 grid (src/main.cpp:38-41: --mimo-res
     100), one frame per call (MIMOWorker::update, once per 256-sample block = every 5.24 ms at 48 828 Hz).  The device time
     per frame, the reference's own delay() on one host thread beside it, and what each makes of the real-time budget."""
     S = pkg.synthetic
-    spec = S.WORKLOADS["ref_default"]
+    spec = S.WORKLOADS[workload]
     xyz = S.geometry(spec)
     off, frac = S.delay_table(spec, xyz)
     frames = S.make_frames(xyz, 4, seed=args.seed)
@@ -903,7 +906,8 @@ def reference_default(pkg, torch, args, dev, local_rank, mode="exact", cpu=True)
     par = full_grid_parity(d_p[0].cpu().numpy(), frames[0], off, frac, mode)
     block_ms = 256 / 48828.0 * 1e3
     out = {
-        "workload": spec.name + ", one frame per call (src/main.cpp:38-41,53-56; aw_processing_unit.cpp:74)", "math": mode,
+        "workload": spec.name + (", one frame per call (src/main.cpp:38-41,53-56; aw_processing_unit.cpp:74)" if workload == "ref_default" else
+                                 ", one frame per call (one AWPU per port, four arrays on the wire: aw_control_unit.cpp:206-213)"), "math": mode,
         "ms_per_frame_device": ms, "value": 1e3 / ms, "unit": "frames/s", "kernel": kernel_name,
         "ms_per_host_call": host_call_ms,
         "realtime_block_ms": block_ms, "fraction_of_realtime_budget": host_call_ms / block_ms,

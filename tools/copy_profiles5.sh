@@ -39,15 +39,30 @@ for name, frames, math in (("default_exact_b128", 128, "exact"), ("fast_b128", 1
 json.dump(out, open(f"{P}/{r}_hbm_traffic.json", "w"), indent=1)
 # the table of profiles/README.md: per configuration, B_alg x frames / warm-median kernel time / 8 TB/s beside the bench line's own fraction
 import csv
-print("| configuration | bench line: value, ms_per_step, roofline.frac | sweep kernel, warm median (rocprofv3) | recomputed frac | VALU insts / launch | traffic / launch |")
-print("|---|---|---|---|---|---|")
+ARGS = {"default_exact_b128": "the driver's command", "fast_b128": "`--math fast`", "exact_batch1": "`--batch 1 --steps 200 --warmup 20`",
+        "c3_fir8_fast": "`--workload c3 --interp fir8 --math fast`", "c5_exact": "`--workload c5`, one rank's slab, 1024 frames in flight"}
+rows_out = ["| config (files `r05_*_<config>.*`) | math | frames / launch | frames/s (bench, not profiled) | ms/step | kernel ms (HIP events, bench) | kernel ms (rocprofv3, warm median) | `B_alg`·frames ÷ warm median ÷ 8 TB/s | bench `roofline.frac` | `valu.frac` | VALU instr. / launch | HBM-side traffic ÷ algorithmic bytes | dominant kernel (+ its pre-pass, warm mean) |",
+            "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for name in ("default_exact_b128", "fast_b128", "exact_batch1", "c3_fir8_fast", "c5_exact"):
     b = json.load(open(f"{P}/{r}_bench_{name}.json"))
     rows = list(csv.DictReader(open(f"{P}/{r}_rocprofv3_kernel_stats_warm_{name}.csv")))
     k = next(x for x in rows if "das_" in x["Name"])
+    pre = [x for x in rows if "pack_" in x["Name"]]
     c, _ = parse(f"{P}/{r}_pmc_summary_{name}.txt")
     alg = b["roofline"]["achieved"] * 1e9 * b["roofline"]["kernel_ms"] * 1e-3  # the line's own algorithmic bytes per launch
     med = float(k["WarmMedianNs"]) * 1e-9
-    print(f"| {name} | {b['value']:.0f} {b['unit']}, {b['ms_per_step']:.3f} ms, {b['roofline']['frac']:.4f} | `{k['Name'][:60]}` {med * 1e3:.3f} ms ({k['WarmCalls']} launches) | "
-          f"{alg / med / 8e12:.4f} | {c.get('SQ_INSTS_VALU', 0) / 1e9:.3f} G | {(128 * c['TCC_MISS_sum'] + 1024 * c['WRITE_SIZE']) / 1e9:.3f} GB |")
+    frames = b["config"].get("frames_per_step", b["config"].get("batch", 0))
+    valu = c.get("SQ_INSTS_VALU", 0)
+    kname = re.sub(r"^void awpu::|\(.*$", "", k["Name"])
+    prepass = f" (+ `{re.sub(r'^void awpu::|^awpu::|[(].*$', '', pre[0]['Name'])}` {float(pre[0]['WarmAverageNs']) / 1e3:.1f} µs)" if pre else ""
+    rows_out.append(f"| `{name}` ({ARGS[name]}) | {b['config'].get('math')} | {frames} | {b['value']:,.0f} | {b['ms_per_step']:.4f} | {b['roofline']['kernel_ms']:.4f} | {med * 1e3:.4f} | "
+                    f"**{alg / med / 8e12:.4f}** | {b['roofline']['frac']:.4f} | {b.get('valu', {}).get('frac', float('nan')):.3f} | "
+                    f"{valu / 1e9:.2f} G | {(128 * c['TCC_MISS_sum'] + 1024 * c['WRITE_SIZE']) / 1e9:.3g} / {alg / 1e9:.3g} GB | `{kname}`{prepass} |")
+table = "\n".join(rows_out)
+print(table)
+readme = open(f"{P}/README.md").read()
+begin, end = "<!-- r05 table begin -->", "<!-- r05 table end -->"
+if begin in readme:
+    readme = readme[:readme.index(begin) + len(begin)] + "\n" + table + "\n" + readme[readme.index(end):]
+    open(f"{P}/README.md", "w").write(readme)
 PY

@@ -1026,7 +1026,8 @@ def block_exact_solo(name, nw=16):
         return L
 
     def chunk_groups():
-        return [f"s_mov_b32 s{S_NG}, %[ngf]", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cselect_b32 s{S_NG}, %[ngl], s{S_NG}", f"s_mov_b32 s{S_LEFT_}, s{S_NG}"]
+        # (S_LEFT = trips of the chunk after its first: the borrow of a trip's decrement is what marks the chunk's last trip)
+        return [f"s_mov_b32 s{S_NG}, %[ngf]", f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cselect_b32 s{S_NG}, %[ngl], s{S_NG}", f"s_sub_u32 s{S_LEFT_}, s{S_NG}, 1"]
 
     cold = []
 
@@ -1045,7 +1046,7 @@ def block_exact_solo(name, nw=16):
         u = uid()
         L = [f".LP{j}_%=:", "s_waitcnt lgkmcnt(0)",  # this trip's elements (requested a trip ago) and entries(n+1)
              f"s_load_dwordx8 s[{nn}:{nn + 7}], %[ptr], s{S_PF_}", f"s_add_u32 s{S_PF_}, s{S_PF_}, 128",
-             f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cmp_eq_u32 s{S_LEFT_}, 0", f"s_cbranch_scc1 .LPlast{u}"]
+             f"s_sub_u32 s{S_LEFT_}, s{S_LEFT_}, 1", f"s_cbranch_scc1 .LPlast{u}"]
         L += reads(SL[(j + 1) % 3], nxt) + dma_piece()
         tail = []
         for i in range(4):
