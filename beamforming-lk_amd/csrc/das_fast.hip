@@ -1392,10 +1392,15 @@ struct NdQueues {
         return i < (unsigned) head(x) ? x * per + (int) i : -1;
     }
     __device__ __forceinline__ int take_common() const {
+        // run after run, not a ticket to every run in turn: the workgroups that share the tail then work on ONE frame pair group's rows
+        // at a time.  (Dealt round-robin, every XCD had eight pair groups' rows in flight during the tail -- more than its L2 holds --
+        // and an eighth of the launch's items re-read their rows from beyond it: 2.81 -> 2.04 GB per launch, FAST 1.82 -> 1.00; 0.1-0.3 % of
+        // the time: profiles/r05_ablation_nd_kernel.txt.)
+        if (tail <= 0) return -1;
         for (;;) {
             const unsigned j = atomicAdd(&q[8], 1u);
-            const int run = (int) (j & 7u), k = (int) (j >> 3);
-            if (k >= tail) return -1;  // (k only grows: every run's tail is dealt)
+            const int run = (int) (j / (unsigned) tail), k = (int) (j - (unsigned) run * (unsigned) tail);
+            if (run >= 8) return -1;
             if (k < len(run) - head(run)) return run * per + head(run) + k;
         }
     }
