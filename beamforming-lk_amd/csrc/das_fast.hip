@@ -1695,6 +1695,9 @@ __global__ __launch_bounds__(1024) void das_exact_ndh_kernel(ExactNdhArgs a) {
             }
         }
         __syncthreads();
+#ifdef AWPU_NDH_STAGE_ONLY  // timing experiment (tools/build_variant.sh): what the launch and the staging cost without the sweep
+        if (lds[threadIdx.x] != 12345.678f) return;
+#endif
     } else {
         constexpr int kPieces = (BUF + kThreads * 16 - 1) / (kThreads * 16);
         frame_rows = a.packed + (size_t) frame * a.usable_pad * row_floats;
