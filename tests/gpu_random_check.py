@@ -44,6 +44,8 @@ def main(seed: int, cases: int) -> int:
             P = cols * int(rng.choice([1, 2, 3, 5, 8]))
             grid_columns = cols
         batch = int(rng.integers(1, 8))
+        if os.environ.get("AWPU_TEST_BATCH") == "1":  # one frame per call in every case (the single-frame kernels)
+            batch = 1
         usable = int(rng.integers(1, n_streams + 1))
         reach = 257 + (6 if FIR8 else 0)
         spread = int(rng.choice([0, 3, 40, 120, hist - reach]))  # window width control

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
     {"AWPU_TEST_MATH": "exact", "AWPU_SHAPE": "exact_verify"},  # the round-1 verification kernel (the bf16 mode's structure)
     {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_SHAPE": "exact_nd2"},  # the {next, d} kernel on RANDOM delays: every pixel leaves the reference's address (its read-on-the-spot paths), batches of one as a pair with itself
     {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1", "AWPU_SHAPE": "exact_nd1"},  # ... one quad per wave, delays that mostly coincide
-    {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_SHAPE": "exact_ndp"},  # single frames: one pixel per wave, on random delays (batches >= 2: the {next, d} kernel)
+    {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_BATCH": "1", "AWPU_SHAPE": "exact_ndp"},  # single frames: one pixel per wave, on random delays, every case one frame per call
     {"AWPU_TEST_MATH": "exact", "AWPU_TEST_GRID": "1", "AWPU_TEST_COINCIDE": "1", "AWPU_SHAPE": "exact_quad"},  # round 4's quad kernel on raw sample pairs (still the fallback)
     {"AWPU_TEST_PATH": "device"},                               # device-resident frames + two pixel shards per case
     {"AWPU_TEST_INTERP": "fir8"},                               # the 8-tap variant of delay()

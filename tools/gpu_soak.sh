@@ -37,5 +37,9 @@ for seed in ${SEEDS:-11 12 13}; do
   run exact_nd2_coincide $seed 20 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1 AWPU_SHAPE=exact_nd2
   run exact_nd1_coincide $seed 20 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1 AWPU_SHAPE=exact_nd1
   run exact_quad_r4 $seed 12 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1 AWPU_SHAPE=exact_quad
+  run exact_ndp_random $seed 20 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_BATCH=1 AWPU_SHAPE=exact_ndp
+  run exact_ndp_coincide $seed 20 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1 AWPU_TEST_BATCH=1 AWPU_SHAPE=exact_ndp
+  run exact_single_default $seed 20 AWPU_TEST_MATH=exact AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1 AWPU_TEST_BATCH=1
+  run fast_single_default $seed 20 AWPU_TEST_GRID=1 AWPU_TEST_COINCIDE=1 AWPU_TEST_BATCH=1
 done
 exit $fail
