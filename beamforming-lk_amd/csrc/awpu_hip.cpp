@@ -1041,7 +1041,7 @@ int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_pow
     for (int k = 0; k < a.usable && a.identity; k++) a.identity = h->index[k] == k;
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     if (!stationary)
-        AWPU_HIP_TRY(awpu::launch_pack_ndh(d_frames, h->cfg.n_streams, pitch, wstart_eff, h->d_index, h->usable(), pp.usable_pad, h->d_gain, pp.wr,
+        AWPU_HIP_TRY(awpu::launch_pack_ndh(d_frames, h->cfg.n_streams, pitch, wstart_eff, a.identity ? nullptr : h->d_index, h->usable(), pp.usable_pad, h->d_gain, pp.wr,
                                            batch, h->d_pack, s));
     if (pixel_per_wave) {
         AWPU_HIP_TRY(awpu::launch_das_exact_ndp(a, {h->quad_lut_entries[kQuadExactNdh], h->pack_cap}, s));

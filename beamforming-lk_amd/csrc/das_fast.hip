@@ -1613,7 +1613,8 @@ __global__ void pack_ndh_kernel(const float *frames, int n_streams, int pitch, i
         for (int t = threadIdx.x; t < wh; t += blockDim.x) dst[t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
         return;
     }
-    const float *x = frames + ((size_t) frame * n_streams + index[s]) * pitch + wstart;
+    // (index == null: the identity list -- the common case -- spares the look-up, a dependent round trip in a pass that is all latency)
+    const float *x = frames + ((size_t) frame * n_streams + (index ? index[s] : s)) * pitch + wstart;
     const float gm = gain ? gain[s] : 1.0f;
     for (int t = threadIdx.x; t < wh; t += blockDim.x) {  // (t + 129 <= window - 1: inside the stream's history)
         const f2 lo = next_and_difference(x[t], x[t + 1], gm), hi = next_and_difference(x[t + 128], x[t + 129], gm);
@@ -1807,8 +1808,7 @@ __global__ __launch_bounds__(1024) void das_exact_ndp_kernel(ExactNdhArgs a) {
                                              (__attribute__((address_space(3))) void *) dst, 16, 0, 0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // (no wait, no barrier here: the block has both, behind its first table loads)
 
     f4 O;  // (float out[N_SAMPLES] = {0.0}, mimo.cpp:122: the block zeroes it itself)
     {

@@ -1062,7 +1062,9 @@ def block_exact_solo(name, nw=16):
           f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[isrc]", f"s_mov_b32 s{S_DST}, %[ddst]"]
     L += refill_params(first=True)
     L += [f"s_load_dwordx8 s[{E[0]}:{E[0] + 7}], %[ptr], 0x0", f"s_load_dwordx8 s[{E[1]}:{E[1] + 7}], %[ptr], 0x80"]
-    L += chunk_groups() + [f"s_movk_i32 s{S_PF_}, 0x100", "s_waitcnt lgkmcnt(0)"] + reads(SL[0], E[0])
+    # chunk 0 was requested by the kernel in front of the block (LDS-DMA); its wait and the workgroup's barrier stand HERE, behind the
+    # first table loads, so that the entries travel while the rows land
+    L += chunk_groups() + [f"s_movk_i32 s{S_PF_}, 0x100", "s_waitcnt vmcnt(0)", "s_barrier", "s_waitcnt lgkmcnt(0)"] + reads(SL[0], E[0])
     L += trip_p(0) + trip_p(1) + trip_p(2) + cold
     L += [".LPexit_%=:", "s_waitcnt lgkmcnt(0)", f"s_mov_b32 m0, s{S_M0}"]
     if "nobarrier" in ND_TIMING:
@@ -1081,7 +1083,8 @@ def block_exact_solo(name, nw=16):
 // block_exact_solo.  `row` = the PIXEL's entries of the item's first group in the quad-major table (32 bytes of each group's 128-byte line:
 // [mic] x (fraction, address); groups 128 bytes apart, contiguous across chunks); reads two groups past the last.  ngf / ngl / nch / isrc /
 // dbf / dbl / ddst / delta / lbytes / lane_addr as sweep_exact_ndh_item1.  O (output: zeroed here) = out[l + 64 k] of either half, pinned
-// at v[{O}:{O + 3}]; temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}.  Executes nch s_barrier instructions.
+// at v[{O}:{O + 3}]; temps v{vregs[0]}..v{vregs[-1]}, s{sregs[0]}..s{sregs[-1]}.  Executes nch + 1 s_barrier instructions: the first one -- behind
+// s_waitcnt vmcnt(0) -- is the barrier of chunk 0's staging, which the caller has requested and NOT waited for.
 __device__ __forceinline__ void {name}(f4 &O, const void *row, int ngf, int ngl, int nch, unsigned &lane_addr, const void *isrc, unsigned dbf,
                                        unsigned dbl, unsigned ddst, int delta, unsigned lbytes) {{
     asm volatile(
