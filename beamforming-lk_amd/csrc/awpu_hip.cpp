@@ -154,6 +154,7 @@ struct awpu_hip {
     float *d_frames = nullptr;
     float *h_live_in = nullptr, *h_live_out = nullptr;  // pinned staging of awpu_hip_process's one-frame calls (the live path): window in, powers out
     size_t live_in_cap = 0, live_out_cap = 0;           // in floats
+    unsigned live_calls = 0;                            // ... how many of them this handle has served (every 32nd is timed by events)
     float *d_power = nullptr;
     size_t frames_cap = 0, power_cap = 0;  // in floats
     int wstart = 0, window = 0, tau_max = 0;
@@ -1045,10 +1046,10 @@ int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_pow
                                            batch, h->d_pack, s));
     if (pixel_per_wave) {
         AWPU_HIP_TRY(awpu::launch_das_exact_ndp(a, {h->quad_lut_entries[kQuadExactNdh], h->pack_cap}, s));
-        return finish_launch(h, batch, s, AWPU_KERNEL_EXACT_NDP);
+    } else {
+        AWPU_HIP_TRY(awpu::launch_das_exact_ndh(a, stationary, {h->quad_lut_entries[stationary ? kQuadExactNdhStationary : kQuadExactNdh], stationary ? 0 : h->pack_cap}, s));
     }
-    AWPU_HIP_TRY(awpu::launch_das_exact_ndh(a, stationary, {h->quad_lut_entries[stationary ? kQuadExactNdhStationary : kQuadExactNdh], stationary ? 0 : h->pack_cap}, s));
-    return finish_launch(h, batch, s, stationary ? AWPU_KERNEL_EXACT_NDH_STATIONARY : AWPU_KERNEL_EXACT_NDH);
+    return finish_launch(h, batch, s, pixel_per_wave ? AWPU_KERNEL_EXACT_NDP : stationary ? AWPU_KERNEL_EXACT_NDH_STATIONARY : AWPU_KERNEL_EXACT_NDH);
 }
 
 int launch_exact(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int hist_eff, int wstart_eff) {
@@ -1739,9 +1740,13 @@ int wait_and_time(awpu_hip *h);
 // through the runtime's own bounce buffers in several synchronous steps (measured at the reference's default shape: 58-64 us per call
 // around a 20 us sweep).  Here the touched window of every stream is gathered into a PINNED buffer of the handle by the CPU (64 rows x
 // 1.2 KB), crosses PCIe in ONE piece read by a small kernel (a DMA-engine copy of 75 KB is mostly start-up), and the sweep stores its
-// powers straight into a pinned buffer.  Measured at the reference's shape (C level; Python adds ~6 us): 53 -> 43 us exact, 48 -> 38 us
-// fast, of which 35 / 32 us are the device's (upload 3 + sweep 22 / 19.5 + two dispatch latencies + the completion signal); spinning on
-// hipStreamQuery instead of hipStreamSynchronize and a stream-written flag (hipStreamWriteValue32) were measured: equal / 18 us slower.
+// powers straight into a pinned buffer.  Measured at the reference's shape (C level; Python adds ~5 us): 53 -> 43 us exact, 48 -> 38 us
+// fast, and -- with the event bracket around the sweep sampled instead of recorded on every call -- 42 / 37 us: gather 1.3, the two launches
+// 2.8 + ~3, then ~33 us until the stream is idle (upload 3 + sweep 21.6 / 19.5 + dispatch latencies + the end-of-kernel release and its
+// signal), copy out 2.0.  Measured and not kept: spinning on hipStreamQuery instead of hipStreamSynchronize (equal); a stream-written flag
+// (hipStreamWriteValue32: 18 us slower); a flag stored by the sweep's last workgroup (tools/microbench/done_flag.hip: 3 us sooner than
+// the stream's signal in isolation, but the powers must then be written through to the host as they are stored -- 10 000 four-byte
+// PCIe writes, +60 us -- or gathered into whole lines first).
 int live_host_call(awpu_hip *h, const float *frames, float *power) {
     int rc = check_ready(h, 1);
     if (rc != AWPU_OK) return rc;
@@ -1803,12 +1808,22 @@ int live_host_call(awpu_hip *h, const float *frames, float *power) {
 #endif
     // (the sweep stores its powers straight into the pinned buffer -- one 4-byte store per pixel over PCIe, complete when the kernel
     // is: a device-to-host copy behind the sweep would be one more DMA start-up, ~10 us, for 40 KB)
-    rc = launch(h, h->d_frames, 1, h->h_live_out, h->stream, compact ? kCompact : kFull);
-    if (rc != AWPU_OK) return rc;
+    // the event bracket around the sweep (awpu_hip_stats.last_kernel_ms) is two more packets on the stream and two more runtime calls:
+    // 3.3 us of a call of 50 (measured from Python, both modes).  This path brackets its first call and every 32nd after it; the other
+    // calls leave last_kernel_ms / total_kernel_ms as they are
+    {
+        const bool timed = (h->live_calls++ & 31) == 0;
+        const bool keep = h->timing;
+        h->timing = keep && timed;
+        rc = launch(h, h->d_frames, 1, h->h_live_out, h->stream, compact ? kCompact : kFull);
+        if (rc == AWPU_OK) {
 #ifdef AWPU_TUNING_BUILD
-    if (live_timing) lap(2, t);
+            if (live_timing) lap(2, t);
 #endif
-    rc = wait_and_time(h);
+            rc = wait_and_time(h);
+        }
+        h->timing = keep;
+    }
     if (rc != AWPU_OK) return rc;
 #ifdef AWPU_TUNING_BUILD
     if (live_timing) lap(3, t);

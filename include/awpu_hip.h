@@ -144,7 +144,9 @@ typedef struct {
 typedef struct {
     uint64_t frames;          /* frames processed since creation */
     uint64_t launches;        /* sweep kernel launches */
-    double last_kernel_ms;    /* device time of the last sweep launch (hipEvent) */
+    double last_kernel_ms;    /* device time of the last sweep launch that was timed (hipEvent): every launch, except that the synchronous
+                                 one-frame host call (awpu_hip_process, batch 1) times its first call and every 32nd after it -- the two
+                                 event records cost 3 us of a 45 us call */
     double total_kernel_ms;   /* sum over launches */
     uint64_t alg_bytes_frame; /* 4*U*W + 8*P*U + 4*P, W = 256 + tau_max + 1 */
     uint64_t alg_flops_frame; /* 4*P*U*256 + 6*P*254 */
