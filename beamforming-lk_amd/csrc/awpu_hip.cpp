@@ -155,6 +155,11 @@ struct awpu_hip {
     float *h_live_in = nullptr, *h_live_out = nullptr;  // pinned staging of awpu_hip_process's one-frame calls (the live path): window in, powers out
     size_t live_in_cap = 0, live_out_cap = 0;           // in floats
     unsigned live_calls = 0;                            // ... how many of them this handle has served (every 32nd is timed by events)
+    // ... their completion flag (das_exact_ndh_kernel<1, true>): the device counter the workgroups count themselves on, what it will read
+    // when every launch armed so far is over, the pinned flag and the sequence number of the last armed launch
+    unsigned long long *d_done_counter = nullptr, done_total = 0;
+    unsigned *h_done_flag = nullptr, done_seq = 0;
+    bool done_arm = false, done_used = false;           // arm: the next single-frame sweep is to raise the flag; used: it will
     float *d_power = nullptr;
     size_t frames_cap = 0, power_cap = 0;  // in floats
     int wstart = 0, window = 0, tau_max = 0;
@@ -327,6 +332,10 @@ void release_device(awpu_hip *h) {
     h->nd_items_cap = 0;
     h->nd_items_key = -1;
     dev_free(h->d_nd_queue);
+    dev_free(h->d_done_counter);
+    if (h->h_done_flag) (void) hipHostFree(h->h_done_flag);
+    h->h_done_flag = nullptr;
+    h->done_total = 0;
     dev_free(h->d_exact_nd_lut);
     dev_free(h->d_exact_ndh_lut);
     dev_free(h->d_exact_ndhs_lut);
@@ -1040,6 +1049,21 @@ int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_pow
     a.lut_cols = (a.cols + 31) / 32 * 32;
     a.identity = 1;
     for (int k = 0; k < a.usable && a.identity; k++) a.identity = h->index[k] == k;
+    h->done_used = false;
+    if (h->done_arm && s == h->stream && stationary && nq == 1 && !pixel_per_wave) {  // (the one-frame host call: live_host_call)
+        if (!h->d_done_counter) {
+            AWPU_HIP_TRY(hipMalloc(&h->d_done_counter, sizeof(unsigned long long)));
+            AWPU_HIP_TRY(hipMemset(h->d_done_counter, 0, sizeof(unsigned long long)));
+            AWPU_HIP_TRY(hipDeviceSynchronize());
+            AWPU_HIP_TRY(hipHostMalloc(&h->h_done_flag, 64, hipHostMallocDefault));
+            *h->h_done_flag = 0;
+            h->done_total = 0;
+        }
+        a.done_counter = h->d_done_counter;
+        a.done_flag = h->h_done_flag;
+        a.done_target = h->done_total + (unsigned long long) batch * a.tiles;
+        a.done_seq = h->done_seq + 1;
+    }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     if (!stationary)
         AWPU_HIP_TRY(awpu::launch_pack_ndh(d_frames, h->cfg.n_streams, pitch, wstart_eff, a.identity ? nullptr : h->d_index, h->usable(), pp.usable_pad, h->d_gain, pp.wr,
@@ -1048,6 +1072,11 @@ int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_pow
         AWPU_HIP_TRY(awpu::launch_das_exact_ndp(a, {h->quad_lut_entries[kQuadExactNdh], h->pack_cap}, s));
     } else {
         AWPU_HIP_TRY(awpu::launch_das_exact_ndh(a, stationary, {h->quad_lut_entries[stationary ? kQuadExactNdhStationary : kQuadExactNdh], stationary ? 0 : h->pack_cap}, s));
+    }
+    if (a.done_flag) {  // (the launch went out: its workgroups will count themselves)
+        h->done_total = a.done_target;
+        h->done_seq = a.done_seq;
+        h->done_used = true;
     }
     return finish_launch(h, batch, s, pixel_per_wave ? AWPU_KERNEL_EXACT_NDP : stationary ? AWPU_KERNEL_EXACT_NDH_STATIONARY : AWPU_KERNEL_EXACT_NDH);
 }
@@ -1743,10 +1772,11 @@ int wait_and_time(awpu_hip *h);
 // powers straight into a pinned buffer.  Measured at the reference's shape (C level; Python adds ~5 us): 53 -> 43 us exact, 48 -> 38 us
 // fast, and -- with the event bracket around the sweep sampled instead of recorded on every call -- 42 / 37 us: gather 1.3, the two launches
 // 2.8 + ~3, then ~33 us until the stream is idle (upload 3 + sweep 21.6 / 19.5 + dispatch latencies + the end-of-kernel release and its
-// signal), copy out 2.0.  Measured and not kept: spinning on hipStreamQuery instead of hipStreamSynchronize (equal); a stream-written flag
-// (hipStreamWriteValue32: 18 us slower); a flag stored by the sweep's last workgroup (tools/microbench/done_flag.hip: 3 us sooner than
-// the stream's signal in isolation, but the powers must then be written through to the host as they are stored -- 10 000 four-byte
-// PCIe writes, +60 us -- or gathered into whole lines first).
+// signal), copy out 2.0; and in the default mode at the reference's shape -- completion by a flag the resident kernel's last workgroup
+// stores behind its powers (launch_exact_ndh: done_*) instead of by the stream's signal -- 36.5 us.  Measured and not kept: spinning on
+// hipStreamQuery instead of hipStreamSynchronize (equal); a stream-written flag (hipStreamWriteValue32: 18 us slower); the workgroup flag
+// with the powers written through as they are stored (10 000 acknowledged four-byte PCIe writes: +60 us; gathered into 64-byte lines
+// first: what ships).
 int live_host_call(awpu_hip *h, const float *frames, float *power) {
     int rc = check_ready(h, 1);
     if (rc != AWPU_OK) return rc;
@@ -1815,12 +1845,29 @@ int live_host_call(awpu_hip *h, const float *frames, float *power) {
         const bool timed = (h->live_calls++ & 31) == 0;
         const bool keep = h->timing;
         h->timing = keep && timed;
+        h->done_arm = !h->timing;  // (a timed call waits for the stream: its end event)
         rc = launch(h, h->d_frames, 1, h->h_live_out, h->stream, compact ? kCompact : kFull);
+        h->done_arm = false;
         if (rc == AWPU_OK) {
 #ifdef AWPU_TUNING_BUILD
             if (live_timing) lap(2, t);
 #endif
-            rc = wait_and_time(h);
+            bool seen = false;
+            if (h->done_used) {
+                // the sweep's last workgroup stores the call's number behind its powers (das_fast.hip, das_exact_ndh_kernel's end): ~3 us
+                // sooner than the stream's completion signal.  Should it not arrive within 20 ms (it arrives within the sweep's ~25 us),
+                // the stream's own completion decides
+                const auto spin_from = std::chrono::steady_clock::now();
+                for (unsigned spins = 0;; spins++) {
+                    if (__atomic_load_n(h->h_done_flag, __ATOMIC_ACQUIRE) == h->done_seq) {
+                        seen = true;
+                        break;
+                    }
+                    __builtin_ia32_pause();
+                    if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - spin_from > std::chrono::milliseconds(20)) break;
+                }
+            }
+            if (!seen) rc = wait_and_time(h);
         }
         h->timing = keep;
     }

@@ -1765,6 +1765,26 @@ __global__ __launch_bounds__(1024) void das_exact_ndh_kernel(ExactNdhArgs a) {
     // das_exact_nd_kernel's reduction tree (wave_sum8 of eight per-lane sums) whatever NQ: the same bits as a frame swept in a pair
     const float total = wave_sum8(part[0], part[1], part[2], part[3], part[4], part[5], part[6], part[7], lane);
     const int value = kWaveSum8Value(lane >> 3), row = 4 * row4 + (value & 3), col = col0 + (value >> 2);
+    if constexpr (STATIONARY && NQ == 1) {
+        if (a.done_flag) {  // (uniform) the one-frame host call: powers into pinned memory, completion by flag
+            // The host learns that the powers are in its pinned buffer from a flag instead of from the stream's completion signal (the
+            // end-of-kernel release and the signal cost ~3 us more: tools/microbench/done_flag.hip).  The powers must then be written
+            // THROUGH as they are stored: as 4-byte stores that is 10 000 acknowledged PCIe writes (+60 us, measured); gathered in the LDS
+            // -- its rows are dead behind the block's last barrier -- the tile leaves as four 64-byte stores of wave 0.  No
+            // __threadfence_system(): on this chip it writes back and invalidates the whole L2 (+35 us in the microbenchmark).
+            if ((lane & 7) == 0 && (value >> 2) < NQ) lds[(value & 3) * 16 + wave] = total / norm;  // [row of the tile][column of the tile]
+            __syncthreads();
+            if (wave == 0) {
+                const int r = 4 * row4 + (lane >> 4), c = (tile - row4 * tiles_per_row4) * tile_cols + (lane & 15);
+                if (r < a.rows && c < a.cols)
+                    __hip_atomic_store(&a.power[(size_t) frame * a.pixel_count + (size_t) r * a.cols + c], lds[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged
+                if (lane == 0 && __hip_atomic_fetch_add(a.done_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull == a.done_target)
+                    __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
     if ((lane & 7) == 0 && (value >> 2) < NQ && row < a.rows && col < a.cols)
         a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;
 }

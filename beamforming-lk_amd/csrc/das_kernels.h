@@ -197,6 +197,13 @@ struct ExactNdhArgs {
     int32_t tiles;         // ndh_tiles(rows, cols, nq)
     int32_t lut_cols;      // columns of the table (the grid's, padded to whole tiles of 32)
     int32_t identity;      // stationary: the active-mic list is 0 .. usable-1 (rows need no look-up)
+    // completion flag (the synchronous one-frame host call on the resident kernel with one quad per wave; null = none): a workgroup's
+    // 64 powers leave as four 64-byte system-scope stores, the workgroup counts itself on *done_counter when they are acknowledged,
+    // and the one that brings the counter to done_target stores done_seq to *done_flag (pinned host memory)
+    unsigned long long *done_counter;
+    unsigned *done_flag;
+    unsigned long long done_target;
+    uint32_t done_seq;
 };
 inline int ndh_tiles(int rows, int cols, int nq) { return ((rows + 3) / 4) * ((cols + 16 * nq - 1) / (16 * nq)); }
 bool exact_ndh_plan(int window, int usable, bool stationary, FastPlan *plan);  // plan->wr = wh, row_bytes = 16 wh

@@ -1801,6 +1801,41 @@ def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
     check_full_grid(oracle, single, X, off, frac, f"{case}: one frame per call, reference order", index=index)
 
 
+@pytest.mark.parametrize("math", ["exact", "fast"])
+def test_one_frame_host_calls_equal_the_device_path(pkg, oracle, math):
+    """awpu_hip_process on ONE pageable host frame -- the call MIMOWorker::update makes every block (mimo.cpp:100-103) -- at the
+    reference's shipped shape, 70 calls in a row on changing frames: pinned staging, upload by a kernel, powers straight into pinned
+    memory, the event bracket only on the first call and every 32nd, and (default mode) completion by the flag of the sweep's last
+    workgroup instead of the stream's signal.  Every call must return the bits the device-pointer path returns for that frame (a
+    result read before it was complete, or left over from the call before, would differ), and the oracle's powers."""
+    import torch
+
+    S = pkg.synthetic
+    spec = S.WORKLOADS["ref_default"]
+    xyz = S.geometry(spec)
+    off, frac = S.delay_table(spec, xyz)
+    frames = S.make_frames(xyz, 7, seed=99)
+    frames *= (1.0 + np.arange(7, dtype=np.float32))[:, None, None]  # seven frames of different scale: powers differ by far more than an ulp
+    math_id = pkg.MATH_F32_EXACT if math == "exact" else pkg.MATH_F32_FAST
+    with pkg.Engine(n_pixels=spec.n_pixels, n_streams=64, math=math_id, max_batch=1, grid_columns=spec.res) as eng:
+        eng.set_delay_table(off, frac)
+        eng.set_active_mics(None)
+        want = []
+        for k in range(7):
+            d_X = torch.from_numpy(frames[k:k + 1].copy()).cuda()
+            d_P = torch.zeros((1, spec.n_pixels), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            eng.process_device(d_X.data_ptr(), 1, d_P.data_ptr())
+            eng.synchronize()
+            want.append(d_P.cpu().numpy()[0])
+        for call in range(70):
+            k = (3 * call) % 7
+            got = eng.process(frames[k:k + 1])[0]
+            assert np.array_equal(got, want[k]), (call, k, np.argwhere(got != want[k])[:4])
+        assert eng.stats().last_kernel_ms > 0  # (the sampled bracket did time a call)
+    check_full_grid(oracle, want[0], frames[0], off, frac, f"reference default, one frame per host call ({math})")
+
+
 @pytest.mark.parametrize("wl,offset", [("c2", 0.25), ("c2", 1e-2), ("headline", 0.25)])
 def test_exact_mode_is_within_1e5_of_the_reference_on_dc_biased_full_grids(pkg, oracle, wl, offset):
     """DC-biased plane-wave frames on FULL grids (beam nulls included), AWPU_MATH_F32_EXACT against the reference's
