@@ -155,7 +155,7 @@ struct awpu_hip {
     float *h_live_in = nullptr, *h_live_out = nullptr;  // pinned staging of awpu_hip_process's one-frame calls (the live path): window in, powers out
     size_t live_in_cap = 0, live_out_cap = 0;           // in floats
     unsigned live_calls = 0;                            // ... how many of them this handle has served (every 32nd is timed by events)
-    // ... their completion flag (das_exact_ndh_kernel<1, true>): the device counter the workgroups count themselves on, what it will read
+    // ... their completion flag (the resident single-frame kernels with one quad per wave): the device counter the workgroups count themselves on, what it will read
     // when every launch armed so far is over, the pinned flag and the sequence number of the last armed launch
     unsigned long long *d_done_counter = nullptr, done_total = 0;
     unsigned *h_done_flag = nullptr, done_seq = 0;
@@ -1014,6 +1014,29 @@ bool takes_exact_nd(awpu_hip *h, int batch, int *nq) {
     return true;
 }
 
+// The completion flag of the synchronous one-frame host call (das_kernels.h: DoneFlag; das_fast.hip: store_tile_and_signal): what the
+// next armed launch of `workgroups` workgroups gets, and what the handle remembers once that launch has gone out.
+int arm_done_flag(awpu_hip *h, unsigned long long workgroups, awpu::DoneFlag *out) {
+    if (!h->d_done_counter) {
+        AWPU_HIP_TRY(hipMalloc(&h->d_done_counter, sizeof(unsigned long long)));
+        AWPU_HIP_TRY(hipMemset(h->d_done_counter, 0, sizeof(unsigned long long)));
+        AWPU_HIP_TRY(hipDeviceSynchronize());
+        AWPU_HIP_TRY(hipHostMalloc(&h->h_done_flag, 64, hipHostMallocDefault));
+        *h->h_done_flag = 0;
+        h->done_total = 0;
+    }
+    out->counter = h->d_done_counter;
+    out->flag = h->h_done_flag;
+    out->target = h->done_total + workgroups;
+    out->seq = h->done_seq + 1;
+    return AWPU_OK;
+}
+void done_flag_armed(awpu_hip *h, const awpu::DoneFlag &d) {
+    h->done_total = d.target;
+    h->done_seq = d.seq;
+    h->done_used = true;
+}
+
 // single frames in the reference's order: the halves form of the {next, d} layout (das_exact_ndh_kernel) -- every mic resident and
 // staged by the workgroups themselves (one array), or chunked behind a pack pre-pass.  `pitch` = floats between two streams of a frame
 int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_power, hipStream_t s, int pitch, int wstart_eff, bool stationary,
@@ -1051,18 +1074,8 @@ int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_pow
     for (int k = 0; k < a.usable && a.identity; k++) a.identity = h->index[k] == k;
     h->done_used = false;
     if (h->done_arm && s == h->stream && stationary && nq == 1 && !pixel_per_wave) {  // (the one-frame host call: live_host_call)
-        if (!h->d_done_counter) {
-            AWPU_HIP_TRY(hipMalloc(&h->d_done_counter, sizeof(unsigned long long)));
-            AWPU_HIP_TRY(hipMemset(h->d_done_counter, 0, sizeof(unsigned long long)));
-            AWPU_HIP_TRY(hipDeviceSynchronize());
-            AWPU_HIP_TRY(hipHostMalloc(&h->h_done_flag, 64, hipHostMallocDefault));
-            *h->h_done_flag = 0;
-            h->done_total = 0;
-        }
-        a.done_counter = h->d_done_counter;
-        a.done_flag = h->h_done_flag;
-        a.done_target = h->done_total + (unsigned long long) batch * a.tiles;
-        a.done_seq = h->done_seq + 1;
+        rc = arm_done_flag(h, (unsigned long long) batch * a.tiles, &a.done);
+        if (rc != AWPU_OK) return rc;
     }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     if (!stationary)
@@ -1073,11 +1086,7 @@ int launch_exact_ndh(awpu_hip *h, const float *d_frames, int batch, float *d_pow
     } else {
         AWPU_HIP_TRY(awpu::launch_das_exact_ndh(a, stationary, {h->quad_lut_entries[stationary ? kQuadExactNdhStationary : kQuadExactNdh], stationary ? 0 : h->pack_cap}, s));
     }
-    if (a.done_flag) {  // (the launch went out: its workgroups will count themselves)
-        h->done_total = a.done_target;
-        h->done_seq = a.done_seq;
-        h->done_used = true;
-    }
+    if (a.done.flag) done_flag_armed(h, a.done);  // (the launch went out: its workgroups will count themselves)
     return finish_launch(h, batch, s, pixel_per_wave ? AWPU_KERNEL_EXACT_NDP : stationary ? AWPU_KERNEL_EXACT_NDH_STATIONARY : AWPU_KERNEL_EXACT_NDH);
 }
 
@@ -1358,8 +1367,14 @@ int launch_quadsh_stationary(awpu_hip *h, const float *d_frames, int batch, floa
     qa.row_limit = pitch;  // (the ring's rows are 2048 floats of which any 1024 + window are valid: double-written)
     if (!awpu::quadh_stationary_raw(pp, qa.usable, wstart_eff, qa.row_limit, &qa.raw_begin, &qa.raw_wr, &qa.image_offset))
         return invalid("the raw window does not fit the LDS beside the halves image");  // (launch() asks before it comes here)
+    h->done_used = false;
+    if (h->done_arm && s == h->stream && qpw == 1) {  // (the one-frame host call: live_host_call)
+        rc = arm_done_flag(h, (unsigned long long) batch * awpu::quad1_tiles(qa.rows, qa.cols, 1), &qa.done);
+        if (rc != AWPU_OK) return rc;
+    }
     if (h->timing) AWPU_HIP_TRY(hipEventRecord(h->ev_begin, s));
     AWPU_HIP_TRY(awpu::launch_das_quadh_stationary(qa, qpw, {h->quad_lut_entries[kQuadHalvesStationary], 0}, s));
+    if (qa.done.flag) done_flag_armed(h, qa.done);
     return finish_launch(h, batch, s, AWPU_KERNEL_QUADH_STATIONARY);
 }
 
@@ -1854,7 +1869,7 @@ int live_host_call(awpu_hip *h, const float *frames, float *power) {
 #endif
             bool seen = false;
             if (h->done_used) {
-                // the sweep's last workgroup stores the call's number behind its powers (das_fast.hip, das_exact_ndh_kernel's end): ~3 us
+                // the sweep's last workgroup stores the call's number behind its powers (das_fast.hip: store_tile_and_signal): ~7 us
                 // sooner than the stream's completion signal.  Should it not arrive within 20 ms (it arrives within the sweep's ~25 us),
                 // the stream's own completion decides
                 const auto spin_from = std::chrono::steady_clock::now();

@@ -1593,6 +1593,25 @@ __global__ __launch_bounds__(1024, 4) void das_exact_nd_kernel(ExactNdArgs a) {
 #endif
 }
 
+// The synchronous one-frame host call learns that a sweep's powers are in its pinned buffer from a flag instead of from the stream's
+// completion signal (the end-of-kernel release and the signal cost ~7 us more in the call; tools/microbench/done_flag.hip).  The powers
+// must then be written THROUGH as they are stored: as 4-byte stores that is 10 000 acknowledged PCIe writes (+60 us, measured); here the
+// 4-row x 16-column tile of a 16-wave workgroup is gathered in the LDS (its rows are dead once every wave has arrived) and leaves as four
+// 64-byte stores of wave 0.  No __threadfence_system(): on this chip it writes back and invalidates the whole L2 (+35 us in the
+// microbenchmark).  `holder`: this lane holds the power of row `tile_row` of the wave's column.
+__device__ __forceinline__ void store_tile_and_signal(float *lds, bool holder, int tile_row, int wave, int lane, float value, float *power, int row0,
+                                                      int col0, int rows, int cols, const DoneFlag &done) {
+    __syncthreads();
+    if (holder) lds[tile_row * 16 + wave] = value;
+    __syncthreads();
+    if (wave != 0) return;
+    const int r = row0 + (lane >> 4), c = col0 + (lane & 15);
+    if (r < rows && c < cols) __hip_atomic_store(&power[(size_t) r * cols + c], lds[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged
+    if (lane == 0 && __hip_atomic_fetch_add(done.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull == done.target)
+        __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------------------------------
 // Single frames in the reference's order (round 5): the halves form of the {next, d} layout.  MIMOWorker::update sweeps ONE
 // 256-sample block per call (worker.h:212-224, mimo.cpp:97-151); das_exact_nd_kernel would sweep it as a pair with itself, half its
@@ -1766,22 +1785,9 @@ __global__ __launch_bounds__(1024) void das_exact_ndh_kernel(ExactNdhArgs a) {
     const float total = wave_sum8(part[0], part[1], part[2], part[3], part[4], part[5], part[6], part[7], lane);
     const int value = kWaveSum8Value(lane >> 3), row = 4 * row4 + (value & 3), col = col0 + (value >> 2);
     if constexpr (STATIONARY && NQ == 1) {
-        if (a.done_flag) {  // (uniform) the one-frame host call: powers into pinned memory, completion by flag
-            // The host learns that the powers are in its pinned buffer from a flag instead of from the stream's completion signal (the
-            // end-of-kernel release and the signal cost ~3 us more: tools/microbench/done_flag.hip).  The powers must then be written
-            // THROUGH as they are stored: as 4-byte stores that is 10 000 acknowledged PCIe writes (+60 us, measured); gathered in the LDS
-            // -- its rows are dead behind the block's last barrier -- the tile leaves as four 64-byte stores of wave 0.  No
-            // __threadfence_system(): on this chip it writes back and invalidates the whole L2 (+35 us in the microbenchmark).
-            if ((lane & 7) == 0 && (value >> 2) < NQ) lds[(value & 3) * 16 + wave] = total / norm;  // [row of the tile][column of the tile]
-            __syncthreads();
-            if (wave == 0) {
-                const int r = 4 * row4 + (lane >> 4), c = (tile - row4 * tiles_per_row4) * tile_cols + (lane & 15);
-                if (r < a.rows && c < a.cols)
-                    __hip_atomic_store(&a.power[(size_t) frame * a.pixel_count + (size_t) r * a.cols + c], lds[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged
-                if (lane == 0 && __hip_atomic_fetch_add(a.done_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull == a.done_target)
-                    __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+        if (a.done.flag) {  // (uniform) the one-frame host call: powers into pinned memory, completion by flag
+            store_tile_and_signal(lds, (lane & 7) == 0 && (value >> 2) < NQ, value & 3, wave, lane, total / norm, a.power + (size_t) frame * a.pixel_count,
+                                  4 * row4, (tile - row4 * tiles_per_row4) * tile_cols, a.rows, a.cols, a.done);
             return;
         }
     }
@@ -2581,6 +2587,13 @@ __global__ __launch_bounds__(1024, 4) void das_quadh_stationary_kernel(QuadhStat
         total = wave_sum4(p0, p1, p2, p3);
         slot = kWaveSum4Value(lane >> 4);
         first = (lane & 15) == 0;
+    }
+    if constexpr (QPW == 1) {
+        if (a.done.flag && NW == 16) {  // (uniform) the one-frame host call: completion by flag (store_tile_and_signal)
+            store_tile_and_signal(lds, first, slot & 3, wave, lane, total / norm, a.power + (size_t) frame * a.pixel_count, 4 * row4,
+                                  (tile - row4 * tiles_per_row4) * tile_cols, a.rows, a.cols, a.done);
+            return;
+        }
     }
     const int col = col0 + (slot >> 2), row = 4 * row4 + (slot & 3);
     if (first && col < a.cols && row < a.rows) a.power[(size_t) frame * a.pixel_count + (size_t) row * a.cols + col] = total / norm;

@@ -182,6 +182,15 @@ hipError_t launch_das_exact_nd(const ExactNdArgs &a, const Extents &have, hipStr
 // lanes are the two halves of the 256-sample block, as in das_quadh_kernel.  Chunked (rows packed by launch_pack_ndh, the item block
 // refilling the other image) or STATIONARY (every active mic resident, the workgroup forming the elements itself from the caller's
 // frame: no pre-pass, no chunks -- one array at the reference's default resolution).
+// Completion flag of the synchronous one-frame host call (the resident single-frame kernels, one quad per wave; flag == null: none): a
+// workgroup's 64 powers leave as four 64-byte system-scope stores, the workgroup counts itself on *counter -- which only ever grows --
+// when they are acknowledged, and the one that brings it to `target` stores `seq` to *flag (pinned host memory), where the host spins.
+struct DoneFlag {
+    unsigned long long *counter;
+    unsigned *flag;
+    unsigned long long target;
+    uint32_t seq;
+};
 struct ExactNdhArgs {
     const float *packed;   // chunked: [batch][usable_pad][wh][4], padding rows zero; stationary: unused
     const float *frames;   // stationary: [batch][n_streams][pitch]
@@ -197,13 +206,7 @@ struct ExactNdhArgs {
     int32_t tiles;         // ndh_tiles(rows, cols, nq)
     int32_t lut_cols;      // columns of the table (the grid's, padded to whole tiles of 32)
     int32_t identity;      // stationary: the active-mic list is 0 .. usable-1 (rows need no look-up)
-    // completion flag (the synchronous one-frame host call on the resident kernel with one quad per wave; null = none): a workgroup's
-    // 64 powers leave as four 64-byte system-scope stores, the workgroup counts itself on *done_counter when they are acknowledged,
-    // and the one that brings the counter to done_target stores done_seq to *done_flag (pinned host memory)
-    unsigned long long *done_counter;
-    unsigned *done_flag;
-    unsigned long long done_target;
-    uint32_t done_seq;
+    DoneFlag done;         // the resident kernel with one quad per wave only
 };
 inline int ndh_tiles(int rows, int cols, int nq) { return ((rows + 3) / 4) * ((cols + 16 * nq - 1) / (16 * nq)); }
 bool exact_ndh_plan(int window, int usable, bool stationary, FastPlan *plan);  // plan->wr = wh, row_bytes = 16 wh
@@ -278,6 +281,7 @@ hipError_t launch_das_quadh(const QuadhArgs &a, int qpw, const Extents &have, hi
 // the same for arrays small enough that every active mic's halves row fits the LDS at once (das_quadh_stationary_kernel): the
 // workgroup stages (and filters) the window itself from the caller's frame -- no pack pre-pass, no chunks
 struct QuadhStationaryArgs {
+    DoneFlag done;            // one quad per wave only
     const float *frames;      // [batch][n_streams][pitch] (pitch = hist, or 2048 for a frame read in place from the ingest ring)
     const QuadEntry *lut;     // quad-major table, slot = mic: address = s * wp * 8 + (off - wstart) * 8
     const int32_t *index;     // [usable]

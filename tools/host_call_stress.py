@@ -16,7 +16,7 @@ xyz = S.geometry(spec)
 off, frac = S.delay_table(spec, xyz)
 frames = S.make_frames(xyz, 7, seed=5)
 frames *= (1.0 + np.arange(7, dtype=np.float32))[:, None, None]
-with pkg.Engine(n_pixels=spec.n_pixels, n_streams=64, math=pkg.MATH_F32_EXACT, max_batch=1, grid_columns=spec.res) as eng:
+with pkg.Engine(n_pixels=spec.n_pixels, n_streams=64, math=(pkg.MATH_F32_FAST if "fast" in sys.argv else pkg.MATH_F32_EXACT), max_batch=1, grid_columns=spec.res) as eng:
     eng.set_delay_table(off, frac); eng.set_active_mics(None)
     want = []
     for k in range(7):
