@@ -44,7 +44,9 @@ host-test: $(LIB) oracle
 example: $(LIB)
 	gcc -O2 -Wall -Iinclude examples/heatmap_min.c -L$(PKG) -lawpu_hip -lm -Wl,-rpath,'$$ORIGIN/../$(PKG)' \
 	    -Wl,-rpath,/opt/rocm/lib -o examples/heatmap_min
+	gcc -O2 -Wall -Iinclude examples/live_call_rate.c -L$(PKG) -lawpu_hip -lm -Wl,-rpath,'$$ORIGIN/../$(PKG)' \
+	    -Wl,-rpath,/opt/rocm/lib -o examples/live_call_rate
 
 clean:
-	rm -f $(LIB) tests/host/test_mimo_worker tests/host/test_exact_signatures examples/heatmap_min
+	rm -f $(LIB) tests/host/test_mimo_worker tests/host/test_exact_signatures examples/heatmap_min examples/live_call_rate
 	$(MAKE) -C oracle clean
