@@ -913,7 +913,8 @@ def reference_default(pkg, torch, args, dev, local_rank, mode="exact", cpu=True,
         "realtime_block_ms": block_ms, "fraction_of_realtime_budget": host_call_ms / block_ms,
         "parity_max_rel_unfloored": par["max_rel_unfloored"], "parity_ok": par["ok"], "pixels_checked": par["pixels"],
         "note": "device time per frame from back-to-back device-pointer calls; ms_per_host_call = awpu_hip_process on a pageable "
-                "host frame (upload + sweep + read-back), the call MIMOWorker::update would make every 5.24 ms",
+                "host frame (upload + sweep + read-back) through the Python binding, the call MIMOWorker::update would make every 5.24 ms "
+                "(the binding adds ~5 us: the same call from C, examples/live_call_rate.c, is in profiles/r05_live_call_rate_c.txt)",
     }
     if cpu and args.cpu_seconds > 0:
         cpu = cpu_baseline(spec, off, frac, frames[0], min(3.0, args.cpu_seconds))
