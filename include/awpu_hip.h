@@ -94,7 +94,7 @@ typedef enum {
     AWPU_KERNEL_EXACT_ND = 14,        /* das_exact_nd_kernel: the reference's order on the {next, d} layout (cur - next formed once per sample) */
     AWPU_KERNEL_EXACT_NDH = 15,       /* das_exact_ndh_kernel: single frames in the reference's order (the two halves of the block in the packed lanes) */
     AWPU_KERNEL_EXACT_NDH_STATIONARY = 16, /* ... with every active mic resident and staged by the workgroups themselves (the reference's own shape) */
-    AWPU_KERNEL_EXACT_NDP = 17        /* das_exact_ndp_kernel: ... one pixel per wave (grids of at most 16 pixels per CU: one AWPU's 4 arrays on a 64 x 64 grid) */
+    AWPU_KERNEL_EXACT_NDP = 17        /* das_exact_ndp_kernel: ... one pixel per wave (grids of at most 32 pixels per CU: one AWPU's 4 arrays on a 64 x 64 grid; FAST takes it up to 16) */
 } awpu_kernel_id;
 
 typedef struct awpu_hip awpu_hip_t;
