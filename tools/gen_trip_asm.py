@@ -658,6 +658,7 @@ ND_ACC = 10    # block_exact_nd: out[] of quad q, pixel p pinned at v[ND_ACC + 3
 ND_TMP = 74    # its 52 temps (two 16-register slots for the reference pixel's elements, one for whichever pixel leaves it, t, address)
 ND_PPT_H = int(os.environ.get("ND_PPT_H", "1"))  # refill pieces per trip of the single-frame blocks, in units of 16 KiB
 ND_TIMING = os.environ.get("ND_TIMING", "")  # tuning builds only (see the end of block_exact_nd)
+ND_PRIO = int(os.environ.get("ND_PRIO", "5"))  # tuning builds only: the wave-priority scheme of block_exact_nd's trips
 
 
 def block_exact_nd(name, nq, nk=4, nw=16):
@@ -816,7 +817,11 @@ def block_exact_nd(name, nq, nk=4, nw=16):
         # c2 69 -> 71 / 81 us at 2 / 5 pieces per trip; profiles/r05_single_frame_ablation.txt)
         for _ in range((16 // nw) * (ND_PPT_H if nk == 2 else 1)):
             L += dma_piece()
-        L += select_prio(S_PRIO, 1, QUAD_XMAP) if par == 0 else select_prio(S_RANK, 0, QUAD_YMAP)  # rotation / youngest first, trip by trip
+        # rotation / youngest first, trip by trip (tuning knob ND_PRIO: 3 = rotation in every trip, 4 = youngest first in every trip)
+        if ND_PRIO == 3 or (ND_PRIO == 5 and par == 0):
+            L += select_prio(S_PRIO, 1, QUAD_XMAP)
+        else:
+            L += select_prio(S_RANK, 0, QUAD_YMAP)
         if nq > 1:  # a quad's last trip of the chunk fetches the OTHER quad's next entries (its own continue where they stopped)
             u = uid()
             L += [f"s_cmp_lg_u32 s{S_LEFT_}, 1", f"s_cbranch_scc1 .Lnsw{u}",
