@@ -1019,8 +1019,8 @@ bool takes_exact_nd(awpu_hip *h, int batch, int *nq) {
 int arm_done_flag(awpu_hip *h, unsigned long long workgroups, awpu::DoneFlag *out) {
     if (!h->d_done_counter) {
         AWPU_HIP_TRY(hipMalloc(&h->d_done_counter, sizeof(unsigned long long)));
-        AWPU_HIP_TRY(hipMemset(h->d_done_counter, 0, sizeof(unsigned long long)));
-        AWPU_HIP_TRY(hipDeviceSynchronize());
+        AWPU_HIP_TRY(hipMemsetAsync(h->d_done_counter, 0, sizeof(unsigned long long), h->stream));
+        AWPU_HIP_TRY(hipStreamSynchronize(h->stream));  // (the handle's own stream: nothing device-wide from inside a sweep call)
         AWPU_HIP_TRY(hipHostMalloc(&h->h_done_flag, 64, hipHostMallocDefault));
         *h->h_done_flag = 0;
         h->done_total = 0;
