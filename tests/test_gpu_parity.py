@@ -1731,13 +1731,14 @@ def test_exact_mode_sums_equal_the_oracle_on_every_pixel(pkg, oracle, wl, cols, 
         assert util.power_rel_err_unfloored(power[b], want_p) < 3e-6
 
 
-@pytest.mark.parametrize("case", ["ref_default", "ref_default_ragged_gains", "odd_grid", "c2", "c2_short", "c2_wide", "c2_ragged_gains", "c2_96", "c1"])
+@pytest.mark.parametrize("case", ["ref_default", "ref_default_ragged_gains", "odd_grid", "c2", "c2_short", "c2_wide", "c2_ragged_gains", "c2_96", "c2_128x256", "c1"])
 def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
     """One frame per call in the reference's order -- MIMOWorker::update's regime (worker.h:212-224, mimo.cpp:97-151) -- on the halves
     form of the {next, d} layout (das_exact_ndh_kernel): one array at the reference's default resolution with every mic resident
     (100 x 100, main.cpp:38-41; also a ragged mic list with gains, and an odd grid), four arrays chunked behind the pack pre-pass
     (64 x 64, 30 x 64 -- a last quad of two live pixels -- and 64 x 96 -- two rounds of workgroups --: one pixel per wave,
-    das_exact_ndp_kernel, a ragged mic list with gains there too; 96 x 96: quads, das_exact_ndh_kernel<1, false>), and c1, whose
+    das_exact_ndp_kernel, a ragged mic list with gains there too; 96 x 96: quads, das_exact_ndh_kernel<1, false>; 128 x 256: two quads
+    per wave, das_exact_ndh_kernel<2, false>), and c1, whose
     table's quads do not share (batches go to das_exact_pair_kernel there, whose powers are reduced in another order: no bit-equality
     with the batch is asked of it).  The pre-epilogue sums equal oracle_das_f32's out[] bit for bit on EVERY
     pixel (DC-biased plane-wave frames), the powers are the bits the same frame gets inside a batch (das_exact_nd_kernel), and within
@@ -1757,6 +1758,9 @@ def test_exact_mode_single_frames_are_the_reference_bits(pkg, oracle, case):
             off, frac = pkg.build_delay_table(xyz, rows, cols, 180.0)
         if case == "c2_96":  # 576 tiles of 16 pixels would be a third round: quads
             rows, cols, want = 96, 96, "exact_ndh"
+            off, frac = pkg.build_delay_table(xyz, rows, cols, 180.0)
+        if case == "c2_128x256":  # 32 768 pixels: 256 tiles of TWO quads per wave (das_exact_ndh_kernel<2, false>)
+            rows, cols, want = 128, 256, "exact_ndh"
             off, frac = pkg.build_delay_table(xyz, rows, cols, 180.0)
         if case == "c2_ragged_gains":  # 205 active mics (a last group of one live mic + three silent ones), gains on
             index = np.array([k for k in range(256) if k % 5 != 2], np.int32)
