@@ -1750,9 +1750,18 @@ __global__ __launch_bounds__(1024) void das_exact_ndh_kernel(ExactNdhArgs a) {
         const void *isrc = uniform_ptr(STATIONARY ? (const void *) a.lut : (const void *) frame_rows);  // (one chunk: nothing is refilled)
         const unsigned *no_queue = (const unsigned *) uniform_ptr(nullptr);  // (one item per workgroup: no queue)
         unsigned no_ticket;
-        if constexpr (NQ == 1) {
+        if constexpr (NQ == 1 && STATIONARY) {  // (the block without refill code: one chunk)
+            sweep_exact_ndh_resident1(O[0][0], O[0][1], O[0][2], O[0][3], uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
+                                      lane_addr, rank, isrc, dbf, dbl, isrc, 0u, ddst, BUF, lane_bytes, no_queue, no_ticket);
+        } else if constexpr (NQ == 1) {
             sweep_exact_ndh_item1(O[0][0], O[0][1], O[0][2], O[0][3], uniform_ptr(quad_lut), ngf, ngl, __builtin_amdgcn_readfirstlane(n_chunks),
                                   lane_addr, rank, isrc, dbf, dbl, isrc, 0u, ddst, BUF, lane_bytes, no_queue, no_ticket);
+        } else if constexpr (STATIONARY) {
+            static_assert(NQ == 2, "blocks are generated for one and two quads per wave");
+            const int qstride = __builtin_amdgcn_readfirstlane(groups_total * 16 * (int) sizeof(QuadEntry));  // the next column's quad
+            sweep_exact_ndh_resident2(O[0][0], O[0][1], O[0][2], O[0][3], O[1][0], O[1][1], O[1][2], O[1][3], uniform_ptr(quad_lut), qstride, ngf, ngl,
+                                      __builtin_amdgcn_readfirstlane(n_chunks), lane_addr, rank, isrc, dbf, dbl, isrc, 0u, ddst, BUF, lane_bytes, no_queue,
+                                      no_ticket);
         } else {
             static_assert(NQ == 2, "blocks are generated for one and two quads per wave");
             const int qstride = __builtin_amdgcn_readfirstlane(groups_total * 16 * (int) sizeof(QuadEntry));  // the next column's quad

@@ -661,7 +661,7 @@ ND_TIMING = os.environ.get("ND_TIMING", "")  # tuning builds only (see the end o
 ND_PRIO = int(os.environ.get("ND_PRIO", "5"))  # tuning builds only: the wave-priority scheme of block_exact_nd's trips
 
 
-def block_exact_nd(name, nq, nk=4, nw=16):
+def block_exact_nd(name, nq, nk=4, nw=16, refill=True):
     """Reference-order sweep (AWPU_MATH_F32_EXACT, round 5) of a WHOLE item -- frame pair x tile, `nq` quads of four vertically
     adjacent pixels per wave -- on the {next, d} layout: pack_nd_kernel stores, per mic and sample t of the window, the 16-byte element
         { next_a, next_b, d_a, d_b },   next = X[t + 1],  d = X[t] - X[t + 1]      (a, b = the two frames of the pair)
@@ -691,6 +691,9 @@ def block_exact_nd(name, nq, nk=4, nw=16):
     owns samples l and l + 64 of either half -- two register pairs per pixel, two ds_read_b128 per distinct address, four packed
     VALU instructions per (pixel, mic).
 
+    refill = False: the block of the RESIDENT single-frame kernel (every mic's row in the LDS, one chunk): no refill code at all -- the
+    pieces' per-trip test alone is two instructions of a trip that the kernel's one wave per SIMD issues back to back.
+
     nw = waves per workgroup (a refill piece is nw x 1 KiB): 16.  (8 and 4 were built for single frames on small grids -- c2 76.6 ->
     71.7 / 68.9 us -- until one pixel per wave, block_exact_solo, replaced them.)"""
     DMA_PIECE = nw * 1024
@@ -702,6 +705,10 @@ def block_exact_nd(name, nq, nk=4, nw=16):
     # the address temp is t's last register: a reads() sequence (address add, then its ds_reads, which take the address as they
     # issue) never runs between an FMA into t and the add that consumes it
     addr_t = TT + 3
+    # nk = 2 (single frames: registers to spare): the refill's running byte offset of this lane inside the chunk being fetched, so that a
+    # piece is seven instructions -- M0 the running LDS destination -- instead of thirteen (block_exact_solo's; the frame-pair blocks
+    # have no register left for it)
+    LB = addr_t + 1 if nk == 2 else None
     E = (36, 68)
     S_NG, S_PFO, S_CH, S_SB, S_TMP, S_PF_, S_LEFT_, S_DST, S_REM, S_K, S_NP, S_M0, S_DELTA = 17, 18, 19, 20, 22, 23, 24, 25, 28, 29, 30, 31, 35
 
@@ -799,7 +806,17 @@ def block_exact_nd(name, nq, nk=4, nw=16):
 
     def dma_piece():
         """one 16 KiB piece of the refill, if any is left (block_quad's)"""
+        if not refill:
+            return []
         u = uid()
+        if LB is not None:
+            return [f"v_cmp_gt_u32 vcc, s{S_REM}, v{LB}",  # lanes whose 16 bytes lie inside the chunk
+                    f"s_cbranch_vccz .Lndskip{u}",
+                    "s_mov_b64 exec, vcc",
+                    f"global_load_lds_dwordx4 v{LB}, s[{S_SB}:{S_SB + 1}]",
+                    "s_mov_b64 exec, -1",
+                    f"v_add_u32 v{LB}, {hex(DMA_PIECE)}, v{LB}",
+                    f"s_add_u32 m0, m0, {hex(DMA_PIECE)}", f".Lndskip{u}:"]
         return [f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Lndskip{u}",
                 f"v_cmp_gt_u32 vcc, s{S_REM}, %[lbytes]",  # lanes whose 16 bytes lie inside the chunk
                 "s_mov_b64 exec, vcc",
@@ -847,8 +864,20 @@ def block_exact_nd(name, nq, nk=4, nw=16):
         """S_SB / S_REM / S_NP / S_K for the refill that runs beside the chunk about to be swept (S_CH = chunks left, that one
         included): the item's next chunk, dbf bytes on, or -- beside the item's last chunk -- the NEXT item's first chunk (nsrc, dbn
         bytes; dbn = 0: none), so that a persistent workgroup begins its next item on rows that are in the LDS already."""
+        if not refill:
+            return []
         u = uid()
         L = []
+        if LB is not None:  # (nothing to undo: neither the source nor the destination base was advanced)
+            if not first:
+                L += [f"s_sub_u32 s{S_DST}, s{S_DST}, s{S_DELTA}", f"s_sub_u32 s{S_DELTA}, 0, s{S_DELTA}"]
+            return L + [f"s_cmp_eq_u32 s{S_CH}, 1", f"s_cbranch_scc1 .Lnrnext{u}",
+                        f"s_add_u32 s{S_SB}, s{S_SB}, %[dbf]", f"s_addc_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
+                        f"s_mov_b32 s{S_REM}, %[dbf]", f"s_cmp_eq_u32 s{S_CH}, 2", f"s_cselect_b32 s{S_REM}, %[dbl], s{S_REM}",
+                        f"s_branch .Lnrset{u}", f".Lnrnext{u}:",
+                        f"s_mov_b64 s[{S_SB}:{S_SB + 1}], %[nsrc]", f"s_mov_b32 s{S_REM}, %[dbn]",
+                        f".Lnrset{u}:",
+                        f"v_mov_b32 v{LB}, %[lbytes]", f"s_mov_b32 m0, s{S_DST}"]
         if not first:
             L += [f"s_lshl_b32 s{S_TMP}, s{S_K}, {DMA_PIECE.bit_length() - 1}",   # undo the pieces' advance
                   f"s_sub_u32 s{S_SB}, s{S_SB}, s{S_TMP}", f"s_subb_u32 s{S_SB + 1}, s{S_SB + 1}, 0",
@@ -870,8 +899,14 @@ def block_exact_nd(name, nq, nk=4, nw=16):
 
     def boundary(next_set, resume):
         u = uid()
-        L = ["s_waitcnt lgkmcnt(0)",  # this chunk's last elements, and the reads issued for a trip that does not come
-             f".Lnmore{u}:", f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Lnnomore{u}"] + dma_piece() + [f"s_branch .Lnmore{u}", f".Lnnomore{u}:"]
+        if not refill:
+            L = ["s_waitcnt lgkmcnt(0)"]
+        elif LB is not None:
+            piece = dma_piece()
+            L = ["s_waitcnt lgkmcnt(0)", f".Lnmore{u}:"] + piece[:-1] + [f"s_branch .Lnmore{u}"] + piece[-1:]
+        else:
+            L = ["s_waitcnt lgkmcnt(0)",  # this chunk's last elements, and the reads issued for a trip that does not come
+                 f".Lnmore{u}:", f"s_cmp_ge_u32 s{S_K}, s{S_NP}", f"s_cbranch_scc1 .Lnnomore{u}"] + dma_piece() + [f"s_branch .Lnmore{u}", f".Lnnomore{u}:"]
         L += ["s_waitcnt vmcnt(0)", "s_barrier",  # my pieces of the next chunk have landed; so has everybody's, and all are done with this image
               f"s_sub_u32 s{S_CH}, s{S_CH}, 1", f"s_cmp_eq_u32 s{S_CH}, 0", "s_cbranch_scc1 .LNexit_%=",
               f"v_add_u32 %[lane], s{S_DELTA}, %[lane]"]  # the sweep moves to the image just filled
@@ -927,7 +962,7 @@ def block_exact_nd(name, nq, nk=4, nw=16):
     if "noprio" in ND_TIMING:
         L = [l for l in L if not l.startswith("s_setprio")]
     body = "\n".join(f'        "{l}\\n\\t"' for l in L)
-    vregs = list(range(ND_TMP, addr_t + 1))
+    vregs = list(range(ND_TMP, (LB if LB is not None else addr_t) + 1))
     sregs = sorted({S_NG, S_PFO, S_CH, S_SB, S_SB + 1, S_TMP, S_PF_, S_LEFT_, S_DST, S_RANK, S_PRIO, S_REM, S_K, S_NP, S_M0, S_DELTA}) + list(range(36, 100))
     clobbers = ", ".join([f'"v{r}"' for r in vregs] + [f'"s{r}"' for r in sregs] + ['"scc"', '"vcc"', '"memory"'])
     acc_params = ", ".join(f"{'f8' if nk == 4 else 'f4'} &O{q}{p}" for q in range(nq) for p in range(4))
@@ -2160,6 +2195,8 @@ def main():
     out.append(block_exact_nd("sweep_exact_nd_item2", 2))  # das_exact_nd_kernel<2>: two quads per wave (the default batch kernel of the reference order)
     out.append(block_exact_nd("sweep_exact_ndh_item1", 1, nk=2))  # das_exact_ndh_kernel<1, *>: single frames, the halves form of the layout
     out.append(block_exact_nd("sweep_exact_ndh_item2", 2, nk=2))  # das_exact_ndh_kernel<2, *>
+    out.append(block_exact_nd("sweep_exact_ndh_resident1", 1, nk=2, refill=False))  # das_exact_ndh_kernel<1, true>: every mic resident, nothing to refill
+    out.append(block_exact_nd("sweep_exact_ndh_resident2", 2, nk=2, refill=False))  # das_exact_ndh_kernel<2, true>
     out.append(block_exact_solo("sweep_exact_ndp_item"))  # das_exact_ndp_kernel: one pixel per wave (grids of at most 16 pixels per CU)
     out += [f"constexpr bool kQuadChain = {'true' if CHAIN else 'false'};  // the quad blocks keep V3 = S3 - S2 (else S3 - S1)", ""]
     out.append(block_quad("sweep_quad_sum", chain=CHAIN))
